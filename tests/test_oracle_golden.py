@@ -1,0 +1,120 @@
+"""The oracle restatement (oracle/mdm_oracle.py) against fixtures produced by the UPSTREAM REFERENCE
+itself (oracle/make_golden.py, run in the build container).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mdm_oracle as orc
+from oracle.synth import synth_state_dict, synth_y
+
+TOL = 2e-5   # fp32 reorder floor of two CPU implementations over a 50-step CFG trajectory is ~5e-6
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synth_state_dict(seed=0)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def test_pin_report_is_tight(golden_dir):
+    rep = json.load(open(os.path.join(golden_dir, "PIN_REPORT.json")))
+    assert rep["noise_stream_identical"] is True
+    assert rep["schedule_maxabs_50"] < 1e-12 and rep["schedule_maxabs_1000"] < 1e-10
+    for name, rec in rep["cases"].items():
+        for k, v in rec.items():
+            if k != "ref_absmax":
+                assert v < TOL, (name, k, v)
+
+
+@pytest.mark.parametrize("steps", [50, 1000])
+def test_schedule_tables(golden_dir, steps):
+    g = _load(golden_dir, f"schedule_cosine_{steps}")
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    for nm in ("betas", "alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+               "posterior_mean_coef1", "posterior_mean_coef2", "sqrt_recip_alphas_cumprod",
+               "sqrt_recipm1_alphas_cumprod"):
+        np.testing.assert_allclose(getattr(tab, nm), g[nm], rtol=0, atol=1e-9)
+    assert list(g["timestep_map"]) == list(range(steps))
+    assert tab.posterior_mean_coef1[0] == 1.0 and tab.posterior_mean_coef2[0] == 0.0
+
+
+def test_forward_golden(golden_dir, sd):
+    g = _load(golden_dir, "fwd_B3_T196")
+    B, T = 3, 196
+    y = synth_y(B, T, seed=int(g["y_seed"]), lengths=list(g["lengths"]))
+    x = torch.randn(B, 263, 1, T, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    t = torch.from_numpy(g["t"])
+    oc = orc.mdm_forward(sd, x, t, y)
+    ou = orc.mdm_forward(sd, x, t, {**y, "uncond": True})
+    og = orc.cfg_forward(sd, x, t, y)
+    assert np.abs(oc.numpy() - g["out_cond"]).max() < TOL
+    assert np.abs(ou.numpy() - g["out_uncond"]).max() < TOL
+    assert np.abs(og.numpy() - g["out_cfg"]).max() < TOL
+    gm = _load(golden_dir, "fwd_nomask_B3_T196")
+    onm = orc.mdm_forward(sd, x, t, y, mask_frames=False)
+    assert np.abs(onm.numpy() - gm["out_cond"]).max() < TOL
+    # the key-padding mask matters for the padded samples, and only for them
+    d = np.abs(onm.numpy() - g["out_cond"]).reshape(B, -1).max(1)
+    assert d[0] < TOL and d[1] > 1e-3 and d[2] > 1e-3
+
+
+LOOPS = ["loop50_nocfg_B2_T64", "ddim50_B2_T64", "ddim50_eta1_B2_T64", "inpaint50_B2_T64", "skip20_init_B2_T64"]
+
+
+def _run_loop_case(g, sd, dtype=torch.float32):
+    steps, B, T, seed = int(g["steps"]), int(g["B"]), int(g["T"]), int(g["seed"])
+    skip = int(g["skip"])
+    shape = (B, 263, 1, T)
+    y = synth_y(B, T, seed=seed + 1000, lengths=list(g["lengths"]), scale=float(g["scale"]))
+    gi = torch.Generator().manual_seed(seed + 2000)
+    init_image = torch.randn(*shape, generator=gi) if bool(g["init"]) else None
+    if bool(g["inpaint"]):
+        m = torch.zeros(shape, dtype=torch.bool)
+        m[:, :4, :, :] = True
+        m[..., : T // 4] = True
+        y["inpainting_mask"] = m
+        y["inpainted_motion"] = torch.randn(*shape, generator=gi)
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    x_T, noises = orc.make_noise(shape, steps - skip, seed)
+    return orc.sample_loop(sd, tab, shape, y, x_T, noises, cfg=bool(g["cfg"]), ddim=bool(g["ddim"]),
+                           eta=float(g["eta"]), skip_timesteps=skip, init_image=init_image, return_all=True,
+                           dtype=dtype)
+
+
+@pytest.mark.parametrize("name", LOOPS)
+def test_loop_golden_small(golden_dir, sd, name):
+    g = _load(golden_dir, name)
+    final, _ = _run_loop_case(g, sd)
+    assert np.abs(final.numpy() - g["final"]).max() < TOL
+
+
+def test_inpainting_reproduces_fixed_region(golden_dir, sd):
+    g = _load(golden_dir, "inpaint50_B2_T64")
+    # at t=0 coef1=1, coef2=0, no noise => the returned sample equals the blended x0
+    B, T, seed = 2, 64, int(g["seed"])
+    gi = torch.Generator().manual_seed(seed + 2000)
+    motion = torch.randn(B, 263, 1, T, generator=gi)
+    assert np.array_equal(g["final"][:, :4], motion.numpy()[:, :4])
+    assert np.array_equal(g["final"][..., : T // 4], motion.numpy()[..., : T // 4])
+
+
+@pytest.mark.slow
+def test_loop_golden_full_T196(golden_dir, sd):
+    g = _load(golden_dir, "loop50_B2_T196")
+    final, traj = _run_loop_case(g, sd)
+    assert np.abs(final.numpy() - g["final"]).max() < TOL
+    for k in g["dump_steps"]:
+        assert np.abs(traj[int(k)].numpy() - g[f"dump{int(k)}"]).max() < TOL
+
+
+@pytest.mark.slow
+def test_loop_golden_1000_steps(golden_dir, sd):
+    g = _load(golden_dir, "loop1000_B1_T32")
+    final, _ = _run_loop_case(g, sd)
+    assert np.abs(final.numpy() - g["final"]).max() < TOL
