@@ -1,0 +1,163 @@
+/* mdm_hip.h -- C ABI of libmdm_hip.so: the MI355X (gfx950) implementation of MDM's DDPM sampling hot path.
+ *
+ * The upstream project (GuyTevet/motion-diffusion-model) has no FFI: its boundary is three Python
+ * duck-typed seams.  This header is the native layer *beneath* those seams; each entry
+ * point names the reference interface it replaces (paths relative to the upstream tree).  The Python
+ * mirror of the seams lives in motion-diffusion-model_amd/ and INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer named *_dev / documented "device" is a caller-owned HIP device pointer (e.g. memory of
+ *     a torch tensor); the library never allocates, frees or retains tensor memory except the weight
+ *     pointers registered with mdm_set_weight (which must stay valid while the model is used);
+ *   - all work is enqueued asynchronously on the hipStream_t passed as `stream` (void* to keep this header
+ *     free of HIP types); nothing synchronises the device;
+ *   - every function returns MDM_OK (0) or a negative MDM_E* code; mdm_last_error() gives the message of the
+ *     calling thread's last failure.  No C++ exception crosses the ABI;
+ *   - a model handle may be used from one thread / one stream at a time.
+ *   - all tensors are fp32, dense, in the reference's layouts: poses [B, njoints, nfeats, T] (T contiguous).
+ */
+#ifndef MDM_HIP_H
+#define MDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDM_OK 0
+#define MDM_EINVAL (-1)   /* bad argument / shape                              */
+#define MDM_ESTATE (-2)   /* missing weight, mdm_prepare not called, ...       */
+#define MDM_ENOSPC (-3)   /* workspace too small                               */
+#define MDM_EHIP (-4)     /* a HIP runtime call failed                         */
+#define MDM_EUNSUPPORTED (-5)
+
+#define MDM_ABI_VERSION 1
+
+typedef struct mdm_model mdm_model_t;
+
+/* Hyper-parameters of model/mdm.py:11-135 (arch='trans_enc', data_rep='hml_vec', cond_mode='text'). */
+typedef struct mdm_config {
+  int32_t njoints;      /* 263  (utils/model_util.py:43)                        */
+  int32_t nfeats;       /* 1                                                    */
+  int32_t latent_dim;   /* 512  (utils/parser_util.py:106); multiple of 256     */
+  int32_t ff_size;      /* 1024 (utils/model_util.py:63)                        */
+  int32_t num_layers;   /* 8                                                    */
+  int32_t num_heads;    /* 4  -> head dim must be 128                           */
+  int32_t clip_dim;     /* 512: width of y['text_embed']                        */
+  int32_t max_len;      /* rows of the positional table `sequence_pos_encoder.pe` (5000) */
+  int32_t mask_frames;  /* args.mask_frames (model/mdm.py:48, :243)             */
+} mdm_config_t;
+
+int mdm_abi_version(void);
+const char* mdm_last_error(void);
+
+/* MDM(...) constructor (model/mdm.py:11-135) -- shapes only, no weights yet. */
+int mdm_create(const mdm_config_t* cfg, mdm_model_t** out);
+void mdm_destroy(mdm_model_t* m);
+
+/* load_state_dict (utils/model_util.py:8-15): register the device pointer of one state-dict tensor under
+ * its REFERENCE key, e.g. "seqTransEncoder.layers.3.self_attn.in_proj_weight".  `numel` is checked against
+ * the shape the config implies.  The positional table is registered as "sequence_pos_encoder.pe"
+ * ([max_len, latent_dim], computed by the host exactly as model/mdm.py:301-305 does). */
+int mdm_set_weight(mdm_model_t* m, const char* name, const float* dev_ptr, int64_t numel);
+
+/* Bytes of caller-owned, model-lifetime device scratch for derived tables (16-byte-aligned padded
+ * poseEmbedding weight, the time-MLP table TimestepEmbedder(pe[t]) for every t: model/mdm.py:316-330). */
+size_t mdm_const_bytes(const mdm_model_t* m);
+/* Validates that every weight is present and (re)builds the derived tables.  Call again after weights change. */
+int mdm_prepare(mdm_model_t* m, void* const_ws_dev, size_t const_ws_bytes, void* stream);
+
+/* Per-call activation workspace for `nseq` token sequences (B, or 2B under classifier-free guidance)
+ * of `nframes` frames each. */
+size_t mdm_workspace_bytes(const mdm_model_t* m, int32_t nseq, int32_t nframes);
+
+#define MDM_BRANCH_COND 0    /* y['uncond'] absent/False                     */
+#define MDM_BRANCH_UNCOND 1  /* y['uncond'] == True  (model/mdm.py:155-156, :208) */
+#define MDM_BRANCH_BOTH 2    /* both, batched: out = [cond(B) ; uncond(B)]   */
+
+/* MDM.forward(x, timesteps, y)  (model/mdm.py:189-283).
+ *   x_dev          [B, njoints, nfeats, T]
+ *   timesteps_dev  [B] int64
+ *   text_embed_dev [B, clip_dim] = y['text_embed'][0]; may be NULL for MDM_BRANCH_UNCOND
+ *   lengths_dev    [B] int32 = number of valid frames (y['mask'] rows are prefixes: data_loaders/tensors.py:3-8);
+ *                  NULL = no key-padding mask (all frames valid, or mask_frames == 0)
+ *   out_dev        [B or 2B, njoints, nfeats, T]                                                   */
+int mdm_forward(mdm_model_t* m, const float* x_dev, const int64_t* timesteps_dev, const float* text_embed_dev,
+                const int32_t* lengths_dev, int32_t B, int32_t T, int32_t branches, float* out_dev, void* ws_dev,
+                size_t ws_bytes, void* stream);
+
+/* One fused sampler update given model outputs (the tail of GaussianDiffusion.p_sample / ddim_sample,
+ * diffusion/gaussian_diffusion.py:489-541, :729-779, incl. ClassifierFreeSampleModel's combine
+ * utils/sampler_util.py:34 and the inpainting blend :300-304):
+ *   x0     = out_uncond ? out_uncond + scale[b]*(out_cond - out_uncond) : out_cond
+ *   x0     = inpaint_mask ? (mask ? motion : x0) : x0 ;  clamp to [-1,1] if clip_denoised
+ *   x_prev = a_x0*x0 + a_xt*x_t + sigma*eps,   eps = noise_dev ? noise_dev : Philox(seed, sample, draw)
+ * a_x0/a_xt/sigma are the host-folded per-step scalars (posterior_mean_coef1/2, exp(.5*log_var)*[t!=0]). */
+typedef struct mdm_step {
+  float a_x0, a_xt, sigma;
+  int32_t clip_denoised;
+  uint64_t seed;         /* Philox key                                           */
+  uint32_t sample_base;  /* global index of local sample 0 (shard-invariant RNG) */
+  uint32_t draw;         /* draw index: 0 = x_T, 1+k = k-th loop iteration       */
+} mdm_step_t;
+
+int mdm_sampler_step(const float* x_t_dev, const float* out_cond_dev, const float* out_uncond_dev,
+                     const float* scale_dev, const uint8_t* inpaint_mask_dev, const float* inpaint_motion_dev,
+                     const float* noise_dev, float* x_prev_dev, float* x0_dev, int32_t B, int32_t per_sample,
+                     const mdm_step_t* step, void* stream);
+
+/* th.randn(*shape) / q_sample (gaussian_diffusion.py:691, :226-244, :693-700) from the counter-based stream:
+ *   out = init ? a*init + s*eps : eps,  eps = eps_dev ? eps_dev : Philox(seed, sample_base+b, draw).     */
+int mdm_randn(float* out_dev, const float* init_dev, const float* eps_dev, float a, float s, int32_t B,
+              int32_t per_sample, uint64_t seed, uint32_t sample_base, uint32_t draw, void* stream);
+
+/* GaussianDiffusion.p_sample_loop / ddim_sample_loop (diffusion/gaussian_diffusion.py:591-727, :876-990)
+ * over ClassifierFreeSampleModel(MDM) (or bare MDM when scale_dev == NULL), entirely on `stream`:
+ * per step  InputProcess GEMM -> condition token -> 8 encoder layers -> OutputProcess GEMM whose epilogue
+ * performs the CFG combine + posterior/DDIM update in place on x.  Host arrays are indexed by the
+ * (respaced) diffusion index i = start_index .. 0. */
+typedef struct mdm_sample_params {
+  int32_t B, T;
+  int32_t num_timesteps;        /* length of the host tables below                                   */
+  int32_t start_index;          /* first i (= num_timesteps-1-skip_timesteps)                        */
+  const float* a_x0;            /* host [num_timesteps]                                              */
+  const float* a_xt;            /* host [num_timesteps]                                              */
+  const float* sigma;           /* host [num_timesteps]  (0 at i == 0)                               */
+  const int32_t* timestep_map;  /* host [num_timesteps]: model timestep for index i (respace.py:125-130) */
+  const float* text_embed_dev;  /* [B, clip_dim] or NULL (unconditional)                             */
+  const float* scale_dev;       /* [B] guidance scale y['scale'], NULL = no CFG (single branch)      */
+  const int32_t* lengths_dev;   /* [B] or NULL                                                       */
+  const uint8_t* inpaint_mask_dev;   /* [B,J,F,T] or NULL  (y['inpainting_mask'])                    */
+  const float* inpaint_motion_dev;   /* [B,J,F,T] or NULL  (y['inpainted_motion'])                   */
+  const float* noise_dev;       /* [nsteps, B,J,F,T] injected per-step noise, NULL = Philox          */
+  uint64_t seed;
+  uint32_t sample_base;
+  int32_t clip_denoised;
+  int32_t force_uncond;         /* 1: y['uncond']=True for the single-branch case                    */
+  float* x0_dev;                /* optional: pred_xstart of the last executed step                   */
+  const int32_t* dump_steps;    /* host, ascending loop indices k to snapshot (p_sample_loop dump_steps) */
+  int32_t num_dump;
+  float* dump_dev;              /* [num_dump, B,J,F,T]                                               */
+} mdm_sample_params_t;
+
+/* x_dev [B,J,F,T]: in = x at index start_index (x_T, or q_sample(init) -- see mdm_randn), out = sample. */
+int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x_dev, void* ws_dev, size_t ws_bytes,
+                    void* stream);
+
+/* Building blocks, exported for the parity tests and for callers that compose their own layers.
+ *   mdm_linear:    out[M,N] = act(in[M,K] . w[N,K]^T + bias) (+ res)     act: 0 none, 1 gelu(erf), 2 silu
+ *   mdm_layernorm: in-place LayerNorm over rows of D (eps 1e-5)
+ *   mdm_attention: softmax(QK^T + keypad) V per (sequence, head) on a packed [nseq*S, 3D] qkv buffer whose
+ *                  Q columns are pre-scaled by 1/sqrt(head_dim); lengths as in mdm_forward (indexed seq % B). */
+int mdm_linear(const float* in_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* out_dev,
+               int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
+int mdm_layernorm(float* x_dev, const float* gamma_dev, const float* beta_dev, int32_t rows, int32_t D, void* stream);
+int mdm_attention(const float* qkv_dev, float* out_dev, const int32_t* lengths_dev, int32_t nseq, int32_t B,
+                  int32_t S, int32_t D, int32_t H, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDM_HIP_H */

@@ -1,0 +1,136 @@
+"""Native engine handle: owns one `mdm_model_t` (include/mdm_hip.h) per (module, device) and the torch
+tensors that back its pointers.  PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class Engine:
+    """Binds a state-dict (reference key names) to a native model and runs forward / sample loops."""
+
+    def __init__(self, cfg, lib=None):
+        self.lib = lib if lib is not None else nat.load_native()
+        self.is_emulation = not self.lib.path.endswith(nat.LIB_NAME)
+        self.cfg = nat.MdmConfig(**cfg)
+        h = C.c_void_p()
+        self.lib.check(self.lib.mdm_create(C.byref(self.cfg), C.byref(h)), "mdm_create")
+        self.handle = h
+        self._weights = {}      # name -> tensor kept alive
+        self._const_ws = None
+        self._ws = None
+        self.device = None
+        self.ready = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.mdm_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- plumbing -------------------------------------------------------------------------
+    def _check_device(self, t):
+        if not self.is_emulation and not t.is_cuda:
+            raise nat.MdmError("the MI355X HIP path needs tensors on a cuda (ROCm) device; got " + str(t.device))
+
+    def stream(self):
+        if self.device is not None and self.device.type == "cuda":
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return None
+
+    def bind(self, state, device):
+        """Register every tensor of `state` (reference state-dict keys incl. 'sequence_pos_encoder.pe')."""
+        self.device = torch.device(device)
+        self._weights = {}
+        for name, t in state.items():
+            t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            self._check_device(t)
+            self._weights[name] = t
+            self.lib.check(self.lib.mdm_set_weight(self.handle, name.encode(), t.data_ptr(), t.numel()),
+                           f"mdm_set_weight({name})")
+        nbytes = self.lib.mdm_const_bytes(self.handle)
+        self._const_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.lib.check(self.lib.mdm_prepare(self.handle, self._const_ws.data_ptr(), nbytes, self.stream()), "mdm_prepare")
+        self.ready = True
+
+    def workspace(self, nseq, T):
+        need = self.lib.mdm_workspace_bytes(self.handle, nseq, T)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ---- MDM.forward ------------------------------------------------------------------------
+    def forward(self, x, timesteps, text_embed, lengths, branches):
+        B, J, Fe, T = x.shape
+        self._check_device(x)
+        nb = 2 if branches == nat.BRANCH_BOTH else 1
+        out = torch.empty((nb * B, J, Fe, T), dtype=torch.float32, device=x.device)
+        ws = self.workspace(nb * B, T)
+        self.lib.check(self.lib.mdm_forward(self.handle, x.data_ptr(), timesteps.data_ptr(), _ptr(text_embed),
+                                            _ptr(lengths), B, T, branches, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            self.stream()), "mdm_forward")
+        return out
+
+    # ---- fused sampler pieces -----------------------------------------------------------------
+    def sampler_step(self, x_t, out_cond, out_uncond, scale, inpaint_mask, inpaint_motion, noise, a_x0, a_xt, sigma,
+                     clip_denoised=False, seed=0, sample_base=0, draw=0, want_x0=False):
+        B = x_t.shape[0]
+        per = x_t[0].numel()
+        x_prev = torch.empty_like(x_t)
+        x0 = torch.empty_like(x_t) if want_x0 else None
+        st = nat.MdmStep(a_x0, a_xt, sigma, int(bool(clip_denoised)), seed, sample_base, draw)
+        self.lib.check(self.lib.mdm_sampler_step(x_t.data_ptr(), out_cond.data_ptr(), _ptr(out_uncond), _ptr(scale),
+                                                 _ptr(inpaint_mask), _ptr(inpaint_motion), _ptr(noise),
+                                                 x_prev.data_ptr(), _ptr(x0), B, per, C.byref(st), self.stream()),
+                       "mdm_sampler_step")
+        return x_prev, x0
+
+    def randn(self, shape, device, seed, sample_base, draw, init=None, eps=None, a=0.0, s=1.0):
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+        self._check_device(out)
+        B = shape[0]
+        self.lib.check(self.lib.mdm_randn(out.data_ptr(), _ptr(init), _ptr(eps), a, s, B, out[0].numel(), seed,
+                                          sample_base, draw, self.stream()), "mdm_randn")
+        return out
+
+    def sample_loop(self, x, *, a_x0, a_xt, sigma, timestep_map, start_index, text_embed, scale, lengths,
+                    inpaint_mask=None, inpaint_motion=None, noise=None, seed=0, sample_base=0, clip_denoised=False,
+                    force_uncond=False, want_x0=False, dump_steps=None):
+        """In-place loop on x [B,J,F,T] (x at index start_index).  Returns (x, x0 or None, dumps or None)."""
+        B, J, Fe, T = x.shape
+        self._check_device(x)
+        n = len(a_x0)
+        a0 = np.ascontiguousarray(a_x0, dtype=np.float32)
+        at = np.ascontiguousarray(a_xt, dtype=np.float32)
+        sg = np.ascontiguousarray(sigma, dtype=np.float32)
+        tm = np.ascontiguousarray(timestep_map, dtype=np.int32)
+        assert len(at) == n and len(sg) == n and len(tm) == n
+        nb = 2 if scale is not None else 1
+        ws = self.workspace(nb * B, T)
+        x0 = torch.empty_like(x) if want_x0 else None
+        dumps = dsteps = None
+        if dump_steps:
+            dsteps = np.ascontiguousarray(sorted(dump_steps), dtype=np.int32)
+            dumps = torch.empty((len(dsteps),) + tuple(x.shape), dtype=torch.float32, device=x.device)
+        p = nat.MdmSampleParams(
+            B=B, T=T, num_timesteps=n, start_index=int(start_index),
+            a_x0=a0.ctypes.data, a_xt=at.ctypes.data, sigma=sg.ctypes.data, timestep_map=tm.ctypes.data,
+            text_embed_dev=_ptr(text_embed), scale_dev=_ptr(scale), lengths_dev=_ptr(lengths),
+            inpaint_mask_dev=_ptr(inpaint_mask), inpaint_motion_dev=_ptr(inpaint_motion), noise_dev=_ptr(noise),
+            seed=int(seed), sample_base=int(sample_base), clip_denoised=int(bool(clip_denoised)),
+            force_uncond=int(bool(force_uncond)), x0_dev=_ptr(x0),
+            dump_steps=(dsteps.ctypes.data if dsteps is not None else None),
+            num_dump=(len(dsteps) if dsteps is not None else 0), dump_dev=_ptr(dumps))
+        self.lib.check(self.lib.mdm_sample_loop(self.handle, C.byref(p), x.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                self.stream()), "mdm_sample_loop")
+        return x, x0, dumps

@@ -1,0 +1,104 @@
+"""ctypes binding of libmdm_hip.so (C ABI: include/mdm_hip.h).
+
+The product path REQUIRES the HIP library: `load_native()` raises if it is missing -- there is no CPU
+or eager-PyTorch fallback.  (tests/emu builds a CPU emulation of the same sources purely as test
+infrastructure and points `MdmLib` at it explicitly.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libmdm_hip.so"
+LIB_PATH = os.path.join(_HERE, "csrc", LIB_NAME)
+
+MDM_OK = 0
+BRANCH_COND, BRANCH_UNCOND, BRANCH_BOTH = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+
+EXPORTED_SYMBOLS = [
+    "mdm_abi_version", "mdm_last_error", "mdm_create", "mdm_destroy", "mdm_set_weight", "mdm_const_bytes",
+    "mdm_prepare", "mdm_workspace_bytes", "mdm_forward", "mdm_sampler_step", "mdm_randn", "mdm_sample_loop",
+    "mdm_linear", "mdm_layernorm", "mdm_attention",
+]
+
+
+class MdmConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("njoints", "nfeats", "latent_dim", "ff_size", "num_layers", "num_heads",
+                                         "clip_dim", "max_len", "mask_frames")]
+
+
+class MdmStep(C.Structure):
+    _fields_ = [("a_x0", C.c_float), ("a_xt", C.c_float), ("sigma", C.c_float), ("clip_denoised", C.c_int32),
+                ("seed", C.c_uint64), ("sample_base", C.c_uint32), ("draw", C.c_uint32)]
+
+
+class MdmSampleParams(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32), ("num_timesteps", C.c_int32), ("start_index", C.c_int32),
+        ("a_x0", C.c_void_p), ("a_xt", C.c_void_p), ("sigma", C.c_void_p), ("timestep_map", C.c_void_p),
+        ("text_embed_dev", C.c_void_p), ("scale_dev", C.c_void_p), ("lengths_dev", C.c_void_p),
+        ("inpaint_mask_dev", C.c_void_p), ("inpaint_motion_dev", C.c_void_p), ("noise_dev", C.c_void_p),
+        ("seed", C.c_uint64), ("sample_base", C.c_uint32), ("clip_denoised", C.c_int32),
+        ("force_uncond", C.c_int32), ("x0_dev", C.c_void_p), ("dump_steps", C.c_void_p), ("num_dump", C.c_int32),
+        ("dump_dev", C.c_void_p),
+    ]
+
+
+class MdmError(RuntimeError):
+    pass
+
+
+class MdmLib:
+    """Thin typed view of the shared library.  Pointers are passed as integers (tensor.data_ptr())."""
+
+    def __init__(self, path):
+        if not os.path.isfile(path):
+            raise MdmError(
+                f"{path} not found: the MI355X HIP extension is not built. Run `python __graft_entry__.py build` "
+                f"(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+        self.path = path
+        lib = self.lib = C.CDLL(path)
+        vp, i32, i64, u32, u64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t
+        P = C.POINTER
+        sig = {
+            "mdm_abi_version": (C.c_int, []),
+            "mdm_last_error": (C.c_char_p, []),
+            "mdm_create": (C.c_int, [P(MdmConfig), P(vp)]),
+            "mdm_destroy": (None, [vp]),
+            "mdm_set_weight": (C.c_int, [vp, C.c_char_p, vp, i64]),
+            "mdm_const_bytes": (sz, [vp]),
+            "mdm_prepare": (C.c_int, [vp, vp, sz, vp]),
+            "mdm_workspace_bytes": (sz, [vp, i32, i32]),
+            "mdm_forward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]),
+            "mdm_sampler_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, P(MdmStep), vp]),
+            "mdm_randn": (C.c_int, [vp, vp, vp, f32, f32, i32, i32, u64, u32, u32, vp]),
+            "mdm_sample_loop": (C.c_int, [vp, P(MdmSampleParams), vp, vp, sz, vp]),
+            "mdm_linear": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+            "mdm_layernorm": (C.c_int, [vp, vp, vp, i32, i32, vp]),
+            "mdm_attention": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.mdm_abi_version() != 1:
+            raise MdmError(f"{path}: ABI version {lib.mdm_abi_version()} != 1")
+
+    def check(self, rc, what):
+        if rc != MDM_OK:
+            msg = self.lib.mdm_last_error()
+            raise MdmError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+    def __getattr__(self, name):
+        return getattr(self.lib, name)
+
+
+_LIB = None
+
+
+def load_native():
+    """The one and only way the product path reaches its kernels; raises MdmError if the .so is absent."""
+    global _LIB
+    if _LIB is None:
+        _LIB = MdmLib(os.environ.get("MDM_HIP_LIB", LIB_PATH))
+    return _LIB

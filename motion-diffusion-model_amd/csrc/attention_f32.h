@@ -1,0 +1,165 @@
+// Fused multi-head self-attention for the MDM encoder (exact fp32 on v_mfma_f32_32x32x2_f32).
+//
+// Replaces, per layer, torch's in-proj split / head transposes / scaled_dot_product_attention / head
+// merge (F.multi_head_attention_forward as driven by nn.TransformerEncoderLayer, model/mdm.py:77-84,
+// :253) and the key-padding mask of mdm.py:241-247.
+//
+//   qkv  [nseq*S, 3*D]  row = (sequence, token);  Q cols [0,D) already scaled by 1/sqrt(hd), K [D,2D), V [2D,3D)
+//   out  [nseq*S, D]    head h occupies cols [h*hd, (h+1)*hd)
+//
+// One workgroup per (sequence, head); hd = 128; S <= 32*NKT <= 224.  Wave w owns query rows
+// [32w, 32w+32).  Everything is computed TRANSPOSED so that the softmax axis is lane-local and the
+// probabilities never move:
+//   phase 1  St[key][query] = K . Q^T      A-operand = K rows (LDS, conflict-free b128 reads),
+//                                           B-operand = this wave's Q rows (registers)
+//            -> lane (query = l&31, half = l>>5) holds, for every 32-key tile, the 16 keys
+//               mfma_row(reg, half): softmax = in-register max/sum + ONE cross-half shuffle.
+//   phase 2  Ot[d][query]  = V^T . P^T     B-operand = the probability registers AS THEY ARE
+//               (MFMA #reg of a tile consumes key mfma_row(reg, half) from each half),
+//            A-operand = V[key][d-tile*32 + lane&31] (LDS, ds_read_b32, conflict-free).
+// K and V share one LDS buffer (K for phase 1, V for phase 2, then the output tile is staged
+// through it for coalesced 16-byte stores).  Padded keys (>= S, or masked frames) get p = 0 and
+// their K/V rows are zero-filled, so no NaN/Inf can leak from uninitialised memory.
+#pragma once
+#include "common.h"
+
+namespace mdm {
+
+constexpr int ATT_HD = 128;
+constexpr int ATT_KLD = ATT_HD + 4;  // K / O staging row stride (floats)
+
+template <int NKT>
+__global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float* __restrict__ qkv,
+                                                                   float* __restrict__ out,
+                                                                   const int* __restrict__ lengths,  // [B] or null
+                                                                   int S, int D, int H, int B) {
+  MDM_DYN_SMEM(float, smem);  // NKT*32 rows x ATT_KLD floats
+  constexpr int NT = 64 * NKT;
+  constexpr int ROWS = 32 * NKT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int seq = blockIdx.x / H, head = blockIdx.x - seq * H;
+  const int ld = 3 * D;
+  const float* base = qkv + (size_t)seq * S * ld + head * ATT_HD;
+
+  // number of valid keys: token 0 (the condition token) is never masked; frame j-1 must be < length
+  int nvalid = S;
+  if (lengths != nullptr) {
+    const int len = lengths[seq % B];
+    nvalid = min(S, 1 + len);
+  }
+
+  // ---- Q fragment: query row q = 32w + r, this lane-half's 64 d's
+  const int q = 32 * w + r;
+  float qf[64];
+  {
+    const float* qp = base + (size_t)q * ld + 64 * h;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float4 v = (q < S) ? ld4(qp + 4 * j) : zero4();
+      qf[4 * j + 0] = v.x; qf[4 * j + 1] = v.y; qf[4 * j + 2] = v.z; qf[4 * j + 3] = v.w;
+    }
+  }
+  // ---- stage K (rows >= S zero-filled)
+  for (int idx = tid; idx < ROWS * 32; idx += NT) {
+    const int key = idx >> 5, c4 = idx & 31;
+    float4 v = (key < S) ? ld4(base + (size_t)key * ld + D + 4 * c4) : zero4();
+    st4(&smem[key * ATT_KLD + 4 * c4], v);
+  }
+  __syncthreads();
+
+  // ---- phase 1: St tiles
+  f32x16 p[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const float* kp = &smem[(kt * 32 + r) * ATT_KLD + 64 * h];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float4 kf = ld4(kp + 4 * c);
+      acc = mfma_f32(kf.x, qf[4 * c + 0], acc);
+      acc = mfma_f32(kf.y, qf[4 * c + 1], acc);
+      acc = mfma_f32(kf.z, qf[4 * c + 2], acc);
+      acc = mfma_f32(kf.w, qf[4 * c + 3], acc);
+    }
+    p[kt] = acc;
+  }
+
+  // ---- softmax over keys (lane-local + one cross-half exchange)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = kt * 32 + mfma_row(e, h);
+      const float s = (key < nvalid) ? p[kt][e] : -INFINITY;
+      p[kt][e] = s;
+      mx = fmaxf(mx, s);
+    }
+  mx = fmaxf(mx, shfl_xor_f32(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pe = expf(p[kt][e] - mx);  // exp(-inf) = 0 for masked keys; key 0 is always valid
+      p[kt][e] = pe;
+      sum += pe;
+    }
+  sum += shfl_xor_f32(sum, 32);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) p[kt][e] *= inv;
+
+  __syncthreads();  // every wave is done reading K
+  // ---- stage V into the same buffer, row stride ATT_HD (rows >= S zero-filled)
+  for (int idx = tid; idx < ROWS * 32; idx += NT) {
+    const int key = idx >> 5, c4 = idx & 31;
+    float4 v = (key < S) ? ld4(base + (size_t)key * ld + 2 * D + 4 * c4) : zero4();
+    st4(&smem[key * ATT_HD + 4 * c4], v);
+  }
+  __syncthreads();
+
+  // ---- phase 2: Ot[d][query]
+  f32x16 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float* vp = &smem[(kt * 32 + mfma_row(e, h)) * ATT_HD + r];
+      const float pv = p[kt][e];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma_f32(vp[32 * dt], pv, o[dt]);
+    }
+  }
+  __syncthreads();  // every wave is done reading V
+
+  // ---- stage O[q][d] (row stride ATT_KLD) and store coalesced
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = dt * 32 + 8 * g + 4 * h;  // rows mfma_row(4g..4g+3, h) are 4 consecutive d's
+      st4(&smem[q * ATT_KLD + d0], make_float4(o[dt][4 * g + 0], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]));
+    }
+  __syncthreads();
+  float* obase = out + (size_t)seq * S * D + head * ATT_HD;
+  for (int idx = tid; idx < ROWS * 32; idx += NT) {
+    const int qq = idx >> 5, c4 = idx & 31;
+    if (qq < S) st4(obase + (size_t)qq * D + 4 * c4, ld4(&smem[qq * ATT_KLD + 4 * c4]));
+  }
+}
+
+inline size_t attention_lds_bytes(int nkt) { return (size_t)nkt * 32 * ATT_KLD * sizeof(float); }
+
+}  // namespace mdm

@@ -1,0 +1,108 @@
+// Shared device helpers for the MDM hot-path kernels (gfx950 / CDNA4 only).
+//
+// The only non-HIP build of these sources is the CPU test emulator (tests/emu, -DMDM_EMU), which
+// exists because the build container has no GPU; it is test infrastructure, never a product path.
+#pragma once
+#ifdef MDM_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define MDM_DYN_SMEM(type, name) \
+  extern __shared__ __attribute__((aligned(16))) unsigned char mdm_dyn_smem_raw[]; \
+  type* name = reinterpret_cast<type*>(mdm_dyn_smem_raw)
+#define MDM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__)
+#endif
+#include <stdint.h>
+
+namespace mdm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kWave = 64;
+
+// v_mfma_f32_32x32x2_f32: exact-fp32 matrix FMA (64 cyc/SIMD, 157 TF chip peak).
+//   lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+//   D[reg] is row i = (reg&3) + 8*(reg>>2) + 4*(l>>5), column j = l&31.
+__device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
+#ifdef MDM_EMU
+  return emu::mfma_f32_32x32x2(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+// v_mfma_f32_32x32x16_bf16: lane l supplies 8 consecutive-k bf16 of row/col (l&31), k-block (l>>5).
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef MDM_EMU
+  return emu::mfma_f32_32x32x16_bf16(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// row of accumulator register `reg` inside a 32x32 MFMA tile, for lane-half h = lane>>5
+__device__ __forceinline__ int mfma_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ float shfl_xor_f32(float v, int mask) {
+#ifdef MDM_EMU
+  return emu::shfl_f32(v, emu::lane_id() ^ mask);
+#else
+  return __shfl_xor(v, mask, 64);
+#endif
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// XCD-aware bijective remap of a linear workgroup id (cdna_hip_programming.md T1): hardware places
+// block b on XCD b%8; give each XCD a contiguous chunk of logical tiles so neighbours share its L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  if (nwg < 2 * nx) return bid;
+  int xcd = bid % nx, q = nwg / nx, r = nwg % nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + bid / nx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG: Philox4x32-10 keyed by (seed), counter = (element, global sample, step, stream).
+// One call per output element keeps the stream independent of sharding and of the launch geometry.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
+                                                      uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                       uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Standard normal for (element e of global sample n, draw index `step`): Box-Muller on two 24-bit uniforms.
+__host__ __device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t elem, uint32_t sample, uint32_t step) {
+  uint32_t r[4];
+  philox4x32_10(elem, sample, step, 0x4d444d31u /* "MDM1" */, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const float u1 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+}  // namespace mdm

@@ -1,0 +1,125 @@
+// HBM-bound pieces of the MDM sampling step (gfx950): LayerNorm, condition-token assembly, the fused
+// sampler update, Philox noise.  All are coalesced 16-byte-per-lane streams; none touch MFMA.
+#pragma once
+#include "common.h"
+#include "gemm_f32.h"  // StepCoefs / NoiseSource
+
+namespace mdm {
+
+// In-place LayerNorm over rows of D = 256*NV floats (norm1/norm2 of nn.TransformerEncoderLayer,
+// eps = 1e-5, biased variance; torch transformer.py:951-956).  One wave per row, NV float4 per lane,
+// two-pass (mean, then centred sum of squares) entirely in registers.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int rows, float eps) {
+  constexpr int D = 256 * NV;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;  // whole wave exits together (row is wave-uniform)
+  float* xr = x + (size_t)row * D;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = ld4(xr + 256 * i + 4 * lane);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += shfl_xor_f32(s, m);
+  const float mean = s * (1.0f / D);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) ss += shfl_xor_f32(ss, m);
+  const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 g = ld4(gamma + 256 * i + 4 * lane), b = ld4(beta + 256 * i + 4 * lane);
+    st4(xr + 256 * i + 4 * lane, make_float4(v[i].x * rstd * g.x + b.x, v[i].y * rstd * g.y + b.y,
+                                             v[i].z * rstd * g.z + b.z, v[i].w * rstd * g.w + b.w));
+  }
+}
+
+// Token 0 of every sequence: embed_text(cond) (or its bias for the uncond branch) + time-MLP(pe[t]) + pe[0]
+// (mdm.py:195, :218-220, :251-252).  cond_emb may be null for a branch => bias only (mask_cond zeroes the
+// input: mdm.py:155-156).  Grid = nbranch*B blocks, D/4 threads... each thread 4 consecutive channels.
+__global__ __launch_bounds__(256) void cond_token_kernel(float* __restrict__ tok, const float* __restrict__ cond_emb,
+                                                         const float* __restrict__ text_bias,
+                                                         const float* __restrict__ time_table,
+                                                         const long long* __restrict__ timesteps,  // [B] or null
+                                                         int t_uniform,  // used when timesteps == null
+                                                         const float* __restrict__ pe, int B, int S, int D,
+                                                         int uncond_from_branch, int table_rows) {
+  const int seq = blockIdx.x, b = seq % B, br = seq / B;
+  long long t = (timesteps != nullptr) ? timesteps[b] : (long long)t_uniform;
+  if (t < 0) t = 0;
+  if (t >= table_rows) t = table_rows - 1;
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+    const float4 e = (br >= uncond_from_branch || cond_emb == nullptr) ? ld4(text_bias + c)
+                                                                      : ld4(cond_emb + (size_t)b * D + c);
+    const float4 tt = ld4(time_table + (size_t)t * D + c);
+    const float4 p0 = ld4(pe + c);
+    st4(tok + (size_t)seq * S * D + c, make_float4(e.x + tt.x + p0.x, e.y + tt.y + p0.y, e.z + tt.z + p0.z, e.w + tt.w + p0.w));
+  }
+}
+
+// Stand-alone fused sampler update: classifier-free-guidance combine
+// (utils/sampler_util.py:34), inpainting blend (gaussian_diffusion.py:300-304), optional clamp (:347-353),
+// posterior mean / DDIM mean with host-folded coefficients, noise add with the t != 0 mask folded into
+// sigma (:525-540, :729-779).  Used when the model output comes from outside the fused loop; inside the
+// loop the same arithmetic runs in the OutputProcess GEMM epilogue (OutProjEpilogue).
+__global__ __launch_bounds__(256) void sampler_step_kernel(const float* __restrict__ x_t,
+                                                           const float* __restrict__ out_cond,
+                                                           const float* __restrict__ out_uncond,  // may be null
+                                                           const float* __restrict__ scale,       // [B] or null
+                                                           const unsigned char* __restrict__ inpaint_mask,
+                                                           const float* __restrict__ inpaint_motion,
+                                                           float* __restrict__ x_prev, float* __restrict__ x0_out,
+                                                           int per_sample, int B, StepCoefs co, NoiseSource ns) {
+  const size_t total = (size_t)per_sample * B;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_sample);
+    const uint32_t e = (uint32_t)(i - (size_t)b * per_sample);
+    float x0 = out_cond[i];
+    if (out_uncond != nullptr) {
+      const float u = out_uncond[i];
+      x0 = u + scale[b] * (x0 - u);
+    }
+    if (inpaint_mask != nullptr && inpaint_mask[i]) x0 = inpaint_motion[i];
+    if (co.clip_denoised) x0 = fminf(1.f, fmaxf(-1.f, x0));
+    float v = co.a_x0 * x0 + co.a_xt * x_t[i];
+    if (co.sigma != 0.f) v += co.sigma * ns.get(b, e, i);
+    if (x0_out != nullptr) x0_out[i] = x0;
+    x_prev[i] = v;
+  }
+}
+
+// x = N(0, I) from the counter-based stream (draw index ns.draw), optionally q_sample'd onto an init image:
+// out = a * init + s * eps   (gaussian_diffusion.py:226-244, :693-700).  init == null -> out = eps.
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, const float* __restrict__ init,
+                                                    const float* __restrict__ eps_in, float a, float s,
+                                                    int per_sample, int B, NoiseSource ns) {
+  const size_t total = (size_t)per_sample * B;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_sample);
+    const uint32_t e = (uint32_t)(i - (size_t)b * per_sample);
+    const float eps = (eps_in != nullptr) ? eps_in[i] : ns.get(b, e, i);
+    out[i] = (init != nullptr) ? a * init[i] + s * eps : eps;
+  }
+}
+
+// dst[r][0..ld_dst) = src[r][0..cols) zero-padded (16-byte-aligns the 263-wide poseEmbedding weight rows).
+__global__ __launch_bounds__(256) void pad_rows_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                       int rows, int cols, int ld_dst) {
+  const size_t total = (size_t)rows * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_dst), c = (int)(i - (size_t)r * ld_dst);
+    dst[i] = (c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  }
+}
+
+}  // namespace mdm

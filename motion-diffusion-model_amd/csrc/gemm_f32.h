@@ -1,0 +1,303 @@
+// Exact-fp32 MFMA GEMM for the MDM denoiser:  C[m][n] = sum_k A[m][k] * B[n][k]   ("NT": both
+// operands are K-contiguous, which is what nn.Linear's [out, in] weights and row-major token
+// matrices give us for free).
+//
+// Replaces the reference's `addmm` calls: in_proj / out_proj /
+// linear1 / linear2 of torch's TransformerEncoderLayer (model/mdm.py:77-84), InputProcess
+// (mdm.py:343-349), OutputProcess (mdm.py:372-386), TimestepEmbedder (mdm.py:329-330), embed_text
+// (mdm.py:218).  Operand gathering and the epilogue are policy structs so the layout shuffles the
+// reference performs as separate `copy_` kernels (35 % of its CPU time) disappear into the GEMM.
+//
+// Machine mapping (gfx950): 256 threads = 4 waves in a 2x2 grid, block tile 128x128, wave tile
+// 64x64 = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 acc VGPRs), BK = 32.
+//   * LDS tiles are [rows][32+4] floats: the +4 pad makes the per-lane 16-byte fragment reads
+//     (row = lane&31, 16 consecutive k starting at 16*(lane>>5)) hit 16 distinct 16-B slots per
+//     ds_read_b128 lane group -> conflict-free.
+//   * lane-half h owns k in [16h, 16h+16) of every BK tile for BOTH operands, so the MFMA's two
+//     k-slots always pair matching k's; the k summation order differs from a sequential loop only
+//     in association, and every product/accumulate is an exact fp32 fma.
+//   * global->LDS: register-staged; the next K tile's global loads are issued before the MFMAs of
+//     the current tile (latency hidden behind 32 MFMAs x 64 cycles per wave).
+//   * linear block id is remapped per XCD so the n-tiles that share an A row-panel share an L2.
+#pragma once
+#include "common.h"
+
+namespace mdm {
+
+constexpr int GEMM_BM = 128;
+constexpr int GEMM_BN = 128;
+constexpr int GEMM_BK = 32;
+constexpr int GEMM_LDS_LD = GEMM_BK + 4;  // floats per LDS row
+constexpr int GEMM_THREADS = 256;
+
+// ------------------------------------------------------------------------------------------------
+// Operand loaders.  load4(row, k) returns logical elements (row, k..k+3); out-of-range -> 0.
+// kColumnStaging selects the thread->element map used while staging: false = 8 threads sweep the
+// 32 k's of one row (row-major sources), true = consecutive threads take consecutive rows (sources
+// that are contiguous along the row index, e.g. the [B, J, 1, T] pose tensor).
+// ------------------------------------------------------------------------------------------------
+struct RowMajorLoader {
+  static constexpr bool kColumnStaging = false;
+  const float* p;
+  int ld;    // floats between rows (multiple of 4)
+  int rows;  // valid rows
+  int K;     // valid k (multiple of 4)
+  __device__ __forceinline__ float4 load4(int row, int k) const {
+    if (row < rows && k < K) return ld4(p + (size_t)row * ld + k);
+    return zero4();
+  }
+};
+
+// A-operand of InputProcess: logical row m = b*T + t, logical k = feature jf in [0, J*F):
+// element = x[b][jf][t] of the contiguous [B, J*F, T] pose tensor (mdm.py:345 permute+reshape fused away).
+struct PoseGatherLoader {
+  static constexpr bool kColumnStaging = true;
+  const float* x;
+  int T, JF, rows;
+  __device__ __forceinline__ float4 load4(int row, int k) const {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+      const int b = row / T, t = row - b * T;
+      const float* base = x + ((size_t)b * JF) * T + t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (k + i < JF) v[i] = base[(size_t)(k + i) * T];
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+// B-operand of OutputProcess (computed transposed, see OutProjEpilogue): logical row n = b*T + t maps to
+// token row (b*S + 1 + t) of the final encoder output -- the `[1:]` slice of mdm.py:253 -- and, when
+// classifier-free guidance is on, combines the cond / uncond branches *before* the projection:
+//   W (u + s (c - u)) + b  ==  (W u + b) + s ((W c + b) - (W u + b))      (utils/sampler_util.py:34)
+// which halves this GEMM and removes the separate combine pass.
+struct CfgTokenLoader {
+  static constexpr bool kColumnStaging = false;
+  const float* tok;    // [nbranch*B*S, D]
+  const float* scale;  // [B] or nullptr (single branch)
+  int B, T, S, D, rows;
+  __device__ __forceinline__ float4 load4(int row, int k) const {
+    if (row >= rows || k >= D) return zero4();
+    const int b = row / T, t = row - b * T;
+    const float4 c = ld4(tok + ((size_t)b * S + 1 + t) * D + k);
+    if (scale == nullptr) return c;
+    const float4 u = ld4(tok + ((size_t)(B + b) * S + 1 + t) * D + k);
+    const float s = scale[b];
+    return make_float4(u.x + s * (c.x - u.x), u.y + s * (c.y - u.y), u.z + s * (c.z - u.z), u.w + s * (c.w - u.w));
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues.  A lane owns 2 output columns (n) and 32 output rows (m) of its wave tile; the kernel
+// asks the policy for a per-row and a per-column context once and then calls store() per element, so
+// the index arithmetic (divisions by T, base offsets) is not repeated 64 times.  Lanes 0..31 of a wave
+// hold 32 consecutive n for a fixed m, so n-contiguous destinations are written in 128-byte runs.
+// ------------------------------------------------------------------------------------------------
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
+
+// out[m][n] = act(acc + bias[n]) * (n < scale_cols ? col_scale : 1) + (res ? res[m][n] : 0)
+struct LinearEpilogue {
+  float* out;
+  const float* bias;
+  const float* res;  // may alias out (each element is read then written by the same lane)
+  int ld;
+  int act;
+  int scale_cols;   // columns [0, scale_cols) are multiplied by col_scale (q * 1/sqrt(hd) for in_proj)
+  float col_scale;
+  struct Row { size_t base; };
+  struct Col { int n; float bias, mult; };
+  __device__ __forceinline__ Row row(int m) const { return Row{(size_t)m * ld}; }
+  __device__ __forceinline__ Col col(int n) const { return Col{n, bias[n], n < scale_cols ? col_scale : 1.f}; }
+  __device__ __forceinline__ void store(const Row& r, const Col& c, float acc) const {
+    float v = acc + c.bias;
+    if (act == ACT_GELU) v = gelu_erf(v);
+    else if (act == ACT_SILU) v = silu(v);
+    v *= c.mult;
+    const size_t o = r.base + c.n;
+    if (res != nullptr) v += res[o];
+    out[o] = v;
+  }
+};
+
+// InputProcess epilogue: token (b, s = 1 + t) of every branch gets  acc + b_in[n] + pe[s][n]
+// (mdm.py:348, :251-252); the frame tokens are identical in the cond and uncond branches.
+struct EmbedEpilogue {
+  float* tok;          // [nbranch*B*S, D]
+  const float* bias;   // [D]
+  const float* pe;     // [max_len, D]
+  int B, T, S, D, nbranch;
+  struct Row { size_t tok_off, pe_off; };
+  struct Col { int n; float bias; };
+  __device__ __forceinline__ Row row(int m) const {
+    const int b = m / T, t = m - b * T;
+    return Row{((size_t)b * S + 1 + t) * D, (size_t)(1 + t) * D};
+  }
+  __device__ __forceinline__ Col col(int n) const { return Col{n, bias[n]}; }
+  __device__ __forceinline__ void store(const Row& r, const Col& c, float acc) const {
+    const float v = acc + c.bias + pe[r.pe_off + c.n];
+    tok[r.tok_off + c.n] = v;
+    if (nbranch == 2) tok[r.tok_off + (size_t)B * S * D + c.n] = v;
+  }
+};
+
+// Per-step scalars of the fused sampler update  x_prev = a_x0 * x0 + a_xt * x_t + sigma * eps  (DDPM
+// posterior mean + noise: gaussian_diffusion.py:246-268, :525-540;  DDIM: :729-779, folded on host).
+struct StepCoefs {
+  float a_x0, a_xt, sigma;
+  int clip_denoised;
+};
+
+struct NoiseSource {
+  const float* noise;  // [B, JF, T] injected noise for this step, or nullptr -> Philox
+  uint64_t seed;
+  uint32_t sample_base;  // global index of local sample 0 (sharding-invariant streams)
+  uint32_t draw;         // draw index: 0 = x_T, 1 + k = k-th step
+  __device__ __forceinline__ float get(int b, uint32_t elem, size_t off) const {
+    if (noise != nullptr) return noise[off];
+    return philox_normal(seed, elem, sample_base + (uint32_t)b, draw);
+  }
+};
+
+// OutputProcess computed transposed (m = feature jf, n = b*T + t) so that lanes run along t, the
+// contiguous axis of the [B, J, F, T] pose tensors.  mode 0: plain model output (MDM.forward seam);
+// mode 1: fused p_sample/ddim_sample tail (inpainting blend, clamp, posterior mean, noise add); the
+// step's noise is a buffer (injected by the caller, or filled by randn_kernel just before).
+struct OutProjEpilogue {
+  const float* bias;   // [JF]
+  float* out;          // mode 0: model output [nb, JF, T];  mode 1: x_prev [B, JF, T]
+  float* x0_out;       // mode 1: optional pred_xstart [B, JF, T]
+  const float* x_t;    // mode 1
+  const float* noise;  // mode 1: [B, JF, T] or nullptr when sigma == 0
+  const unsigned char* inpaint_mask;  // mode 1 optional [B, JF, T] (1 = take inpainted_motion)
+  const float* inpaint_motion;
+  int T, JF, mode;
+  StepCoefs co;
+  struct Row { size_t off; float bias; };
+  struct Col { size_t base; };
+  __device__ __forceinline__ Row row(int m) const { return Row{(size_t)m * T, bias[m]}; }
+  __device__ __forceinline__ Col col(int n) const {
+    const int b = n / T, t = n - b * T;
+    return Col{(size_t)b * JF * T + t};
+  }
+  __device__ __forceinline__ void store(const Row& r, const Col& c, float acc) const {
+    const size_t off = c.base + r.off;
+    float x0 = acc + r.bias;
+    if (mode == 0) { out[off] = x0; return; }
+    if (inpaint_mask != nullptr && inpaint_mask[off]) x0 = inpaint_motion[off];
+    if (co.clip_denoised) x0 = fminf(1.f, fmaxf(-1.f, x0));
+    float v = co.a_x0 * x0 + co.a_xt * x_t[off];
+    if (noise != nullptr) v += co.sigma * noise[off];
+    if (x0_out != nullptr) x0_out[off] = x0;
+    out[off] = v;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+template <class AL, class BL, class EP>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl, EP ep, int M, int N, int K,
+                                                                    int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float As[GEMM_BM * GEMM_LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[GEMM_BN * GEMM_LDS_LD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
+
+  // staging coordinates: 4 float4 per operand per thread
+  int a_row[4], a_k[4], b_row[4], b_k[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (AL::kColumnStaging) { a_row[i] = tid & 127; a_k[i] = ((tid >> 7) + 2 * i) * 4; }
+    else { a_row[i] = (tid >> 3) + 32 * i; a_k[i] = (tid & 7) * 4; }
+    if (BL::kColumnStaging) { b_row[i] = tid & 127; b_k[i] = ((tid >> 7) + 2 * i) * 4; }
+    else { b_row[i] = (tid >> 3) + 32 * i; b_k[i] = (tid & 7) * 4; }
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[4], rb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = al.load4(m0 + a_row[i], a_k[i]);
+    rb[i] = bl.load4(n0 + b_row[i], b_k[i]);
+  }
+
+  const int nk = (K + GEMM_BK - 1) / GEMM_BK;
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      st4(&As[a_row[i] * GEMM_LDS_LD + a_k[i]], ra[i]);
+      st4(&Bs[b_row[i] * GEMM_LDS_LD + b_k[i]], rb[i]);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      const int kb = (kt + 1) * GEMM_BK;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = al.load4(m0 + a_row[i], kb + a_k[i]);
+        rb[i] = bl.load4(n0 + b_row[i], kb + b_k[i]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // 4 chunks of 4 k-pairs each
+      float4 fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[t] = ld4(&As[(wm * 64 + t * 32 + r) * GEMM_LDS_LD + 16 * h + 4 * c]);
+        fb[t] = ld4(&Bs[(wn * 64 + t * 32 + r) * GEMM_LDS_LD + 16 * h + 4 * c]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = mfma_f32(fa[i].x, fb[j].x, acc[i][j]);
+          acc[i][j] = mfma_f32(fa[i].y, fb[j].y, acc[i][j]);
+          acc[i][j] = mfma_f32(fa[i].z, fb[j].z, acc[i][j]);
+          acc[i][j] = mfma_f32(fa[i].w, fb[j].w, acc[i][j]);
+        }
+    }
+    __syncthreads();
+  }
+
+  typename EP::Col cc[2];
+  bool nv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + r;
+    nv[j] = n < N;
+    cc[j] = ep.col(nv[j] ? n : 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * 64 + i * 32 + mfma_row(e, h);
+      if (m < M) {
+        const typename EP::Row rc = ep.row(m);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (nv[j]) ep.store(rc, cc[j], acc[i][j][e]);
+      }
+    }
+}
+
+template <class AL, class BL, class EP>
+inline void launch_gemm_f32(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream) {
+  const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+  auto kfn = &gemm_f32_kernel<AL, BL, EP>;
+  MDM_LAUNCH(kfn, dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K, tiles_n);
+}
+
+}  // namespace mdm

@@ -1,0 +1,455 @@
+// libmdm_hip.so -- host orchestration + C ABI (include/mdm_hip.h) for the MDM sampling hot path.
+// Native counterpart of: MDM.forward (model/mdm.py:189-283), ClassifierFreeSampleModel.forward
+// (utils/sampler_util.py:27-34), GaussianDiffusion.p_sample_loop / ddim_sample_loop
+// (diffusion/gaussian_diffusion.py:591-727, :876-990).  No torch, no allocation: caller-owned pointers.
+#include "../../include/mdm_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "attention_f32.h"
+#include "common.h"
+#include "elementwise.h"
+#include "gemm_f32.h"
+
+using namespace mdm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#ifdef MDM_EMU
+inline int rt_launch_status() { return 0; }
+inline int rt_copy(void* dst, const void* src, size_t bytes, hipStream_t) { memcpy(dst, src, bytes); return 0; }
+template <class K> inline int rt_allow_lds(K, size_t) { return 0; }
+#else
+inline int rt_launch_status() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MDM_EHIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
+  return 0;
+}
+inline int rt_copy(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return fail(MDM_EHIP, std::string("hipMemcpyAsync failed: ") + hipGetErrorString(e));
+  return 0;
+}
+template <class K> inline int rt_allow_lds(K kernel, size_t bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail(MDM_EHIP, std::string("hipFuncSetAttribute failed: ") + hipGetErrorString(e));
+  return 0;
+}
+#endif
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct mdm_model {
+  mdm_config_t cfg;
+  std::map<std::string, const float*> w;
+  std::map<std::string, int64_t> expect;  // name -> numel
+  bool prepared = false;
+  float* w_in_pad = nullptr;    // [D][JFpad]
+  float* time_table = nullptr;  // [max_len][D]
+  int jf = 0, jf_pad = 0;
+
+  const float* W(const std::string& k) const { return w.at(k); }
+  const float* L(int layer, const char* suffix) const {
+    return w.at("seqTransEncoder.layers." + std::to_string(layer) + "." + suffix);
+  }
+};
+
+namespace {
+
+struct Workspace {
+  float *tok, *qkv, *att, *ffn, *cond;
+  size_t bytes;
+};
+
+Workspace carve(const mdm_model* m, int nseq, int T, void* base) {
+  const size_t D = m->cfg.latent_dim, FF = m->cfg.ff_size, S = (size_t)T + 1, M = (size_t)nseq * S;
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    size_t o = off;
+    off += align_up(floats * sizeof(float), 256);
+    return base ? reinterpret_cast<float*>(static_cast<char*>(base) + o) : nullptr;
+  };
+  Workspace w;
+  w.tok = take(M * D);
+  w.qkv = take(M * 3 * D);
+  w.att = take(M * D);
+  w.ffn = take(M * FF);
+  w.cond = take((size_t)nseq * D);
+  w.bytes = off;
+  return w;
+}
+
+int launch_layernorm(float* x, const float* g, const float* b, int rows, int D, hipStream_t s) {
+  const dim3 grid((rows + 3) / 4), block(256);
+  switch (D / 256) {
+    case 1: { auto k = &layernorm_kernel<1>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f); break; }
+    case 2: { auto k = &layernorm_kernel<2>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f); break; }
+    case 3: { auto k = &layernorm_kernel<3>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f); break; }
+    case 4: { auto k = &layernorm_kernel<4>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f); break; }
+    default: return fail(MDM_EUNSUPPORTED, "layernorm: D must be 256, 512, 768 or 1024");
+  }
+  return rt_launch_status();
+}
+
+template <int NKT>
+int launch_attention_t(const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D, int H,
+                       hipStream_t s) {
+  auto k = &attention_f32_kernel<NKT>;
+  const size_t lds = attention_lds_bytes(NKT);
+  if (int rc = rt_allow_lds(k, lds)) return rc;
+  MDM_LAUNCH(k, dim3(nseq * H), dim3(64 * NKT), lds, s, qkv, out, lengths, S, D, H, B);
+  return rt_launch_status();
+}
+
+int launch_attention(const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D, int H,
+                     hipStream_t s) {
+  if (D != H * ATT_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
+  if (S < 1 || S > 224) return fail(MDM_EUNSUPPORTED, "attention: 1 <= S <= 224 tokens (T <= 223 frames)");
+  switch ((S + 31) / 32) {
+    case 1: return launch_attention_t<1>(qkv, out, lengths, nseq, B, S, D, H, s);
+    case 2: return launch_attention_t<2>(qkv, out, lengths, nseq, B, S, D, H, s);
+    case 3: return launch_attention_t<3>(qkv, out, lengths, nseq, B, S, D, H, s);
+    case 4: return launch_attention_t<4>(qkv, out, lengths, nseq, B, S, D, H, s);
+    case 5: return launch_attention_t<5>(qkv, out, lengths, nseq, B, S, D, H, s);
+    case 6: return launch_attention_t<6>(qkv, out, lengths, nseq, B, S, D, H, s);
+    default: return launch_attention_t<7>(qkv, out, lengths, nseq, B, S, D, H, s);
+  }
+}
+
+int launch_linear(const float* in, int ld_in, const float* w, const float* bias, const float* res, float* out,
+                  int M, int N, int K, int act, int scale_cols, float col_scale, hipStream_t s) {
+  if (K % 4 != 0 || ld_in % 4 != 0) return fail(MDM_EINVAL, "linear: K and the row stride must be multiples of 4");
+  RowMajorLoader al{in, ld_in, M, K};
+  RowMajorLoader bl{w, K, N, K};
+  LinearEpilogue ep{out, bias, res, N, act, scale_cols, col_scale};
+  launch_gemm_f32(al, bl, ep, M, N, K, s);
+  return rt_launch_status();
+}
+
+// Tokens for every sequence: frame tokens via the InputProcess GEMM, token 0 via cond_token_kernel.
+int embed_tokens(const mdm_model* m, const Workspace& ws, const float* x, const long long* timesteps,
+                 long long t_uniform_unused, const float* cond_emb, int B, int T, int nbranch,
+                 int uncond_from_branch, hipStream_t s) {
+  (void)t_uniform_unused;
+  const int D = m->cfg.latent_dim, S = T + 1;
+  PoseGatherLoader al{x, T, m->jf, B * T};
+  RowMajorLoader bl{m->w_in_pad, m->jf_pad, D, m->jf_pad};
+  EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D,
+                   nbranch};
+  launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
+  if (int rc = rt_launch_status()) return rc;
+  MDM_LAUNCH(cond_token_kernel, dim3(nbranch * B), dim3(128), 0, s, ws.tok, cond_emb, m->W("embed_text.bias"),
+             (const float*)m->time_table, timesteps, 0, m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from_branch,
+             (int)m->cfg.max_len);
+  return rt_launch_status();
+}
+
+// seqTransEncoder: num_layers post-norm layers over ws.tok [nseq*S, D] (in place).
+int encoder(const mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int* lengths, hipStream_t s) {
+  const int D = m->cfg.latent_dim, FF = m->cfg.ff_size, H = m->cfg.num_heads, M = nseq * S;
+  const float qscale = 1.0f / sqrtf((float)(D / H));
+  for (int l = 0; l < m->cfg.num_layers; ++l) {
+    if (int rc = launch_linear(ws.tok, D, m->L(l, "self_attn.in_proj_weight"), m->L(l, "self_attn.in_proj_bias"),
+                               nullptr, ws.qkv, M, 3 * D, D, ACT_NONE, D, qscale, s)) return rc;
+    if (int rc = launch_attention(ws.qkv, ws.att, lengths, nseq, B, S, D, H, s)) return rc;
+    if (int rc = launch_linear(ws.att, D, m->L(l, "self_attn.out_proj.weight"), m->L(l, "self_attn.out_proj.bias"),
+                               ws.tok, ws.tok, M, D, D, ACT_NONE, 0, 1.f, s)) return rc;
+    if (int rc = launch_layernorm(ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, s)) return rc;
+    if (int rc = launch_linear(ws.tok, D, m->L(l, "linear1.weight"), m->L(l, "linear1.bias"), nullptr, ws.ffn, M,
+                               FF, D, ACT_GELU, 0, 1.f, s)) return rc;
+    if (int rc = launch_linear(ws.ffn, FF, m->L(l, "linear2.weight"), m->L(l, "linear2.bias"), ws.tok, ws.tok, M,
+                               D, FF, ACT_NONE, 0, 1.f, s)) return rc;
+    if (int rc = launch_layernorm(ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, s)) return rc;
+  }
+  return 0;
+}
+
+int check_ready(const mdm_model* m) {
+  if (m == nullptr) return fail(MDM_EINVAL, "null model");
+  if (!m->prepared) return fail(MDM_ESTATE, "mdm_prepare has not been called (or weights changed since)");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdm_abi_version(void) { return MDM_ABI_VERSION; }
+const char* mdm_last_error(void) { return g_err.c_str(); }
+
+int mdm_create(const mdm_config_t* cfg, mdm_model_t** out) {
+  if (cfg == nullptr || out == nullptr) return fail(MDM_EINVAL, "mdm_create: null argument");
+  const int D = cfg->latent_dim, H = cfg->num_heads;
+  if (D <= 0 || D % 256 != 0 || D > 1024) return fail(MDM_EUNSUPPORTED, "latent_dim must be 256, 512, 768 or 1024");
+  if (H <= 0 || D != H * ATT_HD) return fail(MDM_EUNSUPPORTED, "latent_dim / num_heads must be 128");
+  if (cfg->ff_size <= 0 || cfg->ff_size % 4) return fail(MDM_EUNSUPPORTED, "ff_size must be a positive multiple of 4");
+  if (cfg->clip_dim <= 0 || cfg->clip_dim % 4) return fail(MDM_EUNSUPPORTED, "clip_dim must be a positive multiple of 4");
+  if (cfg->njoints <= 0 || cfg->nfeats <= 0 || cfg->num_layers <= 0 || cfg->max_len < 2)
+    return fail(MDM_EINVAL, "mdm_create: non-positive dimension");
+  mdm_model* m = new (std::nothrow) mdm_model();
+  if (m == nullptr) return fail(MDM_EINVAL, "out of host memory");
+  m->cfg = *cfg;
+  m->jf = cfg->njoints * cfg->nfeats;
+  m->jf_pad = (m->jf + 3) / 4 * 4;
+  const int64_t d = D, ff = cfg->ff_size, jf = m->jf;
+  auto& e = m->expect;
+  e["input_process.poseEmbedding.weight"] = d * jf;
+  e["input_process.poseEmbedding.bias"] = d;
+  for (int l = 0; l < cfg->num_layers; ++l) {
+    const std::string p = "seqTransEncoder.layers." + std::to_string(l) + ".";
+    e[p + "self_attn.in_proj_weight"] = 3 * d * d;
+    e[p + "self_attn.in_proj_bias"] = 3 * d;
+    e[p + "self_attn.out_proj.weight"] = d * d;
+    e[p + "self_attn.out_proj.bias"] = d;
+    e[p + "linear1.weight"] = ff * d;
+    e[p + "linear1.bias"] = ff;
+    e[p + "linear2.weight"] = d * ff;
+    e[p + "linear2.bias"] = d;
+    e[p + "norm1.weight"] = d;
+    e[p + "norm1.bias"] = d;
+    e[p + "norm2.weight"] = d;
+    e[p + "norm2.bias"] = d;
+  }
+  e["embed_timestep.time_embed.0.weight"] = d * d;
+  e["embed_timestep.time_embed.0.bias"] = d;
+  e["embed_timestep.time_embed.2.weight"] = d * d;
+  e["embed_timestep.time_embed.2.bias"] = d;
+  e["embed_text.weight"] = d * cfg->clip_dim;
+  e["embed_text.bias"] = d;
+  e["output_process.poseFinal.weight"] = jf * d;
+  e["output_process.poseFinal.bias"] = jf;
+  e["sequence_pos_encoder.pe"] = (int64_t)cfg->max_len * d;
+  *out = m;
+  return MDM_OK;
+}
+
+void mdm_destroy(mdm_model_t* m) { delete m; }
+
+int mdm_set_weight(mdm_model_t* m, const char* name, const float* dev_ptr, int64_t numel) {
+  if (m == nullptr || name == nullptr || dev_ptr == nullptr) return fail(MDM_EINVAL, "mdm_set_weight: null argument");
+  auto it = m->expect.find(name);
+  if (it == m->expect.end()) return fail(MDM_EINVAL, std::string("unexpected state-dict key: ") + name);
+  if (it->second != numel)
+    return fail(MDM_EINVAL, std::string("size mismatch for ") + name + ": expected " + std::to_string(it->second) +
+                                " elements, got " + std::to_string(numel));
+  if ((reinterpret_cast<uintptr_t>(dev_ptr) & 15) != 0) return fail(MDM_EINVAL, std::string(name) + ": pointer must be 16-byte aligned");
+  m->w[name] = dev_ptr;
+  m->prepared = false;
+  return MDM_OK;
+}
+
+size_t mdm_const_bytes(const mdm_model_t* m) {
+  if (m == nullptr) return 0;
+  const size_t D = m->cfg.latent_dim;
+  return align_up(D * m->jf_pad * sizeof(float), 256) + 2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256);
+}
+
+int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* stream) {
+  if (m == nullptr || const_ws == nullptr) return fail(MDM_EINVAL, "mdm_prepare: null argument");
+  for (const auto& kv : m->expect)
+    if (m->w.find(kv.first) == m->w.end()) return fail(MDM_ESTATE, "missing weight: " + kv.first);
+  if (const_ws_bytes < mdm_const_bytes(m)) return fail(MDM_ENOSPC, "mdm_prepare: const workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int D = m->cfg.latent_dim, R = m->cfg.max_len;
+  char* base = static_cast<char*>(const_ws);
+  m->w_in_pad = reinterpret_cast<float*>(base);
+  base += align_up((size_t)D * m->jf_pad * sizeof(float), 256);
+  m->time_table = reinterpret_cast<float*>(base);
+  base += align_up((size_t)R * D * sizeof(float), 256);
+  float* hidden = reinterpret_cast<float*>(base);
+  MDM_LAUNCH(pad_rows_kernel, dim3(256), dim3(256), 0, s, m->w_in_pad, m->W("input_process.poseEmbedding.weight"), D,
+             m->jf, m->jf_pad);
+  if (int rc = rt_launch_status()) return rc;
+  // TimestepEmbedder for every possible t (model/mdm.py:323-330): table[t] = W2 silu(W0 pe[t] + b0) + b2
+  if (int rc = launch_linear(m->W("sequence_pos_encoder.pe"), D, m->W("embed_timestep.time_embed.0.weight"),
+                             m->W("embed_timestep.time_embed.0.bias"), nullptr, hidden, R, D, D, ACT_SILU, 0, 1.f, s))
+    return rc;
+  if (int rc = launch_linear(hidden, D, m->W("embed_timestep.time_embed.2.weight"),
+                             m->W("embed_timestep.time_embed.2.bias"), nullptr, m->time_table, R, D, D, ACT_NONE, 0,
+                             1.f, s))
+    return rc;
+  m->prepared = true;
+  return MDM_OK;
+}
+
+size_t mdm_workspace_bytes(const mdm_model_t* m, int32_t nseq, int32_t nframes) {
+  if (m == nullptr || nseq <= 0 || nframes <= 0) return 0;
+  return carve(m, nseq, nframes, nullptr).bytes;
+}
+
+int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const float* text_embed,
+                const int32_t* lengths, int32_t B, int32_t T, int32_t branches, float* out, void* ws_dev,
+                size_t ws_bytes, void* stream) {
+  if (int rc = check_ready(m)) return rc;
+  if (x == nullptr || timesteps == nullptr || out == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_forward: null pointer");
+  if (B <= 0 || T <= 0 || T + 1 > 224) return fail(MDM_EINVAL, "mdm_forward: need B >= 1 and 1 <= T <= 223");
+  if (branches < 0 || branches > 2) return fail(MDM_EINVAL, "mdm_forward: bad branches");
+  if (branches != MDM_BRANCH_UNCOND && text_embed == nullptr) return fail(MDM_EINVAL, "mdm_forward: text_embed required");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nbranch = (branches == MDM_BRANCH_BOTH) ? 2 : 1;
+  const int nseq = nbranch * B, S = T + 1, D = m->cfg.latent_dim;
+  Workspace ws = carve(m, nseq, T, ws_dev);
+  if (ws_bytes < ws.bytes) return fail(MDM_ENOSPC, "mdm_forward: workspace too small");
+  const int* len = m->cfg.mask_frames ? lengths : nullptr;
+  if (branches != MDM_BRANCH_UNCOND)
+    if (int rc = launch_linear(text_embed, m->cfg.clip_dim, m->W("embed_text.weight"), m->W("embed_text.bias"), nullptr,
+                               ws.cond, B, D, m->cfg.clip_dim, ACT_NONE, 0, 1.f, s)) return rc;
+  const int uncond_from = (branches == MDM_BRANCH_UNCOND) ? 0 : 1;
+  if (int rc = embed_tokens(m, ws, x, reinterpret_cast<const long long*>(timesteps), 0, ws.cond, B, T, nbranch,
+                            uncond_from, s)) return rc;
+  if (int rc = encoder(m, ws, nseq, B, S, len, s)) return rc;
+  // OutputProcess, plain: every branch's tokens -> [nseq, JF, T]
+  RowMajorLoader al{m->W("output_process.poseFinal.weight"), D, m->jf, D};
+  CfgTokenLoader bl{ws.tok, nullptr, nseq, T, S, D, nseq * T};
+  OutProjEpilogue ep{};
+  ep.bias = m->W("output_process.poseFinal.bias");
+  ep.out = out;
+  ep.T = T; ep.JF = m->jf; ep.mode = 0;
+  launch_gemm_f32(al, bl, ep, m->jf, nseq * T, D, s);
+  return rt_launch_status();
+}
+
+int mdm_sampler_step(const float* x_t, const float* out_cond, const float* out_uncond, const float* scale,
+                     const uint8_t* inpaint_mask, const float* inpaint_motion, const float* noise, float* x_prev,
+                     float* x0, int32_t B, int32_t per_sample, const mdm_step_t* st, void* stream) {
+  if (x_t == nullptr || out_cond == nullptr || x_prev == nullptr || st == nullptr) return fail(MDM_EINVAL, "mdm_sampler_step: null pointer");
+  if (out_uncond != nullptr && scale == nullptr) return fail(MDM_EINVAL, "mdm_sampler_step: scale required with out_uncond");
+  if ((inpaint_mask == nullptr) != (inpaint_motion == nullptr)) return fail(MDM_EINVAL, "mdm_sampler_step: inpainting needs mask and motion");
+  if (B <= 0 || per_sample <= 0) return fail(MDM_EINVAL, "mdm_sampler_step: bad shape");
+  StepCoefs co{st->a_x0, st->a_xt, st->sigma, st->clip_denoised};
+  NoiseSource ns{noise, st->seed, st->sample_base, st->draw};
+  const size_t total = (size_t)B * per_sample;
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 2048);
+  MDM_LAUNCH(sampler_step_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x_t, out_cond,
+             out_uncond, scale, inpaint_mask, inpaint_motion, x_prev, x0, per_sample, B, co, ns);
+  return rt_launch_status();
+}
+
+int mdm_randn(float* out, const float* init, const float* eps, float a, float s, int32_t B, int32_t per_sample,
+              uint64_t seed, uint32_t sample_base, uint32_t draw, void* stream) {
+  if (out == nullptr || B <= 0 || per_sample <= 0) return fail(MDM_EINVAL, "mdm_randn: bad argument");
+  NoiseSource ns{nullptr, seed, sample_base, draw};
+  const size_t total = (size_t)B * per_sample;
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 2048);
+  MDM_LAUNCH(randn_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), out, init, eps, a, s,
+             per_sample, B, ns);
+  return rt_launch_status();
+}
+
+int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void* ws_dev, size_t ws_bytes,
+                    void* stream) {
+  if (int rc = check_ready(m)) return rc;
+  if (p == nullptr || x == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop: null pointer");
+  const int B = p->B, T = p->T;
+  if (B <= 0 || T <= 0 || T + 1 > 224) return fail(MDM_EINVAL, "mdm_sample_loop: need B >= 1 and 1 <= T <= 223");
+  if (p->num_timesteps <= 0 || p->start_index < 0 || p->start_index >= p->num_timesteps)
+    return fail(MDM_EINVAL, "mdm_sample_loop: bad start_index / num_timesteps");
+  if (!p->a_x0 || !p->a_xt || !p->sigma || !p->timestep_map) return fail(MDM_EINVAL, "mdm_sample_loop: null schedule table");
+  if ((p->inpaint_mask_dev == nullptr) != (p->inpaint_motion_dev == nullptr))
+    return fail(MDM_EINVAL, "mdm_sample_loop: inpainting needs mask and motion");
+  const bool cfg = p->scale_dev != nullptr;
+  const bool uncond_only = !cfg && (p->force_uncond || p->text_embed_dev == nullptr);
+  if (cfg && p->text_embed_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop: CFG needs text_embed");
+  if (p->num_dump > 0 && (p->dump_steps == nullptr || p->dump_dev == nullptr)) return fail(MDM_EINVAL, "mdm_sample_loop: dump buffers missing");
+  for (int i = 0; i <= p->start_index; ++i)
+    if (p->timestep_map[i] < 0 || p->timestep_map[i] >= m->cfg.max_len) return fail(MDM_EINVAL, "mdm_sample_loop: timestep outside the positional table");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nbranch = cfg ? 2 : 1, nseq = nbranch * B, S = T + 1, D = m->cfg.latent_dim;
+  Workspace ws = carve(m, nseq, T, ws_dev);
+  if (ws_bytes < ws.bytes) return fail(MDM_ENOSPC, "mdm_sample_loop: workspace too small");
+  const int* len = m->cfg.mask_frames ? p->lengths_dev : nullptr;
+  const size_t per_sample = (size_t)m->jf * T;
+
+  // step-invariant: embed_text(cond) once per loop (gaussian_diffusion.py:633-635 caches the encoder side;
+  // the Linear on top is also constant across steps)
+  if (!uncond_only)
+    if (int rc = launch_linear(p->text_embed_dev, m->cfg.clip_dim, m->W("embed_text.weight"), m->W("embed_text.bias"),
+                               nullptr, ws.cond, B, D, m->cfg.clip_dim, ACT_NONE, 0, 1.f, s)) return rc;
+  const int uncond_from = uncond_only ? 0 : 1;
+
+  int dump_i = 0, k = 0;
+  for (int i = p->start_index; i >= 0; --i, ++k) {
+    // frame tokens + condition token for model timestep timestep_map[i]
+    {
+      PoseGatherLoader al{x, T, m->jf, B * T};
+      RowMajorLoader bl{m->w_in_pad, m->jf_pad, D, m->jf_pad};
+      EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D, nbranch};
+      launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
+      if (int rc = rt_launch_status()) return rc;
+      MDM_LAUNCH(cond_token_kernel, dim3(nseq), dim3(128), 0, s, ws.tok, (const float*)ws.cond,
+                 m->W("embed_text.bias"), (const float*)m->time_table, (const long long*)nullptr,
+                 (int)p->timestep_map[i], m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from,
+                 (int)m->cfg.max_len);
+      if (int rc = rt_launch_status()) return rc;
+    }
+    if (int rc = encoder(m, ws, nseq, B, S, len, s)) return rc;
+    // this step's eps: injected, or drawn from the counter-based stream into the (now dead) attention buffer
+    const float* step_noise = nullptr;
+    if (p->sigma[i] != 0.f) {
+      if (p->noise_dev != nullptr) step_noise = p->noise_dev + (size_t)k * B * per_sample;
+      else {
+        if (int rc = mdm_randn(ws.att, nullptr, nullptr, 0.f, 1.f, B, (int)per_sample, p->seed, p->sample_base,
+                               (uint32_t)(1 + k), stream)) return rc;
+        step_noise = ws.att;
+      }
+    }
+    // OutputProcess + CFG combine + sampler update, in place on x
+    {
+      RowMajorLoader al{m->W("output_process.poseFinal.weight"), D, m->jf, D};
+      CfgTokenLoader bl{ws.tok, cfg ? p->scale_dev : nullptr, B, T, S, D, B * T};
+      OutProjEpilogue ep{};
+      ep.bias = m->W("output_process.poseFinal.bias");
+      ep.out = x;
+      ep.x0_out = (i == 0) ? p->x0_dev : nullptr;
+      ep.x_t = x;
+      ep.inpaint_mask = p->inpaint_mask_dev;
+      ep.inpaint_motion = p->inpaint_motion_dev;
+      ep.T = T; ep.JF = m->jf; ep.mode = 1;
+      ep.co = StepCoefs{p->a_x0[i], p->a_xt[i], p->sigma[i], p->clip_denoised};
+      ep.noise = step_noise;
+      launch_gemm_f32(al, bl, ep, m->jf, B * T, D, s);
+      if (int rc = rt_launch_status()) return rc;
+    }
+    if (dump_i < p->num_dump && p->dump_steps[dump_i] == k) {
+      if (int rc = rt_copy(p->dump_dev + (size_t)dump_i * B * per_sample, x, (size_t)B * per_sample * sizeof(float), s)) return rc;
+      ++dump_i;
+    }
+  }
+  return MDM_OK;
+}
+
+int mdm_linear(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M, int32_t N,
+               int32_t K, int32_t act, void* stream) {
+  if (!in || !w || !bias || !out || M <= 0 || N <= 0 || K <= 0) return fail(MDM_EINVAL, "mdm_linear: bad argument");
+  return launch_linear(in, K, w, bias, res, out, M, N, K, act, 0, 1.f, static_cast<hipStream_t>(stream));
+}
+
+int mdm_layernorm(float* x, const float* gamma, const float* beta, int32_t rows, int32_t D, void* stream) {
+  if (!x || !gamma || !beta || rows <= 0 || D % 256 != 0) return fail(MDM_EINVAL, "mdm_layernorm: bad argument");
+  return launch_layernorm(x, gamma, beta, rows, D, static_cast<hipStream_t>(stream));
+}
+
+int mdm_attention(const float* qkv, float* out, const int32_t* lengths, int32_t nseq, int32_t B, int32_t S, int32_t D,
+                  int32_t H, void* stream) {
+  if (!qkv || !out || nseq <= 0 || B <= 0) return fail(MDM_EINVAL, "mdm_attention: bad argument");
+  return launch_attention(qkv, out, lengths, nseq, B, S, D, H, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

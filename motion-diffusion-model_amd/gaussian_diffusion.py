@@ -1,0 +1,382 @@
+"""`GaussianDiffusion` -- the reference's sampler seam (diffusion/gaussian_diffusion.py:112-205, :226-268,
+:270-381, :489-541, :591-727, :729-779, :876-990) on the MI355X HIP path.
+
+What is different from the reference, by design:
+  * the per-timestep fp64 tables are folded ON THE HOST into three fp32 scalars per step
+    (x_prev = a_x0 * x0 + a_xt * x_t + sigma * eps), so the six `_extract_into_tensor` H2D copies per step
+    (gaussian_diffusion.py:1602-1615) and the ~20 elementwise kernels disappear;
+  * `p_sample_loop` / `ddim_sample_loop` over our `MDM` (optionally inside `ClassifierFreeSampleModel`) run
+    as ONE native call that enqueues the whole loop on the current stream (`mdm_sample_loop`);
+  * fresh noise comes from a counter-based Philox stream keyed by (seed, global sample index, draw), so a
+    batch sharded across GPUs produces the same samples as the unsharded batch.  The seed is drawn from
+    torch's global CPU generator, so `utils/fixseed.py` still makes runs reproducible.  Parity tests inject
+    the reference's CPU noise stream instead (`noise_sequence=`).
+Scope: ModelMeanType.START_X with FIXED_SMALL / FIXED_LARGE variance (the only configuration
+utils/model_util.py:75-116 creates).  Training losses, PLMS, cond_fn guidance are out of scope and raise.
+"""
+import enum
+import math
+
+import numpy as np
+import torch
+
+from .cfg_sampler import ClassifierFreeSampleModel
+from .mdm import MDM
+
+
+def get_named_beta_schedule(schedule_name, num_diffusion_timesteps, scale_betas=1.):
+    """gaussian_diffusion.py:22-46."""
+    if schedule_name == "linear":
+        scale = scale_betas * 1000 / num_diffusion_timesteps
+        return np.linspace(scale * 0.0001, scale * 0.02, num_diffusion_timesteps, dtype=np.float64)
+    if schedule_name == "cosine":
+        return betas_for_alpha_bar(num_diffusion_timesteps,
+                                   lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2)
+    raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
+
+
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    """gaussian_diffusion.py:49-66."""
+    n = num_diffusion_timesteps
+    return np.array([min(1 - alpha_bar((i + 1) / n) / alpha_bar(i / n), max_beta) for i in range(n)])
+
+
+class ModelMeanType(enum.Enum):
+    PREVIOUS_X = enum.auto()
+    START_X = enum.auto()
+    EPSILON = enum.auto()
+
+
+class ModelVarType(enum.Enum):
+    LEARNED = enum.auto()
+    FIXED_SMALL = enum.auto()
+    FIXED_LARGE = enum.auto()
+    LEARNED_RANGE = enum.auto()
+
+
+class LossType(enum.Enum):
+    MSE = enum.auto()
+    RESCALED_MSE = enum.auto()
+    KL = enum.auto()
+    RESCALED_KL = enum.auto()
+
+    def is_vb(self):
+        return self == LossType.KL or self == LossType.RESCALED_KL
+
+
+def _unwrap(model):
+    """-> (mdm, guided) if `model` is our MDM or ClassifierFreeSampleModel(our MDM) -- possibly inside a
+    respace._WrappedModel -- else (None, False)."""
+    if not isinstance(model, torch.nn.Module) and hasattr(model, "timestep_map") and hasattr(model, "model"):
+        model = model.model
+    if isinstance(model, ClassifierFreeSampleModel) and isinstance(model.model, MDM):
+        return model.model, True
+    if isinstance(model, MDM):
+        return model, False
+    return None, False
+
+
+class GaussianDiffusion:
+    def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False, **kargs):
+        self.model_mean_type = model_mean_type
+        self.model_var_type = model_var_type
+        self.loss_type = loss_type
+        self.rescale_timesteps = rescale_timesteps
+        for k, v in kargs.items():            # lambda_* / data_rep: training-loss knobs, kept as attributes
+            setattr(self, k, v)
+        # compared by name so that the reference's own enum objects are accepted (drop-in via utils/model_util.py)
+        if model_mean_type.name != "START_X":
+            raise NotImplementedError("only ModelMeanType.START_X (utils/model_util.py:77: predict_xstart=True)")
+        if model_var_type.name not in ("FIXED_SMALL", "FIXED_LARGE"):
+            raise NotImplementedError("only FIXED_SMALL / FIXED_LARGE variance (utils/model_util.py:98-109)")
+        if rescale_timesteps:
+            raise NotImplementedError("rescale_timesteps=True is never used by the reference (utils/model_util.py:82)")
+
+        # gaussian_diffusion.py:166-202, float64
+        betas = np.array(betas, dtype=np.float64)
+        self.betas = betas
+        assert len(betas.shape) == 1, "betas must be 1-D"
+        assert (betas > 0).all() and (betas <= 1).all()
+        self.num_timesteps = int(betas.shape[0])
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = np.log(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        self.timestep_map = list(range(self.num_timesteps))   # identity unless SpacedDiffusion overrides it
+
+    # ---- host-folded per-step scalars ----------------------------------------------------------------
+    def ddpm_coefficients(self):
+        """(a_x0, a_xt, sigma)[i] with the reference's fp32 rounding points: each table entry is cast to fp32
+        first (`.float()` in _extract_into_tensor, :1612), sigma = exp(0.5 * logvar) in fp32 (:540), and the
+        `t != 0` mask (:530-532) is folded into sigma."""
+        if self.model_var_type.name == "FIXED_LARGE":                             # :329-333
+            logvar = np.log(np.append(self.posterior_variance[1], self.betas[1:]))
+        else:                                                                     # :334-337
+            logvar = self.posterior_log_variance_clipped
+        a_x0 = self.posterior_mean_coef1.astype(np.float32)
+        a_xt = self.posterior_mean_coef2.astype(np.float32)
+        sigma = np.exp(np.float32(0.5) * logvar.astype(np.float32)).astype(np.float32)
+        sigma[0] = 0.0
+        return a_x0, a_xt, sigma
+
+    def ddim_coefficients(self, eta=0.0):
+        """ddim_sample (:729-779) folded:  eps = (c*x - x0)/d ;  x_prev = x0*sqrt(abp) + sqrt(1-abp-s^2)*eps + s*z
+        => a_x0 = sqrt(abp) - r/d,  a_xt = r*c/d,  r = sqrt(1 - abp - s^2)."""
+        ab, abp = self.alphas_cumprod, self.alphas_cumprod_prev
+        s = eta * np.sqrt((1 - abp) / (1 - ab)) * np.sqrt(1 - ab / abp)
+        r = np.sqrt(np.maximum(1 - abp - s ** 2, 0.0))
+        c, d = self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod
+        a_x0 = (np.sqrt(abp) - r / d).astype(np.float32)
+        a_xt = (r * c / d).astype(np.float32)
+        sigma = s.astype(np.float32)
+        sigma[0] = 0.0
+        return a_x0, a_xt, sigma
+
+    # ---- q(x_t | x_0) -----------------------------------------------------------------------------
+    def q_sample(self, x_start, t, noise=None):
+        """gaussian_diffusion.py:226-244 (t: [B] tensor, may differ per sample)."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        assert noise.shape == x_start.shape
+        a = torch.from_numpy(self.sqrt_alphas_cumprod).to(t.device)[t].float().view(-1, 1, 1, 1)
+        s = torch.from_numpy(self.sqrt_one_minus_alphas_cumprod).to(t.device)[t].float().view(-1, 1, 1, 1)
+        return a * x_start + s * noise
+
+    # ---- one step (the p_sample / ddim_sample seam, usable with any callable model) -------------------
+    def _model_x0_parts(self, model, x, t, model_kwargs):
+        """-> (out_cond, out_uncond|None, scale|None, engine): model evaluation split so that the CFG combine
+        can fuse into the step kernel."""
+        mdm, guided = _unwrap(model)
+        y = (model_kwargs or {}).get('y', {})
+        ts = self._map_timesteps(t)
+        if mdm is not None and guided:
+            oc, ou = mdm.forward_both(x, ts, y)
+            scale = y['scale'].to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+            return oc, ou, scale, mdm.engine()
+        if mdm is not None:
+            return mdm(x, ts, **(model_kwargs or {})), None, None, mdm.engine()
+        raise NotImplementedError("this sampler drives the MI355X MDM (optionally wrapped in "
+                                  "ClassifierFreeSampleModel); foreign models are out of scope")
+
+    def _map_timesteps(self, t):
+        if self.timestep_map == list(range(len(self.timestep_map))):
+            return t
+        return torch.tensor(self.timestep_map, device=t.device, dtype=t.dtype)[t]      # respace.py:125-130
+
+    def _uniform_index(self, t):
+        i = int(t[0])
+        if not bool((t == i).all()):
+            raise NotImplementedError("per-sample timesteps inside one sampler step are not supported")
+        return i
+
+    def _step(self, model, x, t, coefs, clip_denoised, denoised_fn, cond_fn, model_kwargs, noise, draw):
+        if denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("denoised_fn / cond_fn guidance is outside the MI355X hot path (no live caller)")
+        y = (model_kwargs or {}).get('y', {})
+        i = self._uniform_index(t)
+        oc, ou, scale, eng = self._model_x0_parts(model, x, t, model_kwargs)
+        im = y.get('inpainting_mask', None)
+        imo = y.get('inpainted_motion', None)
+        if im is not None and imo is not None:
+            im = im.to(device=x.device).to(torch.uint8).contiguous()
+            imo = imo.to(device=x.device, dtype=torch.float32).contiguous()
+        else:
+            im = imo = None
+        a_x0, a_xt, sigma = coefs
+        seed, base = self._rng_state()
+        x_prev, x0 = eng.sampler_step(x.contiguous(), oc, ou, scale, im, imo,
+                                      None if noise is None else noise.to(x.device, torch.float32).contiguous(),
+                                      float(a_x0[i]), float(a_xt[i]), float(sigma[i]), clip_denoised,
+                                      seed=seed, sample_base=base, draw=draw, want_x0=True)
+        return {"sample": x_prev, "pred_xstart": x0}
+
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                 const_noise=False, noise=None):
+        """gaussian_diffusion.py:489-541.  `noise` (extra kwarg) injects eps; otherwise the Philox stream is used."""
+        if const_noise:
+            raise NotImplementedError("const_noise=True")
+        return self._step(model, x, t, self.ddpm_coefficients(), clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                          noise, draw=self._next_draw())
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0,
+                    noise=None):
+        """gaussian_diffusion.py:729-779."""
+        return self._step(model, x, t, self.ddim_coefficients(eta), clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                          noise, draw=self._next_draw())
+
+    # RNG bookkeeping for the step-at-a-time API
+    _seed = None
+    _draw = 0
+    sample_base = 0          # global index of this process' first sample (set by dist.sample_sharded)
+
+    def _rng_state(self):
+        if self._seed is None:
+            self._seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return self._seed, self.sample_base
+
+    def _next_draw(self):
+        self._draw += 1
+        return self._draw
+
+    def reseed(self, seed=None):
+        """Start a new Philox stream (seed drawn from torch's global CPU generator unless given)."""
+        self._seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
+        self._draw = 0
+        return self._seed
+
+    # ---- the loops ---------------------------------------------------------------------------------
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                      model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
+                      randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False,
+                      noise_sequence=None, seed=None):
+        """gaussian_diffusion.py:591-658.  Returns the final sample (or the list of dumped steps)."""
+        return self._loop(model, shape, self.ddpm_coefficients(), noise, clip_denoised, denoised_fn, cond_fn,
+                          model_kwargs, device, skip_timesteps, init_image, randomize_class, cond_fn_with_grad,
+                          dump_steps, const_noise, noise_sequence, seed)
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
+                         randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False,
+                         noise_sequence=None, seed=None):
+        """gaussian_diffusion.py:876-923."""
+        if dump_steps is not None:
+            raise NotImplementedError()          # as the reference (:900-901)
+        if const_noise == True:                  # noqa: E712  (:902-903)
+            raise NotImplementedError()
+        return self._loop(model, shape, self.ddim_coefficients(eta), noise, clip_denoised, denoised_fn, cond_fn,
+                          model_kwargs, device, skip_timesteps, init_image, randomize_class, cond_fn_with_grad,
+                          None, False, noise_sequence, seed)
+
+    def _loop(self, model, shape, coefs, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
+              skip_timesteps, init_image, randomize_class, cond_fn_with_grad, dump_steps, const_noise,
+              noise_sequence, seed):
+        if denoised_fn is not None or cond_fn is not None or cond_fn_with_grad or randomize_class or const_noise:
+            raise NotImplementedError("cond_fn / denoised_fn / randomize_class / const_noise have no live caller in the "
+                                      "reference sampling path and are outside the MI355X hot path (SURVEY.md 8a)")
+        mdm, guided = _unwrap(model)
+        if mdm is None:
+            raise NotImplementedError("p_sample_loop drives the MI355X MDM (optionally wrapped in "
+                                      "ClassifierFreeSampleModel); foreign models are out of scope")
+        model_kwargs = {} if model_kwargs is None else model_kwargs
+        y = model_kwargs.get('y', {})
+        if device is None:
+            device = next(mdm.parameters()).device
+        assert isinstance(shape, (tuple, list))
+        shape = tuple(int(s) for s in shape)
+        B, J, Fe, T = shape
+        if 'text' in y.keys() and 'text_embed' not in y.keys():
+            # encoding once instead of each iteration (gaussian_diffusion.py:633-635); caches into the caller's dict
+            y['text_embed'] = model.encode_text(y['text'])
+
+        eng = mdm.engine()
+        with torch.no_grad():
+            seed = self.reseed(seed)
+            base = self.sample_base
+            start = self.num_timesteps - 1 - int(skip_timesteps)
+            # x at index `start` (:688-700)
+            if noise is not None:
+                img = noise.to(device=device, dtype=torch.float32).contiguous().clone()
+            elif noise_sequence is not None:
+                img = noise_sequence[0].to(device=device, dtype=torch.float32).contiguous().clone()
+            else:
+                img = None
+            if skip_timesteps and init_image is None:
+                init_image = torch.zeros(shape, dtype=torch.float32, device=device)
+            if init_image is not None:
+                init_image = init_image.to(device=device, dtype=torch.float32).contiguous()
+                img = eng.randn(shape, device, seed, base, 0, init=init_image, eps=img,
+                                a=float(np.float32(self.sqrt_alphas_cumprod[start])),
+                                s=float(np.float32(self.sqrt_one_minus_alphas_cumprod[start])))
+            elif img is None:
+                img = eng.randn(shape, device, seed, base, 0)
+
+            te = mdm.text_embedding(y, device) if 'text' in mdm.cond_mode and not y.get('uncond', False) else None
+            scale = None
+            if guided:
+                scale = y['scale'].to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+                assert scale.numel() == B
+            lengths = mdm.lengths_from_mask(y, T)
+            if lengths is not None:
+                lengths = lengths.to(device)
+            im = imo = None
+            if 'inpainting_mask' in y.keys() and 'inpainted_motion' in y.keys():      # :300-304
+                im = y['inpainting_mask'].to(device=device).expand(shape).to(torch.uint8).contiguous()
+                imo = y['inpainted_motion'].to(device=device, dtype=torch.float32).expand(shape).contiguous()
+            nz = None
+            if noise_sequence is not None:
+                nsteps = start + 1
+                assert len(noise_sequence) >= 1 + nsteps, "noise_sequence = [x_T, eps_0, ..., eps_{nsteps-1}]"
+                nz = torch.stack([n.to(device=device, dtype=torch.float32).contiguous()
+                                  for n in noise_sequence[1:1 + nsteps]]).contiguous()
+            a_x0, a_xt, sigma = coefs
+            kept = sorted(set(int(k) for k in dump_steps if 0 <= int(k) <= start)) if dump_steps is not None else None
+            out, _, dumps = eng.sample_loop(
+                img, a_x0=a_x0, a_xt=a_xt, sigma=sigma, timestep_map=self.timestep_map, start_index=start,
+                text_embed=te, scale=scale, lengths=lengths, inpaint_mask=im, inpaint_motion=imo, noise=nz,
+                seed=seed, sample_base=base, clip_denoised=clip_denoised,
+                force_uncond=bool(y.get('uncond', False)) or mdm.cond_mode == 'no_cond',
+                dump_steps=kept)
+        if dump_steps is not None:      # the reference appends in loop order (:654-657)
+            return [dumps[j] for j in range(len(kept))] if kept else []
+        return out
+
+    # ---- progressive generators (the reference yields per step; kept for callers that iterate) ---------
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                  model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
+                                  randomize_class=False, cond_fn_with_grad=False, const_noise=False, _ddim_eta=None):
+        """gaussian_diffusion.py:660-727: yields {'sample', 'pred_xstart'} per step (one native forward + one fused
+        step kernel per iteration; use p_sample_loop for the fully-fused loop)."""
+        if randomize_class or cond_fn_with_grad or const_noise:
+            raise NotImplementedError("randomize_class / cond_fn_with_grad / const_noise")
+        mdm, _ = _unwrap(model)
+        if mdm is None:
+            raise NotImplementedError("foreign models are out of scope")
+        if device is None:
+            device = next(mdm.parameters()).device
+        shape = tuple(int(s) for s in shape)
+        eng = mdm.engine()
+        seed = self.reseed()
+        start = self.num_timesteps - 1 - int(skip_timesteps)
+        with torch.no_grad():
+            img = noise.to(device=device, dtype=torch.float32).contiguous() if noise is not None else None
+            if skip_timesteps and init_image is None:
+                init_image = torch.zeros(shape, dtype=torch.float32, device=device)
+            if init_image is not None:
+                img = eng.randn(shape, device, seed, self.sample_base, 0,
+                                init=init_image.to(device=device, dtype=torch.float32).contiguous(), eps=img,
+                                a=float(np.float32(self.sqrt_alphas_cumprod[start])),
+                                s=float(np.float32(self.sqrt_one_minus_alphas_cumprod[start])))
+            elif img is None:
+                img = eng.randn(shape, device, seed, self.sample_base, 0)
+            coefs = self.ddpm_coefficients() if _ddim_eta is None else self.ddim_coefficients(_ddim_eta)
+            for i in range(start, -1, -1):
+                t = torch.full((shape[0],), i, device=device, dtype=torch.long)
+                out = self._step(model, img, t, coefs, clip_denoised, denoised_fn, cond_fn, model_kwargs, None,
+                                 draw=self._next_draw())
+                yield out
+                img = out["sample"]
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                     cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,
+                                     skip_timesteps=0, init_image=None, randomize_class=False,
+                                     cond_fn_with_grad=False):
+        """gaussian_diffusion.py:925-990."""
+        return self.p_sample_loop_progressive(model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                                              device, progress, skip_timesteps, init_image, randomize_class,
+                                              cond_fn_with_grad, False, _ddim_eta=eta)
+
+    # ---- explicitly out of scope -----------------------------------------------------------------------
+    def training_losses(self, *a, **k):
+        raise NotImplementedError("training is outside the MI355X sampling hot path (SURVEY.md 2)")
+
+    def plms_sample_loop(self, *a, **k):
+        raise NotImplementedError("PLMS sampling has no live caller in the reference and is out of scope")

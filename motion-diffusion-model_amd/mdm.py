@@ -1,0 +1,254 @@
+"""`MDM` -- the reference's denoiser seam (model/mdm.py:11-293) on the MI355X HIP path.
+
+Same constructor keywords, same `forward(x, timesteps, y)` signature and `y` contract, same state-dict
+keys, so `utils/model_util.py:18-21 create_model_and_diffusion` and
+`load_saved_model` work against it unchanged.  The arithmetic runs in csrc/libmdm_hip.so; the torch
+sub-modules below exist only to hold parameters under the reference's names.
+
+Scope: arch='trans_enc', text conditioning with a cached `y['text_embed']`
+(or no conditioning), inference only.  Everything else raises NotImplementedError loudly.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _native as nat
+from ._engine import Engine
+
+
+class PositionalEncoding(nn.Module):
+    """model/mdm.py:296-313 -- the table is built on the host exactly as the reference builds it."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-np.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0).transpose(0, 1))   # [max_len, 1, d]
+
+
+class TimestepEmbedder(nn.Module):
+    """model/mdm.py:316-330 (parameters only; evaluated as a precomputed table inside the library)."""
+
+    def __init__(self, latent_dim, sequence_pos_encoder):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.sequence_pos_encoder = sequence_pos_encoder
+        self.time_embed = nn.Sequential(nn.Linear(latent_dim, latent_dim), nn.SiLU(), nn.Linear(latent_dim, latent_dim))
+
+
+class InputProcess(nn.Module):
+    """model/mdm.py:333-357 (parameters only)."""
+
+    def __init__(self, data_rep, input_feats, latent_dim):
+        super().__init__()
+        self.data_rep, self.input_feats, self.latent_dim = data_rep, input_feats, latent_dim
+        self.poseEmbedding = nn.Linear(input_feats, latent_dim)
+
+
+class OutputProcess(nn.Module):
+    """model/mdm.py:360-386 (parameters only)."""
+
+    def __init__(self, data_rep, input_feats, latent_dim, njoints, nfeats):
+        super().__init__()
+        self.data_rep, self.input_feats, self.latent_dim = data_rep, input_feats, latent_dim
+        self.njoints, self.nfeats = njoints, nfeats
+        self.poseFinal = nn.Linear(latent_dim, input_feats)
+
+
+class _IdentityRot2xyz:
+    """Stand-in for model/rotation2xyz.py: for data_rep='hml_vec' the callers use pose_rep='xyz', for which the
+    reference returns its input unchanged (rotation2xyz.py:20-21; sample/generate.py:167)."""
+
+    def __init__(self):
+        self.smpl_model = nn.Module()
+
+    def __call__(self, x, mask=None, pose_rep="xyz", **kw):
+        if pose_rep != "xyz":
+            raise NotImplementedError("SMPL forward kinematics is outside the MI355X hot path (SURVEY.md 2)")
+        return x
+
+
+class MDM(nn.Module):
+    def __init__(self, modeltype, njoints, nfeats, num_actions, translation, pose_rep, glob, glob_rot,
+                 latent_dim=256, ff_size=1024, num_layers=8, num_heads=4, dropout=0.1,
+                 ablation=None, activation="gelu", legacy=False, data_rep='rot6d', dataset='amass', clip_dim=512,
+                 arch='trans_enc', emb_trans_dec=False, clip_version=None, **kargs):
+        super().__init__()
+        self.legacy, self.modeltype = legacy, modeltype
+        self.njoints, self.nfeats, self.num_actions = njoints, nfeats, num_actions
+        self.data_rep, self.dataset = data_rep, dataset
+        self.pose_rep, self.glob, self.glob_rot, self.translation = pose_rep, glob, glob_rot, translation
+        self.latent_dim, self.ff_size, self.num_layers, self.num_heads = latent_dim, ff_size, num_layers, num_heads
+        self.dropout, self.ablation, self.activation, self.clip_dim = dropout, ablation, activation, clip_dim
+        self.action_emb = kargs.get('action_emb', None)
+        self.input_feats = njoints * nfeats
+        self.normalize_output = kargs.get('normalize_encoder_output', False)
+        self.cond_mode = kargs.get('cond_mode', 'no_cond')
+        self.cond_mask_prob = kargs.get('cond_mask_prob', 0.)
+        self.mask_frames = kargs.get('mask_frames', False)
+        self.arch = arch
+        self.emb_policy = kargs.get('emb_policy', 'add')
+        self.emb_trans_dec = emb_trans_dec
+        self.pred_len = kargs.get('pred_len', 0)
+        self.context_len = kargs.get('context_len', 0)
+        self.total_len = self.pred_len + self.context_len
+        self.is_prefix_comp = self.total_len > 0
+        self.all_goal_joint_names = kargs.get('all_goal_joint_names', [])
+        self.multi_target_cond = kargs.get('multi_target_cond', False)
+        self.text_encoder_type = kargs.get('text_encoder_type', 'clip')
+        self.clip_version = clip_version
+        self._native_lib = kargs.get('_native_lib', None)      # tests inject the CPU emulation here
+
+        if arch != 'trans_enc':
+            raise NotImplementedError(f"arch={arch!r}: only the trans_enc denoiser is on the MI355X hot path (SURVEY.md 8f)")
+        if activation != "gelu":
+            raise NotImplementedError("only activation='gelu' (the reference's fixed choice, utils/model_util.py:64)")
+        if data_rep == 'rot_vel' or self.is_prefix_comp or self.multi_target_cond or self.emb_policy != 'add':
+            raise NotImplementedError("rot_vel / prefix completion / target conditioning / emb_policy!='add' are out of scope")
+        if self.cond_mode not in ('no_cond', 'text'):
+            raise NotImplementedError(f"cond_mode={self.cond_mode!r}: text or no_cond only")
+        if self.text_encoder_type != 'clip' and 'text' in self.cond_mode:
+            raise NotImplementedError("text_encoder_type='bert' belongs to the DiP (trans_dec) path")
+
+        self.input_process = InputProcess(data_rep, self.input_feats, latent_dim)
+        self.sequence_pos_encoder = PositionalEncoding(latent_dim, dropout, max_len=kargs.get('pos_embed_max_len', 5000))
+        layer = nn.TransformerEncoderLayer(d_model=latent_dim, nhead=num_heads, dim_feedforward=ff_size,
+                                           dropout=dropout, activation=activation)
+        self.seqTransEncoder = nn.TransformerEncoder(layer, num_layers=num_layers, enable_nested_tensor=False)
+        self.embed_timestep = TimestepEmbedder(latent_dim, self.sequence_pos_encoder)
+        if 'text' in self.cond_mode:
+            self.embed_text = nn.Linear(clip_dim, latent_dim)
+            self.clip_model = self._try_load_clip(clip_version)
+        self.output_process = OutputProcess(data_rep, self.input_feats, latent_dim, njoints, nfeats)
+        self.rot2xyz = _IdentityRot2xyz()
+        self._engine = None
+        self._engine_key = None
+
+    # ---- text encoder (outside the hot path: runs once per prompt batch on the host side) ------------
+    @staticmethod
+    def _try_load_clip(clip_version):
+        try:
+            import clip  # noqa: F401  (not installed in the offline image)
+        except ImportError:
+            return None
+        model, _ = clip.load(clip_version, device='cpu', jit=False)
+        model.eval()
+        for p in model.parameters():
+            p.requires_grad = False
+        return model
+
+    def encode_text(self, raw_text):
+        """model/mdm.py:163-178 clip_encode_text."""
+        if getattr(self, 'clip_model', None) is None:
+            raise RuntimeError("CLIP is not available in this environment: pass the cached embedding as "
+                               "y['text_embed'] ([1, B, clip_dim]); see sample/generate.py:130-132")
+        import clip
+        device = next(self.parameters()).device
+        if self.dataset in ['humanml', 'kit']:
+            texts = clip.tokenize(raw_text, context_length=22, truncate=True).to(device)
+            texts = torch.cat([texts, torch.zeros([texts.shape[0], 77 - 22], dtype=texts.dtype, device=device)], dim=1)
+        else:
+            texts = clip.tokenize(raw_text, truncate=True).to(device)
+        return self.clip_model.encode_text(texts).float().unsqueeze(0)
+
+    def parameters_wo_clip(self):
+        return [p for name, p in self.named_parameters() if not name.startswith('clip_model.')]
+
+    def mask_cond(self, cond, force_mask=False):
+        """model/mdm.py:153-161 (inference branches only)."""
+        if force_mask:
+            return torch.zeros_like(cond)
+        if self.training and self.cond_mask_prob > 0.:
+            raise NotImplementedError("training-time condition dropout is outside the inference hot path")
+        return cond
+
+    # ---- native engine management ---------------------------------------------------------------------
+    def _native_state(self):
+        sd = {k: v for k, v in self.state_dict().items()
+              if not k.startswith('clip_model.') and k != 'embed_timestep.sequence_pos_encoder.pe'}
+        sd['sequence_pos_encoder.pe'] = sd['sequence_pos_encoder.pe'].reshape(-1, self.latent_dim)
+        if 'embed_text.weight' not in sd:   # no_cond: the condition token is time-only -> zero text embedding
+            sd['embed_text.weight'] = torch.zeros(self.latent_dim, self.clip_dim)
+            sd['embed_text.bias'] = torch.zeros(self.latent_dim)
+        return sd
+
+    def engine(self):
+        """Native handle bound to the current parameters (rebuilt when they move or change)."""
+        p = self.input_process.poseEmbedding.weight
+        key = (str(p.device),) + tuple((q.data_ptr(), q._version) for q in self.parameters_wo_clip())
+        if self._engine is None or self._engine_key != key:
+            cfg = dict(njoints=self.njoints, nfeats=self.nfeats, latent_dim=self.latent_dim, ff_size=self.ff_size,
+                       num_layers=self.num_layers, num_heads=self.num_heads, clip_dim=self.clip_dim,
+                       max_len=self.sequence_pos_encoder.pe.shape[0], mask_frames=int(bool(self.mask_frames)))
+            eng = Engine(cfg, lib=self._native_lib)
+            eng.bind(self._native_state(), p.device)
+            self._engine, self._engine_key = eng, key
+        return self._engine
+
+    def lengths_from_mask(self, y, T):
+        """y['mask'] [B,1,1,T] bool -> int32 valid-frame counts, or None when the reference would not mask
+        (model/mdm.py:241-247).  collate builds prefix masks (data_loaders/tensors.py:3-8, :22-40)."""
+        mask = y.get('mask', None) if y is not None else None
+        if not self.mask_frames or mask is None or mask.shape[-1] <= 1:
+            return None
+        m = mask[..., :T].reshape(mask.shape[0], -1)
+        return m.sum(dim=1).to(torch.int32).contiguous()
+
+    def text_embedding(self, y, device):
+        """The [B, clip_dim] block the library projects with embed_text (model/mdm.py:209-218)."""
+        if 'text' not in self.cond_mode:
+            return None
+        if 'text_embed' in y.keys():
+            enc = y['text_embed']
+        else:
+            enc = self.encode_text(y['text'])
+        if isinstance(enc, tuple):
+            raise NotImplementedError("token-level (BERT) text embeddings belong to the DiP path")
+        return enc.to(device=device, dtype=torch.float32).reshape(-1, self.clip_dim).contiguous()
+
+    # ---- the seam ----------------------------------------------------------------------------------
+    def forward(self, x, timesteps, y=None):
+        """x: [bs, njoints, nfeats, nframes]; timesteps: [bs] int; y: dict (model/mdm.py:189-194)."""
+        if self.training:
+            raise NotImplementedError("inference only: call .eval() (sample/generate.py:96)")
+        y = {} if y is None else y
+        for k in ('target_cond', 'prefix', 'action'):
+            if k in y:
+                raise NotImplementedError(f"y[{k!r}] is outside the MI355X hot path")
+        bs, njoints, nfeats, nframes = x.shape
+        assert njoints == self.njoints and nfeats == self.nfeats
+        eng = self.engine()
+        x = x.to(torch.float32).contiguous()
+        ts = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
+        uncond = bool(y.get('uncond', False)) or self.cond_mode == 'no_cond'
+        te = None if uncond else self.text_embedding(y, x.device)
+        if te is not None and te.shape[0] != bs:
+            raise ValueError(f"text_embed batch {te.shape[0]} != x batch {bs}")
+        lengths = self.lengths_from_mask(y, nframes)
+        if lengths is not None:
+            lengths = lengths.to(x.device)
+        return eng.forward(x, ts, te, lengths, nat.BRANCH_UNCOND if uncond else nat.BRANCH_COND)
+
+    def forward_both(self, x, timesteps, y):
+        """cond and uncond branches batched through one native call -> (out_cond, out_uncond)."""
+        bs = x.shape[0]
+        eng = self.engine()
+        x = x.to(torch.float32).contiguous()
+        ts = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
+        te = self.text_embedding(y, x.device)
+        lengths = self.lengths_from_mask(y, x.shape[-1])
+        if lengths is not None:
+            lengths = lengths.to(x.device)
+        out = eng.forward(x, ts, te, lengths, nat.BRANCH_BOTH)
+        return out[:bs], out[bs:]
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._engine = None   # parameters moved: rebind lazily
+        return r

@@ -1,0 +1,221 @@
+// TEST INFRASTRUCTURE ONLY: a lock-step host emulator for the HIP kernels in
+// motion-diffusion-model_amd/csrc.  There is no GPU in the build container, so the CPU test-suite
+// compiles the *same* kernel sources with -DMDM_EMU against this header and executes every thread
+// of a workgroup as a ucontext fiber on one OS thread:
+//   * __syncthreads()             -> workgroup barrier between fibers
+//   * wave collectives (shuffles, MFMA) -> 64-fiber exchange through a per-wave buffer
+//   * MFMA lane<->element maps    -> exactly the gfx950 layouts (cdna_hip_programming.md section 3):
+//       v_mfma_f32_32x32x2_f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+//                                D[reg]: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5); k-ordered fmaf chain
+//       v_mfma_f32_32x32x16_bf16: A/B 8 bf16 per lane, k = 8*(l>>5)+e ; same D layout, fp32 accumulate
+// It validates index math / masking / epilogues, NOT timing, and is never part of the product path.
+#pragma once
+#include <ucontext.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __restrict__
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
+typedef void* hipStream_t;
+using std::min;
+using std::max;
+
+namespace emu {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+  dim3 tid;
+};
+
+struct WaveBuf {
+  float fa[64], fb[64];
+  bf16x8 ha[64], hb[64];
+  int arrive = 0;
+  unsigned gen = 0;
+};
+
+struct Block {
+  std::vector<Fiber> fibers;
+  std::vector<WaveBuf> waves;
+  int nthreads = 0;
+  int bar_arrive = 0;
+  unsigned bar_gen = 0;
+  dim3 bid, bdim, gdim;
+  char* dyn = nullptr;
+  ucontext_t sched;
+  int cur = 0;
+  const std::function<void()>* body = nullptr;
+};
+
+inline Block*& g_block() { static Block* b = nullptr; return b; }
+inline Block& blk() { return *g_block(); }
+inline Fiber& cur() { return blk().fibers[blk().cur]; }
+inline int lane_id() { return blk().cur & 63; }
+inline int wave_id() { return blk().cur >> 6; }
+
+inline void yield() { Block& b = blk(); swapcontext(&b.fibers[b.cur].ctx, &b.sched); }
+
+inline void block_barrier() {
+  Block& b = blk();
+  unsigned g = b.bar_gen;
+  if (++b.bar_arrive == b.nthreads) { b.bar_arrive = 0; ++b.bar_gen; return; }
+  while (b.bar_gen == g) yield();
+}
+inline void wave_barrier() {
+  Block& b = blk();
+  WaveBuf& w = b.waves[wave_id()];
+  int wsize = std::min(64, b.nthreads - wave_id() * 64);
+  unsigned g = w.gen;
+  if (++w.arrive == wsize) { w.arrive = 0; ++w.gen; return; }
+  while (w.gen == g) yield();
+}
+
+inline float shfl_f32(float v, int src_lane) {
+  WaveBuf& w = blk().waves[wave_id()];
+  w.fa[lane_id()] = v;
+  wave_barrier();
+  float r = w.fa[src_lane & 63];
+  wave_barrier();
+  return r;
+}
+
+inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
+  WaveBuf& w = blk().waves[wave_id()];
+  int l = lane_id();
+  w.fa[l] = a;
+  w.fb[l] = b;
+  wave_barrier();
+  int j = l & 31, h = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+    float acc = c[r];
+    acc = fmaf(w.fa[i], w.fb[j], acc);            // k = 0
+    acc = fmaf(w.fa[i + 32], w.fb[j + 32], acc);  // k = 1
+    c[r] = acc;
+  }
+  wave_barrier();
+  return c;
+}
+
+inline float bf16_to_f32(short s) {
+  uint32_t u = ((uint32_t)(uint16_t)s) << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+inline f32x16 mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  WaveBuf& w = blk().waves[wave_id()];
+  int l = lane_id();
+  w.ha[l] = a;
+  w.hb[l] = b;
+  wave_barrier();
+  int j = l & 31, h = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+    float acc = c[r];
+    for (int g = 0; g < 2; ++g)
+      for (int e = 0; e < 8; ++e)
+        acc = fmaf(bf16_to_f32(w.ha[i + 32 * g][e]), bf16_to_f32(w.hb[j + 32 * g][e]), acc);
+    c[r] = acc;
+  }
+  wave_barrier();
+  return c;
+}
+
+inline void fiber_entry() {
+  Block& b = blk();
+  (*b.body)();
+  b.fibers[b.cur].done = true;
+  swapcontext(&b.fibers[b.cur].ctx, &b.sched);
+}
+
+inline void run_block(Block& b) {
+  g_block() = &b;
+  const size_t STK = 256 * 1024;
+  for (int t = 0; t < b.nthreads; ++t) {
+    Fiber& f = b.fibers[t];
+    f.done = false;
+    if (!f.stack) f.stack = (char*)malloc(STK);
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = STK;
+    f.ctx.uc_link = &b.sched;
+    makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+  }
+  int remaining = b.nthreads;
+  while (remaining > 0) {
+    for (int t = 0; t < b.nthreads; ++t) {
+      if (b.fibers[t].done) continue;
+      b.cur = t;
+      swapcontext(&b.sched, &b.fibers[t].ctx);
+      if (b.fibers[t].done) --remaining;
+    }
+  }
+}
+
+// Launch: every block of the grid runs sequentially; `max_blocks` (env MDM_EMU_MAX_BLOCKS) lets a
+// test execute only a sample of the blocks of a big grid.
+inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+  Block b;
+  b.nthreads = block.x * block.y * block.z;
+  b.fibers.resize(b.nthreads);
+  b.waves.resize((b.nthreads + 63) / 64);
+  b.bdim = block;
+  b.gdim = grid;
+  b.body = &body;
+  std::vector<char> dyn(shmem + 64);
+  b.dyn = (char*)(((uintptr_t)dyn.data() + 15) & ~(uintptr_t)15);
+  for (int t = 0; t < b.nthreads; ++t) {
+    b.fibers[t].tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+  }
+  for (unsigned z = 0; z < grid.z; ++z)
+    for (unsigned y = 0; y < grid.y; ++y)
+      for (unsigned x = 0; x < grid.x; ++x) {
+        b.bid = dim3(x, y, z);
+        b.bar_arrive = 0;
+        for (auto& w : b.waves) w.arrive = 0;
+        run_block(b);
+      }
+  for (auto& f : b.fibers) free(f.stack);
+  g_block() = nullptr;
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::cur().tid)
+#define blockIdx (emu::blk().bid)
+#define blockDim (emu::blk().bdim)
+#define gridDim (emu::blk().gdim)
+#define __syncthreads() emu::block_barrier()
+#define MDM_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(emu::blk().dyn)
+#define MDM_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+  emu::launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })
