@@ -146,6 +146,22 @@ typedef struct mdm_sample_params {
 int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x_dev, void* ws_dev, size_t ws_bytes,
                     void* stream);
 
+/* Opt-in per-launch timing, for bench.py's roofline line.  While enabled, every kernel the model launches is
+ * bracketed by a hipEvent pair on the launch stream and bucketed by kernel class; mdm_profile_read waits for
+ * the events of one class and returns their summed duration, the launch count and the ALGORITHMIC flops of
+ * those launches (2MNK per GEMM, 4 S^2 hd per (sequence, head) of attention; 0 for the HBM-bound classes).
+ * The event records perturb the stream slightly, so throughput is always timed with profiling off. */
+#define MDM_PROF_LINEAR 0       /* encoder GEMMs: in_proj, out_proj, linear1, linear2 */
+#define MDM_PROF_ATTENTION 1
+#define MDM_PROF_LAYERNORM 2
+#define MDM_PROF_EMBED 3        /* InputProcess GEMM                                  */
+#define MDM_PROF_OUTPROJ 4      /* OutputProcess GEMM (+ fused sampler update)        */
+#define MDM_PROF_ELEMENTWISE 5  /* condition token, Philox noise                      */
+#define MDM_PROF_NUM 6
+int mdm_profile_enable(mdm_model_t* m, int on);
+int mdm_profile_read(mdm_model_t* m, int32_t category, double* total_ms, int64_t* launches, double* flops);
+int mdm_profile_reset(mdm_model_t* m);
+
 /* Building blocks, exported for the parity tests and for callers that compose their own layers.
  *   mdm_linear:    out[M,N] = act(in[M,K] . w[N,K]^T + bias) (+ res)     act: 0 none, 1 gelu(erf), 2 silu
  *   mdm_layernorm: in-place LayerNorm over rows of D (eps 1e-5)

@@ -69,6 +69,21 @@ class Engine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    # ---- per-kernel-class timing (bench.py roofline) ------------------------------------------------
+    def profile(self, on):
+        self.lib.check(self.lib.mdm_profile_reset(self.handle), "mdm_profile_reset")
+        self.lib.check(self.lib.mdm_profile_enable(self.handle, int(bool(on))), "mdm_profile_enable")
+
+    def profile_read(self):
+        """{class: {"ms": total, "launches": n, "flops": algorithmic flops}} of everything recorded since profile(True)."""
+        out = {}
+        for i, name in enumerate(nat.PROF_CLASSES):
+            ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+            self.lib.check(self.lib.mdm_profile_read(self.handle, i, C.byref(ms), C.byref(n), C.byref(fl)),
+                           "mdm_profile_read")
+            out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value}
+        return out
+
     # ---- MDM.forward ------------------------------------------------------------------------
     def forward(self, x, timesteps, text_embed, lengths, branches):
         B, J, Fe, T = x.shape

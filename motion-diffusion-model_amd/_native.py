@@ -14,11 +14,12 @@ LIB_PATH = os.path.join(_HERE, "csrc", LIB_NAME)
 MDM_OK = 0
 BRANCH_COND, BRANCH_UNCOND, BRANCH_BOTH = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+PROF_CLASSES = ("linear", "attention", "layernorm", "embed", "outproj", "elementwise")
 
 EXPORTED_SYMBOLS = [
     "mdm_abi_version", "mdm_last_error", "mdm_create", "mdm_destroy", "mdm_set_weight", "mdm_const_bytes",
     "mdm_prepare", "mdm_workspace_bytes", "mdm_forward", "mdm_sampler_step", "mdm_randn", "mdm_sample_loop",
-    "mdm_linear", "mdm_layernorm", "mdm_attention",
+    "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset",
 ]
 
 
@@ -76,6 +77,9 @@ class MdmLib:
             "mdm_linear": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
             "mdm_layernorm": (C.c_int, [vp, vp, vp, i32, i32, vp]),
             "mdm_attention": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+            "mdm_profile_enable": (C.c_int, [vp, C.c_int]),
+            "mdm_profile_read": (C.c_int, [vp, i32, P(C.c_double), P(i64), P(C.c_double)]),
+            "mdm_profile_reset": (C.c_int, [vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is missing

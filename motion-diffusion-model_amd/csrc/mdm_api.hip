@@ -56,8 +56,45 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+// Opt-in per-launch timing (mdm_profile_enable): one hipEvent pair per kernel launch, bucketed by kernel class.
+struct Profiler {
+  bool on = false;
+#ifndef MDM_EMU
+  struct Rec { int cat; hipEvent_t a, b; double flops; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  ~Profiler() {
+    for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : pool) (void)hipEventDestroy(e);
+  }
+#endif
+};
+
+struct ProfScope {   // records start on construction, stop on destruction (both on the launch stream)
+#ifndef MDM_EMU
+  Profiler* p; size_t idx; hipStream_t s;
+  ProfScope(Profiler* prof, int cat, double flops, hipStream_t st) : p(prof && prof->on ? prof : nullptr), idx(0), s(st) {
+    if (!p) return;
+    Profiler::Rec r{cat, p->get(), p->get(), flops};
+    (void)hipEventRecord(r.a, s);
+    idx = p->recs.size();
+    p->recs.push_back(r);
+  }
+  ~ProfScope() { if (p) (void)hipEventRecord(p->recs[idx].b, s); }
+#else
+  ProfScope(Profiler*, int, double, hipStream_t) {}
+#endif
+};
+
 struct mdm_model {
   mdm_config_t cfg;
+  Profiler prof;
   std::map<std::string, const float*> w;
   std::map<std::string, int64_t> expect;  // name -> numel
   bool prepared = false;
@@ -96,7 +133,8 @@ Workspace carve(const mdm_model* m, int nseq, int T, void* base) {
   return w;
 }
 
-int launch_layernorm(float* x, const float* g, const float* b, int rows, int D, hipStream_t s) {
+int launch_layernorm(Profiler* pf, float* x, const float* g, const float* b, int rows, int D, hipStream_t s) {
+  ProfScope ps(pf, MDM_PROF_LAYERNORM, 0.0, s);
   const dim3 grid((rows + 3) / 4), block(256);
   switch (D / 256) {
     case 1: { auto k = &layernorm_kernel<1>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f); break; }
@@ -118,8 +156,9 @@ int launch_attention_t(const float* qkv, float* out, const int* lengths, int nse
   return rt_launch_status();
 }
 
-int launch_attention(const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D, int H,
-                     hipStream_t s) {
+int launch_attention(Profiler* pf, const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D,
+                     int H, hipStream_t s) {
+  ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * H * (double)S * S * ATT_HD, s);
   if (D != H * ATT_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
   if (S < 1 || S > 224) return fail(MDM_EUNSUPPORTED, "attention: 1 <= S <= 224 tokens (T <= 223 frames)");
   switch ((S + 31) / 32) {
@@ -133,8 +172,9 @@ int launch_attention(const float* qkv, float* out, const int* lengths, int nseq,
   }
 }
 
-int launch_linear(const float* in, int ld_in, const float* w, const float* bias, const float* res, float* out,
-                  int M, int N, int K, int act, int scale_cols, float col_scale, hipStream_t s) {
+int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, const float* bias, const float* res,
+                  float* out, int M, int N, int K, int act, int scale_cols, float col_scale, hipStream_t s) {
+  ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
   if (K % 4 != 0 || ld_in % 4 != 0) return fail(MDM_EINVAL, "linear: K and the row stride must be multiples of 4");
   RowMajorLoader al{in, ld_in, M, K};
   RowMajorLoader bl{w, K, N, K};
@@ -144,7 +184,7 @@ int launch_linear(const float* in, int ld_in, const float* w, const float* bias,
 }
 
 // Tokens for every sequence: frame tokens via the InputProcess GEMM, token 0 via cond_token_kernel.
-int embed_tokens(const mdm_model* m, const Workspace& ws, const float* x, const long long* timesteps,
+int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long long* timesteps,
                  long long t_uniform_unused, const float* cond_emb, int B, int T, int nbranch,
                  int uncond_from_branch, hipStream_t s) {
   (void)t_uniform_unused;
@@ -153,8 +193,12 @@ int embed_tokens(const mdm_model* m, const Workspace& ws, const float* x, const 
   RowMajorLoader bl{m->w_in_pad, m->jf_pad, D, m->jf_pad};
   EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D,
                    nbranch};
-  launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
+  {
+    ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
+    launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
+  }
   if (int rc = rt_launch_status()) return rc;
+  ProfScope ps(&m->prof, MDM_PROF_ELEMENTWISE, 0.0, s);
   MDM_LAUNCH(cond_token_kernel, dim3(nbranch * B), dim3(128), 0, s, ws.tok, cond_emb, m->W("embed_text.bias"),
              (const float*)m->time_table, timesteps, 0, m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from_branch,
              (int)m->cfg.max_len);
@@ -162,21 +206,22 @@ int embed_tokens(const mdm_model* m, const Workspace& ws, const float* x, const 
 }
 
 // seqTransEncoder: num_layers post-norm layers over ws.tok [nseq*S, D] (in place).
-int encoder(const mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int* lengths, hipStream_t s) {
+int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int* lengths, hipStream_t s) {
+  Profiler* pf = &m->prof;
   const int D = m->cfg.latent_dim, FF = m->cfg.ff_size, H = m->cfg.num_heads, M = nseq * S;
   const float qscale = 1.0f / sqrtf((float)(D / H));
   for (int l = 0; l < m->cfg.num_layers; ++l) {
-    if (int rc = launch_linear(ws.tok, D, m->L(l, "self_attn.in_proj_weight"), m->L(l, "self_attn.in_proj_bias"),
+    if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "self_attn.in_proj_weight"), m->L(l, "self_attn.in_proj_bias"),
                                nullptr, ws.qkv, M, 3 * D, D, ACT_NONE, D, qscale, s)) return rc;
-    if (int rc = launch_attention(ws.qkv, ws.att, lengths, nseq, B, S, D, H, s)) return rc;
-    if (int rc = launch_linear(ws.att, D, m->L(l, "self_attn.out_proj.weight"), m->L(l, "self_attn.out_proj.bias"),
+    if (int rc = launch_attention(pf, ws.qkv, ws.att, lengths, nseq, B, S, D, H, s)) return rc;
+    if (int rc = launch_linear(pf, ws.att, D, m->L(l, "self_attn.out_proj.weight"), m->L(l, "self_attn.out_proj.bias"),
                                ws.tok, ws.tok, M, D, D, ACT_NONE, 0, 1.f, s)) return rc;
-    if (int rc = launch_layernorm(ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, s)) return rc;
-    if (int rc = launch_linear(ws.tok, D, m->L(l, "linear1.weight"), m->L(l, "linear1.bias"), nullptr, ws.ffn, M,
+    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, s)) return rc;
+    if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "linear1.weight"), m->L(l, "linear1.bias"), nullptr, ws.ffn, M,
                                FF, D, ACT_GELU, 0, 1.f, s)) return rc;
-    if (int rc = launch_linear(ws.ffn, FF, m->L(l, "linear2.weight"), m->L(l, "linear2.bias"), ws.tok, ws.tok, M,
+    if (int rc = launch_linear(pf, ws.ffn, FF, m->L(l, "linear2.weight"), m->L(l, "linear2.bias"), ws.tok, ws.tok, M,
                                D, FF, ACT_NONE, 0, 1.f, s)) return rc;
-    if (int rc = launch_layernorm(ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, s)) return rc;
+    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, s)) return rc;
   }
   return 0;
 }
@@ -278,10 +323,10 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
              m->jf, m->jf_pad);
   if (int rc = rt_launch_status()) return rc;
   // TimestepEmbedder for every possible t (model/mdm.py:323-330): table[t] = W2 silu(W0 pe[t] + b0) + b2
-  if (int rc = launch_linear(m->W("sequence_pos_encoder.pe"), D, m->W("embed_timestep.time_embed.0.weight"),
+  if (int rc = launch_linear(nullptr, m->W("sequence_pos_encoder.pe"), D, m->W("embed_timestep.time_embed.0.weight"),
                              m->W("embed_timestep.time_embed.0.bias"), nullptr, hidden, R, D, D, ACT_SILU, 0, 1.f, s))
     return rc;
-  if (int rc = launch_linear(hidden, D, m->W("embed_timestep.time_embed.2.weight"),
+  if (int rc = launch_linear(nullptr, hidden, D, m->W("embed_timestep.time_embed.2.weight"),
                              m->W("embed_timestep.time_embed.2.bias"), nullptr, m->time_table, R, D, D, ACT_NONE, 0,
                              1.f, s))
     return rc;
@@ -309,7 +354,7 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
   if (ws_bytes < ws.bytes) return fail(MDM_ENOSPC, "mdm_forward: workspace too small");
   const int* len = m->cfg.mask_frames ? lengths : nullptr;
   if (branches != MDM_BRANCH_UNCOND)
-    if (int rc = launch_linear(text_embed, m->cfg.clip_dim, m->W("embed_text.weight"), m->W("embed_text.bias"), nullptr,
+    if (int rc = launch_linear(nullptr, text_embed, m->cfg.clip_dim, m->W("embed_text.weight"), m->W("embed_text.bias"), nullptr,
                                ws.cond, B, D, m->cfg.clip_dim, ACT_NONE, 0, 1.f, s)) return rc;
   const int uncond_from = (branches == MDM_BRANCH_UNCOND) ? 0 : 1;
   if (int rc = embed_tokens(m, ws, x, reinterpret_cast<const long long*>(timesteps), 0, ws.cond, B, T, nbranch,
@@ -322,6 +367,7 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
   ep.bias = m->W("output_process.poseFinal.bias");
   ep.out = out;
   ep.T = T; ep.JF = m->jf; ep.mode = 0;
+  ProfScope ps(&m->prof, MDM_PROF_OUTPROJ, 2.0 * nseq * T * (double)D * m->jf, s);
   launch_gemm_f32(al, bl, ep, m->jf, nseq * T, D, s);
   return rt_launch_status();
 }
@@ -380,7 +426,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
   // step-invariant: embed_text(cond) once per loop (gaussian_diffusion.py:633-635 caches the encoder side;
   // the Linear on top is also constant across steps)
   if (!uncond_only)
-    if (int rc = launch_linear(p->text_embed_dev, m->cfg.clip_dim, m->W("embed_text.weight"), m->W("embed_text.bias"),
+    if (int rc = launch_linear(nullptr, p->text_embed_dev, m->cfg.clip_dim, m->W("embed_text.weight"), m->W("embed_text.bias"),
                                nullptr, ws.cond, B, D, m->cfg.clip_dim, ACT_NONE, 0, 1.f, s)) return rc;
   const int uncond_from = uncond_only ? 0 : 1;
 
@@ -391,8 +437,12 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
       PoseGatherLoader al{x, T, m->jf, B * T};
       RowMajorLoader bl{m->w_in_pad, m->jf_pad, D, m->jf_pad};
       EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D, nbranch};
-      launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
+      {
+        ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
+        launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
+      }
       if (int rc = rt_launch_status()) return rc;
+      ProfScope ps(&m->prof, MDM_PROF_ELEMENTWISE, 0.0, s);
       MDM_LAUNCH(cond_token_kernel, dim3(nseq), dim3(128), 0, s, ws.tok, (const float*)ws.cond,
                  m->W("embed_text.bias"), (const float*)m->time_table, (const long long*)nullptr,
                  (int)p->timestep_map[i], m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from,
@@ -405,6 +455,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
     if (p->sigma[i] != 0.f) {
       if (p->noise_dev != nullptr) step_noise = p->noise_dev + (size_t)k * B * per_sample;
       else {
+        ProfScope ps(&m->prof, MDM_PROF_ELEMENTWISE, 0.0, s);
         if (int rc = mdm_randn(ws.att, nullptr, nullptr, 0.f, 1.f, B, (int)per_sample, p->seed, p->sample_base,
                                (uint32_t)(1 + k), stream)) return rc;
         step_noise = ws.att;
@@ -424,6 +475,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
       ep.T = T; ep.JF = m->jf; ep.mode = 1;
       ep.co = StepCoefs{p->a_x0[i], p->a_xt[i], p->sigma[i], p->clip_denoised};
       ep.noise = step_noise;
+      ProfScope ps(&m->prof, MDM_PROF_OUTPROJ, 2.0 * B * T * (double)D * m->jf, s);
       launch_gemm_f32(al, bl, ep, m->jf, B * T, D, s);
       if (int rc = rt_launch_status()) return rc;
     }
@@ -435,21 +487,55 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
   return MDM_OK;
 }
 
+int mdm_profile_enable(mdm_model_t* m, int on) {
+  if (m == nullptr) return fail(MDM_EINVAL, "mdm_profile_enable: null model");
+  m->prof.on = on != 0;
+  return MDM_OK;
+}
+
+int mdm_profile_read(mdm_model_t* m, int32_t category, double* total_ms, int64_t* launches, double* flops) {
+  if (m == nullptr || category < 0 || category >= MDM_PROF_NUM) return fail(MDM_EINVAL, "mdm_profile_read: bad argument");
+  double ms = 0.0, fl = 0.0;
+  int64_t n = 0;
+#ifndef MDM_EMU
+  for (const auto& r : m->prof.recs) {
+    if (r.cat != category) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess) return fail(MDM_EHIP, "mdm_profile_read: hipEventSynchronize failed");
+    float dt = 0.f;
+    if (hipEventElapsedTime(&dt, r.a, r.b) != hipSuccess) return fail(MDM_EHIP, "mdm_profile_read: hipEventElapsedTime failed");
+    ms += dt; fl += r.flops; ++n;
+  }
+#endif
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  if (flops) *flops = fl;
+  return MDM_OK;
+}
+
+int mdm_profile_reset(mdm_model_t* m) {
+  if (m == nullptr) return fail(MDM_EINVAL, "mdm_profile_reset: null model");
+#ifndef MDM_EMU
+  for (auto& r : m->prof.recs) { m->prof.pool.push_back(r.a); m->prof.pool.push_back(r.b); }
+  m->prof.recs.clear();
+#endif
+  return MDM_OK;
+}
+
 int mdm_linear(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M, int32_t N,
                int32_t K, int32_t act, void* stream) {
   if (!in || !w || !bias || !out || M <= 0 || N <= 0 || K <= 0) return fail(MDM_EINVAL, "mdm_linear: bad argument");
-  return launch_linear(in, K, w, bias, res, out, M, N, K, act, 0, 1.f, static_cast<hipStream_t>(stream));
+  return launch_linear(nullptr, in, K, w, bias, res, out, M, N, K, act, 0, 1.f, static_cast<hipStream_t>(stream));
 }
 
 int mdm_layernorm(float* x, const float* gamma, const float* beta, int32_t rows, int32_t D, void* stream) {
   if (!x || !gamma || !beta || rows <= 0 || D % 256 != 0) return fail(MDM_EINVAL, "mdm_layernorm: bad argument");
-  return launch_layernorm(x, gamma, beta, rows, D, static_cast<hipStream_t>(stream));
+  return launch_layernorm(nullptr, x, gamma, beta, rows, D, static_cast<hipStream_t>(stream));
 }
 
 int mdm_attention(const float* qkv, float* out, const int32_t* lengths, int32_t nseq, int32_t B, int32_t S, int32_t D,
                   int32_t H, void* stream) {
   if (!qkv || !out || nseq <= 0 || B <= 0) return fail(MDM_EINVAL, "mdm_attention: bad argument");
-  return launch_attention(qkv, out, lengths, nseq, B, S, D, H, static_cast<hipStream_t>(stream));
+  return launch_attention(nullptr, qkv, out, lengths, nseq, B, S, D, H, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,69 @@
+"""Shared test scaffolding: build the MI355X model/diffusion pair from the synthetic state-dict the golden
+fixtures were made with, and run golden loop cases through the product seams."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import mdm_amd  # noqa: E402,F401
+from mdm_amd import model_util  # noqa: E402
+from mdm_amd.cfg_sampler import ClassifierFreeSampleModel  # noqa: E402
+from oracle import mdm_oracle as orc  # noqa: E402
+from oracle.synth import synth_state_dict, synth_y  # noqa: E402
+
+
+def make_pair(sd, steps, device, guided=True, native_lib=None, **arg_over):
+    """(model, diffusion) exactly as sample/generate.py:85-96 assembles them."""
+    layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("seqTransEncoder.layers."))
+    d = sd["input_process.poseEmbedding.weight"].shape[0]
+    args = model_util.default_args(diffusion_steps=steps, layers=layers, latent_dim=d, **arg_over)
+    model, diffusion = model_util.create_model_and_diffusion(args, _native_lib=native_lib, num_heads=d // 128)
+    model_util.load_model_wo_clip(model, sd)
+    if guided:
+        model = ClassifierFreeSampleModel(model)
+    model.to(device)
+    model.eval()
+    return model, diffusion
+
+
+def golden_loop_inputs(g):
+    """Rebuild the inputs of one tests/golden loop case (same recipe as oracle/make_golden.py)."""
+    steps, B, T, seed, skip = int(g["steps"]), int(g["B"]), int(g["T"]), int(g["seed"]), int(g["skip"])
+    shape = (B, 263, 1, T)
+    y = synth_y(B, T, seed=seed + 1000, lengths=list(g["lengths"]), scale=float(g["scale"]))
+    gi = torch.Generator().manual_seed(seed + 2000)
+    init_image = torch.randn(*shape, generator=gi) if bool(g["init"]) else None
+    if bool(g["inpaint"]):
+        m = torch.zeros(shape, dtype=torch.bool)
+        m[:, :4, :, :] = True
+        m[..., : T // 4] = True
+        y["inpainting_mask"] = m
+        y["inpainted_motion"] = torch.randn(*shape, generator=gi)
+    x_T, noises = orc.make_noise(shape, steps - skip, seed)
+    return dict(steps=steps, shape=shape, y=y, init_image=init_image, skip=skip, x_T=x_T, noises=noises,
+                cfg=bool(g["cfg"]), ddim=bool(g["ddim"]), eta=float(g["eta"]))
+
+
+def run_product_loop(sd, case, device, native_lib=None, dump_steps=None):
+    """The golden case through SpacedDiffusion.p_sample_loop / ddim_sample_loop of the product."""
+    model, diffusion = make_pair(sd, case["steps"], device, guided=case["cfg"], native_lib=native_lib)
+    seq = [case["x_T"]] + [n.contiguous() for n in case["noises"]]
+    kw = dict(clip_denoised=False, model_kwargs={"y": dict(case["y"])}, skip_timesteps=case["skip"],
+              init_image=case["init_image"], noise_sequence=seq)
+    if case["ddim"]:
+        return diffusion.ddim_sample_loop(model, case["shape"], eta=case["eta"], **kw)
+    return diffusion.p_sample_loop(model, case["shape"], dump_steps=dump_steps, **kw)
+
+
+def small_state_dict(seed=0, latent_dim=256, num_layers=2, ff_size=1024):
+    """A shallow/narrow configuration for the CPU emulator (same key names; head dim stays 128)."""
+    return synth_state_dict(seed=seed, latent_dim=latent_dim, ff_size=ff_size, num_layers=num_layers)
+
+
+def maxabs(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
