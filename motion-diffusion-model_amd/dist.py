@@ -61,9 +61,13 @@ def all_gather_samples(local, B, world):
         out = torch.empty((B,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())
         return out
-    bufs = [torch.empty((n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device) for n in sizes]
-    dist.all_gather(bufs, local.contiguous())
-    return torch.cat(bufs)
+    # ragged by one sample: pad every shard to the largest, gather once, drop the pad rows
+    n_max = max(sizes)
+    padded = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    out = torch.empty((world * n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded)
+    return torch.cat([out[r * n_max: r * n_max + n] for r, n in enumerate(sizes)])
 
 
 def sample_sharded(diffusion, model, shape, model_kwargs, *, seed, ddim=False, gather=True, **loop_kw):

@@ -1,0 +1,76 @@
+"""The C-ABI library builds for gfx950, loads without a GPU and exports every symbol include/mdm_hip.h declares.
+Only host-side entry points are called here (no kernel launches): argument validation and error reporting."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from helpers import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()                                     # cross-compiles csrc/ for gfx950 if stale
+    from mdm_amd import _native
+    return _native.MdmLib(_native.LIB_PATH)
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mdm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mdm_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from mdm_amd import _native
+    names = _declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib.lib, n), f"{n} declared in include/mdm_hip.h but not exported"
+    assert sorted(_native.EXPORTED_SYMBOLS) == names       # the ctypes view covers the whole header
+    assert lib.mdm_abi_version() == 1
+
+
+def test_no_cuda_or_torch_in_the_abi():
+    src = open(os.path.join(ROOT, "include", "mdm_hip.h")).read()
+    assert "torch" not in src.lower().replace("pytorch", "").replace("a torch tensor", "")
+    assert "#include <hip" not in src and "cuda" not in src.lower()
+
+
+def _cfg(**over):
+    from mdm_amd import _native
+    base = dict(njoints=263, nfeats=1, latent_dim=512, ff_size=1024, num_layers=8, num_heads=4, clip_dim=512,
+                max_len=5000, mask_frames=1)
+    base.update(over)
+    return _native.MdmConfig(**base)
+
+
+def test_create_validates_shapes_and_reports_errors(lib):
+    h = C.c_void_p()
+    assert lib.mdm_create(C.byref(_cfg()), C.byref(h)) == 0 and h.value
+    # state-dict contract of utils/model_util.py:8-15: unexpected keys and wrong sizes are rejected by name
+    buf = (C.c_float * 16)()
+    rc = lib.mdm_set_weight(h, b"seqTransEncoder.layers.8.linear1.bias", C.addressof(buf), 1024)
+    assert rc == -1 and b"unexpected state-dict key" in lib.mdm_last_error()
+    rc = lib.mdm_set_weight(h, b"embed_text.bias", C.addressof(buf), 511)
+    assert rc == -1 and b"size mismatch" in lib.mdm_last_error()
+    # nothing may run before every weight is registered and mdm_prepare has been called
+    assert lib.mdm_prepare(h, C.addressof(buf), 64, None) == -2 and b"missing weight" in lib.mdm_last_error()
+    assert lib.mdm_forward(h, 1, 1, 1, None, 1, 8, 0, 1, 1, 0, None) == -2
+    assert lib.mdm_workspace_bytes(h, 256, 196) > 256 * 197 * (512 * 5 + 1024) * 4
+    assert lib.mdm_const_bytes(h) >= 512 * 264 * 4 + 2 * 5000 * 512 * 4
+    lib.mdm_destroy(h)
+    for bad in (dict(latent_dim=384), dict(num_heads=8), dict(ff_size=1023), dict(num_layers=0)):
+        h2 = C.c_void_p()
+        assert lib.mdm_create(C.byref(_cfg(**bad)), C.byref(h2)) < 0
+        assert lib.mdm_last_error()
+
+
+def test_product_path_fails_loudly_without_the_extension(monkeypatch, tmp_path):
+    from mdm_amd import _native
+    monkeypatch.setenv("MDM_HIP_LIB", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_native, "_LIB", None)
+    with pytest.raises(_native.MdmError, match="no CPU fallback"):
+        _native.load_native()
