@@ -42,7 +42,7 @@ typedef struct mdm_config {
   int32_t njoints;      /* 263  (utils/model_util.py:43)                        */
   int32_t nfeats;       /* 1                                                    */
   int32_t latent_dim;   /* 512  (utils/parser_util.py:106); multiple of 256     */
-  int32_t ff_size;      /* 1024 (utils/model_util.py:63)                        */
+  int32_t ff_size;      /* 1024 (utils/model_util.py:63); multiple of 32        */
   int32_t num_layers;   /* 8                                                    */
   int32_t num_heads;    /* 4  -> head dim must be 128                           */
   int32_t clip_dim;     /* 512: width of y['text_embed']                        */
@@ -68,6 +68,18 @@ int mdm_set_weight(mdm_model_t* m, const char* name, const float* dev_ptr, int64
 size_t mdm_const_bytes(const mdm_model_t* m);
 /* Validates that every weight is present and (re)builds the derived tables.  Call again after weights change. */
 int mdm_prepare(mdm_model_t* m, void* const_ws_dev, size_t const_ws_bytes, void* stream);
+
+/* Arithmetic of the encoder's dense contractions (in_proj / out_proj / linear1 / linear2):
+ *   MDM_PREC_F32     exact fp32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an fp32 fma chain; the on-device parity
+ *                    reference (157 TFLOP/s peak);
+ *   MDM_PREC_BF16X3  default: operands split into bf16 hi + lo planes, three bf16 MFMA products per fp32 product
+ *                    (hi*hi + hi*lo + lo*hi), fp32 accumulation: ~2^-16 relative per product, well inside the
+ *                    1e-3 trajectory bar (2.5 PFLOP/s bf16 peak / 3 passes).
+ * Attention, LayerNorm, GELU, softmax, the 263-wide input/output projections and the sampler update are fp32 in
+ * both modes.  May be called any time after mdm_create. */
+#define MDM_PREC_F32 0
+#define MDM_PREC_BF16X3 1
+int mdm_set_precision(mdm_model_t* m, int32_t mode);
 
 /* Per-call activation workspace for `nseq` token sequences (B, or 2B under classifier-free guidance)
  * of `nframes` frames each. */
@@ -169,6 +181,12 @@ int mdm_profile_reset(mdm_model_t* m);
  *                  Q columns are pre-scaled by 1/sqrt(head_dim); lengths as in mdm_forward (indexed seq % B). */
 int mdm_linear(const float* in_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* out_dev,
                int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
+/*   mdm_linear_bf16x3: the same contract as mdm_linear computed by the split-precision kernel (K % 32 == 0);
+ *                      `scratch_dev` (mdm_linear_bf16x3_scratch_bytes) receives the bf16 planes of both operands. */
+size_t mdm_linear_bf16x3_scratch_bytes(int32_t M, int32_t N, int32_t K);
+int mdm_linear_bf16x3(const float* in_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
+                      float* out_dev, int32_t M, int32_t N, int32_t K, int32_t act, void* scratch_dev,
+                      size_t scratch_bytes, void* stream);
 int mdm_layernorm(float* x_dev, const float* gamma_dev, const float* beta_dev, int32_t rows, int32_t D, void* stream);
 int mdm_attention(const float* qkv_dev, float* out_dev, const int32_t* lengths_dev, int32_t nseq, int32_t B,
                   int32_t S, int32_t D, int32_t H, void* stream);

@@ -16,13 +16,14 @@ def _ptr(t):
 class Engine:
     """Binds a state-dict (reference key names) to a native model and runs forward / sample loops."""
 
-    def __init__(self, cfg, lib=None):
+    def __init__(self, cfg, lib=None, precision="bf16x3"):
         self.lib = lib if lib is not None else nat.load_native()
         self.is_emulation = not self.lib.path.endswith(nat.LIB_NAME)
         self.cfg = nat.MdmConfig(**cfg)
         h = C.c_void_p()
         self.lib.check(self.lib.mdm_create(C.byref(self.cfg), C.byref(h)), "mdm_create")
         self.handle = h
+        self.set_precision(precision)
         self._weights = {}      # name -> tensor kept alive
         self._const_ws = None
         self._ws = None
@@ -36,6 +37,13 @@ class Engine:
                 self.handle = None
         except Exception:
             pass
+
+    def set_precision(self, precision):
+        """'bf16x3' (default: split-precision bf16 MFMA for the encoder GEMMs) or 'f32' (exact-fp32 MFMA)."""
+        if precision not in nat.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(nat.PRECISIONS)}, got {precision!r}")
+        self.lib.check(self.lib.mdm_set_precision(self.handle, nat.PRECISIONS[precision]), "mdm_set_precision")
+        self.precision = precision
 
     # ---- plumbing -------------------------------------------------------------------------
     def _check_device(self, t):

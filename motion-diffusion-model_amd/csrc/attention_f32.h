@@ -32,7 +32,8 @@ template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float* __restrict__ qkv,
                                                                    float* __restrict__ out,
                                                                    const int* __restrict__ lengths,  // [B] or null
-                                                                   int S, int D, int H, int B) {
+                                                                   int S, int D, int H, int B,
+                                                                   bf16_t* __restrict__ oh, bf16_t* __restrict__ ol) {
   MDM_DYN_SMEM(float, smem);  // NKT*32 rows x ATT_KLD floats
   constexpr int NT = 64 * NKT;
   constexpr int ROWS = 32 * NKT;
@@ -153,10 +154,15 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float* __
       st4(&smem[q * ATT_KLD + d0], make_float4(o[dt][4 * g + 0], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]));
     }
   __syncthreads();
-  float* obase = out + (size_t)seq * S * D + head * ATT_HD;
+  const size_t obase = (size_t)seq * S * D + head * ATT_HD;
   for (int idx = tid; idx < ROWS * 32; idx += NT) {
     const int qq = idx >> 5, c4 = idx & 31;
-    if (qq < S) st4(obase + (size_t)qq * D + 4 * c4, ld4(&smem[qq * ATT_KLD + 4 * c4]));
+    if (qq < S) {
+      const float4 v = ld4(&smem[qq * ATT_KLD + 4 * c4]);
+      const size_t o = obase + (size_t)qq * D + 4 * c4;
+      if (out != nullptr) st4(out + o, v);
+      if (oh != nullptr) split4_store(oh + o, ol + o, v);  // planes for the out_proj bf16x3 GEMM
+    }
   }
 }
 

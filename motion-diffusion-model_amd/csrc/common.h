@@ -57,6 +57,71 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// ---------------------------------------------------------------------------------------------
+// Split-precision helpers: x = hi + lo (+ O(2^-17 |x|)), hi = bf16_rne(x), lo = bf16_rne(x - hi).
+// A fp32 product a*w is then carried by three bf16 MFMA products  ah*wh + ah*wl + al*wh  (the al*wl term,
+// ~2^-16 relative, is dropped), accumulated in fp32: SURVEY.md section 7 "Precision vs. peak".
+// ---------------------------------------------------------------------------------------------
+typedef unsigned short bf16_t;
+
+__host__ __device__ __forceinline__ float bf16_bits_to_f32(bf16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+
+__host__ __device__ __forceinline__ bf16_t f32_to_bf16_rne(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(unsigned short, (__bf16)x);   // v_cvt_pk_bf16_f32 (round-to-nearest-even)
+#else
+  uint32_t u;
+  __builtin_memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+#endif
+}
+
+__host__ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = f32_to_bf16_rne(x);
+  lo = f32_to_bf16_rne(x - bf16_bits_to_f32(hi));
+}
+
+// 4 consecutive values -> 8-byte packed hi and lo groups
+__device__ __forceinline__ void split4_store(bf16_t* hi_p, bf16_t* lo_p, float4 v) {
+  bf16_t h[4], l[4];
+  split_bf16(v.x, h[0], l[0]); split_bf16(v.y, h[1], l[1]); split_bf16(v.z, h[2], l[2]); split_bf16(v.w, h[3], l[3]);
+  *reinterpret_cast<uint2*>(hi_p) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+  *reinterpret_cast<uint2*>(lo_p) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+}
+
+// Direct global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the LDS destination is
+// `lds_wave_base + lane*16` (wave-uniform base, lane-linear image); the global source is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_base) {
+#ifdef MDM_EMU
+  memcpy(static_cast<char*>(lds_wave_base) + 16 * emu::lane_id(), gsrc_lane, 16);
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+// Workgroup barrier that does NOT drain the vector-memory queue (cdna_hip_programming.md section 5: __syncthreads()
+// would wait vmcnt(0) while an LDS-DMA is in flight); pair it with an explicit wait where the data is consumed.
+__device__ __forceinline__ void wg_barrier() {
+#ifdef MDM_EMU
+  emu::block_barrier();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#endif
+}
+__device__ __forceinline__ void wait_vmem_all() {
+#ifndef MDM_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 

@@ -11,7 +11,8 @@ namespace mdm {
 // two-pass (mean, then centred sum of squares) entirely in registers.
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, int rows, float eps) {
+                                                        const float* __restrict__ beta, int rows, float eps,
+                                                        bf16_t* __restrict__ xh, bf16_t* __restrict__ xl) {
   constexpr int D = 256 * NV;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -39,8 +40,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const float4 g = ld4(gamma + 256 * i + 4 * lane), b = ld4(beta + 256 * i + 4 * lane);
-    st4(xr + 256 * i + 4 * lane, make_float4(v[i].x * rstd * g.x + b.x, v[i].y * rstd * g.y + b.y,
-                                             v[i].z * rstd * g.z + b.z, v[i].w * rstd * g.w + b.w));
+    const float4 o = make_float4(v[i].x * rstd * g.x + b.x, v[i].y * rstd * g.y + b.y, v[i].z * rstd * g.z + b.z,
+                                 v[i].w * rstd * g.w + b.w);
+    st4(xr + 256 * i + 4 * lane, o);
+    if (xh != nullptr) {  // split planes for the next bf16x3 GEMM
+      const size_t off = (size_t)row * D + 256 * i + 4 * lane;
+      split4_store(xh + off, xl + off, o);
+    }
   }
 }
 
@@ -53,7 +59,8 @@ __global__ __launch_bounds__(256) void cond_token_kernel(float* __restrict__ tok
                                                          const long long* __restrict__ timesteps,  // [B] or null
                                                          int t_uniform,  // used when timesteps == null
                                                          const float* __restrict__ pe, int B, int S, int D,
-                                                         int uncond_from_branch, int table_rows) {
+                                                         int uncond_from_branch, int table_rows,
+                                                         bf16_t* __restrict__ th, bf16_t* __restrict__ tl) {
   const int seq = blockIdx.x, b = seq % B, br = seq / B;
   long long t = (timesteps != nullptr) ? timesteps[b] : (long long)t_uniform;
   if (t < 0) t = 0;
@@ -63,7 +70,9 @@ __global__ __launch_bounds__(256) void cond_token_kernel(float* __restrict__ tok
                                                                       : ld4(cond_emb + (size_t)b * D + c);
     const float4 tt = ld4(time_table + (size_t)t * D + c);
     const float4 p0 = ld4(pe + c);
-    st4(tok + (size_t)seq * S * D + c, make_float4(e.x + tt.x + p0.x, e.y + tt.y + p0.y, e.z + tt.z + p0.z, e.w + tt.w + p0.w));
+    const float4 o = make_float4(e.x + tt.x + p0.x, e.y + tt.y + p0.y, e.z + tt.z + p0.z, e.w + tt.w + p0.w);
+    st4(tok + (size_t)seq * S * D + c, o);
+    if (th != nullptr) split4_store(th + (size_t)seq * S * D + c, tl + (size_t)seq * S * D + c, o);
   }
 }
 
@@ -110,6 +119,13 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, con
     const float eps = (eps_in != nullptr) ? eps_in[i] : ns.get(b, e, i);
     out[i] = (init != nullptr) ? a * init[i] + s * eps : eps;
   }
+}
+
+// hi/lo bf16 planes of a fp32 array (weights at mdm_prepare; test inputs).  n must be a multiple of 4.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi,
+                                                           bf16_t* __restrict__ lo, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    split4_store(hi + 4 * i, lo + 4 * i, ld4(src + 4 * i));
 }
 
 // dst[r][0..ld_dst) = src[r][0..cols) zero-padded (16-byte-aligns the 263-wide poseEmbedding weight rows).

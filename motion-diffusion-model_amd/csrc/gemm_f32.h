@@ -96,15 +96,18 @@ struct CfgTokenLoader {
 // ------------------------------------------------------------------------------------------------
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
 
-// out[m][n] = act(acc + bias[n]) * (n < scale_cols ? col_scale : 1) + (res ? res[m][n] : 0)
+// v = act(acc + bias[n]) * (n < scale_cols ? col_scale : 1) + (res ? res[m][n] : 0);
+// out[m][n] = v (if out) and/or the bf16 split planes oh/ol[m][n] = hi/lo(v) (if oh) for a following bf16x3 GEMM.
 struct LinearEpilogue {
-  float* out;
+  float* out;        // may be null when only the planes are wanted
   const float* bias;
   const float* res;  // may alias out (each element is read then written by the same lane)
   int ld;
   int act;
   int scale_cols;   // columns [0, scale_cols) are multiplied by col_scale (q * 1/sqrt(hd) for in_proj)
   float col_scale;
+  bf16_t* oh;       // optional split planes, same [M][ld] shape
+  bf16_t* ol;
   struct Row { size_t base; };
   struct Col { int n; float bias, mult; };
   __device__ __forceinline__ Row row(int m) const { return Row{(size_t)m * ld}; }
@@ -116,7 +119,8 @@ struct LinearEpilogue {
     v *= c.mult;
     const size_t o = r.base + c.n;
     if (res != nullptr) v += res[o];
-    out[o] = v;
+    if (out != nullptr) out[o] = v;
+    if (oh != nullptr) split_bf16(v, oh[o], ol[o]);
   }
 };
 
@@ -127,6 +131,8 @@ struct EmbedEpilogue {
   const float* bias;   // [D]
   const float* pe;     // [max_len, D]
   int B, T, S, D, nbranch;
+  bf16_t* th;          // optional split planes of tok (bf16x3 mode)
+  bf16_t* tl;
   struct Row { size_t tok_off, pe_off; };
   struct Col { int n; float bias; };
   __device__ __forceinline__ Row row(int m) const {
@@ -138,6 +144,12 @@ struct EmbedEpilogue {
     const float v = acc + c.bias + pe[r.pe_off + c.n];
     tok[r.tok_off + c.n] = v;
     if (nbranch == 2) tok[r.tok_off + (size_t)B * S * D + c.n] = v;
+    if (th != nullptr) {
+      bf16_t hi, lo;
+      split_bf16(v, hi, lo);
+      th[r.tok_off + c.n] = hi; tl[r.tok_off + c.n] = lo;
+      if (nbranch == 2) { th[r.tok_off + (size_t)B * S * D + c.n] = hi; tl[r.tok_off + (size_t)B * S * D + c.n] = lo; }
+    }
   }
 };
 

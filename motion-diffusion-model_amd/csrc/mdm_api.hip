@@ -17,6 +17,7 @@
 #include "common.h"
 #include "elementwise.h"
 #include "gemm_f32.h"
+#include "gemm_bf16x3.h"
 
 using namespace mdm;
 
@@ -101,6 +102,9 @@ struct mdm_model {
   float* w_in_pad = nullptr;    // [D][JFpad]
   float* time_table = nullptr;  // [max_len][D]
   int jf = 0, jf_pad = 0;
+  int precision = MDM_PREC_BF16X3;
+  struct LayerPlanes { X3Operand in_proj, out_proj, linear1, linear2; };
+  std::vector<LayerPlanes> planes;  // bf16 hi/lo planes of the encoder weights (built by mdm_prepare)
 
   const float* W(const std::string& k) const { return w.at(k); }
   const float* L(int layer, const char* suffix) const {
@@ -112,6 +116,9 @@ namespace {
 
 struct Workspace {
   float *tok, *qkv, *att, *ffn, *cond;
+  bf16_t *tokh, *tokl;  // split planes of tok (bf16x3 mode)
+  bf16_t *atth, *attl;  // alias att: the attention output is only consumed by the out_proj GEMM
+  bf16_t *ffnh, *ffnl;  // alias ffn: the GELU output is only consumed by the linear2 GEMM
   size_t bytes;
 };
 
@@ -129,18 +136,26 @@ Workspace carve(const mdm_model* m, int nseq, int T, void* base) {
   w.att = take(M * D);
   w.ffn = take(M * FF);
   w.cond = take((size_t)nseq * D);
+  float* tp = take(M * D);  // two bf16 planes = one fp32 array's worth of bytes
+  w.tokh = reinterpret_cast<bf16_t*>(tp);
+  w.tokl = tp ? w.tokh + M * D : nullptr;
+  w.atth = reinterpret_cast<bf16_t*>(w.att);
+  w.attl = w.att ? w.atth + M * D : nullptr;
+  w.ffnh = reinterpret_cast<bf16_t*>(w.ffn);
+  w.ffnl = w.ffn ? w.ffnh + M * FF : nullptr;
   w.bytes = off;
   return w;
 }
 
-int launch_layernorm(Profiler* pf, float* x, const float* g, const float* b, int rows, int D, hipStream_t s) {
+int launch_layernorm(Profiler* pf, float* x, const float* g, const float* b, int rows, int D, bf16_t* xh, bf16_t* xl,
+                     hipStream_t s) {
   ProfScope ps(pf, MDM_PROF_LAYERNORM, 0.0, s);
   const dim3 grid((rows + 3) / 4), block(256);
   switch (D / 256) {
-    case 1: { auto k = &layernorm_kernel<1>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f); break; }
-    case 2: { auto k = &layernorm_kernel<2>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f); break; }
-    case 3: { auto k = &layernorm_kernel<3>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f); break; }
-    case 4: { auto k = &layernorm_kernel<4>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f); break; }
+    case 1: { auto k = &layernorm_kernel<1>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl); break; }
+    case 2: { auto k = &layernorm_kernel<2>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl); break; }
+    case 3: { auto k = &layernorm_kernel<3>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl); break; }
+    case 4: { auto k = &layernorm_kernel<4>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl); break; }
     default: return fail(MDM_EUNSUPPORTED, "layernorm: D must be 256, 512, 768 or 1024");
   }
   return rt_launch_status();
@@ -148,27 +163,27 @@ int launch_layernorm(Profiler* pf, float* x, const float* g, const float* b, int
 
 template <int NKT>
 int launch_attention_t(const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D, int H,
-                       hipStream_t s) {
+                       bf16_t* oh, bf16_t* ol, hipStream_t s) {
   auto k = &attention_f32_kernel<NKT>;
   const size_t lds = attention_lds_bytes(NKT);
   if (int rc = rt_allow_lds(k, lds)) return rc;
-  MDM_LAUNCH(k, dim3(nseq * H), dim3(64 * NKT), lds, s, qkv, out, lengths, S, D, H, B);
+  MDM_LAUNCH(k, dim3(nseq * H), dim3(64 * NKT), lds, s, qkv, out, lengths, S, D, H, B, oh, ol);
   return rt_launch_status();
 }
 
 int launch_attention(Profiler* pf, const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D,
-                     int H, hipStream_t s) {
+                     int H, bf16_t* oh, bf16_t* ol, hipStream_t s) {
   ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * H * (double)S * S * ATT_HD, s);
   if (D != H * ATT_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
   if (S < 1 || S > 224) return fail(MDM_EUNSUPPORTED, "attention: 1 <= S <= 224 tokens (T <= 223 frames)");
   switch ((S + 31) / 32) {
-    case 1: return launch_attention_t<1>(qkv, out, lengths, nseq, B, S, D, H, s);
-    case 2: return launch_attention_t<2>(qkv, out, lengths, nseq, B, S, D, H, s);
-    case 3: return launch_attention_t<3>(qkv, out, lengths, nseq, B, S, D, H, s);
-    case 4: return launch_attention_t<4>(qkv, out, lengths, nseq, B, S, D, H, s);
-    case 5: return launch_attention_t<5>(qkv, out, lengths, nseq, B, S, D, H, s);
-    case 6: return launch_attention_t<6>(qkv, out, lengths, nseq, B, S, D, H, s);
-    default: return launch_attention_t<7>(qkv, out, lengths, nseq, B, S, D, H, s);
+    case 1: return launch_attention_t<1>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
+    case 2: return launch_attention_t<2>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
+    case 3: return launch_attention_t<3>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
+    case 4: return launch_attention_t<4>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
+    case 5: return launch_attention_t<5>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
+    case 6: return launch_attention_t<6>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
+    default: return launch_attention_t<7>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
   }
 }
 
@@ -178,8 +193,27 @@ int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, cons
   if (K % 4 != 0 || ld_in % 4 != 0) return fail(MDM_EINVAL, "linear: K and the row stride must be multiples of 4");
   RowMajorLoader al{in, ld_in, M, K};
   RowMajorLoader bl{w, K, N, K};
-  LinearEpilogue ep{out, bias, res, N, act, scale_cols, col_scale};
+  LinearEpilogue ep{out, bias, res, N, act, scale_cols, col_scale, nullptr, nullptr};
   launch_gemm_f32(al, bl, ep, M, N, K, s);
+  return rt_launch_status();
+}
+
+// bf16x3 GEMM on pre-split operands; writes fp32 `out` and/or split planes oh/ol.
+int launch_linear_x3(Profiler* pf, X3Operand a, X3Operand w, const float* bias, const float* res, float* out,
+                     bf16_t* oh, bf16_t* ol, int M, int N, int K, int act, int scale_cols, float col_scale,
+                     hipStream_t s) {
+  if (K % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 linear: K must be a multiple of 32");
+  ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
+  LinearEpilogue ep{out, bias, res, N, act, scale_cols, col_scale, oh, ol};
+  launch_gemm_bf16x3(a, w, ep, M, N, K, s);
+  return rt_launch_status();
+}
+
+int launch_split(const float* src, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t s) {
+  if (n % 4 != 0) return fail(MDM_EINVAL, "split: element count must be a multiple of 4");
+  const size_t n4 = n / 4;
+  const int grid = (int)std::min<size_t>((n4 + 255) / 256, 4096);
+  MDM_LAUNCH(split_planes_kernel, dim3(grid), dim3(256), 0, s, src, hi, lo, n4);
   return rt_launch_status();
 }
 
@@ -191,8 +225,9 @@ int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long l
   const int D = m->cfg.latent_dim, S = T + 1;
   PoseGatherLoader al{x, T, m->jf, B * T};
   RowMajorLoader bl{m->w_in_pad, m->jf_pad, D, m->jf_pad};
+  const bool x3 = m->precision == MDM_PREC_BF16X3;
   EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D,
-                   nbranch};
+                   nbranch, x3 ? ws.tokh : nullptr, x3 ? ws.tokl : nullptr};
   {
     ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
     launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
@@ -201,7 +236,7 @@ int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long l
   ProfScope ps(&m->prof, MDM_PROF_ELEMENTWISE, 0.0, s);
   MDM_LAUNCH(cond_token_kernel, dim3(nbranch * B), dim3(128), 0, s, ws.tok, cond_emb, m->W("embed_text.bias"),
              (const float*)m->time_table, timesteps, 0, m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from_branch,
-             (int)m->cfg.max_len);
+             (int)m->cfg.max_len, x3 ? ws.tokh : (bf16_t*)nullptr, x3 ? ws.tokl : (bf16_t*)nullptr);
   return rt_launch_status();
 }
 
@@ -210,18 +245,37 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
   Profiler* pf = &m->prof;
   const int D = m->cfg.latent_dim, FF = m->cfg.ff_size, H = m->cfg.num_heads, M = nseq * S;
   const float qscale = 1.0f / sqrtf((float)(D / H));
+  if (m->precision == MDM_PREC_BF16X3) {
+    // tok (fp32, residual stream) travels with its split planes tokh/tokl; attention and GELU outputs exist only as planes
+    const X3Operand tokp{ws.tokh, ws.tokl}, attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
+    for (int l = 0; l < m->cfg.num_layers; ++l) {
+      const mdm_model::LayerPlanes& P = m->planes[l];
+      if (int rc = launch_linear_x3(pf, tokp, P.in_proj, m->L(l, "self_attn.in_proj_bias"), nullptr, ws.qkv, nullptr,
+                                    nullptr, M, 3 * D, D, ACT_NONE, D, qscale, s)) return rc;
+      if (int rc = launch_attention(pf, ws.qkv, nullptr, lengths, nseq, B, S, D, H, ws.atth, ws.attl, s)) return rc;
+      if (int rc = launch_linear_x3(pf, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"), ws.tok, ws.tok, nullptr,
+                                    nullptr, M, D, D, ACT_NONE, 0, 1.f, s)) return rc;
+      if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, ws.tokh, ws.tokl, s)) return rc;
+      if (int rc = launch_linear_x3(pf, tokp, P.linear1, m->L(l, "linear1.bias"), nullptr, nullptr, ws.ffnh, ws.ffnl, M,
+                                    FF, D, ACT_GELU, 0, 1.f, s)) return rc;
+      if (int rc = launch_linear_x3(pf, ffnp, P.linear2, m->L(l, "linear2.bias"), ws.tok, ws.tok, nullptr, nullptr, M, D,
+                                    FF, ACT_NONE, 0, 1.f, s)) return rc;
+      if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, ws.tokh, ws.tokl, s)) return rc;
+    }
+    return 0;
+  }
   for (int l = 0; l < m->cfg.num_layers; ++l) {
     if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "self_attn.in_proj_weight"), m->L(l, "self_attn.in_proj_bias"),
                                nullptr, ws.qkv, M, 3 * D, D, ACT_NONE, D, qscale, s)) return rc;
-    if (int rc = launch_attention(pf, ws.qkv, ws.att, lengths, nseq, B, S, D, H, s)) return rc;
+    if (int rc = launch_attention(pf, ws.qkv, ws.att, lengths, nseq, B, S, D, H, nullptr, nullptr, s)) return rc;
     if (int rc = launch_linear(pf, ws.att, D, m->L(l, "self_attn.out_proj.weight"), m->L(l, "self_attn.out_proj.bias"),
                                ws.tok, ws.tok, M, D, D, ACT_NONE, 0, 1.f, s)) return rc;
-    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, s)) return rc;
+    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, nullptr, nullptr, s)) return rc;
     if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "linear1.weight"), m->L(l, "linear1.bias"), nullptr, ws.ffn, M,
                                FF, D, ACT_GELU, 0, 1.f, s)) return rc;
     if (int rc = launch_linear(pf, ws.ffn, FF, m->L(l, "linear2.weight"), m->L(l, "linear2.bias"), ws.tok, ws.tok, M,
                                D, FF, ACT_NONE, 0, 1.f, s)) return rc;
-    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, s)) return rc;
+    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, nullptr, nullptr, s)) return rc;
   }
   return 0;
 }
@@ -244,7 +298,7 @@ int mdm_create(const mdm_config_t* cfg, mdm_model_t** out) {
   const int D = cfg->latent_dim, H = cfg->num_heads;
   if (D <= 0 || D % 256 != 0 || D > 1024) return fail(MDM_EUNSUPPORTED, "latent_dim must be 256, 512, 768 or 1024");
   if (H <= 0 || D != H * ATT_HD) return fail(MDM_EUNSUPPORTED, "latent_dim / num_heads must be 128");
-  if (cfg->ff_size <= 0 || cfg->ff_size % 4) return fail(MDM_EUNSUPPORTED, "ff_size must be a positive multiple of 4");
+  if (cfg->ff_size <= 0 || cfg->ff_size % 32) return fail(MDM_EUNSUPPORTED, "ff_size must be a positive multiple of 32");
   if (cfg->clip_dim <= 0 || cfg->clip_dim % 4) return fail(MDM_EUNSUPPORTED, "clip_dim must be a positive multiple of 4");
   if (cfg->njoints <= 0 || cfg->nfeats <= 0 || cfg->num_layers <= 0 || cfg->max_len < 2)
     return fail(MDM_EINVAL, "mdm_create: non-positive dimension");
@@ -303,7 +357,10 @@ int mdm_set_weight(mdm_model_t* m, const char* name, const float* dev_ptr, int64
 size_t mdm_const_bytes(const mdm_model_t* m) {
   if (m == nullptr) return 0;
   const size_t D = m->cfg.latent_dim;
-  return align_up(D * m->jf_pad * sizeof(float), 256) + 2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256);
+  const size_t FF = m->cfg.ff_size;
+  const size_t per_layer = align_up(3 * D * D * 4, 256) + align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
+  return align_up(D * m->jf_pad * sizeof(float), 256) + 2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) +
+         (size_t)m->cfg.num_layers * per_layer;
 }
 
 int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* stream) {
@@ -330,7 +387,33 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
                              m->W("embed_timestep.time_embed.2.bias"), nullptr, m->time_table, R, D, D, ACT_NONE, 0,
                              1.f, s))
     return rc;
+  // bf16 hi/lo planes of the encoder weights (always built: the precision mode can be switched afterwards)
+  base += align_up((size_t)R * D * sizeof(float), 256);
+  const size_t FF = m->cfg.ff_size;
+  m->planes.assign(m->cfg.num_layers, mdm_model::LayerPlanes{});
+  auto make_planes = [&](const float* src, size_t n, X3Operand& op) -> int {
+    bf16_t* hi = reinterpret_cast<bf16_t*>(base);
+    bf16_t* lo = hi + n;
+    base += align_up(n * 4, 256);
+    op = X3Operand{hi, lo};
+    return launch_split(src, hi, lo, n, s);
+  };
+  for (int l = 0; l < m->cfg.num_layers; ++l) {
+    if (int rc = make_planes(m->L(l, "self_attn.in_proj_weight"), (size_t)3 * D * D, m->planes[l].in_proj)) return rc;
+    if (int rc = make_planes(m->L(l, "self_attn.out_proj.weight"), (size_t)D * D, m->planes[l].out_proj)) return rc;
+    if (int rc = make_planes(m->L(l, "linear1.weight"), FF * D, m->planes[l].linear1)) return rc;
+    if (int rc = make_planes(m->L(l, "linear2.weight"), (size_t)D * FF, m->planes[l].linear2)) return rc;
+  }
   m->prepared = true;
+  return MDM_OK;
+}
+
+int mdm_set_precision(mdm_model_t* m, int32_t mode) {
+  if (m == nullptr) return fail(MDM_EINVAL, "mdm_set_precision: null model");
+  if (mode != MDM_PREC_F32 && mode != MDM_PREC_BF16X3) return fail(MDM_EINVAL, "mdm_set_precision: unknown mode");
+  if (mode == MDM_PREC_BF16X3 && (m->cfg.latent_dim % X3_BK != 0 || m->cfg.ff_size % X3_BK != 0))
+    return fail(MDM_EUNSUPPORTED, "bf16x3 needs latent_dim and ff_size to be multiples of 32");
+  m->precision = mode;
   return MDM_OK;
 }
 
@@ -436,7 +519,9 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
     {
       PoseGatherLoader al{x, T, m->jf, B * T};
       RowMajorLoader bl{m->w_in_pad, m->jf_pad, D, m->jf_pad};
-      EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D, nbranch};
+      const bool x3 = m->precision == MDM_PREC_BF16X3;
+      EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D, nbranch,
+                       x3 ? ws.tokh : nullptr, x3 ? ws.tokl : nullptr};
       {
         ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
         launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
@@ -446,7 +531,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
       MDM_LAUNCH(cond_token_kernel, dim3(nseq), dim3(128), 0, s, ws.tok, (const float*)ws.cond,
                  m->W("embed_text.bias"), (const float*)m->time_table, (const long long*)nullptr,
                  (int)p->timestep_map[i], m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from,
-                 (int)m->cfg.max_len);
+                 (int)m->cfg.max_len, x3 ? ws.tokh : (bf16_t*)nullptr, x3 ? ws.tokl : (bf16_t*)nullptr);
       if (int rc = rt_launch_status()) return rc;
     }
     if (int rc = encoder(m, ws, nseq, B, S, len, s)) return rc;
@@ -527,15 +612,35 @@ int mdm_linear(const float* in, const float* w, const float* bias, const float* 
   return launch_linear(nullptr, in, K, w, bias, res, out, M, N, K, act, 0, 1.f, static_cast<hipStream_t>(stream));
 }
 
+size_t mdm_linear_bf16x3_scratch_bytes(int32_t M, int32_t N, int32_t K) {
+  return align_up((size_t)M * K * 4, 256) + align_up((size_t)N * K * 4, 256);
+}
+
+int mdm_linear_bf16x3(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M,
+                      int32_t N, int32_t K, int32_t act, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!in || !w || !bias || !out || !scratch || M <= 0 || N <= 0 || K <= 0) return fail(MDM_EINVAL, "mdm_linear_bf16x3: bad argument");
+  if (K % X3_BK != 0) return fail(MDM_EINVAL, "mdm_linear_bf16x3: K must be a multiple of 32");
+  if (scratch_bytes < mdm_linear_bf16x3_scratch_bytes(M, N, K)) return fail(MDM_ENOSPC, "mdm_linear_bf16x3: scratch too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bf16_t* ah = static_cast<bf16_t*>(scratch);
+  bf16_t* al = ah + (size_t)M * K;
+  bf16_t* wh = reinterpret_cast<bf16_t*>(static_cast<char*>(scratch) + align_up((size_t)M * K * 4, 256));
+  bf16_t* wl = wh + (size_t)N * K;
+  if (int rc = launch_split(in, ah, al, (size_t)M * K, s)) return rc;
+  if (int rc = launch_split(w, wh, wl, (size_t)N * K, s)) return rc;
+  return launch_linear_x3(nullptr, X3Operand{ah, al}, X3Operand{wh, wl}, bias, res, out, nullptr, nullptr, M, N, K, act, 0,
+                          1.f, s);
+}
+
 int mdm_layernorm(float* x, const float* gamma, const float* beta, int32_t rows, int32_t D, void* stream) {
   if (!x || !gamma || !beta || rows <= 0 || D % 256 != 0) return fail(MDM_EINVAL, "mdm_layernorm: bad argument");
-  return launch_layernorm(nullptr, x, gamma, beta, rows, D, static_cast<hipStream_t>(stream));
+  return launch_layernorm(nullptr, x, gamma, beta, rows, D, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int mdm_attention(const float* qkv, float* out, const int32_t* lengths, int32_t nseq, int32_t B, int32_t S, int32_t D,
                   int32_t H, void* stream) {
   if (!qkv || !out || nseq <= 0 || B <= 0) return fail(MDM_EINVAL, "mdm_attention: bad argument");
-  return launch_attention(nullptr, qkv, out, lengths, nseq, B, S, D, H, static_cast<hipStream_t>(stream));
+  return launch_attention(nullptr, qkv, out, lengths, nseq, B, S, D, H, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

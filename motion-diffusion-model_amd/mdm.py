@@ -9,6 +9,7 @@ Scope: arch='trans_enc', text conditioning with a cached `y['text_
 (or no conditioning), inference only.  Everything else raises NotImplementedError loudly.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -104,6 +105,8 @@ class MDM(nn.Module):
         self.text_encoder_type = kargs.get('text_encoder_type', 'clip')
         self.clip_version = clip_version
         self._native_lib = kargs.get('_native_lib', None)      # tests inject the CPU emulation here
+        # arithmetic of the encoder GEMMs (include/mdm_hip.h mdm_set_precision): 'bf16x3' | 'f32'
+        self.precision = kargs.get('precision', os.environ.get('MDM_PRECISION', 'bf16x3'))
 
         if arch != 'trans_enc':
             raise NotImplementedError(f"arch={arch!r}: only the trans_enc denoiser is on the MI355X hot path (SURVEY.md 8f)")
@@ -181,12 +184,12 @@ class MDM(nn.Module):
     def engine(self):
         """Native handle bound to the current parameters (rebuilt when they move or change)."""
         p = self.input_process.poseEmbedding.weight
-        key = (str(p.device),) + tuple((q.data_ptr(), q._version) for q in self.parameters_wo_clip())
+        key = (str(p.device), self.precision) + tuple((q.data_ptr(), q._version) for q in self.parameters_wo_clip())
         if self._engine is None or self._engine_key != key:
             cfg = dict(njoints=self.njoints, nfeats=self.nfeats, latent_dim=self.latent_dim, ff_size=self.ff_size,
                        num_layers=self.num_layers, num_heads=self.num_heads, clip_dim=self.clip_dim,
                        max_len=self.sequence_pos_encoder.pe.shape[0], mask_frames=int(bool(self.mask_frames)))
-            eng = Engine(cfg, lib=self._native_lib)
+            eng = Engine(cfg, lib=self._native_lib, precision=self.precision)
             eng.bind(self._native_state(), p.device)
             self._engine, self._engine_key = eng, key
         return self._engine

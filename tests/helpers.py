@@ -17,12 +17,13 @@ from oracle import mdm_oracle as orc  # noqa: E402
 from oracle.synth import synth_state_dict, synth_y  # noqa: E402
 
 
-def make_pair(sd, steps, device, guided=True, native_lib=None, **arg_over):
+def make_pair(sd, steps, device, guided=True, native_lib=None, precision="bf16x3", **arg_over):
     """(model, diffusion) exactly as sample/generate.py:85-96 assembles them."""
     layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("seqTransEncoder.layers."))
     d = sd["input_process.poseEmbedding.weight"].shape[0]
     args = model_util.default_args(diffusion_steps=steps, layers=layers, latent_dim=d, **arg_over)
-    model, diffusion = model_util.create_model_and_diffusion(args, _native_lib=native_lib, num_heads=d // 128)
+    model, diffusion = model_util.create_model_and_diffusion(args, _native_lib=native_lib, num_heads=d // 128,
+                                                             precision=precision)
     model_util.load_model_wo_clip(model, sd)
     if guided:
         model = ClassifierFreeSampleModel(model)
@@ -49,9 +50,10 @@ def golden_loop_inputs(g):
                 cfg=bool(g["cfg"]), ddim=bool(g["ddim"]), eta=float(g["eta"]))
 
 
-def run_product_loop(sd, case, device, native_lib=None, dump_steps=None):
+def run_product_loop(sd, case, device, native_lib=None, dump_steps=None, precision="bf16x3"):
     """The golden case through SpacedDiffusion.p_sample_loop / ddim_sample_loop of the product."""
-    model, diffusion = make_pair(sd, case["steps"], device, guided=case["cfg"], native_lib=native_lib)
+    model, diffusion = make_pair(sd, case["steps"], device, guided=case["cfg"], native_lib=native_lib,
+                                 precision=precision)
     seq = [case["x_T"]] + [n.contiguous() for n in case["noises"]]
     kw = dict(clip_denoised=False, model_kwargs={"y": dict(case["y"])}, skip_timesteps=case["skip"],
               init_image=case["init_image"], noise_sequence=seq)

@@ -20,10 +20,11 @@ def lib():
     return emu()
 
 
-def test_emulated_cfg_loop_matches_oracle(lib):
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-4), ("f32", 2e-5)])
+def test_emulated_cfg_loop_matches_oracle(lib, prec, tol):
     steps, B, T = 2, 2, 9
     sd = small_state_dict(num_layers=1)
-    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, precision=prec)
     y = synth_y(B, T, seed=5, lengths=[T, 4])
     shape = (B, 263, 1, T)
     x_T, noises = orc.make_noise(shape, steps, 11)
@@ -31,13 +32,13 @@ def test_emulated_cfg_loop_matches_oracle(lib):
                                   noise_sequence=[x_T] + [n.contiguous() for n in noises])
     want = orc.sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), shape, y, x_T, noises, cfg=True,
                            num_heads=2)
-    assert maxabs(got, want) < 2e-5
+    assert maxabs(got, want) < tol
 
 
 def test_emulated_forward_branches(lib):
     B, T = 2, 33                                   # S = 34: two key tiles, ragged tail
     sd = small_state_dict(num_layers=1)
-    model, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib)
+    model, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib, precision="f32")
     y = synth_y(B, T, seed=2, lengths=[33, 5])
     g = torch.Generator().manual_seed(0)
     x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 0])
@@ -58,6 +59,25 @@ def test_emulated_linear(lib, M, N, K, act, res):
     if res:
         ref = ref + torch.from_numpy(r).double()
     assert maxabs(out, ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(130, 70, 64, 0, True), (5, 129, 32, 1, False), (260, 256, 96, 0, False)])
+def test_emulated_linear_bf16x3(lib, M, N, K, act, res):
+    """LDS-DMA source swizzle, fragment reads and the 3-product accumulation of gemm_bf16x3.h, incl. ragged M/N tiles."""
+    rng = np.random.default_rng(M)
+    a, w = f32(rng.standard_normal((M, K))), f32(rng.standard_normal((N, K)) / np.sqrt(K))
+    b = f32(rng.standard_normal(N))
+    r = f32(rng.standard_normal((M, N))) if res else None
+    out = np.full((M, N), np.nan, np.float32)
+    nb = lib.mdm_linear_bf16x3_scratch_bytes(M, N, K)
+    scratch = np.zeros(nb, np.uint8)
+    lib.check(lib.mdm_linear_bf16x3(ptr(a), ptr(w), ptr(b), ptr(r) if res else None, ptr(out), M, N, K, act,
+                                    ptr(scratch), nb, None), "linear_bf16x3")
+    ref = torch.from_numpy(a).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(b).double()
+    ref = torch.nn.functional.gelu(ref) if act == 1 else ref
+    if res:
+        ref = ref + torch.from_numpy(r).double()
+    assert maxabs(out, ref.numpy()) < 6e-5
 
 
 def test_emulated_attention_mask(lib):
