@@ -5,92 +5,132 @@
 // Why: the reference computes these `addmm`s in fp32 (model/mdm.py:77-84 -> torch TransformerEncoderLayer) and
 // BASELINE's parity bar is 1e-3 max-abs over a 50-step guided trajectory.  gfx950 has no TF32; exact-fp32 MFMA
 // peaks at 157 TFLOP/s, bf16 MFMA at 2.5 PFLOP/s, so three bf16 passes carry a ~2^-16-relative fp32 product at up to
-// ~5x the fp32 rate (measured trajectory error ~4e-5).  Replaces in_proj / out_proj / linear1 /
+// ~5x the fp32 rate (measured trajectory error ~3e-5).  Replaces in_proj / out_proj / linear1 /
 // linear2; the 263-wide input/output projections stay on the exact-fp32 kernel (gemm_f32.h).
 //
 // Data layout: both operands are stored K-contiguous as two bf16 planes [rows][K] (hi, lo).  Weights are split
 // once in mdm_prepare; activations are split by the PRODUCING kernel's epilogue (LayerNorm, attention, GELU), so the
 // main loop is pure LDS-DMA + MFMA.
 //
-// Machine mapping (gfx950): 256 threads = 4 waves (2x2), block tile 128x128, wave tile 64x64 = 2x2 MFMA tiles
-// (64 accumulator VGPRs), BK = 32.  One LDS stage = 4 planes x [128 rows][32 k] bf16 = 32 KB; two stages (64 KB,
-// two workgroups per CU).
+// Machine mapping (gfx950): 512 threads = 8 waves, one workgroup per CU.  Block tile = up to 224 rows x 256 columns;
+// the row extent is chosen by the host as a whole number of token sequences (S = 197 -> one sequence per tile), so
+// the headline shape (256 sequences, N in {512, 1024, 1536}) gives exactly N/256 equal tiles per CU: no tail wave.
+// Wave w owns columns [32w, 32w+32) x all 7 row sub-tiles (7 accumulators = 112 VGPRs); its W fragment feeds 21
+// MFMAs per 16-deep k sub-step.  BK = 32; one LDS stage = Ah|Al [224][32] + Wh|Wl [256][32] bf16 = 60 KB, two stages.
 //   * global -> LDS by global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass); the next stage is issued
-//     before the MFMAs of the current one and retired by ONE s_waitcnt vmcnt(0) + s_barrier per K step;
+//     before the MFMAs of the current one (2 waves/SIMD x 42 MFMAs = 2.7k matrix-pipe cycles of cover) and retired
+//     by ONE s_waitcnt vmcnt(0) + s_barrier per K step;
 //   * the LDS image of a plane tile is row-major with 64-byte rows; the 16-byte chunk index is XOR-swizzled with
 //     (row>>2)&3 so the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots of the 256-byte bank row.
 //     LDS-DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address and to the reads
 //     (cdna_hip_programming.md rule 21);
-//   * per 16-deep k sub-step a wave issues 8 ds_read_b128 and 12 MFMAs (each fragment feeds 2-3 products);
-//   * XCD-aware tile order (n fastest inside an XCD's contiguous chunk) keeps an A row-panel in one L2.
+//   * XCD-aware tile order (the column tiles of one row panel are adjacent inside an XCD's contiguous chunk) keeps a
+//     sequence's activation planes in one L2; the weight planes of a layer (<= 3 MB) stay L2-resident everywhere.
 #pragma once
 #include "common.h"
-#include "gemm_f32.h"  // LinearEpilogue
+#include "gemm_f32.h"  // ACT_* enums
 
 namespace mdm {
 
-constexpr int X3_BM = 128, X3_BN = 128, X3_BK = 32, X3_THREADS = 256;
-constexpr int X3_PLANE_BYTES = X3_BM * X3_BK * 2;  // 8 KB
-constexpr int X3_STAGE_BYTES = 4 * X3_PLANE_BYTES;  // Ah, Al, Wh, Wl
+constexpr int X3_TM = 224, X3_TN = 256, X3_BK = 32, X3_THREADS = 512;
+constexpr int X3_MSUB = X3_TM / 32;                              // 7 row sub-tiles
+constexpr int X3_A_BYTES = X3_TM * X3_BK * 2;                    // one A plane tile: 14336
+constexpr int X3_W_BYTES = X3_TN * X3_BK * 2;                    // one W plane tile: 16384
+constexpr int X3_STAGE_BYTES = 2 * X3_A_BYTES + 2 * X3_W_BYTES;  // 61440
+constexpr int X3_LDS_BYTES = 2 * X3_STAGE_BYTES;                 // 122880
+constexpr int X3_GROUPS = X3_STAGE_BYTES / 1024;                 // 60 LDS-DMA wave-instructions per stage
 
 struct X3Operand {
   const bf16_t* hi;
   const bf16_t* lo;
 };
 
-template <class EP>
-__global__ __launch_bounds__(X3_THREADS, 2) void gemm_bf16x3_kernel(X3Operand A, X3Operand W, EP ep, int M, int N,
-                                                                     int K, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X3_STAGE_BYTES];
+// v = act(acc + bias[n]) * (n < scale_cols ? col_scale : 1) + (res ? res[m][n] : 0) -> fp32 out and/or split planes.
+struct X3Epilogue {
+  float* out;        // [M][ld] or null
+  const float* bias;
+  const float* res;  // [M][ld] or null; may alias out
+  bf16_t* oh;        // [M][ld] split planes or null
+  bf16_t* ol;
+  int ld;
+  int scale_cols;
+  float col_scale;
+};
+
+// exact-GELU with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, i.e. fp32-rounding class): one v_exp, one v_rcp
+// and a 5-term Horner chain instead of the ~40-instruction libm erff; used only in this split-precision path.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = 1.0f / (1.0f + 0.3275911f * z);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+#ifdef MDM_EMU
+  const float erfc_z = p * t * expf(-z * z);
+#else
+  const float erfc_z = p * t * __expf(-z * z);
+#endif
+  const float erf_abs = 1.0f - erfc_z;
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+template <int ACT, bool HAS_RES, bool OUT_F32, bool OUT_PLANES>
+__global__ __launch_bounds__(X3_THREADS, 2) void gemm_bf16x3_kernel(X3Operand A, X3Operand W, X3Epilogue ep, int M, int N,
+                                                                     int K, int rows_per_tile, int tiles_n) {
+  MDM_DYN_SMEM(unsigned char, lds);
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
+  const int lane = tid & 63;
+#ifdef MDM_EMU
+  const int wid = tid >> 6;
+#else
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
   const int r = lane & 31, h = lane >> 5;
-  const int wm = wid >> 1, wn = wid & 1;
 
   const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
-  const int m0 = tile_m * X3_BM, n0 = tile_n * X3_BN;
+  const int m0 = tile_m * rows_per_tile, n0 = tile_n * X3_TN;
 
-  // ---- LDS-DMA source offsets.  One wave instruction fills 16 rows x 64 B of a plane tile: lane -> (row = lane>>2,
-  // stored chunk = lane&3); the logical k-chunk it must fetch is stored ^ ((row>>2)&3) = (lane&3) ^ ((lane>>4)&3).
-  const int srow = wid * 16 + (lane >> 2);
+  // ---- LDS-DMA sources.  Stage image = 60 groups of 1 KB (16 rows x 64 B): groups 0-13 Ah, 14-27 Al, 28-43 Wh,
+  // 44-59 Wl.  Wave w issues groups w, w+8, ...  Lane -> (row = lane>>2, stored chunk = lane&3); the logical k-chunk it
+  // fetches is stored ^ ((row>>2)&3) = (lane&3) ^ ((lane>>4)&3).  Rows past the tile / matrix are clamped (their
+  // products are never stored).
   const int schunk = (lane & 3) ^ ((lane >> 4) & 3);
-  size_t a_off[2], w_off[2];
+  const bf16_t* src[8];
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    a_off[half] = (size_t)min(m0 + half * 64 + srow, M - 1) * K + schunk * 8;
-    w_off[half] = (size_t)min(n0 + half * 64 + srow, N - 1) * K + schunk * 8;
-  }
-  unsigned char* const lds_wave = lds + wid * 16 * 64;  // + stage + plane + half*4096
-
-  auto stage = [&](int buf, int k0) {
-    unsigned char* base = lds_wave + buf * X3_STAGE_BYTES;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      glds16(A.hi + a_off[half] + k0, base + 0 * X3_PLANE_BYTES + half * 4096);
-      glds16(A.lo + a_off[half] + k0, base + 1 * X3_PLANE_BYTES + half * 4096);
-      glds16(W.hi + w_off[half] + k0, base + 2 * X3_PLANE_BYTES + half * 4096);
-      glds16(W.lo + w_off[half] + k0, base + 3 * X3_PLANE_BYTES + half * 4096);
+  for (int i = 0; i < 8; ++i) {
+    const int q = wid + 8 * i;
+    if (q < 2 * X3_MSUB * 2) {  // A planes (28 groups)
+      const int g = (q < 14) ? q : q - 14;
+      const int row = min(m0 + g * 16 + (lane >> 2), M - 1);
+      src[i] = ((q < 14) ? A.hi : A.lo) + (size_t)row * K + schunk * 8;
+    } else {
+      const int qq = q - 28;
+      const int g = (qq < 16) ? qq : qq - 16;
+      const int row = min(n0 + g * 16 + (lane >> 2), N - 1);
+      src[i] = ((qq < 16) ? W.hi : W.lo) + (size_t)row * K + schunk * 8;
     }
+  }
+  auto stage = [&](int buf, int k0) {
+    unsigned char* base = lds + buf * X3_STAGE_BYTES + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (wid + 8 * i < X3_GROUPS) glds16(src[i] + k0, base + i * 8192);
   };
 
   // ---- fragment read offsets (bytes inside a plane tile): row*64 + ((ksub*2 + h) ^ sw)*16, sw = (row>>2)&3
   const int sw = (r >> 2) & 3;
-  int fa[2], fw[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    fa[t] = (wm * 64 + t * 32 + r) * 64;
-    fw[t] = (wn * 64 + t * 32 + r) * 64;
-  }
+  const int fa = r * 64;                 // + t*2048 per row sub-tile
+  const int fw = (wid * 32 + r) * 64;
 
-  f32x16 acc[2][2];
+  f32x16 acc[X3_MSUB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int t = 0; t < X3_MSUB; ++t)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
   const int nk = K / X3_BK;
   stage(0, 0);
@@ -99,59 +139,91 @@ __global__ __launch_bounds__(X3_THREADS, 2) void gemm_bf16x3_kernel(X3Operand A,
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * X3_BK);
-    const unsigned char* sb = lds + cur * X3_STAGE_BYTES;
+    const unsigned char* sa = lds + cur * X3_STAGE_BYTES;
+    const unsigned char* sw_ = sa + 2 * X3_A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int co = ((ks * 2 + h) ^ sw) * 16;
-      bf16x8 ah[2], al[2], wh[2], wl[2];
+      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(sw_ + fw + co);
+      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(sw_ + X3_W_BYTES + fw + co);
+      bf16x8 ah[X3_MSUB], al[X3_MSUB];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        ah[t] = *reinterpret_cast<const bf16x8*>(sb + 0 * X3_PLANE_BYTES + fa[t] + co);
-        al[t] = *reinterpret_cast<const bf16x8*>(sb + 1 * X3_PLANE_BYTES + fa[t] + co);
-        wh[t] = *reinterpret_cast<const bf16x8*>(sb + 2 * X3_PLANE_BYTES + fw[t] + co);
-        wl[t] = *reinterpret_cast<const bf16x8*>(sb + 3 * X3_PLANE_BYTES + fw[t] + co);
+      for (int t = 0; t < X3_MSUB; ++t) {
+        ah[t] = *reinterpret_cast<const bf16x8*>(sa + fa + t * 2048 + co);
+        al[t] = *reinterpret_cast<const bf16x8*>(sa + X3_A_BYTES + fa + t * 2048 + co);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = mfma_bf16(al[i], wh[j], acc[i][j]);
-          acc[i][j] = mfma_bf16(ah[i], wl[j], acc[i][j]);
-          acc[i][j] = mfma_bf16(ah[i], wh[j], acc[i][j]);
-        }
+      for (int t = 0; t < X3_MSUB; ++t) {
+        acc[t] = mfma_bf16(al[t], wh, acc[t]);
+        acc[t] = mfma_bf16(ah[t], wl, acc[t]);
+        acc[t] = mfma_bf16(ah[t], wh, acc[t]);
+      }
     }
     wait_vmem_all();
     wg_barrier();
   }
 
-  typename EP::Col cc[2];
-  bool nv[2];
+  // ---- epilogue: lane owns column n and rows t*32 + mfma_row(e, h)
+  const int n = n0 + wid * 32 + r;
+  if (n >= N) return;
+  const float bias = ep.bias[n];
+  const float mult = (n < ep.scale_cols) ? ep.col_scale : 1.f;
+  const int m_end = min(M, m0 + rows_per_tile);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + r;
-    nv[j] = n < N;
-    cc[j] = ep.col(nv[j] ? n : 0);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int t = 0; t < X3_MSUB; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int m = m0 + wm * 64 + i * 32 + mfma_row(e, h);
-      if (m < M) {
-        const typename EP::Row rc = ep.row(m);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (nv[j]) ep.store(rc, cc[j], acc[i][j][e]);
+      const int m = m0 + t * 32 + mfma_row(e, h);
+      if (m < m_end) {
+        const size_t o = (size_t)m * ep.ld + n;
+        float v = acc[t][e] + bias;
+        if (ACT == ACT_GELU) v = gelu_erf_fast(v);
+        else if (ACT == ACT_SILU) v = silu(v);
+        v *= mult;
+        if (HAS_RES) v += ep.res[o];
+        if (OUT_F32) ep.out[o] = v;
+        if (OUT_PLANES) split_bf16(v, ep.oh[o], ep.ol[o]);
       }
     }
 }
 
-template <class EP>
-inline void launch_gemm_bf16x3(const X3Operand& A, const X3Operand& W, const EP& ep, int M, int N, int K,
-                               hipStream_t stream) {
-  const int tiles_m = (M + X3_BM - 1) / X3_BM, tiles_n = (N + X3_BN - 1) / X3_BN;
-  auto kfn = &gemm_bf16x3_kernel<EP>;
-  MDM_LAUNCH(kfn, dim3(tiles_m * tiles_n), dim3(X3_THREADS), 0, stream, A, W, ep, M, N, K, tiles_n);
+// rows per block tile: a whole number of sequences when the row space is sequence-structured (keeps the tile count a
+// multiple of the sequence count -> no ragged last wave of workgroups), else the full 224.
+inline int x3_rows_per_tile(int M, int seq_len) {
+  if (seq_len > 0 && seq_len <= X3_TM && M % seq_len == 0) return (X3_TM / seq_len) * seq_len;
+  return X3_TM;
+}
+
+template <int ACT, bool HAS_RES, bool OUT_F32, bool OUT_PLANES>
+inline int launch_gemm_bf16x3_t(const X3Operand& A, const X3Operand& W, const X3Epilogue& ep, int M, int N, int K,
+                                int seq_len, hipStream_t stream) {
+  const int rpt = x3_rows_per_tile(M, seq_len);
+  const int tiles_m = (M + rpt - 1) / rpt, tiles_n = (N + X3_TN - 1) / X3_TN;
+  auto kfn = &gemm_bf16x3_kernel<ACT, HAS_RES, OUT_F32, OUT_PLANES>;
+#ifndef MDM_EMU
+  static bool configured = false;  // per instantiation
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            X3_LDS_BYTES) != hipSuccess)
+      return -1;
+    configured = true;
+  }
+#endif
+  MDM_LAUNCH(kfn, dim3(tiles_m * tiles_n), dim3(X3_THREADS), X3_LDS_BYTES, stream, A, W, ep, M, N, K, rpt, tiles_n);
+  return 0;
+}
+
+// runtime (act, res, outputs) -> one of the instantiations the encoder needs
+inline int launch_gemm_bf16x3(const X3Operand& A, const X3Operand& W, const X3Epilogue& ep, int M, int N, int K, int act,
+                              int seq_len, hipStream_t s) {
+  const bool res = ep.res != nullptr, f32 = ep.out != nullptr, pl = ep.oh != nullptr;
+  if (act == ACT_NONE && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_NONE, false, true, false>(A, W, ep, M, N, K, seq_len, s);
+  if (act == ACT_NONE && res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_NONE, true, true, false>(A, W, ep, M, N, K, seq_len, s);
+  if (act == ACT_GELU && !res && !f32 && pl) return launch_gemm_bf16x3_t<ACT_GELU, false, false, true>(A, W, ep, M, N, K, seq_len, s);
+  if (act == ACT_GELU && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_GELU, false, true, false>(A, W, ep, M, N, K, seq_len, s);
+  if (act == ACT_GELU && res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_GELU, true, true, false>(A, W, ep, M, N, K, seq_len, s);
+  if (act == ACT_SILU && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_SILU, false, true, false>(A, W, ep, M, N, K, seq_len, s);
+  return -2;
 }
 
 }  // namespace mdm

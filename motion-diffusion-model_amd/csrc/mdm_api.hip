@@ -198,14 +198,17 @@ int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, cons
   return rt_launch_status();
 }
 
-// bf16x3 GEMM on pre-split operands; writes fp32 `out` and/or split planes oh/ol.
+// bf16x3 GEMM on pre-split operands; writes fp32 `out` and/or split planes oh/ol.  seq_len > 0 tells the tiler that
+// the M rows are token sequences of that length (tile = whole sequences).
 int launch_linear_x3(Profiler* pf, X3Operand a, X3Operand w, const float* bias, const float* res, float* out,
-                     bf16_t* oh, bf16_t* ol, int M, int N, int K, int act, int scale_cols, float col_scale,
+                     bf16_t* oh, bf16_t* ol, int M, int N, int K, int act, int scale_cols, float col_scale, int seq_len,
                      hipStream_t s) {
   if (K % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 linear: K must be a multiple of 32");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
-  LinearEpilogue ep{out, bias, res, N, act, scale_cols, col_scale, oh, ol};
-  launch_gemm_bf16x3(a, w, ep, M, N, K, s);
+  X3Epilogue ep{out, bias, res, oh, ol, N, scale_cols, col_scale};
+  const int rc = launch_gemm_bf16x3(a, w, ep, M, N, K, act, seq_len, s);
+  if (rc == -1) return fail(MDM_EHIP, "bf16x3 linear: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 linear: unsupported (activation, residual, output) combination");
   return rt_launch_status();
 }
 
@@ -251,15 +254,15 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
     for (int l = 0; l < m->cfg.num_layers; ++l) {
       const mdm_model::LayerPlanes& P = m->planes[l];
       if (int rc = launch_linear_x3(pf, tokp, P.in_proj, m->L(l, "self_attn.in_proj_bias"), nullptr, ws.qkv, nullptr,
-                                    nullptr, M, 3 * D, D, ACT_NONE, D, qscale, s)) return rc;
+                                    nullptr, M, 3 * D, D, ACT_NONE, D, qscale, S, s)) return rc;
       if (int rc = launch_attention(pf, ws.qkv, nullptr, lengths, nseq, B, S, D, H, ws.atth, ws.attl, s)) return rc;
       if (int rc = launch_linear_x3(pf, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"), ws.tok, ws.tok, nullptr,
-                                    nullptr, M, D, D, ACT_NONE, 0, 1.f, s)) return rc;
+                                    nullptr, M, D, D, ACT_NONE, 0, 1.f, S, s)) return rc;
       if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, ws.tokh, ws.tokl, s)) return rc;
       if (int rc = launch_linear_x3(pf, tokp, P.linear1, m->L(l, "linear1.bias"), nullptr, nullptr, ws.ffnh, ws.ffnl, M,
-                                    FF, D, ACT_GELU, 0, 1.f, s)) return rc;
+                                    FF, D, ACT_GELU, 0, 1.f, S, s)) return rc;
       if (int rc = launch_linear_x3(pf, ffnp, P.linear2, m->L(l, "linear2.bias"), ws.tok, ws.tok, nullptr, nullptr, M, D,
-                                    FF, ACT_NONE, 0, 1.f, s)) return rc;
+                                    FF, ACT_NONE, 0, 1.f, S, s)) return rc;
       if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, ws.tokh, ws.tokl, s)) return rc;
     }
     return 0;
@@ -629,7 +632,7 @@ int mdm_linear_bf16x3(const float* in, const float* w, const float* bias, const 
   if (int rc = launch_split(in, ah, al, (size_t)M * K, s)) return rc;
   if (int rc = launch_split(w, wh, wl, (size_t)N * K, s)) return rc;
   return launch_linear_x3(nullptr, X3Operand{ah, al}, X3Operand{wh, wl}, bias, res, out, nullptr, nullptr, M, N, K, act, 0,
-                          1.f, s);
+                          1.f, 0, s);
 }
 
 int mdm_layernorm(float* x, const float* gamma, const float* beta, int32_t rows, int32_t D, void* stream) {
