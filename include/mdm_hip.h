@@ -173,6 +173,8 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x_dev, 
 int mdm_profile_enable(mdm_model_t* m, int on);
 int mdm_profile_read(mdm_model_t* m, int32_t category, double* total_ms, int64_t* launches, double* flops);
 int mdm_profile_reset(mdm_model_t* m);
+/* Kernel-ablation switches for profiling experiments (what = 0: bf16x3 GEMM; value 0 = production behaviour). */
+int mdm_debug_set(int what, int value);
 
 /* Building blocks, exported for the parity tests and for callers that compose their own layers.
  *   mdm_linear:    out[M,N] = act(in[M,K] . w[N,K]^T + bias) (+ res)     act: 0 none, 1 gelu(erf), 2 silu

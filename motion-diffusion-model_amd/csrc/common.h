@@ -116,6 +116,20 @@ __device__ __forceinline__ void wg_barrier() {
   __builtin_amdgcn_s_barrier();
 #endif
 }
+// Lanes of one wave exchange data through a wave-private LDS region: the hardware executes a wave's LDS
+// instructions in order, so no barrier instruction is needed -- only the emulator (lanes are fibers) must rendezvous.
+__device__ __forceinline__ void wave_lds_fence() {
+#ifdef MDM_EMU
+  emu::wave_barrier();
+#else
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
+__device__ __forceinline__ void wait_vmem_upto3() {  // at most 3 vector-memory operations of this wave still pending
+#ifndef MDM_EMU
+  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
+}
 __device__ __forceinline__ void wait_vmem_all() {
 #ifndef MDM_EMU
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

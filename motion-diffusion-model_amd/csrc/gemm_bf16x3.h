@@ -36,9 +36,13 @@ constexpr int X3_TM = 224, X3_TN = 256, X3_BK = 32, X3_THREADS = 512;
 constexpr int X3_MSUB = X3_TM / 32;                              // 7 row sub-tiles
 constexpr int X3_A_BYTES = X3_TM * X3_BK * 2;                    // one A plane tile: 14336
 constexpr int X3_W_BYTES = X3_TN * X3_BK * 2;                    // one W plane tile: 16384
-constexpr int X3_STAGE_BYTES = 2 * X3_A_BYTES + 2 * X3_W_BYTES;  // 61440
-constexpr int X3_LDS_BYTES = 2 * X3_STAGE_BYTES;                 // 122880
-constexpr int X3_GROUPS = X3_STAGE_BYTES / 1024;                 // 60 LDS-DMA wave-instructions per stage
+constexpr int X3_A_STAGE = 2 * X3_A_BYTES;                       // Ah|Al: 28672
+constexpr int X3_W_STAGE = 2 * X3_W_BYTES;                       // Wh|Wl: 32768
+constexpr int X3_A_RING = 3, X3_W_RING = 2;                      // activations come from MALL/HBM: prefetch 2 ahead;
+                                                                 // the weight tile is L2-hot (every CU reads it): 1 ahead
+constexpr int X3_W_BASE = X3_A_RING * X3_A_STAGE;
+constexpr int X3_LDS_BYTES = X3_W_BASE + X3_W_RING * X3_W_STAGE;  // 151552
+constexpr int X3_A_GROUPS = X3_A_STAGE / 1024, X3_W_GROUPS = X3_W_STAGE / 1024;  // 28 + 32 LDS-DMA wave-instructions
 
 struct X3Operand {
   const bf16_t* hi;
@@ -55,6 +59,8 @@ struct X3Epilogue {
   int ld;
   int scale_cols;
   float col_scale;
+  int ablate;        // profiling experiments only (0 in production): 1 = no epilogue stores, 2 = no loads after stage 0,
+                     // 4 = no MFMAs
 };
 
 // exact-GELU with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, i.e. fp32-rounding class): one v_exp, one v_rcp
@@ -94,31 +100,34 @@ __global__ __launch_bounds__(X3_THREADS, 2) void gemm_bf16x3_kernel(X3Operand A,
   const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
   const int m0 = tile_m * rows_per_tile, n0 = tile_n * X3_TN;
 
-  // ---- LDS-DMA sources.  Stage image = 60 groups of 1 KB (16 rows x 64 B): groups 0-13 Ah, 14-27 Al, 28-43 Wh,
-  // 44-59 Wl.  Wave w issues groups w, w+8, ...  Lane -> (row = lane>>2, stored chunk = lane&3); the logical k-chunk it
-  // fetches is stored ^ ((row>>2)&3) = (lane&3) ^ ((lane>>4)&3).  Rows past the tile / matrix are clamped (their
-  // products are never stored).
+  // ---- LDS-DMA sources.  A stage image = 28 groups of 1 KB (16 rows x 64 B): groups 0-13 Ah, 14-27 Al; W stage image =
+  // 32 groups: 0-15 Wh, 16-31 Wl.  Wave w issues groups w, w+8, ...  Lane -> (row = lane>>2, stored chunk = lane&3);
+  // the logical k-chunk it fetches is stored ^ ((row>>2)&3) = (lane&3) ^ ((lane>>4)&3).  Rows past the tile / matrix
+  // are clamped (their products are never stored).
   const int schunk = (lane & 3) ^ ((lane >> 4) & 3);
-  const bf16_t* src[8];
+  const bf16_t* asrc[4];
+  const bf16_t* wsrc[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int q = wid + 8 * i;
-    if (q < 2 * X3_MSUB * 2) {  // A planes (28 groups)
-      const int g = (q < 14) ? q : q - 14;
-      const int row = min(m0 + g * 16 + (lane >> 2), M - 1);
-      src[i] = ((q < 14) ? A.hi : A.lo) + (size_t)row * K + schunk * 8;
-    } else {
-      const int qq = q - 28;
-      const int g = (qq < 16) ? qq : qq - 16;
-      const int row = min(n0 + g * 16 + (lane >> 2), N - 1);
-      src[i] = ((qq < 16) ? W.hi : W.lo) + (size_t)row * K + schunk * 8;
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int qa = wid + 8 * i;  // < 28 for i < 3, and for i == 3 when wid < 4
+    const int ga = (qa < 14) ? qa : qa - 14;
+    const int arow = min(m0 + ga * 16 + (lane >> 2), M - 1);
+    asrc[i] = ((qa < 14) ? A.hi : A.lo) + (size_t)arow * K + schunk * 8;
+    const int qw = wid + 8 * i;  // < 32
+    const int gw = (qw < 16) ? qw : qw - 16;
+    const int wrow = min(n0 + gw * 16 + (lane >> 2), N - 1);
+    wsrc[i] = ((qw < 16) ? W.hi : W.lo) + (size_t)wrow * K + schunk * 8;
   }
-  auto stage = [&](int buf, int k0) {
-    unsigned char* base = lds + buf * X3_STAGE_BYTES + wid * 1024;
+  auto stage_a = [&](int buf, int k0) {
+    unsigned char* base = lds + buf * X3_A_STAGE + wid * 1024;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (wid + 8 * i < X3_GROUPS) glds16(src[i] + k0, base + i * 8192);
+    for (int i = 0; i < 4; ++i)
+      if (wid + 8 * i < X3_A_GROUPS) glds16(asrc[i] + k0, base + i * 8192);
+  };
+  auto stage_w = [&](int buf, int k0) {
+    unsigned char* base = lds + X3_W_BASE + buf * X3_W_STAGE + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(wsrc[i] + k0, base + i * 8192);
   };
 
   // ---- fragment read offsets (bytes inside a plane tile): row*64 + ((ksub*2 + h) ^ sw)*16, sw = (row>>2)&3
@@ -132,59 +141,111 @@ __global__ __launch_bounds__(X3_THREADS, 2) void gemm_bf16x3_kernel(X3Operand A,
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+  // Pipeline: at the top of step kt the LDS holds A(kt), W(kt) [landed, visible] and A(kt+1) [in flight].  Issue
+  // W(kt+1) THEN A(kt+2); after the MFMAs wait until at most the A(kt+2) pieces (3 per wave; waves 0-3 issue a 4th that
+  // is then also waited for) are outstanding -- loads retire in order, so W(kt+1) and A(kt+1) have landed -- and
+  // barrier once.
   const int nk = K / X3_BK;
-  stage(0, 0);
-  wait_vmem_all();
+  stage_w(0, 0);
+  stage_a(0, 0);
+  if (nk > 1) {
+    stage_a(1, X3_BK);
+    wait_vmem_upto3();
+  } else {
+    wait_vmem_all();
+  }
   wg_barrier();
+  int abuf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * X3_BK);
-    const unsigned char* sa = lds + cur * X3_STAGE_BYTES;
-    const unsigned char* sw_ = sa + 2 * X3_A_BYTES;
+    if (!(ep.ablate & 2)) {
+      if (kt + 1 < nk) stage_w((kt + 1) & 1, (kt + 1) * X3_BK);
+      if (kt + 2 < nk) stage_a(abuf >= 1 ? abuf - 1 : 2, (kt + 2) * X3_BK);  // (abuf + 2) % 3
+    }
+    const unsigned char* sa = lds + abuf * X3_A_STAGE;
+    const unsigned char* sw_ = lds + X3_W_BASE + (kt & 1) * X3_W_STAGE;
+    // 14 units per stage (2 k sub-steps x 7 row sub-tiles), each = 2 A-fragment reads + 3 MFMAs, software-pipelined
+    // two units deep so that a ds_read's latency hides under the 6 MFMAs of the two units before it.
+    bf16x8 wh[2], wl[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int co = ((ks * 2 + h) ^ sw) * 16;
-      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(sw_ + fw + co);
-      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(sw_ + X3_W_BYTES + fw + co);
-      bf16x8 ah[X3_MSUB], al[X3_MSUB];
+      wh[ks] = *reinterpret_cast<const bf16x8*>(sw_ + fw + co);
+      wl[ks] = *reinterpret_cast<const bf16x8*>(sw_ + X3_W_BYTES + fw + co);
+    }
+    bf16x8 ah[3], al[3];
 #pragma unroll
-      for (int t = 0; t < X3_MSUB; ++t) {
-        ah[t] = *reinterpret_cast<const bf16x8*>(sa + fa + t * 2048 + co);
-        al[t] = *reinterpret_cast<const bf16x8*>(sa + X3_A_BYTES + fa + t * 2048 + co);
+    for (int u = 0; u < 2 * X3_MSUB + 2; ++u) {
+      if (u < 2 * X3_MSUB) {
+        const int ks = u / X3_MSUB, t = u - ks * X3_MSUB;
+        const int co = ((ks * 2 + h) ^ sw) * 16;
+        ah[u % 3] = *reinterpret_cast<const bf16x8*>(sa + fa + t * 2048 + co);
+        al[u % 3] = *reinterpret_cast<const bf16x8*>(sa + X3_A_BYTES + fa + t * 2048 + co);
+#ifndef MDM_EMU
+        __builtin_amdgcn_sched_barrier(0);  // pin: these reads are issued two units ahead of their MFMAs
+#endif
       }
-#pragma unroll
-      for (int t = 0; t < X3_MSUB; ++t) {
-        acc[t] = mfma_bf16(al[t], wh, acc[t]);
-        acc[t] = mfma_bf16(ah[t], wl, acc[t]);
-        acc[t] = mfma_bf16(ah[t], wh, acc[t]);
+      if (u >= 2) {
+        const int v = u - 2, ks = v / X3_MSUB, t = v - ks * X3_MSUB;
+        if (ep.ablate & 4) {
+#ifndef MDM_EMU
+          asm volatile("" ::"v"(al[v % 3]), "v"(ah[v % 3]), "v"(wh[ks]), "v"(wl[ks]));
+#endif
+          continue;
+        }
+        acc[t] = mfma_bf16(al[v % 3], wh[ks], acc[t]);
+        acc[t] = mfma_bf16(ah[v % 3], wl[ks], acc[t]);
+        acc[t] = mfma_bf16(ah[v % 3], wh[ks], acc[t]);
+#ifndef MDM_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
-    wait_vmem_all();
+    if (kt + 2 < nk) wait_vmem_upto3();
+    else wait_vmem_all();
     wg_barrier();
+    abuf = (abuf == 2) ? 0 : abuf + 1;
   }
 
-  // ---- epilogue: lane owns column n and rows t*32 + mfma_row(e, h)
-  const int n = n0 + wid * 32 + r;
-  if (n >= N) return;
-  const float bias = ep.bias[n];
-  const float mult = (n < ep.scale_cols) ? ep.col_scale : 1.f;
+  // ---- epilogue.  In the accumulator layout a lane owns ONE column and 16 rows of each 32x32 sub-tile, which would
+  // mean 4-byte (fp32) / 2-byte (planes) stores: the store tail is issue-bound (cdna_hip_programming.md T21).  So each
+  // wave transposes its sub-tile through a private 4 KB LDS patch (the operand rings are dead after the last barrier)
+  // and writes 16 bytes per lane: lane -> (row = lane>>3 (+8 per pass), 4 consecutive columns).
+  const int nc = n0 + wid * 32 + r;                    // this lane's column in the accumulator layout
+  const float bias = (nc < N) ? ep.bias[nc] : 0.f;
+  const float mult = (nc < ep.scale_cols) ? ep.col_scale : 1.f;
   const int m_end = min(M, m0 + rows_per_tile);
+  float* patch = reinterpret_cast<float*>(lds) + wid * 1024;  // [32][32] fp32
+  const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+  const int n4 = n0 + wid * 32 + pc4;                  // first of this lane's 4 columns in the row layout
 #pragma unroll
-  for (int t = 0; t < X3_MSUB; ++t)
+  for (int t = 0; t < X3_MSUB; ++t) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int m = m0 + t * 32 + mfma_row(e, h);
-      if (m < m_end) {
-        const size_t o = (size_t)m * ep.ld + n;
-        float v = acc[t][e] + bias;
-        if (ACT == ACT_GELU) v = gelu_erf_fast(v);
-        else if (ACT == ACT_SILU) v = silu(v);
-        v *= mult;
-        if (HAS_RES) v += ep.res[o];
-        if (OUT_F32) ep.out[o] = v;
-        if (OUT_PLANES) split_bf16(v, ep.oh[o], ep.ol[o]);
+      float v = acc[t][e] + bias;
+      if (ACT == ACT_GELU) v = gelu_erf_fast(v);
+      else if (ACT == ACT_SILU) v = silu(v);
+      patch[mfma_row(e, h) * 32 + r] = v * mult;
+    }
+    wave_lds_fence();
+    if (!(ep.ablate & 1)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = prow + 8 * i;
+        const int m = m0 + t * 32 + row;
+        float4 v = ld4(&patch[row * 32 + pc4]);
+        if (m < m_end && n4 < N) {  // N % 4 == 0
+          const size_t o = (size_t)m * ep.ld + n4;
+          if (HAS_RES) {
+            const float4 rr = ld4(ep.res + o);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          if (OUT_F32) st4(ep.out + o, v);
+          if (OUT_PLANES) split4_store(ep.oh + o, ep.ol + o, v);
+        }
       }
     }
+    wave_lds_fence();
+  }
 }
 
 // rows per block tile: a whole number of sequences when the row space is sequence-structured (keeps the tile count a

@@ -24,6 +24,7 @@ using namespace mdm;
 namespace {
 
 thread_local std::string g_err;
+int g_x3_ablate = 0;  // profiling experiments only (mdm_debug_set)
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -204,8 +205,9 @@ int launch_linear_x3(Profiler* pf, X3Operand a, X3Operand w, const float* bias, 
                      bf16_t* oh, bf16_t* ol, int M, int N, int K, int act, int scale_cols, float col_scale, int seq_len,
                      hipStream_t s) {
   if (K % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 linear: K must be a multiple of 32");
+  if (N % 4 != 0) return fail(MDM_EINVAL, "bf16x3 linear: N must be a multiple of 4");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
-  X3Epilogue ep{out, bias, res, oh, ol, N, scale_cols, col_scale};
+  X3Epilogue ep{out, bias, res, oh, ol, N, scale_cols, col_scale, g_x3_ablate};
   const int rc = launch_gemm_bf16x3(a, w, ep, M, N, K, act, seq_len, s);
   if (rc == -1) return fail(MDM_EHIP, "bf16x3 linear: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 linear: unsupported (activation, residual, output) combination");
@@ -572,6 +574,11 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
       ++dump_i;
     }
   }
+  return MDM_OK;
+}
+
+int mdm_debug_set(int what, int value) {
+  if (what == 0) g_x3_ablate = value;
   return MDM_OK;
 }
 

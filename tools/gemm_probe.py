@@ -10,6 +10,8 @@ dev = "cuda:0"
 M = 256 * 197
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 which = sys.argv[2] if len(sys.argv) > 2 else "x3"
+ablate = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+lib.mdm_debug_set(0, ablate)
 shapes = [(M, 1536, 512, 0, False), (M, 512, 512, 0, True), (M, 1024, 512, 1, False), (M, 512, 1024, 0, True)]
 s = torch.cuda.current_stream().cuda_stream
 for (m, n, k, act, res) in shapes:
@@ -30,4 +32,4 @@ for (m, n, k, act, res) in shapes:
     for _ in range(reps): run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print(f"{which} M={m} N={n} K={k} act={act} res={res}: {dt*1e6:.1f} us/call incl. operand split, {2*m*n*k/dt/1e12:.1f} TF algorithmic")
+    print(f"ablate={ablate} {which} M={m} N={n} K={k} act={act} res={res}: {dt*1e6:.1f} us/call incl. operand split, {2*m*n*k/dt/1e12:.1f} TF algorithmic")
