@@ -138,7 +138,9 @@ def test_progressive_generator_equals_fused_loop(sd):
     for out in diffusion.p_sample_loop_progressive(model, (B, 263, 1, T), clip_denoised=False,
                                                    model_kwargs={"y": dict(y)}):
         last = out
-    assert maxabs(fused.cpu(), last["sample"].cpu()) < 1e-5
+    # the fused loop applies the guidance combine to the tokens BEFORE the output projection, the progressive path
+    # after it: a re-association on top of the split-precision GEMMs (default bf16x3), hence 1e-4 and not 1e-5
+    assert maxabs(fused.cpu(), last["sample"].cpu()) < 1e-4
     assert torch.equal(last["sample"], last["pred_xstart"])        # coef1[0]=1, coef2[0]=0, no noise
 
 
