@@ -75,8 +75,9 @@ int mdm_prepare(mdm_model_t* m, void* const_ws_dev, size_t const_ws_bytes, void*
  *   MDM_PREC_BF16X3  default: operands split into bf16 hi + lo planes, three bf16 MFMA products per fp32 product
  *                    (hi*hi + hi*lo + lo*hi), fp32 accumulation: ~2^-16 relative per product, well inside the
  *                    1e-3 trajectory bar (2.5 PFLOP/s bf16 peak / 3 passes).
- * Attention, LayerNorm, GELU, softmax, the 263-wide input/output projections and the sampler update are fp32 in
- * both modes.  May be called any time after mdm_create. */
+ * In MDM_PREC_BF16X3 the attention contractions (QK^T, PV) use the same three-product scheme on planes written by the
+ * in_proj epilogue.  LayerNorm, GELU, softmax, the 263-wide input/output projections and the sampler update are fp32
+ * in both modes.  May be called any time after mdm_create. */
 #define MDM_PREC_F32 0
 #define MDM_PREC_BF16X3 1
 int mdm_set_precision(mdm_model_t* m, int32_t mode);
@@ -173,7 +174,8 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x_dev, 
 int mdm_profile_enable(mdm_model_t* m, int on);
 int mdm_profile_read(mdm_model_t* m, int32_t category, double* total_ms, int64_t* launches, double* flops);
 int mdm_profile_reset(mdm_model_t* m);
-/* Kernel-ablation switches for profiling experiments (what = 0: bf16x3 GEMM; value 0 = production behaviour). */
+/* Switches for profiling experiments; value 0 = production behaviour.  what = 0: bf16x3 GEMM ablation code
+ * (gemm_bf16x3.h ABL); what = 1: mdm_linear_bf16x3 reuses the operand planes already in scratch (kernel-only timing). */
 int mdm_debug_set(int what, int value);
 
 /* Building blocks, exported for the parity tests and for callers that compose their own layers.
@@ -192,6 +194,11 @@ int mdm_linear_bf16x3(const float* in_dev, const float* w_dev, const float* bias
 int mdm_layernorm(float* x_dev, const float* gamma_dev, const float* beta_dev, int32_t rows, int32_t D, void* stream);
 int mdm_attention(const float* qkv_dev, float* out_dev, const int32_t* lengths_dev, int32_t nseq, int32_t B,
                   int32_t S, int32_t D, int32_t H, void* stream);
+/*   mdm_attention_bf16x3: the same contract computed by the split-precision kernel the bf16x3 mode uses (QK^T and PV
+ *                  as three bf16 MFMA products each, fp32 softmax); `scratch_dev` receives the Q/K/V^T bf16 planes. */
+size_t mdm_attention_bf16x3_scratch_bytes(int32_t nseq, int32_t S, int32_t D);
+int mdm_attention_bf16x3(const float* qkv_dev, float* out_dev, const int32_t* lengths_dev, int32_t nseq, int32_t B,
+                         int32_t S, int32_t D, int32_t H, void* scratch_dev, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

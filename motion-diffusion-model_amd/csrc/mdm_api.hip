@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "attention_bf16x3.h"
 #include "attention_f32.h"
 #include "common.h"
 #include "elementwise.h"
@@ -25,6 +26,7 @@ namespace {
 
 thread_local std::string g_err;
 int g_x3_ablate = 0;  // profiling experiments only (mdm_debug_set)
+int g_x3_reuse_planes = 0;  // probes only: mdm_linear_bf16x3 skips the operand split and reuses the planes in scratch
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -117,6 +119,7 @@ namespace {
 
 struct Workspace {
   float *tok, *qkv, *att, *ffn, *cond;
+  QkvPlanes qp;         // bf16x3 mode: the in_proj epilogue writes Q/K/V^T planes over the qkv region
   bf16_t *tokh, *tokl;  // split planes of tok (bf16x3 mode)
   bf16_t *atth, *attl;  // alias att: the attention output is only consumed by the out_proj GEMM
   bf16_t *ffnh, *ffnl;  // alias ffn: the GELU output is only consumed by the linear2 GEMM
@@ -133,7 +136,8 @@ Workspace carve(const mdm_model* m, int nseq, int T, void* base) {
   };
   Workspace w;
   w.tok = take(M * D);
-  w.qkv = take(M * 3 * D);
+  const size_t NKT = (S + 31) / 32, SP = 32 * NKT;
+  w.qkv = take((size_t)nseq * SP * 3 * D);  // fp32 [M][3D] (f32 mode) or six bf16 planes of nseq*SP*D (bf16x3 mode)
   w.att = take(M * D);
   w.ffn = take(M * FF);
   w.cond = take((size_t)nseq * D);
@@ -144,6 +148,12 @@ Workspace carve(const mdm_model* m, int nseq, int T, void* base) {
   w.attl = w.att ? w.atth + M * D : nullptr;
   w.ffnh = reinterpret_cast<bf16_t*>(w.ffn);
   w.ffnl = w.ffn ? w.ffnh + M * FF : nullptr;
+  {
+    const size_t plane = (size_t)nseq * SP * D;
+    bf16_t* q = reinterpret_cast<bf16_t*>(w.qkv);
+    w.qp = QkvPlanes{q, q ? q + plane : nullptr, q ? q + 2 * plane : nullptr, q ? q + 3 * plane : nullptr,
+                     q ? q + 4 * plane : nullptr, q ? q + 5 * plane : nullptr, (int)SP, (int)NKT, m->cfg.num_heads};
+  }
   w.bytes = off;
   return w;
 }
@@ -188,6 +198,33 @@ int launch_attention(Profiler* pf, const float* qkv, float* out, const int* leng
   }
 }
 
+template <int NKT>
+int launch_attention_x3_t(const QkvPlanes& qp, const int* lengths, int nseq, int B, int S, int D, float* out, bf16_t* oh,
+                          bf16_t* ol, hipStream_t s) {
+  auto k = &attention_bf16x3_kernel<NKT>;
+  const size_t lds = attention_x3_lds_bytes(NKT);
+  if (int rc = rt_allow_lds(k, lds)) return rc;
+  MDM_LAUNCH(k, dim3(nseq * qp.H), dim3(64 * NKT), lds, s, qp, lengths, S, D, B, out, oh, ol);
+  return rt_launch_status();
+}
+
+// split-precision attention on the operand planes written by the in_proj epilogue (or qkv_pack_kernel)
+int launch_attention_x3(Profiler* pf, const QkvPlanes& qp, const int* lengths, int nseq, int B, int S, int D, float* out,
+                        bf16_t* oh, bf16_t* ol, hipStream_t s) {
+  ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * qp.H * (double)S * S * AX_HD, s);
+  if (D != qp.H * AX_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
+  if (S < 1 || S > 224) return fail(MDM_EUNSUPPORTED, "attention: 1 <= S <= 224 tokens (T <= 223 frames)");
+  switch (qp.NKT) {
+    case 1: return launch_attention_x3_t<1>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+    case 2: return launch_attention_x3_t<2>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+    case 3: return launch_attention_x3_t<3>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+    case 4: return launch_attention_x3_t<4>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+    case 5: return launch_attention_x3_t<5>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+    case 6: return launch_attention_x3_t<6>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+    default: return launch_attention_x3_t<7>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+  }
+}
+
 int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, const float* bias, const float* res,
                   float* out, int M, int N, int K, int act, int scale_cols, float col_scale, hipStream_t s) {
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
@@ -207,10 +244,22 @@ int launch_linear_x3(Profiler* pf, X3Operand a, X3Operand w, const float* bias, 
   if (K % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 linear: K must be a multiple of 32");
   if (N % 4 != 0) return fail(MDM_EINVAL, "bf16x3 linear: N must be a multiple of 4");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
-  X3Epilogue ep{out, bias, res, oh, ol, N, scale_cols, col_scale, g_x3_ablate};
-  const int rc = launch_gemm_bf16x3(a, w, ep, M, N, K, act, seq_len, s);
+  X3Epilogue ep{out, bias, res, oh, ol, N, scale_cols, col_scale, QkvPlanes{}, 0, 0};
+  const int rc = launch_gemm_bf16x3(a, w, ep, M, N, K, act, seq_len, s, g_x3_ablate);
   if (rc == -1) return fail(MDM_EHIP, "bf16x3 linear: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 linear: unsupported (activation, residual, output) combination");
+  return rt_launch_status();
+}
+
+// in_proj in split precision: tokens -> Q (pre-scaled) / K / V^T operand planes of attention_bf16x3.h
+int launch_in_proj_x3(Profiler* pf, X3Operand a, X3Operand w, const float* bias, const QkvPlanes& qp, int nseq, int S,
+                      int D, float qscale, hipStream_t s) {
+  if (D % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 in_proj: latent_dim must be a multiple of 32");
+  ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * nseq * S * 3.0 * D * (double)D, s);
+  X3Epilogue ep{nullptr, bias, nullptr, nullptr, nullptr, 3 * D, D, qscale, qp, S, D};
+  const int rc = launch_gemm_bf16x3_qkv(a, w, ep, nseq, S, D, s);
+  if (rc == -1) return fail(MDM_EHIP, "bf16x3 in_proj: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 in_proj: sequences longer than 224 tokens");
   return rt_launch_status();
 }
 
@@ -255,9 +304,8 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
     const X3Operand tokp{ws.tokh, ws.tokl}, attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
     for (int l = 0; l < m->cfg.num_layers; ++l) {
       const mdm_model::LayerPlanes& P = m->planes[l];
-      if (int rc = launch_linear_x3(pf, tokp, P.in_proj, m->L(l, "self_attn.in_proj_bias"), nullptr, ws.qkv, nullptr,
-                                    nullptr, M, 3 * D, D, ACT_NONE, D, qscale, S, s)) return rc;
-      if (int rc = launch_attention(pf, ws.qkv, nullptr, lengths, nseq, B, S, D, H, ws.atth, ws.attl, s)) return rc;
+      if (int rc = launch_in_proj_x3(pf, tokp, P.in_proj, m->L(l, "self_attn.in_proj_bias"), ws.qp, nseq, S, D, qscale, s)) return rc;
+      if (int rc = launch_attention_x3(pf, ws.qp, lengths, nseq, B, S, D, nullptr, ws.atth, ws.attl, s)) return rc;
       if (int rc = launch_linear_x3(pf, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"), ws.tok, ws.tok, nullptr,
                                     nullptr, M, D, D, ACT_NONE, 0, 1.f, S, s)) return rc;
       if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, ws.tokh, ws.tokl, s)) return rc;
@@ -579,6 +627,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
 
 int mdm_debug_set(int what, int value) {
   if (what == 0) g_x3_ablate = value;
+  if (what == 1) g_x3_reuse_planes = value;
   return MDM_OK;
 }
 
@@ -636,8 +685,10 @@ int mdm_linear_bf16x3(const float* in, const float* w, const float* bias, const 
   bf16_t* al = ah + (size_t)M * K;
   bf16_t* wh = reinterpret_cast<bf16_t*>(static_cast<char*>(scratch) + align_up((size_t)M * K * 4, 256));
   bf16_t* wl = wh + (size_t)N * K;
-  if (int rc = launch_split(in, ah, al, (size_t)M * K, s)) return rc;
-  if (int rc = launch_split(w, wh, wl, (size_t)N * K, s)) return rc;
+  if (!g_x3_reuse_planes) {
+    if (int rc = launch_split(in, ah, al, (size_t)M * K, s)) return rc;
+    if (int rc = launch_split(w, wh, wl, (size_t)N * K, s)) return rc;
+  }
   return launch_linear_x3(nullptr, X3Operand{ah, al}, X3Operand{wh, wl}, bias, res, out, nullptr, nullptr, M, N, K, act, 0,
                           1.f, 0, s);
 }
@@ -651,6 +702,28 @@ int mdm_attention(const float* qkv, float* out, const int32_t* lengths, int32_t 
                   int32_t H, void* stream) {
   if (!qkv || !out || nseq <= 0 || B <= 0) return fail(MDM_EINVAL, "mdm_attention: bad argument");
   return launch_attention(nullptr, qkv, out, lengths, nseq, B, S, D, H, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+size_t mdm_attention_bf16x3_scratch_bytes(int32_t nseq, int32_t S, int32_t D) {
+  if (nseq <= 0 || S <= 0 || D <= 0) return 0;
+  const size_t SP = (size_t)(S + 31) / 32 * 32;
+  return (size_t)nseq * SP * D * 12;
+}
+
+int mdm_attention_bf16x3(const float* qkv, float* out, const int32_t* lengths, int32_t nseq, int32_t B, int32_t S,
+                         int32_t D, int32_t H, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!qkv || !out || !scratch || nseq <= 0 || B <= 0 || S <= 0 || H <= 0) return fail(MDM_EINVAL, "mdm_attention_bf16x3: bad argument");
+  if (D != H * AX_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
+  if (scratch_bytes < mdm_attention_bf16x3_scratch_bytes(nseq, S, D)) return fail(MDM_ENOSPC, "mdm_attention_bf16x3: scratch too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int NKT = (S + 31) / 32, SP = 32 * NKT;
+  const size_t plane = (size_t)nseq * SP * D;
+  bf16_t* q = static_cast<bf16_t*>(scratch);
+  QkvPlanes qp{q, q + plane, q + 2 * plane, q + 3 * plane, q + 4 * plane, q + 5 * plane, SP, NKT, H};
+  const int grid = (int)std::min<size_t>((plane + 255) / 256, 4096);
+  MDM_LAUNCH(qkv_pack_kernel, dim3(grid), dim3(256), 0, s, qkv, qp, nseq, S, D);
+  if (int rc = rt_launch_status()) return rc;
+  return launch_attention_x3(nullptr, qp, lengths, nseq, B, S, D, out, nullptr, nullptr, s);
 }
 
 }  // extern "C"

@@ -35,16 +35,17 @@ def test_emulated_cfg_loop_matches_oracle(lib, prec, tol):
     assert maxabs(got, want) < tol
 
 
-def test_emulated_forward_branches(lib):
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("bf16x3", 1e-4)])
+def test_emulated_forward_branches(lib, prec, tol):
     B, T = 2, 33                                   # S = 34: two key tiles, ragged tail
     sd = small_state_dict(num_layers=1)
-    model, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib, precision="f32")
+    model, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib, precision=prec)
     y = synth_y(B, T, seed=2, lengths=[33, 5])
     g = torch.Generator().manual_seed(0)
     x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 0])
-    assert maxabs(model(x, t, y=dict(y)), orc.mdm_forward(sd, x, t, y, num_heads=2)) < 1e-5
+    assert maxabs(model(x, t, y=dict(y)), orc.mdm_forward(sd, x, t, y, num_heads=2)) < tol
     yu = {**y, "uncond": True}
-    assert maxabs(model(x, t, y=yu), orc.mdm_forward(sd, x, t, yu, num_heads=2)) < 1e-5
+    assert maxabs(model(x, t, y=yu), orc.mdm_forward(sd, x, t, yu, num_heads=2)) < tol
 
 
 @pytest.mark.parametrize("M,N,K,act,res", [(70, 130, 36, 0, True), (129, 64, 8, 1, False), (3, 5, 4, 2, False)])
@@ -95,3 +96,25 @@ def test_emulated_attention_mask(lib):
         sc[s, :, :, 1 + int(lengths[s]):] = float("-inf")
     ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(nseq * S, D)
     assert maxabs(out, ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("S,lengths", [(37, [36, 3]), (70, [69, 40])])
+def test_emulated_attention_bf16x3(lib, S, lengths):
+    """Split-precision attention: plane layouts (swizzled K rows, MFMA-ordered V^T), masking, deferred normalisation."""
+    nseq, B, D, H, hd = 2, 2, 256, 2, 128
+    rng = np.random.default_rng(S)
+    qkv = f32(rng.standard_normal((nseq * S, 3 * D)))
+    qkv[:, :D] /= np.sqrt(hd)
+    lengths = np.array(lengths, np.int32)
+    out = np.full((nseq * S, D), np.nan, np.float32)
+    nb = lib.mdm_attention_bf16x3_scratch_bytes(nseq, S, D)
+    scratch = np.zeros(nb, np.uint8)
+    lib.check(lib.mdm_attention_bf16x3(ptr(qkv), ptr(out), ptr(lengths), nseq, B, S, D, H, ptr(scratch), nb, None),
+              "attention_bf16x3")
+    t = torch.from_numpy(qkv).double()
+    q, k, v = (u.view(nseq, S, H, hd).transpose(1, 2) for u in t.split(D, -1))
+    sc = q @ k.transpose(-1, -2)
+    for s in range(nseq):
+        sc[s, :, :, 1 + int(lengths[s]):] = float("-inf")
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(nseq * S, D)
+    assert maxabs(out, ref.numpy()) < 5e-5

@@ -298,6 +298,13 @@ def test_mdm_attention(nseq, B, S, lengths):
     lib.check(lib.mdm_attention(qd.data_ptr(), out.data_ptr(), ld.data_ptr() if ld is not None else None, nseq, B, S,
                                 D, H, _stream()), "mdm_attention")
     assert maxabs(out.cpu(), ref) < 1e-5
+    # the split-precision kernel of the bf16x3 mode, same contract (planes packed into scratch)
+    nb = lib.mdm_attention_bf16x3_scratch_bytes(nseq, S, D)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    out3 = torch.full((nseq * S, D), float("nan"), device=DEV)
+    lib.check(lib.mdm_attention_bf16x3(qd.data_ptr(), out3.data_ptr(), ld.data_ptr() if ld is not None else None,
+                                       nseq, B, S, D, H, scratch.data_ptr(), nb, _stream()), "mdm_attention_bf16x3")
+    assert maxabs(out3.cpu(), ref) < 5e-5
 
 
 def test_sampler_step_kernel_matches_oracle():

@@ -1,35 +1,78 @@
-"""Run the four encoder GEMM shapes of the headline config through the C ABI (for rocprofv3 kernel traces / PMC)."""
-import sys, os, time
+"""Kernel probes at the headline shapes (256 sequences x 197 tokens), through the C ABI, timed with events on the launch
+stream.  Usage: python tools/gemm_probe.py [reps] [ablate,ablate,...]
+  * the four encoder GEMM shapes on the bf16x3 kernel, per ablation code (mdm_debug_set(0, code): 0 production,
+    1 no epilogue stores, 2 no loads after the prologue, 4 no MFMAs, 8 LDS-DMA issued as a burst; codes other than 0
+    only exist for the plain fp32-out variant, so every shape is run as (act none, no residual) under ablation);
+  * attention: exact-fp32 kernel vs the split-precision kernel (the latter timed without its test-only pack kernel
+    by timing pack alone and subtracting is NOT done -- the x3 number includes qkv_pack; see the model-level
+    kernel_ms in bench.py for the in-situ figure).
+The GEMM timings are kernel-only: after one normal call, mdm_debug_set(1, 1) makes mdm_linear_bf16x3 reuse the operand
+planes already in its scratch."""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import mdm_amd
+import mdm_amd  # noqa: F401
 from mdm_amd import _native
 
 lib = _native.load_native()
 dev = "cuda:0"
-M = 256 * 197
+NSEQ, S, D, H = 256, 197, 512, 4
+M = NSEQ * S
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-which = sys.argv[2] if len(sys.argv) > 2 else "x3"
-ablate = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-lib.mdm_debug_set(0, ablate)
-shapes = [(M, 1536, 512, 0, False), (M, 512, 512, 0, True), (M, 1024, 512, 1, False), (M, 512, 1024, 0, True)]
-s = torch.cuda.current_stream().cuda_stream
-for (m, n, k, act, res) in shapes:
-    a = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev) / k ** 0.5
-    b = torch.randn(n, device=dev); r = torch.randn(m, n, device=dev) if res else None
+ablates = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
+stream = torch.cuda.current_stream().cuda_stream
+
+
+def timeit(fn, n):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3  # us
+
+
+shapes = [("in_proj", M, 1536, 512, 0, False), ("out_proj", M, 512, 512, 0, True), ("linear1", M, 1024, 512, 1, False),
+          ("linear2", M, 512, 1024, 0, True)]
+for name, m, n, k, act, res in shapes:
+    a = torch.randn(m, k, device=dev)
+    w = torch.randn(n, k, device=dev) / k ** 0.5
+    b = torch.randn(n, device=dev)
+    r = torch.randn(m, n, device=dev) if res else None
     out = torch.empty(m, n, device=dev)
     nb = lib.mdm_linear_bf16x3_scratch_bytes(m, n, k)
     scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-    def run():
-        if which == "x3":
-            lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None,
-                                            out.data_ptr(), m, n, k, act, scratch.data_ptr(), nb, s), "x3")
-        else:
-            lib.check(lib.mdm_linear(a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if res else None,
-                                     out.data_ptr(), m, n, k, act, s), "f32")
-    run(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps): run()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    print(f"ablate={ablate} {which} M={m} N={n} K={k} act={act} res={res}: {dt*1e6:.1f} us/call incl. operand split, {2*m*n*k/dt/1e12:.1f} TF algorithmic")
+    lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), m, n, k, 0,
+                                    scratch.data_ptr(), nb, stream), "x3")   # fills the planes
+    lib.mdm_debug_set(1, 1)
+    for ab in ablates:
+        lib.mdm_debug_set(0, ab)
+        use_act, use_res = (act, res) if ab == 0 else (0, False)
+
+        def run():
+            lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if use_res else None,
+                                            out.data_ptr(), m, n, k, use_act, scratch.data_ptr(), nb, stream), "x3")
+        us = timeit(run, reps)
+        print(f"{name:9s} M={m} N={n} K={k} act={use_act} res={int(use_res)} ablate={ab}: {us:8.1f} us/call "
+              f"kernel-only {2 * m * n * k / us / 1e6:7.1f} TF alg", flush=True)
+    lib.mdm_debug_set(0, 0)
+    lib.mdm_debug_set(1, 0)
+
+# attention
+qkv = torch.randn(M, 3 * D, device=dev)
+qkv[:, :D] *= 128 ** -0.5
+out = torch.empty(M, D, device=dev)
+us32 = timeit(lambda: lib.check(lib.mdm_attention(qkv.data_ptr(), out.data_ptr(), None, NSEQ, NSEQ, S, D, H, stream),
+                                "att"), reps)
+nb = lib.mdm_attention_bf16x3_scratch_bytes(NSEQ, S, D)
+scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+us3 = timeit(lambda: lib.check(lib.mdm_attention_bf16x3(qkv.data_ptr(), out.data_ptr(), None, NSEQ, NSEQ, S, D, H,
+                                                         scratch.data_ptr(), nb, stream), "att3"), reps)
+fl = 4.0 * NSEQ * H * S * S * 128
+print(f"attention f32   : {us32:8.1f} us  {fl / us32 / 1e6:6.1f} TF alg")
+print(f"attention bf16x3: {us3:8.1f} us  (includes the test-only qkv_pack kernel)")
