@@ -14,6 +14,8 @@
   hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__)
 #endif
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 
 namespace mdm {
 
@@ -106,13 +108,84 @@ __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_bas
 #endif
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}), so that the index can
+// feed template arguments / inline-asm immediates (a `#pragma unroll` loop variable cannot)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// LDS fragment read that hipcc does NOT track (cdna_hip_programming.md 5.7 form (ii)): hipcc's waitcnt pass retires
+// tracked ds_reads with lgkmcnt(0) only (measured: a full drain every third MFMA unit halves the matrix-pipe duty of
+// the bf16x3 main loop), so the hot loops issue their reads through lds_read16 and retire them IN ORDER with a counted
+// lds_wait<N>(regs...) that names the registers becoming valid -- no consumer of those registers can be scheduled
+// above the wait, and any copy the compiler made earlier is dead.
+#ifdef MDM_EMU
+__device__ __forceinline__ void lds_read16(bf16x8& dst, const unsigned char* base, uint32_t byte_off) {
+  dst = *reinterpret_cast<const bf16x8*>(base + byte_off);
+}
+template <int N> __device__ __forceinline__ void lds_wait(bf16x8&, bf16x8&) {}
+template <int N> __device__ __forceinline__ void lds_wait(bf16x8&, bf16x8&, bf16x8&, bf16x8&) {}
+template <int N> __device__ __forceinline__ void lds_wait(bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&) {}
+template <int N>
+__device__ __forceinline__ void lds_wait(bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&) {}
+#else
+// `lds_addr` = 32-bit LDS byte address (lds_addr_of), IMM = compile-time byte offset < 65536
+template <int IMM> __device__ __forceinline__ void lds_read16(bf16x8& dst, uint32_t lds_addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(IMM));
+}
+template <int N> __device__ __forceinline__ void lds_wait(bf16x8& a, bf16x8& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N));
+}
+template <int N> __device__ __forceinline__ void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e, bf16x8& f, bf16x8& g,
+                                         bf16x8& h) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)
+               : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e, bf16x8& f) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "i"(N));
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+#endif
+
+// Global 16-byte load that hipcc does NOT track (same form (ii) as lds_read16): beside an LDS-DMA in flight hipcc retires
+// every tracked global load with vmcnt(0), i.e. one full memory latency per load.  The GEMM epilogue streams its
+// residual tile through these instead, two row sub-tiles ahead, retired by a counted vmem_wait<N> where N = number of
+// LOADS issued after the ones awaited (loads return in order; stores in between can only make the wait stricter).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef MDM_EMU
+__device__ __forceinline__ void gload16_async(f32x4& dst, const float* p) {
+  dst = f32x4{p[0], p[1], p[2], p[3]};
+}
+template <int N> __device__ __forceinline__ void vmem_wait(f32x4&, f32x4&, f32x4&, f32x4&) {}
+#else
+__device__ __forceinline__ void gload16_async(f32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N> __device__ __forceinline__ void vmem_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
+}
+#endif
+
 // Workgroup barrier that does NOT drain the vector-memory queue (cdna_hip_programming.md section 5: __syncthreads()
 // would wait vmcnt(0) while an LDS-DMA is in flight); pair it with an explicit wait where the data is consumed.
 __device__ __forceinline__ void wg_barrier() {
 #ifdef MDM_EMU
   emu::block_barrier();
 #else
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); the builtin (unlike inline asm) is visible to hipcc's waitcnt pass
   __builtin_amdgcn_s_barrier();
 #endif
 }
@@ -127,12 +200,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 __device__ __forceinline__ void wait_vmem_upto3() {  // at most 3 vector-memory operations of this wave still pending
 #ifndef MDM_EMU
-  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(3)
 #endif
 }
 __device__ __forceinline__ void wait_vmem_all() {
 #ifndef MDM_EMU
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #endif
 }
 

@@ -37,11 +37,14 @@ def timeit(fn, n):
     return a.elapsed_time(b) / n * 1e3  # us
 
 
+ROUNDS = 5
 shapes = [("in_proj", M, 1536, 512, 0, False), ("out_proj", M, 512, 512, 0, True), ("linear1", M, 1024, 512, 1, False),
           ("linear2", M, 512, 1024, 0, True)]
 for name, m, n, k, act, res in shapes:
     a = torch.randn(m, k, device=dev)
     w = torch.randn(n, k, device=dev) / k ** 0.5
+    if os.environ.get("PROBE_ZERO"):   # DVFS check: zero operands draw less power -> higher clock at identical work
+        a.zero_(); w.zero_()
     b = torch.randn(n, device=dev)
     r = torch.randn(m, n, device=dev) if res else None
     out = torch.empty(m, n, device=dev)
@@ -50,18 +53,26 @@ for name, m, n, k, act, res in shapes:
     lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), m, n, k, 0,
                                     scratch.data_ptr(), nb, stream), "x3")   # fills the planes
     lib.mdm_debug_set(1, 1)
-    for ab in ablates:
-        lib.mdm_debug_set(0, ab)
-        use_act, use_res = (act, res) if ab == 0 else (0, False)
+    # variants: every ablation code on the plain epilogue (act none, no residual) + the production epilogue of this shape
+    variants = [("plain", ab, 0, False) for ab in ablates] + ([("prod", 0, act, res)] if (act or res) else [])
+    times = {v: [] for v in variants}
+    for _ in range(ROUNDS):          # interleaved rounds: the chip's clock drifts with its power state (DVFS), so
+        for v in variants:           # back-to-back blocks per variant would measure the drift, not the kernel
+            _, ab, use_act, use_res = v
+            lib.mdm_debug_set(0, ab)
 
-        def run():
-            lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if use_res else None,
-                                            out.data_ptr(), m, n, k, use_act, scratch.data_ptr(), nb, stream), "x3")
-        us = timeit(run, reps)
-        print(f"{name:9s} M={m} N={n} K={k} act={use_act} res={int(use_res)} ablate={ab}: {us:8.1f} us/call "
-              f"kernel-only {2 * m * n * k / us / 1e6:7.1f} TF alg", flush=True)
+            def run():
+                lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                                r.data_ptr() if use_res else None, out.data_ptr(), m, n, k, use_act,
+                                                scratch.data_ptr(), nb, stream), "x3")
+            times[v].append(timeit(run, reps))
     lib.mdm_debug_set(0, 0)
     lib.mdm_debug_set(1, 0)
+    for v in variants:
+        ts = sorted(times[v])
+        med, mn = ts[len(ts) // 2], ts[0]
+        print(f"{name:9s} N={n} K={k} {v[0]:5s} ablate={v[1]:3d} act={v[2]} res={int(v[3])}: median {med:7.1f} us  min {mn:7.1f} us "
+              f"{2 * m * n * k / med / 1e6:6.1f} TF alg", flush=True)
 
 # attention
 qkv = torch.randn(M, 3 * D, device=dev)

@@ -7,7 +7,7 @@ KEXPR=${2:-"attention or linear_bf16x3 or forward_matches or loop_matches"}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 300 python tools/gemm_probe.py 10 0,1,2,4,5,6,8 > $OUT/probe.txt 2>&1
+timeout 300 python tools/gemm_probe.py 10 ${ABLS:-0,1,2,4,8,16,17,24} > $OUT/probe.txt 2>&1
 cat $OUT/probe.txt
 timeout 900 python -m pytest tests -m gpu -x -q -k "$KEXPR" > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> $OUT/pytest_gpu.log
