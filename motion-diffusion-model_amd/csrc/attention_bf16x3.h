@@ -22,8 +22,8 @@
 //   softmax  per lane over its 16 keys per tile x NKT tiles + ONE cross-half shuffle; normalisation deferred to O
 //   phase 2  Ot[d][query]  = V^T . P^T   A = V^T fragments (LDS, 64-byte rows swizzled like gemm_bf16x3.h)
 //                                        B = split(P) straight from the phase-1 registers
-// K and V^T arrive by global_load_lds_dwordx4 (no staging registers) into ONE LDS buffer used three times
-// (K, then V^T, then the fp32 output tile for coalesced stores).
+// K and V^T arrive by global_load_lds_dwordx4 (no staging registers).  The first V^T key tiles are fetched into spare LDS
+// while phase 1 runs, the rest over the dead K planes while the softmax runs (LDS plan at the kernel).
 #pragma once
 #include "common.h"
 
@@ -50,6 +50,18 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
   }
 }
 
+// LDS plan (bytes).  Region A = the two K planes (2 * SP * 256); region B = as many 16 KB V^T key tiles (hi 8 KB | lo 8 KB)
+// as still fit under 160 KB: they are fetched WHILE phase 1 runs.  The remaining V^T tiles are fetched into region A once
+// every wave is done with K (they land during the softmax and the first part of phase 2); finally the fp32 output tile
+// is staged over everything.
+constexpr int ax_plane_bytes(int nkt) { return nkt * 32 * 256; }
+constexpr int ax_early_tiles(int nkt) { return nkt < 3 ? nkt : 3; }  // 3 x 16 KB beside K(NKT = 7) = 160 KB; also keeps
+                                                                     // every ds_read immediate offset below 64 KB
+constexpr int ax_lds_bytes(int nkt) {
+  const int kv = 2 * ax_plane_bytes(nkt) + ax_early_tiles(nkt) * 16384, o = nkt * 32 * AX_OLD * 4;
+  return kv > o ? kv : o;
+}
+
 template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void attention_bf16x3_kernel(QkvPlanes P, const int* __restrict__ lengths,
                                                                       int S, int D, int B, float* __restrict__ out,
@@ -57,7 +69,10 @@ __global__ __launch_bounds__(64 * NKT) void attention_bf16x3_kernel(QkvPlanes P,
   MDM_DYN_SMEM(unsigned char, lds);
   constexpr int NT = 64 * NKT;
   constexpr int SP = 32 * NKT;
-  constexpr int PLANE = SP * 256;  // bytes of one K plane image == one V^T plane image
+  constexpr int PLANE = ax_plane_bytes(NKT);
+  constexpr int NB = ax_early_tiles(NKT);   // V^T key tiles prefetched into region B during phase 1
+  constexpr int REGION_B = 2 * PLANE;
+  constexpr int LATE_PIECES = (16 * (NKT - NB)) / NKT;  // LDS-DMA pieces of the late tiles every wave issues at least
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -74,7 +89,7 @@ __global__ __launch_bounds__(64 * NKT) void attention_bf16x3_kernel(QkvPlanes P,
   int nvalid = S;  // token 0 (the condition token) is never masked; frame j-1 must be < length (mdm.py:241-247)
   if (lengths != nullptr) nvalid = min(S, 1 + lengths[seq % B]);
 
-  // ---- K planes -> LDS.  One LDS-DMA instruction = 1 KB = 4 rows of 256 B; lane -> (row = lane>>4, stored chunk =
+  // ---- K planes -> region A.  One LDS-DMA instruction = 1 KB = 4 rows of 256 B; lane -> (row = lane>>4, stored chunk =
   // lane&15) fetches logical chunk (lane&15) ^ (row&15): the involution the fragment reads below repeat.
   {
     const bf16_t* kbase[2] = {P.kh + sh * SP * AX_HD, P.kl + sh * SP * AX_HD};
@@ -98,26 +113,65 @@ __global__ __launch_bounds__(64 * NKT) void attention_bf16x3_kernel(QkvPlanes P,
   wait_vmem_all();
   wg_barrier();
 
-  // ---- phase 1: score tiles St[key][query], three products per k-step
+  // ---- V^T tiles.  Per key tile 16 KB = hi [128 d][64 B] | lo [128 d][64 B]; one LDS-DMA instruction = 16 rows; lane ->
+  // (row = lane>>2, stored chunk = lane&3) fetches logical chunk (lane&3) ^ ((row>>2)&3).  Tile kt lives in region B
+  // (kt < NB) or, once K is dead, in region A.
+  const bf16_t* vbase[2] = {P.vh + sh * SP * AX_HD, P.vl + sh * SP * AX_HD};
+  auto v_tile_off = [&](int kt) { return kt < NB ? REGION_B + kt * 16384 : (kt - NB) * 16384; };
+  auto issue_v = [&](int kt_lo, int kt_hi) {
+    for (int i = 16 * kt_lo + w; i < 16 * kt_hi; i += NKT) {
+      const int kt = i >> 4, j = i & 15, plane = j >> 3, idx = j & 7;   // 8 pieces of 16 d-rows per plane
+      const int row = 16 * idx + (lane >> 2);                            // d
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      glds16(vbase[plane] + ((size_t)kt * AX_HD + row) * 32 + chunk * 8, lds + v_tile_off(kt) + plane * 8192 + idx * 1024);
+    }
+  };
+  issue_v(0, NB);
+
+  // ---- phase 1: score tiles St[key][query], three products per 16-deep k step.  The 8*NKT (key tile, k step) units run as
+  // ONE software pipeline: fragment reads two units ahead through untracked ds_reads, counted waits (common.h).
   f32x16 p[NKT];
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    f32x16 acc;
+  for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int key = 32 * kt + r;
-    const unsigned char* krow = lds + key * 256;
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-      const int co = ((2 * st + h) ^ (key & 15)) * 16;
-      const bf16x8 kh = *reinterpret_cast<const bf16x8*>(krow + co);
-      const bf16x8 kl = *reinterpret_cast<const bf16x8*>(krow + PLANE + co);
-      acc = mfma_bf16(kl, qh[st], acc);
-      acc = mfma_bf16(kh, ql[st], acc);
-      acc = mfma_bf16(kh, qh[st], acc);
-    }
-    p[kt] = acc;
+    for (int e = 0; e < 16; ++e) p[kt][e] = 0.f;
+  {
+    // lane part of a K fragment address: row r of the tile, chunk h ^ (r & 15); k step st flips chunk bits 1..3
+    const uint32_t klane = (uint32_t)(r * 256 + ((h ^ (r & 15)) * 16));
+    bf16x8 kh[3], kl[3];
+    constexpr int NU1 = 8 * NKT;
+#ifdef MDM_EMU
+#define AX_RD_K(dst, plane, kt, st) lds_read16(dst, lds, (plane) * PLANE + (kt) * 8192 + (klane ^ ((st) << 5)))
+#else
+    const uint32_t kb0 = lds_addr_of(lds) + klane, kb1 = kb0 + PLANE;
+#define AX_RD_K(dst, plane, kt, st) lds_read16<(kt) * 8192>(dst, ((plane) ? kb1 : kb0) ^ (uint32_t)((st) << 5))
+#endif
+    static_for<NU1 + 2>([&](auto u_tag) __attribute__((always_inline)) {
+      constexpr int u = decltype(u_tag)::value;
+      if constexpr (u < NU1) {
+        AX_RD_K(kh[u % 3], 0, u / 8, u % 8);
+        AX_RD_K(kl[u % 3], 1, u / 8, u % 8);
+      }
+      if constexpr (u >= 2) {
+        constexpr int uv = u - 2, kt = uv / 8, st = uv % 8;
+        constexpr int younger = 2 * ((NU1 - 1 - uv) < 2 ? (NU1 - 1 - uv) : 2);
+        lds_wait<younger>(kh[uv % 3], kl[uv % 3]);
+#ifndef MDM_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        p[kt] = mfma_bf16(kl[uv % 3], qh[st], p[kt]);
+        p[kt] = mfma_bf16(kh[uv % 3], ql[st], p[kt]);
+        p[kt] = mfma_bf16(kh[uv % 3], qh[st], p[kt]);
+#ifndef MDM_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+    });
+#undef AX_RD_K
   }
+
+  wg_barrier();          // every wave is done reading K
+  issue_v(NB, NKT);      // the late V^T tiles go over the K planes
 
   // ---- softmax over keys: lane-local + one cross-half exchange; 1/sum is applied to the output
   float mx = -INFINITY;
@@ -126,9 +180,9 @@ __global__ __launch_bounds__(64 * NKT) void attention_bf16x3_kernel(QkvPlanes P,
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = kt * 32 + mfma_row(e, h);
-      const float s = (key < nvalid) ? p[kt][e] : -INFINITY;
-      p[kt][e] = s;
-      mx = fmaxf(mx, s);
+      const float sc = (key < nvalid) ? p[kt][e] : -INFINITY;
+      p[kt][e] = sc;
+      mx = fmaxf(mx, sc);
     }
   mx = fmaxf(mx, shfl_xor_f32(mx, 32));
   float sum = 0.f;
@@ -143,47 +197,73 @@ __global__ __launch_bounds__(64 * NKT) void attention_bf16x3_kernel(QkvPlanes P,
   sum += shfl_xor_f32(sum, 32);
   const float inv = 1.0f / sum;
 
-  wg_barrier();  // every wave is done reading K
-  // ---- V^T planes -> the same buffer.  Per key tile an 8 KB block [128 d][64 B]; one instruction = 16 rows; lane ->
-  // (row = lane>>2, stored chunk = lane&3) fetches logical chunk (lane&3) ^ ((row>>2)&3).
-  {
-    const bf16_t* vbase[2] = {P.vh + sh * SP * AX_HD, P.vl + sh * SP * AX_HD};
-    for (int i = w; i < 16 * NKT; i += NKT) {
-      const int plane = i / (8 * NKT), idx = i - plane * (8 * NKT);
-      const int row = 16 * idx + (lane >> 2);  // = kt*128 + d
-      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-      glds16(vbase[plane] + (size_t)row * 32 + chunk * 8, lds + plane * PLANE + idx * 1024);
-    }
-  }
-  wait_vmem_all();
+  // the early tiles were issued before the late ones and LDS-DMA retires in order: allow the late pieces to stay in flight
+#ifndef MDM_EMU
+  if constexpr (NB < NKT) __builtin_amdgcn_s_waitcnt(0x0F70 | (LATE_PIECES & 15) | ((LATE_PIECES >> 4) << 14));
+  else __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
   wg_barrier();
 
-  // ---- phase 2: Ot[d][query]; the B operand of k-step (kt, s2) is split(p[kt][8 s2 .. 8 s2 + 7])
+  // ---- phase 2: Ot[d][query]; the B operand of k-step (kt, s2) is split(p[kt][8 s2 .. 8 s2 + 7]); units = (kt, s2, d tile)
   f32x16 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+  {
+    // lane part of a V^T fragment address: row r of a 32-d block, chunk h ^ ((r>>2)&3); s2 flips chunk bit 1
+    const uint32_t vlane = (uint32_t)(r * 64 + ((h ^ ((r >> 2) & 3)) * 16));
+    bf16x8 vh[3], vl[3];
+#ifdef MDM_EMU
+#define AX_RD_V(dst, plane, kt, s2, dt) \
+  lds_read16(dst, lds, ((kt) < NB ? REGION_B + (kt) * 16384 : ((kt) - NB) * 16384) + (plane) * 8192 + (dt) * 2048 + (vlane ^ ((s2) << 5)))
+#else
+    const uint32_t va = lds_addr_of(lds) + vlane, vb = va + REGION_B;
+#define AX_RD_V(dst, plane, kt, s2, dt) \
+  lds_read16<((kt) < NB ? (kt) * 16384 : ((kt) - NB) * 16384) + (plane) * 8192 + (dt) * 2048>(dst, ((kt) < NB ? vb : va) ^ (uint32_t)((s2) << 5))
+#endif
+    auto phase2 = [&](auto lo_tag, auto hi_tag) __attribute__((always_inline)) {
+      constexpr int KT_LO = decltype(lo_tag)::value, KT_HI = decltype(hi_tag)::value;
+      constexpr int NU2 = 8 * (KT_HI - KT_LO);   // units of this part: (kt, s2, dt)
+      if constexpr (NU2 > 0) {
+        bf16x8 ph, pl;
+        static_for<NU2 + 2>([&](auto u_tag) __attribute__((always_inline)) {
+          constexpr int u = decltype(u_tag)::value;
+          if constexpr (u < NU2) {
+            constexpr int kt = KT_LO + u / 8, s2 = (u / 4) % 2, dt = u % 4;
+            AX_RD_V(vh[u % 3], 0, kt, s2, dt);
+            AX_RD_V(vl[u % 3], 1, kt, s2, dt);
+          }
+          if constexpr (u >= 2) {
+            constexpr int uv = u - 2, kt = KT_LO + uv / 8, s2 = (uv / 4) % 2, dt = uv % 4;
+            if constexpr (dt == 0) {
+              float pv[8];
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      float pv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pv[j] = p[kt][8 * s2 + j];
-      bf16x8 ph, pl;
-      split8(pv, ph, pl);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int d = 32 * dt + r;
-        const unsigned char* vrow = lds + kt * 8192 + d * 64 + (((2 * s2 + h) ^ ((d >> 2) & 3)) * 16);
-        const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vrow);
-        const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vrow + PLANE);
-        o[dt] = mfma_bf16(vl, ph, o[dt]);
-        o[dt] = mfma_bf16(vh, pl, o[dt]);
-        o[dt] = mfma_bf16(vh, ph, o[dt]);
+              for (int j = 0; j < 8; ++j) pv[j] = p[kt][8 * s2 + j];
+              split8(pv, ph, pl);
+            }
+            constexpr int younger = 2 * ((NU2 - 1 - uv) < 2 ? (NU2 - 1 - uv) : 2);
+            lds_wait<younger>(vh[uv % 3], vl[uv % 3]);
+#ifndef MDM_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            o[dt] = mfma_bf16(vl[uv % 3], ph, o[dt]);
+            o[dt] = mfma_bf16(vh[uv % 3], pl, o[dt]);
+            o[dt] = mfma_bf16(vh[uv % 3], ph, o[dt]);
+#ifndef MDM_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+          }
+        });
       }
+    };
+    phase2(std::integral_constant<int, 0>{}, std::integral_constant<int, NB>{});
+    if constexpr (NB < NKT) {
+      wait_vmem_all();
+      wg_barrier();
+      phase2(std::integral_constant<int, NB>{}, std::integral_constant<int, NKT>{});
     }
+#undef AX_RD_V
   }
   wg_barrier();  // every wave is done reading V^T
 
@@ -211,7 +291,7 @@ __global__ __launch_bounds__(64 * NKT) void attention_bf16x3_kernel(QkvPlanes P,
   }
 }
 
-inline size_t attention_x3_lds_bytes(int nkt) { return (size_t)nkt * 32 * AX_OLD * sizeof(float); }
+inline size_t attention_x3_lds_bytes(int nkt) { return (size_t)ax_lds_bytes(nkt); }
 
 // Test / building-block helper: fp32 packed qkv [nseq*S][3D] (Q pre-scaled) -> the plane layouts above, pads zeroed.
 // One thread per (sequence, head, padded token, d); 2-byte scattered stores -- not a hot-path kernel (in the model the

@@ -8,55 +8,62 @@
 // ~5x the fp32 rate (measured trajectory error ~3e-5).  Replaces in_proj / out_proj / linear1 /
 // linear2; the 263-wide input/output projections stay on the exact-fp32 kernel (gemm_f32.h).
 //
-// Data layout: both operands are stored K-contiguous as two bf16 planes [rows][K] (hi, lo).  Weights are split
-// once in mdm_prepare; activations are split by the PRODUCING kernel's epilogue (LayerNorm, attention, GELU), so the
-// main loop is pure LDS-DMA + MFMA.
+// Data layout.  Activations: two bf16 planes [rows][K] (hi, lo), K contiguous, written by the PRODUCING kernel's
+// epilogue (LayerNorm, attention, GELU).  Weights: split ONCE (mdm_prepare) and stored in MFMA-FRAGMENT order
+//     Wp[plane][n/32][k/16][lane 0..63][8]      lane = (n%32) + 32*((k%16)/8),  element j = k%8
+// so the B-operand fragment of one wave for one 16-deep k sub-step is ONE contiguous, perfectly coalesced 1 KB
+// global_load_dwordx4 -- weights never pass through LDS (a wave's 32 output columns are private to it, so staging them
+// in LDS bought nothing and cost an LDS-DMA write plus an LDS read per byte).
 //
-// Machine mapping (gfx950): 512 threads = 8 waves, ONE PERSISTENT workgroup per CU that walks its share of the
-// output tiles.  Block tile = up to 224 rows x 256 columns; the row extent is chosen by the host as a whole number
-// of token sequences (S = 197 -> one sequence per tile), so the headline shape (256 sequences, N in {512, 1024,
-// 1536}) gives every CU exactly N/256 equal tiles.  Wave w owns columns [32w, 32w+32) x all 7 row sub-tiles
-// (7 accumulators = 112 VGPRs); its W fragment feeds 21 MFMAs per 16-deep k sub-step.  BK = 32; one LDS stage =
-// Ah|Al [224][32] + Wh|Wl [256][32] bf16 = 60 KB; A ring of 3, W ring of 2, plus a 1 KB per-wave epilogue patch.
-//   * global -> LDS by global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass).  The loads run AHEAD of the
-//     MFMAs as two streams with their own (tile, k) cursors -- W one step ahead, A two -- and simply roll over into
-//     the NEXT tile of this workgroup, so the pipeline never drains at a tile boundary: the epilogue of tile j runs
-//     with the first stages of tile j+1 already in LDS (no per-tile prologue latency, K is only 16-32 steps deep).
-//   * the 7-8 LDS-DMA instructions of a step are issued one at a time BETWEEN the MFMA units of that step, not as a
-//     burst behind the barrier (a burst leaves the matrix pipe idle for the ~100 cycles each one takes to issue);
-//     they are retired by ONE counted s_waitcnt vmcnt + raw s_barrier per K step;
-//   * the LDS image of a plane tile is row-major with 64-byte rows; the 16-byte chunk index is XOR-swizzled with
-//     (row>>2)&3 so the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots of the 256-byte bank row.
-//     LDS-DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address and to the reads
-//     (cdna_hip_programming.md rule 21);
-//   * XCD-aware tile order (the column tiles of one row panel are adjacent inside an XCD's contiguous chunk) keeps a
-//     sequence's activation planes in one L2; the weight planes of a layer (<= 3 MB) stay L2-resident everywhere.
+// Machine mapping (gfx950).  256 threads = 4 waves per workgroup, TWO PERSISTENT workgroups per CU (60 KB of LDS and
+// <= 256 VGPRs each), so every SIMD hosts one wave of each workgroup and the two workgroups -- which share nothing and
+// drift apart in phase -- hide each other's non-MFMA time: the per-step barrier, the LDS-DMA latency, the epilogue's
+// VALU / LDS-transpose / store-issue work.  (Measured on the one-workgroup-per-CU predecessor: MFMA-only 141 us +
+// epilogue stores 40 + fragment reads/barriers 18 + loads 32 = 230 us for in_proj, i.e. the parts ADD when all eight
+// waves of a CU march in lock-step; no instruction-order or wave-priority variant moved that by more than 0.3 %.)
+//   * block tile = up to 224 rows x 128 columns; the row extent is a whole number of token sequences (S = 197 -> one
+//     sequence per tile), so the headline shape (256 sequences, N in {512, 1024, 1536}) gives every workgroup exactly
+//     N/256 tiles.  Wave w owns columns [32w, 32w+32) x all 7 row sub-tiles (7 accumulators = 112 VGPRs).
+//   * A tile: global -> LDS by global_load_lds_dwordx4, BK = 32, two stages of Ah|Al [224][32] = 28 KB; the 7 pieces a
+//     wave issues per step ride BETWEEN the MFMA units; the stream has its own (tile, k) cursor one step ahead and
+//     rolls over into the workgroup's next tile, so the pipeline never drains at a tile boundary;
+//   * LDS image: row-major, 64-byte rows, 16-byte chunk index XOR-swizzled with (row>>2)&3 (conflict-free ds_read_b128
+//     groups); LDS-DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address and to the reads
+//     (cdna_hip_programming.md rule 21).  Fragment reads are issued through untracked inline-asm ds_reads retired by
+//     counted lgkmcnt waits (common.h lds_read16): hipcc only ever emits lgkmcnt(0) beside an LDS-DMA;
+//   * W fragments for step g+1 are fetched into registers during step g (plain loads, waited with the step's vmcnt);
+//   * XCD-aware tile order keeps the workgroups that share an activation row panel on one XCD's L2.
 #pragma once
 #include "attention_bf16x3.h"  // QkvPlanes: the in_proj epilogue writes the attention kernel's operand planes
 #include "common.h"
 #include "gemm_f32.h"  // ACT_* enums
-#include <type_traits>
 
 namespace mdm {
 
-constexpr int X3_TM = 224, X3_TN = 256, X3_BK = 32, X3_THREADS = 512;
+constexpr int X3_TM = 224, X3_BK = 32;
+// WAVES waves per workgroup, each owning 32 output columns: 4 -> 224x128 tiles, two workgroups per CU;
+//                                                            8 -> 224x256 tiles, one workgroup per CU (half the
+//                                                                 activation re-reads from L2, waves in lock-step)
+constexpr int x3_tn(int waves) { return 32 * waves; }
 constexpr int X3_MSUB = X3_TM / 32;                              // 7 row sub-tiles
 constexpr int X3_A_BYTES = X3_TM * X3_BK * 2;                    // one A plane tile: 14336
-constexpr int X3_W_BYTES = X3_TN * X3_BK * 2;                    // one W plane tile: 16384
 constexpr int X3_A_STAGE = 2 * X3_A_BYTES;                       // Ah|Al: 28672
-constexpr int X3_W_STAGE = 2 * X3_W_BYTES;                       // Wh|Wl: 32768
-constexpr int X3_A_RING = 3, X3_W_RING = 2;                      // activations come from MALL/HBM: prefetch 2 ahead;
-                                                                 // the weight tile is L2-hot (every CU reads it): 1 ahead
-constexpr int X3_W_BASE = X3_A_RING * X3_A_STAGE;
-constexpr int X3_PATCH_BASE = X3_W_BASE + X3_W_RING * X3_W_STAGE;  // 151552
-constexpr int X3_PATCH_BYTES = 8 * 32 * 4;                         // per wave: 8 rows x 32 columns fp32
-constexpr int X3_LDS_BYTES = X3_PATCH_BASE + 8 * X3_PATCH_BYTES;   // 159744 (<= 163840)
-constexpr int X3_A_GROUPS = X3_A_STAGE / 1024, X3_W_GROUPS = X3_W_STAGE / 1024;  // 28 + 32 LDS-DMA wave-instructions
+constexpr int X3_A_RING = 2;
+constexpr int X3_PATCH_BASE = X3_A_RING * X3_A_STAGE;            // 57344
+constexpr int X3_PATCH_BYTES = 8 * 32 * 4;                       // per wave: 8 rows x 32 columns fp32
+constexpr int x3_lds_bytes(int waves) { return X3_PATCH_BASE + waves * X3_PATCH_BYTES; }  // 61440 (4 waves) / 65536 (8)
+constexpr int X3_A_GROUPS = X3_A_STAGE / 1024;                   // 28 LDS-DMA wave-instructions per stage
+constexpr int x3_a_pieces(int waves) { return (X3_A_GROUPS + waves - 1) / waves; }  // 7 (4 waves) / 4 (8 waves)
 
-struct X3Operand {
+struct X3Operand {   // activations: [rows][K] planes
   const bf16_t* hi;
   const bf16_t* lo;
 };
+struct X3Weights {   // fragment-ordered planes (see header); rows padded to a multiple of 32
+  const bf16_t* hi;
+  const bf16_t* lo;
+};
+inline size_t x3_packed_weight_elems(int N, int K) { return (size_t)((N + 31) / 32 * 32) * K; }
 
 // v = act(acc + bias[n]) * (n < scale_cols ? col_scale : 1) + (res ? res[m][n] : 0) -> fp32 out and/or split planes,
 // or (OUT_QKV) the attention operand planes of attention_bf16x3.h.
@@ -92,21 +99,42 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
-// One of the two load streams (A or W): which tile of this workgroup and which k step it will fetch next, and the
-// per-lane source element offsets of its (up to) four LDS-DMA pieces for that tile.
+// fp32 [N][K] -> fragment-ordered hi/lo planes (rows >= N zero).  One thread per 8 consecutive k of one row.
+__global__ __launch_bounds__(256) void pack_weight_planes_kernel(const float* __restrict__ w, bf16_t* __restrict__ hi,
+                                                                 bf16_t* __restrict__ lo, int N, int K) {
+  const int npad = (N + 31) / 32 * 32, k8n = K / 8;
+  const size_t total = (size_t)npad * k8n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / k8n), k8 = (int)(i - (size_t)n * k8n);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (n < N) ? w[(size_t)n * K + 8 * k8 + j] : 0.f;
+    bf16x8 h8, l8;
+    split8(v, h8, l8);
+    const int kstep = k8 >> 1, half = k8 & 1, lane = (n & 31) + 32 * half;
+    const size_t o = (((size_t)(n >> 5) * (K / 16) + kstep) * 64 + lane) * 8;
+    *reinterpret_cast<bf16x8*>(hi + o) = h8;
+    *reinterpret_cast<bf16x8*>(lo + o) = l8;
+  }
+}
+
+// The A load stream: which tile of this workgroup and which k step it fetches next, and the per-lane source element
+// offsets of the wave's seven LDS-DMA pieces for that tile.
+template <int PIECES>
 struct X3Cursor {
   int v;        // virtual tile id (blockIdx.x + j * gridDim.x)
   int k;        // next k step
-  uint32_t off[4];
+  uint32_t off[PIECES];
 };
 
 // ABL (profiling experiments only, 0 in production): 1 = no epilogue stores, 2 = no loads after the prologue,
-// 4 = no MFMAs, 8 = LDS-DMA issued as a burst at the top of the step instead of between the MFMA units,
-// 32 = the PAIRED MFMA schedule (see the main loop).
-template <int ACT, bool HAS_RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL>
-__global__ __launch_bounds__(X3_THREADS, 2) void gemm_bf16x3_kernel(X3Operand A, X3Operand W, X3Epilogue ep, int M, int N,
+// 4 = no MFMAs, 8 = loads issued but not waited for.
+template <int WAVES, int ACT, bool HAS_RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL>
+__global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N,
                                                                      int K, int rows_per_tile, int tiles_n, int total) {
   MDM_DYN_SMEM(unsigned char, lds);
+  constexpr int X3_WAVES = WAVES, X3_TN = x3_tn(WAVES), X3_A_PIECES = x3_a_pieces(WAVES);
+  using Cursor = X3Cursor<X3_A_PIECES>;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -126,87 +154,73 @@ __global__ __launch_bounds__(X3_THREADS, 2) void gemm_bf16x3_kernel(X3Operand A,
     n0 = tile_n * X3_TN;
   };
 
-  // ---- LDS-DMA sources.  A stage image = 28 groups of 1 KB (16 rows x 64 B): groups 0-13 Ah, 14-27 Al; W stage image =
-  // 32 groups: 0-15 Wh, 16-31 Wl.  Wave w issues groups w, w+8, ...  Lane -> (row = lane>>2, stored chunk = lane&3);
-  // the logical k-chunk it fetches is stored ^ ((row>>2)&3) = (lane&3) ^ ((lane>>4)&3).  Rows past the tile / matrix
-  // are clamped (their products are never stored).
+  // ---- LDS-DMA sources.  A stage image = 28 groups of 1 KB (16 rows x 64 B): groups 0-13 Ah, 14-27 Al.  Wave w issues
+  // groups w, w+4, ..., w+24.  Lane -> (row = lane>>2, stored chunk = lane&3); the logical k-chunk it fetches is
+  // stored ^ ((row>>2)&3) = (lane&3) ^ ((lane>>4)&3).  Rows past the tile / matrix are clamped (never stored).
   const int schunk = (lane & 3) ^ ((lane >> 4) & 3);
-  auto aim_a = [&](X3Cursor& c) {
+  auto aim_a = [&](Cursor& c) {
     int m0, n0;
     tile_origin(c.v, m0, n0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int qa = wid + 8 * i;  // < 28 for i < 3, and for i == 3 when wid < 4
-      const int ga = (qa < 14) ? qa : qa - 14;
+    for (int i = 0; i < X3_A_PIECES; ++i) {
+      const int q = min(wid + X3_WAVES * i, X3_A_GROUPS - 1);
+      const int ga = (q < 14) ? q : q - 14;
       const int arow = min(m0 + ga * 16 + (lane >> 2), M - 1);
       c.off[i] = (uint32_t)arow * (uint32_t)K + schunk * 8;
     }
   };
-  auto aim_w = [&](X3Cursor& c) {
-    int m0, n0;
-    tile_origin(c.v, m0, n0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int qw = wid + 8 * i;  // < 32
-      const int gw = (qw < 16) ? qw : qw - 16;
-      const int wrow = min(n0 + gw * 16 + (lane >> 2), N - 1);
-      c.off[i] = (uint32_t)wrow * (uint32_t)K + schunk * 8;
-    }
+  auto piece_a = [&](const Cursor& c, int i, int buf) {
+    const int q = wid + X3_WAVES * i;
+    if (q < X3_A_GROUPS)
+      glds16(((q < 14) ? A.hi : A.lo) + c.off[i] + c.k * X3_BK, lds + buf * X3_A_STAGE + q * 1024);
   };
-  auto piece_a = [&](const X3Cursor& c, int i, int buf) {
-    if (i < 3 || wid < 4)  // groups wid + 8 i < 28
-      glds16(((wid + 8 * i < 14) ? A.hi : A.lo) + c.off[i] + c.k * X3_BK, lds + buf * X3_A_STAGE + wid * 1024 + i * 8192);
-  };
-  auto piece_w = [&](const X3Cursor& c, int i, int buf) {
-    glds16(((wid + 8 * i < 16) ? W.hi : W.lo) + c.off[i] + c.k * X3_BK,
-           lds + X3_W_BASE + buf * X3_W_STAGE + wid * 1024 + i * 8192);
-  };
-  // past its last tile a stream simply re-fetches that tile (at most two wasted stages per workgroup): the step body
-  // then needs no "is there anything left to load" branches at all
-  auto advance_a = [&](X3Cursor& c) {
+  // past its last tile the stream simply re-fetches that tile (one wasted stage per workgroup): no "anything left to
+  // load" branches in the step body
+  auto advance_a = [&](Cursor& c) {
     if (++c.k == nk) {
       c.k = 0;
       if (c.v + gstride < total) { c.v += gstride; aim_a(c); }
     }
   };
-  auto advance_w = [&](X3Cursor& c) {
-    if (++c.k == nk) {
-      c.k = 0;
-      if (c.v + gstride < total) { c.v += gstride; aim_w(c); }
-    }
+
+  // ---- W fragments of this wave for k step `k` of tile `v`: four 16-byte loads per lane, each a contiguous 1 KB per wave
+  const size_t wk16 = (size_t)(K / 16);
+  auto load_w = [&](int v, int k, bf16x8 (&fh)[2], bf16x8 (&fl)[2]) {
+    int m0, n0;
+    tile_origin(v, m0, n0);
+    const size_t nb = (size_t)((n0 >> 5) + wid);
+    const size_t o = ((nb * wk16 + 2 * (size_t)k) * 64 + lane) * 8;
+    fh[0] = *reinterpret_cast<const bf16x8*>(W.hi + o);
+    fl[0] = *reinterpret_cast<const bf16x8*>(W.lo + o);
+    fh[1] = *reinterpret_cast<const bf16x8*>(W.hi + o + 512);
+    fl[1] = *reinterpret_cast<const bf16x8*>(W.lo + o + 512);
   };
 
   // ---- fragment read offsets (bytes inside a plane tile): row*64 + ((ksub*2 + h) ^ sw)*16, sw = (row>>2)&3
   const int sw = (r >> 2) & 3;
   const int fa = r * 64;                 // + t*2048 per row sub-tile
-  const int fw = (wid * 32 + r) * 64;
 #ifndef MDM_EMU
   const uint32_t lds_base = lds_addr_of(lds);
 #endif
 
   int v = (int)blockIdx.x;
   if (v >= total) return;
-  X3Cursor ca{v, 0, {0, 0, 0, 0}}, cw{v, 0, {0, 0, 0, 0}};
+  Cursor ca{v, 0, {}};
   aim_a(ca);
-  aim_w(cw);
+  int wv = v, wkk = 0;   // the W stream's (tile, k): one step ahead of the MFMAs, like the A stream
 
-  // Pipeline invariant: at the top of global step g the LDS holds A(g), W(g) [landed, visible] and A(g+1) [in flight].
-  // During the step W(g+1) THEN A(g+2) are issued; at its end wait until at most the A(g+2) pieces (3 per wave; waves
-  // 0-3 issue a 4th that is then also waited for) are outstanding -- loads retire in order, so W(g+1) and A(g+1) have
-  // landed -- and barrier once.  g runs across tile boundaries; epilogue stores only make the count more conservative.
+  // Pipeline invariant: at the top of global step g the LDS holds A(g) [landed, visible] and the registers wh/wl hold
+  // W(g).  During the step A(g+1) is issued into the other stage (its previous content A(g-1) was last read before the
+  // barrier that ended step g-1) and W(g+1) is fetched into wnh/wnl; the step ends with vmcnt(0) + one barrier.
+  bf16x8 wh[2], wl[2], wnh[2], wnl[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) piece_w(cw, i, 0);
-  advance_w(cw);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) piece_a(ca, i, 0);
+  for (int i = 0; i < X3_A_PIECES; ++i) piece_a(ca, i, 0);
   advance_a(ca);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) piece_a(ca, i, 1);
-  advance_a(ca);
-  wait_vmem_upto3();
+  load_w(wv, wkk, wh, wl);
+  wait_vmem_all();
   wg_barrier();
 
-  int abuf = 0, wbuf = 0;
+  int abuf = 0;
   for (; v < total; v += gstride) {
     int m0, n0;
     tile_origin(v, m0, n0);
@@ -225,104 +239,26 @@ __global__ __launch_bounds__(X3_THREADS, 2) void gemm_bf16x3_kernel(X3Operand A,
 #endif
 
     for (int kt = 0; kt < nk; ++kt) {
-      const int abuf_ld = abuf >= 1 ? abuf - 1 : 2;  // (abuf + 2) % 3
+      // W(g+1): advance the W stream and fetch (past the last tile: re-fetch, like the A stream)
+      if (++wkk == nk) {
+        wkk = 0;
+        if (wv + gstride < total) wv += gstride;
+      }
+      if (!(ABL & 2)) load_w(wv, wkk, wnh, wnl);
       // 14 units per stage (2 k sub-steps x 7 row sub-tiles), each = 2 A-fragment reads + 3 MFMAs, software-pipelined
       // DEPTH units deep: the reads of unit u+DEPTH are issued, then a COUNTED wait (2*DEPTH younger reads may stay in
-      // flight) retires unit u's, then its 3 MFMAs go.  One LDS-DMA piece rides behind each of the first eight units: W(g+1) pieces
-      // first, then A(g+2).
+      // flight) retires unit u's, then its 3 MFMAs go.  One LDS-DMA piece of A(g+1) rides behind each of the first seven.
       constexpr int DEPTH = 2, RING = DEPTH + 1;  // fragment-read lookahead in units
-      bf16x8 wh[2], wl[2], ah[RING], al[RING];
+      bf16x8 ah[RING], al[RING];
 #ifdef MDM_EMU
       const unsigned char* sa = lds + abuf * X3_A_STAGE;
-      const unsigned char* sw_ = lds + X3_W_BASE + wbuf * X3_W_STAGE;
 #define X3_RD_A(dst, plane, t, ks) lds_read16(dst, sa, (plane) * X3_A_BYTES + fa + (t) * 2048 + ((((ks) * 2 + h) ^ sw) * 16))
-#define X3_RD_W(dst, plane, ks) lds_read16(dst, sw_, (plane) * X3_W_BYTES + fw + ((((ks) * 2 + h) ^ sw) * 16))
 #else
       // per-lane LDS byte addresses of this stage's fragments for k sub-step 0 / 1 (the XOR swizzle moves with ks)
-      const uint32_t sa0 = lds_base + abuf * X3_A_STAGE + fa, sw0 = lds_base + X3_W_BASE + wbuf * X3_W_STAGE + fw;
+      const uint32_t sa0 = lds_base + abuf * X3_A_STAGE + fa;
       const uint32_t aaddr[2] = {sa0 + ((h ^ sw) * 16), sa0 + (((2 + h) ^ sw) * 16)};
-      const uint32_t waddr[2] = {sw0 + ((h ^ sw) * 16), sw0 + (((2 + h) ^ sw) * 16)};
-#define X3_RD_A(dst, plane, t, ks) do { if constexpr (!(ABL & 512)) lds_read16<(plane) * X3_A_BYTES + (t) * 2048>(dst, aaddr[ks]); } while (0)
-#define X3_RD_W(dst, plane, ks) do { if constexpr (!(ABL & 512)) lds_read16<(plane) * X3_W_BYTES>(dst, waddr[ks]); } while (0)
+#define X3_RD_A(dst, plane, t, ks) lds_read16<(plane) * X3_A_BYTES + (t) * 2048>(dst, aaddr[ks])
 #endif
-      if constexpr ((ABL & 32) != 0) {
-        // PAIRED schedule: units 2p and 2p+1 (always different row sub-tiles) are issued as M_a M_b M_a M_b M_a M_b, so
-        // consecutive MFMAs never share an accumulator and the fragment reads of pair p+2 / the LDS-DMA pieces can sit
-        // BETWEEN them in the matrix pipe's shadow instead of behind a same-accumulator triple (a filler inside such a
-        // triple costs ~43 cycles, behind it ~6 per instruction: MI355X_MICROARCH.md cycle constants).
-        constexpr int NP = X3_MSUB;  // 7 pairs per stage
-        bf16x8 fr[3][4];            // ring of pair fragment sets: {ah_a, al_a, ah_b, al_b}
-        auto rd_pair = [&](auto p_tag) __attribute__((always_inline)) {
-          constexpr int p = decltype(p_tag)::value;
-          if constexpr (p < NP) {
-            constexpr int ua = 2 * p, ub = 2 * p + 1;
-            X3_RD_A(fr[p % 3][0], 0, ua % X3_MSUB, ua / X3_MSUB);
-            X3_RD_A(fr[p % 3][1], 1, ua % X3_MSUB, ua / X3_MSUB);
-            X3_RD_A(fr[p % 3][2], 0, ub % X3_MSUB, ub / X3_MSUB);
-            X3_RD_A(fr[p % 3][3], 1, ub % X3_MSUB, ub / X3_MSUB);
-          }
-        };
-        X3_RD_W(wh[0], 0, 0);
-        X3_RD_W(wl[0], 1, 0);
-        X3_RD_W(wh[1], 0, 1);
-        X3_RD_W(wl[1], 1, 1);
-        rd_pair(std::integral_constant<int, 0>{});
-        rd_pair(std::integral_constant<int, 1>{});
-#ifndef MDM_EMU
-#define X3_PIN() __builtin_amdgcn_sched_barrier(0)
-#else
-#define X3_PIN()
-#endif
-        static_for<NP>([&](auto p_tag) __attribute__((always_inline)) {
-          constexpr int p = decltype(p_tag)::value;
-          constexpr int ua = 2 * p, ub = 2 * p + 1;
-          constexpr int ta = ua % X3_MSUB, ka = ua / X3_MSUB, tb = ub % X3_MSUB, kb = ub / X3_MSUB;
-          constexpr int s = p % 3, sn = (p + 2) % 3;
-          constexpr int younger = (p + 1 < NP) ? 4 : 0;  // pair p+1's reads may stay in flight
-          if constexpr (p == 0)
-            lds_wait<younger>(fr[s][0], fr[s][1], fr[s][2], fr[s][3], wh[0], wl[0], wh[1], wl[1]);
-          else
-            lds_wait<younger>(fr[s][0], fr[s][1], fr[s][2], fr[s][3]);
-          X3_PIN();
-          constexpr bool rd = (p + 2 < NP);
-          constexpr int un = 2 * (p + 2);  // first unit of pair p+2
-          acc[ta] = mfma_bf16(fr[s][1], wh[ka], acc[ta]);
-          X3_PIN();
-          if constexpr (rd) X3_RD_A(fr[sn][0], 0, un % X3_MSUB, un / X3_MSUB);
-          X3_PIN();
-          acc[tb] = mfma_bf16(fr[s][3], wh[kb], acc[tb]);
-          X3_PIN();
-          if constexpr (rd) X3_RD_A(fr[sn][1], 1, un % X3_MSUB, un / X3_MSUB);
-          X3_PIN();
-          acc[ta] = mfma_bf16(fr[s][0], wl[ka], acc[ta]);
-          X3_PIN();
-          if constexpr (rd) X3_RD_A(fr[sn][2], 0, (un + 1) % X3_MSUB, (un + 1) / X3_MSUB);
-          X3_PIN();
-          acc[tb] = mfma_bf16(fr[s][2], wl[kb], acc[tb]);
-          X3_PIN();
-          if constexpr (rd) X3_RD_A(fr[sn][3], 1, (un + 1) % X3_MSUB, (un + 1) / X3_MSUB);
-          X3_PIN();
-          acc[ta] = mfma_bf16(fr[s][0], wh[ka], acc[ta]);
-          X3_PIN();
-          if constexpr (!(ABL & 2)) {
-            if constexpr (p < 2) piece_w(cw, 2 * p, wbuf ^ 1);
-            else if constexpr (p < 4) piece_a(ca, 2 * (p - 2), abuf_ld);
-          }
-          X3_PIN();
-          acc[tb] = mfma_bf16(fr[s][2], wh[kb], acc[tb]);
-          X3_PIN();
-          if constexpr (!(ABL & 2)) {
-            if constexpr (p < 2) piece_w(cw, 2 * p + 1, wbuf ^ 1);
-            else if constexpr (p < 4) piece_a(ca, 2 * (p - 2) + 1, abuf_ld);
-          }
-          X3_PIN();
-        });
-#undef X3_PIN
-      } else {
-      X3_RD_W(wh[0], 0, 0);
-      X3_RD_W(wl[0], 1, 0);
-      X3_RD_W(wh[1], 0, 1);
-      X3_RD_W(wl[1], 1, 1);
       constexpr int NU = 2 * X3_MSUB;  // units per stage
       static_for<NU + DEPTH>([&](auto u_tag) __attribute__((always_inline)) {
         constexpr int u = decltype(u_tag)::value;
@@ -333,24 +269,9 @@ __global__ __launch_bounds__(X3_THREADS, 2) void gemm_bf16x3_kernel(X3Operand A,
         }
         if constexpr (u >= DEPTH) {
           constexpr int uv = u - DEPTH, ks = uv / X3_MSUB, t = uv - ks * X3_MSUB;
-#ifndef MDM_EMU
-          // experiment: a wave that is BEHIND in its step outranks its SIMD partner, so the two waves of a SIMD finish
-          // the step together instead of one parking at the barrier while the other runs alone
-          if constexpr ((ABL & 64) != 0) {
-            if constexpr (uv == 0) __builtin_amdgcn_s_setprio(1);
-            if constexpr (uv == X3_MSUB) __builtin_amdgcn_s_setprio(0);
-          }
-          if constexpr ((ABL & 128) != 0) {
-            if constexpr (uv == 0) __builtin_amdgcn_s_setprio(3);
-            if constexpr (uv == 4) __builtin_amdgcn_s_setprio(2);
-            if constexpr (uv == 7) __builtin_amdgcn_s_setprio(1);
-            if constexpr (uv == 11) __builtin_amdgcn_s_setprio(0);
-          }
-#endif
           // reads allowed to stay in flight: those of the (up to) DEPTH younger units
           constexpr int younger = 2 * ((NU - 1 - uv) < DEPTH ? (NU - 1 - uv) : DEPTH);
-          if constexpr (uv == 0) lds_wait<younger>(ah[0], al[0], wh[0], wl[0], wh[1], wl[1]);
-          else lds_wait<younger>(ah[uv % RING], al[uv % RING]);
+          lds_wait<younger>(ah[uv % RING], al[uv % RING]);
 #ifndef MDM_EMU
           __builtin_amdgcn_sched_barrier(0);  // the MFMAs below must not be hoisted above the wait (rule 18)
 #endif
@@ -366,31 +287,26 @@ __global__ __launch_bounds__(X3_THREADS, 2) void gemm_bf16x3_kernel(X3Operand A,
 #ifndef MDM_EMU
           __builtin_amdgcn_sched_barrier(0);  // keep the same-accumulator triple back to back (no filler inside)
 #endif
-          if constexpr (!(ABL & 2)) {
-            if constexpr (uv < 4) piece_w(cw, uv, wbuf ^ 1);
-            else if constexpr (uv < 8) piece_a(ca, uv - 4, abuf_ld);
-          }
+          if constexpr (!(ABL & 2) && uv < X3_A_PIECES) piece_a(ca, uv, abuf ^ 1);
 #ifndef MDM_EMU
           __builtin_amdgcn_sched_barrier(0);
 #endif
         }
       });
-      }
 #undef X3_RD_A
-#undef X3_RD_W
-      advance_w(cw);
       advance_a(ca);
-      if (ABL & 2) wait_vmem_all();
-      else wait_vmem_upto3();
-      if (!(ABL & 256)) wg_barrier();   // 256: experiment, no per-step barrier (only meaningful with 2 = no loads)
-      abuf = (abuf == 2) ? 0 : abuf + 1;
-      wbuf ^= 1;
+      if (!(ABL & 8)) wait_vmem_all();   // 8: experiment -- loads issued but never waited for (results are garbage)
+      wg_barrier();
+      abuf ^= 1;
+      if (!(ABL & 2)) {
+        wh[0] = wnh[0]; wh[1] = wnh[1]; wl[0] = wnl[0]; wl[1] = wnl[1];
+      }
     }
 
     // ---- epilogue.  In the accumulator layout a lane owns ONE column and 16 rows of each 32x32 sub-tile, which would
     // mean 4-byte (fp32) / 2-byte (planes) stores: the store tail is issue-bound (cdna_hip_programming.md T21).  So
     // each wave transposes 8 rows x 32 columns at a time (accumulator registers 4g..4g+3 of both lane halves) through
-    // its private 1 KB LDS patch -- disjoint from the operand rings, which already hold the next tile's first stages
+    // its private 1 KB LDS patch -- disjoint from the A stages, which already hold the next tile's first stage
     // -- and writes 16 bytes per lane: lane -> (row = lane>>3, 4 consecutive columns).
     const float mult = (nc < ep.scale_cols) ? ep.col_scale : 1.f;
     const int m_end = min(M, m0 + rows_per_tile);
@@ -509,7 +425,7 @@ __global__ __launch_bounds__(X3_THREADS, 2) void gemm_bf16x3_kernel(X3Operand A,
       });
     }
   }
-  wait_vmem_all();  // the streams' last (unused) LDS-DMA stages must land before this workgroup's LDS is released
+  wait_vmem_all();  // the stream's last (unused) LDS-DMA stage must land before this workgroup's LDS is released
 }
 
 // rows per block tile: a whole number of sequences when the row space is sequence-structured (keeps the tile count a
@@ -519,9 +435,10 @@ inline int x3_rows_per_tile(int M, int seq_len) {
   return X3_TM;
 }
 
-// persistent grid: one workgroup per CU (the kernel needs ~156 KB of the CU's 160 KB LDS)
-inline int x3_grid_limit() {
+// persistent grid: `per_cu` workgroups per CU (4-wave: two -- 60 KB of LDS and <= 256 VGPRs each; 8-wave: one)
+inline int x3_grid_limit(int per_cu) {
 #ifdef MDM_EMU
+  (void)per_cu;
   return 3;  // small, so that the emulator exercises the tile roll-over paths
 #else
   static int cus = 0;
@@ -530,35 +447,40 @@ inline int x3_grid_limit() {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
-    cus = cus / 8 * 8;  // xcd_remap keeps a workgroup on one XCD only if the stride is a multiple of 8
-    if (cus <= 0) cus = 8;
   }
-  return cus;
+  const int wgs = per_cu * cus / 8 * 8;  // xcd_remap keeps a workgroup on one XCD only if the stride is a multiple of 8
+  return wgs > 0 ? wgs : 8;
 #endif
 }
 
-template <int ACT, bool HAS_RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL = 0>
-inline int launch_gemm_bf16x3_t(const X3Operand& A, const X3Operand& W, const X3Epilogue& ep, int M, int N, int K,
+// workgroup shape used by the launchers below: 4 or 8 waves (mdm_debug_set(2, waves) for A/B probes)
+inline int& x3_waves_setting() {
+  static int waves = 4;
+  return waves;
+}
+
+template <int WAVES, int ACT, bool HAS_RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL>
+inline int launch_gemm_bf16x3_w(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                                 int rpt, hipStream_t stream) {
-  const int tiles_m = (M + rpt - 1) / rpt, tiles_n = (N + X3_TN - 1) / X3_TN;
+  constexpr int TN = x3_tn(WAVES);
+  const int tiles_m = (M + rpt - 1) / rpt, tiles_n = (N + TN - 1) / TN;
   const int total = tiles_m * tiles_n;
-  auto kfn = &gemm_bf16x3_kernel<ACT, HAS_RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>;
-#ifndef MDM_EMU
-  static bool configured = false;  // per instantiation
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            X3_LDS_BYTES) != hipSuccess)
-      return -1;
-    configured = true;
-  }
-#endif
-  const int grid = std::min(total, x3_grid_limit());
-  MDM_LAUNCH(kfn, dim3(grid), dim3(X3_THREADS), X3_LDS_BYTES, stream, A, W, ep, M, N, K, rpt, tiles_n, total);
+  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, HAS_RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>;
+  const int grid = std::min(total, x3_grid_limit(WAVES == 4 ? 2 : 1));
+  MDM_LAUNCH(kfn, dim3(grid), dim3(64 * WAVES), x3_lds_bytes(WAVES), stream, A, W, ep, M, N, K, rpt, tiles_n, total);
   return 0;
 }
 
+template <int ACT, bool HAS_RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL = 0>
+inline int launch_gemm_bf16x3_t(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
+                                int rpt, hipStream_t stream) {
+  if (x3_waves_setting() == 8)
+    return launch_gemm_bf16x3_w<8, ACT, HAS_RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>(A, W, ep, M, N, K, rpt, stream);
+  return launch_gemm_bf16x3_w<4, ACT, HAS_RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>(A, W, ep, M, N, K, rpt, stream);
+}
+
 // runtime (act, res, outputs) -> one of the instantiations the encoder needs
-inline int launch_gemm_bf16x3(const X3Operand& A, const X3Operand& W, const X3Epilogue& ep, int M, int N, int K, int act,
+inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K, int act,
                               int seq_len, hipStream_t s, int ablate = 0) {
   const bool res = ep.res != nullptr, f32 = ep.out != nullptr, pl = ep.oh != nullptr;
   const int rpt = x3_rows_per_tile(M, seq_len);
@@ -567,14 +489,10 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Operand& W, const X3Ep
     switch (ablate) {
       case 1: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 1>(A, W, ep, M, N, K, rpt, s);
       case 2: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 2>(A, W, ep, M, N, K, rpt, s);
-      case 4: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 4>(A, W, ep, M, N, K, rpt, s);
-      case 32: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 32>(A, W, ep, M, N, K, rpt, s);
-      case 258: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 258>(A, W, ep, M, N, K, rpt, s);
-      case 514: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 514>(A, W, ep, M, N, K, rpt, s);
-      case 770: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 770>(A, W, ep, M, N, K, rpt, s);
       case 3: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 3>(A, W, ep, M, N, K, rpt, s);
-      case 771: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 771>(A, W, ep, M, N, K, rpt, s);
-      case 34: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 34>(A, W, ep, M, N, K, rpt, s);
+      case 4: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 4>(A, W, ep, M, N, K, rpt, s);
+      case 8: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 8>(A, W, ep, M, N, K, rpt, s);
+      case 9: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 9>(A, W, ep, M, N, K, rpt, s);
       default: return -2;
     }
   }
@@ -588,7 +506,7 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Operand& W, const X3Ep
 }
 
 // in_proj: tokens [nseq*S][D] x W [3D][D] -> the attention operand planes; one sequence per tile (tile row == token)
-inline int launch_gemm_bf16x3_qkv(const X3Operand& A, const X3Operand& W, const X3Epilogue& ep, int nseq, int S, int D,
+inline int launch_gemm_bf16x3_qkv(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int nseq, int S, int D,
                                   hipStream_t s) {
   if (S > X3_TM) return -2;
   return launch_gemm_bf16x3_t<ACT_NONE, false, false, false, true>(A, W, ep, nseq * S, 3 * D, D, S, s);

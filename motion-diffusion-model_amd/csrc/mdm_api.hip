@@ -106,8 +106,8 @@ struct mdm_model {
   float* time_table = nullptr;  // [max_len][D]
   int jf = 0, jf_pad = 0;
   int precision = MDM_PREC_BF16X3;
-  struct LayerPlanes { X3Operand in_proj, out_proj, linear1, linear2; };
-  std::vector<LayerPlanes> planes;  // bf16 hi/lo planes of the encoder weights (built by mdm_prepare)
+  struct LayerPlanes { X3Weights in_proj, out_proj, linear1, linear2; };
+  std::vector<LayerPlanes> planes;  // fragment-ordered bf16 hi/lo planes of the encoder weights (mdm_prepare)
 
   const float* W(const std::string& k) const { return w.at(k); }
   const float* L(int layer, const char* suffix) const {
@@ -238,7 +238,7 @@ int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, cons
 
 // bf16x3 GEMM on pre-split operands; writes fp32 `out` and/or split planes oh/ol.  seq_len > 0 tells the tiler that
 // the M rows are token sequences of that length (tile = whole sequences).
-int launch_linear_x3(Profiler* pf, X3Operand a, X3Operand w, const float* bias, const float* res, float* out,
+int launch_linear_x3(Profiler* pf, X3Operand a, X3Weights w, const float* bias, const float* res, float* out,
                      bf16_t* oh, bf16_t* ol, int M, int N, int K, int act, int scale_cols, float col_scale, int seq_len,
                      hipStream_t s) {
   if (K % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 linear: K must be a multiple of 32");
@@ -246,20 +246,27 @@ int launch_linear_x3(Profiler* pf, X3Operand a, X3Operand w, const float* bias, 
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
   X3Epilogue ep{out, bias, res, oh, ol, N, scale_cols, col_scale, QkvPlanes{}, 0, 0};
   const int rc = launch_gemm_bf16x3(a, w, ep, M, N, K, act, seq_len, s, g_x3_ablate);
-  if (rc == -1) return fail(MDM_EHIP, "bf16x3 linear: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 linear: unsupported (activation, residual, output) combination");
   return rt_launch_status();
 }
 
 // in_proj in split precision: tokens -> Q (pre-scaled) / K / V^T operand planes of attention_bf16x3.h
-int launch_in_proj_x3(Profiler* pf, X3Operand a, X3Operand w, const float* bias, const QkvPlanes& qp, int nseq, int S,
+int launch_in_proj_x3(Profiler* pf, X3Operand a, X3Weights w, const float* bias, const QkvPlanes& qp, int nseq, int S,
                       int D, float qscale, hipStream_t s) {
   if (D % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 in_proj: latent_dim must be a multiple of 32");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * nseq * S * 3.0 * D * (double)D, s);
   X3Epilogue ep{nullptr, bias, nullptr, nullptr, nullptr, 3 * D, D, qscale, qp, S, D};
   const int rc = launch_gemm_bf16x3_qkv(a, w, ep, nseq, S, D, s);
-  if (rc == -1) return fail(MDM_EHIP, "bf16x3 in_proj: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 in_proj: sequences longer than 224 tokens");
+  return rt_launch_status();
+}
+
+// fp32 [N][K] weights -> fragment-ordered hi/lo planes (gemm_bf16x3.h header); K % 16 == 0
+int launch_pack_weights(const float* src, bf16_t* hi, bf16_t* lo, int N, int K, hipStream_t s) {
+  if (K % 16 != 0) return fail(MDM_EINVAL, "pack_weights: K must be a multiple of 16");
+  const size_t n = x3_packed_weight_elems(N, K) / 8;
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  MDM_LAUNCH(pack_weight_planes_kernel, dim3(grid), dim3(256), 0, s, src, hi, lo, N, K);
   return rt_launch_status();
 }
 
@@ -444,18 +451,19 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
   base += align_up((size_t)R * D * sizeof(float), 256);
   const size_t FF = m->cfg.ff_size;
   m->planes.assign(m->cfg.num_layers, mdm_model::LayerPlanes{});
-  auto make_planes = [&](const float* src, size_t n, X3Operand& op) -> int {
+  auto make_planes = [&](const float* src, int N, int K, X3Weights& op) -> int {
+    const size_t n = x3_packed_weight_elems(N, K);
     bf16_t* hi = reinterpret_cast<bf16_t*>(base);
     bf16_t* lo = hi + n;
     base += align_up(n * 4, 256);
-    op = X3Operand{hi, lo};
-    return launch_split(src, hi, lo, n, s);
+    op = X3Weights{hi, lo};
+    return launch_pack_weights(src, hi, lo, N, K, s);
   };
   for (int l = 0; l < m->cfg.num_layers; ++l) {
-    if (int rc = make_planes(m->L(l, "self_attn.in_proj_weight"), (size_t)3 * D * D, m->planes[l].in_proj)) return rc;
-    if (int rc = make_planes(m->L(l, "self_attn.out_proj.weight"), (size_t)D * D, m->planes[l].out_proj)) return rc;
-    if (int rc = make_planes(m->L(l, "linear1.weight"), FF * D, m->planes[l].linear1)) return rc;
-    if (int rc = make_planes(m->L(l, "linear2.weight"), (size_t)D * FF, m->planes[l].linear2)) return rc;
+    if (int rc = make_planes(m->L(l, "self_attn.in_proj_weight"), 3 * D, D, m->planes[l].in_proj)) return rc;
+    if (int rc = make_planes(m->L(l, "self_attn.out_proj.weight"), D, D, m->planes[l].out_proj)) return rc;
+    if (int rc = make_planes(m->L(l, "linear1.weight"), (int)FF, D, m->planes[l].linear1)) return rc;
+    if (int rc = make_planes(m->L(l, "linear2.weight"), D, (int)FF, m->planes[l].linear2)) return rc;
   }
   m->prepared = true;
   return MDM_OK;
@@ -628,6 +636,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
 int mdm_debug_set(int what, int value) {
   if (what == 0) g_x3_ablate = value;
   if (what == 1) g_x3_reuse_planes = value;
+  if (what == 2 && (value == 4 || value == 8)) x3_waves_setting() = value;
   return MDM_OK;
 }
 
@@ -672,7 +681,7 @@ int mdm_linear(const float* in, const float* w, const float* bias, const float* 
 }
 
 size_t mdm_linear_bf16x3_scratch_bytes(int32_t M, int32_t N, int32_t K) {
-  return align_up((size_t)M * K * 4, 256) + align_up((size_t)N * K * 4, 256);
+  return align_up((size_t)M * K * 4, 256) + align_up(x3_packed_weight_elems(N, K) * 4, 256);
 }
 
 int mdm_linear_bf16x3(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M,
@@ -684,12 +693,12 @@ int mdm_linear_bf16x3(const float* in, const float* w, const float* bias, const 
   bf16_t* ah = static_cast<bf16_t*>(scratch);
   bf16_t* al = ah + (size_t)M * K;
   bf16_t* wh = reinterpret_cast<bf16_t*>(static_cast<char*>(scratch) + align_up((size_t)M * K * 4, 256));
-  bf16_t* wl = wh + (size_t)N * K;
+  bf16_t* wl = wh + x3_packed_weight_elems(N, K);
   if (!g_x3_reuse_planes) {
     if (int rc = launch_split(in, ah, al, (size_t)M * K, s)) return rc;
-    if (int rc = launch_split(w, wh, wl, (size_t)N * K, s)) return rc;
+    if (int rc = launch_pack_weights(w, wh, wl, N, K, s)) return rc;
   }
-  return launch_linear_x3(nullptr, X3Operand{ah, al}, X3Operand{wh, wl}, bias, res, out, nullptr, nullptr, M, N, K, act, 0,
+  return launch_linear_x3(nullptr, X3Operand{ah, al}, X3Weights{wh, wl}, bias, res, out, nullptr, nullptr, M, N, K, act, 0,
                           1.f, 0, s);
 }
 

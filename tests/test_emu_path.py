@@ -98,7 +98,7 @@ def test_emulated_attention_mask(lib):
     assert maxabs(out, ref.numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("S,lengths", [(37, [36, 3]), (70, [69, 40])])
+@pytest.mark.parametrize("S,lengths", [(37, [36, 3]), (70, [69, 40]), (197, [196, 100])])
 def test_emulated_attention_bf16x3(lib, S, lengths):
     """Split-precision attention: plane layouts (swizzled K rows, MFMA-ordered V^T), masking, deferred normalisation."""
     nseq, B, D, H, hd = 2, 2, 256, 2, 128

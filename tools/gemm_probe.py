@@ -54,12 +54,15 @@ for name, m, n, k, act, res in shapes:
                                     scratch.data_ptr(), nb, stream), "x3")   # fills the planes
     lib.mdm_debug_set(1, 1)
     # variants: every ablation code on the plain epilogue (act none, no residual) + the production epilogue of this shape
-    variants = [("plain", ab, 0, False) for ab in ablates] + ([("prod", 0, act, res)] if (act or res) else [])
+    waves_list = [int(x) for x in os.environ.get("PROBE_WAVES", "4").split(",")]
+    variants = [(f"w{wv}", ab, 0, False) for wv in waves_list for ab in ablates] + \
+               ([(f"w{wv}p", 0, act, res) for wv in waves_list] if (act or res) else [])
     times = {v: [] for v in variants}
     for _ in range(ROUNDS):          # interleaved rounds: the chip's clock drifts with its power state (DVFS), so
         for v in variants:           # back-to-back blocks per variant would measure the drift, not the kernel
-            _, ab, use_act, use_res = v
+            tag, ab, use_act, use_res = v
             lib.mdm_debug_set(0, ab)
+            lib.mdm_debug_set(2, int(tag[1]))
 
             def run():
                 lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(),
@@ -68,6 +71,7 @@ for name, m, n, k, act, res in shapes:
             times[v].append(timeit(run, reps))
     lib.mdm_debug_set(0, 0)
     lib.mdm_debug_set(1, 0)
+    lib.mdm_debug_set(2, 4)
     for v in variants:
         ts = sorted(times[v])
         med, mn = ts[len(ts) // 2], ts[0]
