@@ -176,7 +176,7 @@ int mdm_profile_read(mdm_model_t* m, int32_t category, double* total_ms, int64_t
 int mdm_profile_reset(mdm_model_t* m);
 /* Switches for profiling experiments; value 0 = production behaviour.  what = 0: bf16x3 GEMM ablation code
  * (gemm_bf16x3.h ABL); what = 1: mdm_linear_bf16x3 reuses the operand planes already in scratch (kernel-only timing); what = 2: waves per
- * bf16x3 GEMM workgroup, 4 (default: 224x128 tiles, two workgroups per CU) or 8 (224x256 tiles, one per CU). */
+ * bf16x3 GEMM workgroup, 8 (default: 224x256 tiles, one workgroup per CU) or 4 (224x128 tiles, two per CU). */
 int mdm_debug_set(int what, int value);
 
 /* Building blocks, exported for the parity tests and for callers that compose their own layers.

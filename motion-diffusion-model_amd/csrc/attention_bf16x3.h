@@ -7,13 +7,13 @@
 // the key-padding mask of mdm.py:241-247.  The exact-fp32 kernel (attention_f32.h) remains the `f32` mode.
 //
 // Operand planes (all bf16, hi and lo; SP = tokens padded to a multiple of 32, NKT = SP/32):
-//   Q, K   [nseq][H][SP][128]            row = token, Q pre-scaled by 1/sqrt(128); pad rows are zero
+//   Q, K   [nseq][H][SP][128]            row = token, Q pre-scaled by 1/sqrt(128); pad rows: any FINITE values
 //   V^T    [nseq][H][NKT][128][32]       per 32-key tile: row = d, 32 keys of that tile in MFMA ORDER: inside each
 //                                        group of 16 keys, position p holds key (p&3) + 8*((p>>2)&1) + 4*(p>>3).
 //                                        That is the order in which a lane of a 32x32 MFMA accumulator holds its 16
 //                                        rows, so (a) the in_proj epilogue stores V^T straight from its accumulators
 //                                        with 16-byte stores and (b) the probabilities, which come out of phase 1 in
-//                                        accumulator registers, are already the matching B operand.  Pad keys zero.
+//                                        accumulator registers, are already the matching B operand.  Pad keys: finite.
 //
 // One workgroup per (sequence, head); wave w owns queries [32w, 32w+32).  Everything is computed TRANSPOSED so the
 // softmax axis is lane-local (cdna_hip_programming.md T12's "swapped QK^T"):

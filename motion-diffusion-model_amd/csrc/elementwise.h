@@ -121,6 +121,54 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, con
   }
 }
 
+// Tail of the split-precision OutputProcess: the bf16x3 GEMM leaves every token's 263 output features as a fp32 ROW
+// (out_tok [nseq*S][ldo]); this kernel drops token 0 (mdm.py:253), transposes 32x32 tiles through LDS into the
+// reference's [.., JF, T] pose layout (mdm.py:385) and fuses, per element, what OutProjEpilogue fuses in the fp32 path:
+// mode 0 plain model output for every sequence; mode 1 classifier-free-guidance combine of the two branches
+// (utils/sampler_util.py:34 -- here AFTER the projection, which is linear), inpainting blend, clamp, posterior /
+// DDIM update with this step's noise (gaussian_diffusion.py:300-304, :347-353, :525-540).
+// grid (ceil(T/32), ceil(JF/32), sequences or samples), 256 threads = 32 x 8.
+__global__ __launch_bounds__(256) void outproj_finish_kernel(const float* __restrict__ out_tok, int ldo, int S, int T,
+                                                             int JF, int B, const float* __restrict__ scale, int mode,
+                                                             float* __restrict__ out, float* __restrict__ x0_out,
+                                                             const float* __restrict__ x_t,
+                                                             const float* __restrict__ noise,
+                                                             const unsigned char* __restrict__ inpaint_mask,
+                                                             const float* __restrict__ inpaint_motion, StepCoefs co) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int t0 = blockIdx.x * 32, j0 = blockIdx.y * 32, b = blockIdx.z;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, j = j0 + tx;
+    float v = 0.f;
+    if (t < T && j < JF) {
+      v = out_tok[((size_t)b * S + 1 + t) * ldo + j];
+      if (mode == 1 && scale != nullptr) {
+        const float u = out_tok[((size_t)(B + b) * S + 1 + t) * ldo + j];
+        v = u + scale[b] * (v - u);
+      }
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = j0 + ty + 8 * i, t = t0 + tx;
+    if (j < JF && t < T) {
+      const size_t off = ((size_t)b * JF + j) * T + t;
+      float x0 = tile[tx][ty + 8 * i];
+      if (mode == 0) { out[off] = x0; continue; }
+      if (inpaint_mask != nullptr && inpaint_mask[off]) x0 = inpaint_motion[off];
+      if (co.clip_denoised) x0 = fminf(1.f, fmaxf(-1.f, x0));
+      float v = co.a_x0 * x0 + co.a_xt * x_t[off];
+      if (noise != nullptr) v += co.sigma * noise[off];
+      if (x0_out != nullptr) x0_out[off] = x0;
+      out[off] = v;
+    }
+  }
+}
+
 // hi/lo bf16 planes of a fp32 array (weights at mdm_prepare; test inputs).  n must be a multiple of 4.
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi,
                                                            bf16_t* __restrict__ lo, size_t n4) {

@@ -37,6 +37,7 @@
 #include "attention_bf16x3.h"  // QkvPlanes: the in_proj epilogue writes the attention kernel's operand planes
 #include "common.h"
 #include "gemm_f32.h"  // ACT_* enums
+#include <cstdlib>
 
 namespace mdm {
 
@@ -316,51 +317,58 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
 
     if (OUT_QKV) {
       // in_proj -> attention operand planes (attention_bf16x3.h).  rows_per_tile == S: tile row == token, tile_m == sequence.
-      const int Dm = ep.D, Sq = ep.S, SPq = ep.qkv.SP, Hq = ep.qkv.H;
+      // Pad tokens (S <= token < SP) are written with whatever finite values the clamped / neighbouring activation rows
+      // produce: the attention kernel selects -inf for their scores (p == 0 exactly) and never stores their queries, so
+      // they only need to be finite -- masking them here cost 112 hoisted lane masks (280 spilled SGPRs).
+      const int Dm = ep.D, SPq = ep.qkv.SP, Hq = ep.qkv.H;
       const int which = ncol0 / Dm, hcol = ncol0 - which * Dm, head = hcol >> 7, d0 = hcol & 127;
       const size_t shq = (size_t)(m0 / rows_per_tile) * Hq + head;
       if (ncol0 < N && !(ABL & 1)) {
         if (which == 2) {
           // V^T: accumulator registers 8 s2 .. 8 s2 + 7 of a lane ARE positions 8h .. 8h+7 of 16-key group s2
+          bf16_t* vhp = ep.qkv.vh + ((shq * ep.qkv.NKT) * AX_HD + d0 + r) * 32 + 8 * h;
+          bf16_t* vlp = ep.qkv.vl + ((shq * ep.qkv.NKT) * AX_HD + d0 + r) * 32 + 8 * h;
+          const int nkt = ep.qkv.NKT;
 #pragma unroll
           for (int t = 0; t < X3_MSUB; ++t) {
-            if (t < ep.qkv.NKT) {
+            if (t < nkt) {
 #pragma unroll
               for (int s2 = 0; s2 < 2; ++s2) {
                 float vv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                  const int tok = 32 * t + mfma_row(8 * s2 + j, h);
-                  vv[j] = (tok < Sq) ? acc[t][8 * s2 + j] + bias : 0.f;
-                }
+                for (int j = 0; j < 8; ++j) vv[j] = acc[t][8 * s2 + j] + bias;
                 bf16x8 vh8, vl8;
                 split8(vv, vh8, vl8);
-                const size_t o = ((shq * ep.qkv.NKT + t) * AX_HD + d0 + r) * 32 + 16 * s2 + 8 * h;
-                *reinterpret_cast<bf16x8*>(ep.qkv.vh + o) = vh8;
-                *reinterpret_cast<bf16x8*>(ep.qkv.vl + o) = vl8;
+                *reinterpret_cast<bf16x8*>(vhp + t * (AX_HD * 32) + 16 * s2) = vh8;
+                *reinterpret_cast<bf16x8*>(vlp + t * (AX_HD * 32) + 16 * s2) = vl8;
               }
             }
           }
         } else {
-          bf16_t* dh = which == 0 ? ep.qkv.qh : ep.qkv.kh;
-          bf16_t* dl = which == 0 ? ep.qkv.ql : ep.qkv.kl;
+          // Q / K rows: same pipelined patch rounds as the plain epilogue below (round j+1's patch writes sit between
+          // round j's patch read and its stores); one base pointer per plane, 32-bit offsets
+          bf16_t* dh = (which == 0 ? ep.qkv.qh : ep.qkv.kh) + shq * SPq * AX_HD + d0 + pc4;
+          bf16_t* dl = (which == 0 ? ep.qkv.ql : ep.qkv.kl) + shq * SPq * AX_HD + d0 + pc4;
+          const int nkt = ep.qkv.NKT;
+          auto qk_write = [&](auto j_tag) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
+            if constexpr (j < 4 * X3_MSUB) {
 #pragma unroll
-          for (int t = 0; t < X3_MSUB; ++t) {
-            if (t < ep.qkv.NKT) {
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = (acc[t][4 * g + e] + bias) * mult;
-                wave_lds_fence();
-                const int tok = 32 * t + 8 * g + prow;
-                float4 v4 = ld4(&patch[prow * 32 + pc4]);
-                if (tok >= Sq) v4 = zero4();
-                const size_t o = (shq * SPq + tok) * AX_HD + d0 + pc4;
-                split4_store(dh + o, dl + o, v4);
-                wave_lds_fence();
-              }
+              for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = (acc[t][4 * g + e] + bias) * mult;
             }
-          }
+          };
+          qk_write(std::integral_constant<int, 0>{});
+          static_for<4 * X3_MSUB>([&](auto j_tag) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
+            wave_lds_fence();
+            float4 v4 = ld4(&patch[prow * 32 + pc4]);
+            wave_lds_fence();
+            qk_write(std::integral_constant<int, j + 1>{});
+            if (t < nkt) {
+              const int tok = 32 * t + 8 * g + prow;
+              split4_store(dh + tok * AX_HD, dl + tok * AX_HD, v4);
+            }
+          });
         }
       }
     } else {
@@ -453,9 +461,13 @@ inline int x3_grid_limit(int per_cu) {
 #endif
 }
 
-// workgroup shape used by the launchers below: 4 or 8 waves (mdm_debug_set(2, waves) for A/B probes)
+// workgroup shape used by the launchers below: 8 waves (default: whole-bench A/B on one box 307 vs 302 motions/s) or 4
+// (mdm_debug_set(2, waves) / MDM_X3_WAVES for A/B probes)
 inline int& x3_waves_setting() {
-  static int waves = 4;
+  static int waves = [] {
+    const char* e = getenv("MDM_X3_WAVES");   // A/B runs of whole benchmarks
+    return (e != nullptr && e[0] == '4') ? 4 : 8;
+  }();
   return waves;
 }
 

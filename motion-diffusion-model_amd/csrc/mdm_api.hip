@@ -108,6 +108,9 @@ struct mdm_model {
   int precision = MDM_PREC_BF16X3;
   struct LayerPlanes { X3Weights in_proj, out_proj, linear1, linear2; };
   std::vector<LayerPlanes> planes;  // fragment-ordered bf16 hi/lo planes of the encoder weights (mdm_prepare)
+  X3Weights out_planes{nullptr, nullptr};  // poseFinal.weight, rows padded to jf_out (bf16x3 OutputProcess)
+  float* out_bias_pad = nullptr;            // poseFinal.bias padded to jf_out
+  int jf_out = 0;                           // njoints*nfeats rounded up to a multiple of 4
 
   const float* W(const std::string& k) const { return w.at(k); }
   const float* L(int layer, const char* suffix) const {
@@ -340,6 +343,22 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
   return 0;
 }
 
+// OutputProcess, split precision: every sequence's tokens x poseFinal -> fp32 rows in the (dead) qkv region, then the
+// transposing / fusing tail kernel (elementwise.h outproj_finish_kernel).
+int outproj_x3(mdm_model* m, const Workspace& ws, int nseq, int B, int T, const float* scale, int mode, float* out,
+               float* x0_out, const float* x_t, const float* noise, const unsigned char* inpaint_mask,
+               const float* inpaint_motion, StepCoefs co, hipStream_t s) {
+  const int D = m->cfg.latent_dim, S = T + 1, ldo = m->jf_out;
+  float* out_tok = ws.qkv;
+  ProfScope ps(&m->prof, MDM_PROF_OUTPROJ, 2.0 * nseq * T * (double)D * m->jf, s);
+  if (int rc = launch_linear_x3(nullptr, X3Operand{ws.tokh, ws.tokl}, m->out_planes, m->out_bias_pad, nullptr, out_tok,
+                                nullptr, nullptr, nseq * S, ldo, D, ACT_NONE, 0, 1.f, S, s)) return rc;
+  const int nb = (mode == 1) ? B : nseq;
+  MDM_LAUNCH(outproj_finish_kernel, dim3((T + 31) / 32, (m->jf + 31) / 32, nb), dim3(256), 0, s, (const float*)out_tok,
+             ldo, S, T, m->jf, B, scale, mode, out, x0_out, x_t, noise, inpaint_mask, inpaint_motion, co);
+  return rt_launch_status();
+}
+
 int check_ready(const mdm_model* m) {
   if (m == nullptr) return fail(MDM_EINVAL, "null model");
   if (!m->prepared) return fail(MDM_ESTATE, "mdm_prepare has not been called (or weights changed since)");
@@ -367,6 +386,7 @@ int mdm_create(const mdm_config_t* cfg, mdm_model_t** out) {
   m->cfg = *cfg;
   m->jf = cfg->njoints * cfg->nfeats;
   m->jf_pad = (m->jf + 3) / 4 * 4;
+  m->jf_out = m->jf_pad;
   const int64_t d = D, ff = cfg->ff_size, jf = m->jf;
   auto& e = m->expect;
   e["input_process.poseEmbedding.weight"] = d * jf;
@@ -420,7 +440,8 @@ size_t mdm_const_bytes(const mdm_model_t* m) {
   const size_t FF = m->cfg.ff_size;
   const size_t per_layer = align_up(3 * D * D * 4, 256) + align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
   return align_up(D * m->jf_pad * sizeof(float), 256) + 2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) +
-         (size_t)m->cfg.num_layers * per_layer;
+         (size_t)m->cfg.num_layers * per_layer + align_up(x3_packed_weight_elems(m->jf_out, (int)D) * 4, 256) +
+         align_up((size_t)m->jf_out * sizeof(float), 256);
 }
 
 int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* stream) {
@@ -465,6 +486,13 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
     if (int rc = make_planes(m->L(l, "linear1.weight"), (int)FF, D, m->planes[l].linear1)) return rc;
     if (int rc = make_planes(m->L(l, "linear2.weight"), D, (int)FF, m->planes[l].linear2)) return rc;
   }
+  // OutputProcess in split precision: weight rows / bias padded to jf_out (the pad rows are zero)
+  if (int rc = make_planes(m->W("output_process.poseFinal.weight"), m->jf, D, m->out_planes)) return rc;
+  m->out_bias_pad = reinterpret_cast<float*>(base);
+  base += align_up((size_t)m->jf_out * sizeof(float), 256);
+  MDM_LAUNCH(pad_rows_kernel, dim3(1), dim3(256), 0, s, m->out_bias_pad, m->W("output_process.poseFinal.bias"), 1, m->jf,
+             m->jf_out);
+  if (int rc = rt_launch_status()) return rc;
   m->prepared = true;
   return MDM_OK;
 }
@@ -505,6 +533,8 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
                             uncond_from, s)) return rc;
   if (int rc = encoder(m, ws, nseq, B, S, len, s)) return rc;
   // OutputProcess, plain: every branch's tokens -> [nseq, JF, T]
+  if (m->precision == MDM_PREC_BF16X3)
+    return outproj_x3(m, ws, nseq, B, T, nullptr, 0, out, nullptr, nullptr, nullptr, nullptr, nullptr, StepCoefs{}, s);
   RowMajorLoader al{m->W("output_process.poseFinal.weight"), D, m->jf, D};
   CfgTokenLoader bl{ws.tok, nullptr, nseq, T, S, D, nseq * T};
   OutProjEpilogue ep{};
@@ -608,7 +638,11 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
       }
     }
     // OutputProcess + CFG combine + sampler update, in place on x
-    {
+    if (m->precision == MDM_PREC_BF16X3) {
+      if (int rc = outproj_x3(m, ws, nseq, B, T, cfg ? p->scale_dev : nullptr, 1, x, (i == 0) ? p->x0_dev : nullptr, x,
+                              step_noise, p->inpaint_mask_dev, p->inpaint_motion_dev,
+                              StepCoefs{p->a_x0[i], p->a_xt[i], p->sigma[i], p->clip_denoised}, s)) return rc;
+    } else {
       RowMajorLoader al{m->W("output_process.poseFinal.weight"), D, m->jf, D};
       CfgTokenLoader bl{ws.tok, cfg ? p->scale_dev : nullptr, B, T, S, D, B * T};
       OutProjEpilogue ep{};
