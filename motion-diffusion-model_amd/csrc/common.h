@@ -179,6 +179,25 @@ template <int N> __device__ __forceinline__ void vmem_wait(f32x4& a, f32x4& b, f
 }
 #endif
 
+// 8-byte flavour (four bf16 of one plane): the residual stream of the bf16x3 mode lives only as hi/lo planes
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#ifdef MDM_EMU
+__device__ __forceinline__ void gload8_async(u32x2& dst, const void* p) { memcpy(&dst, p, 8); }
+template <int N>
+__device__ __forceinline__ void vmem_wait(u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&) {}
+#else
+__device__ __forceinline__ void gload8_async(u32x2& dst, const void* p) {
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vmem_wait(u32x2& a, u32x2& b, u32x2& c, u32x2& d, u32x2& e, u32x2& f, u32x2& g, u32x2& h) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)
+               : "i"(N)
+               : "memory");
+}
+#endif
+
 // Workgroup barrier that does NOT drain the vector-memory queue (cdna_hip_programming.md section 5: __syncthreads()
 // would wait vmcnt(0) while an LDS-DMA is in flight); pair it with an explicit wait where the data is consumed.
 __device__ __forceinline__ void wg_barrier() {

@@ -6,13 +6,14 @@
 
 namespace mdm {
 
-// In-place LayerNorm over rows of D = 256*NV floats (norm1/norm2 of nn.TransformerEncoderLayer,
+// LayerNorm over rows of D = 256*NV floats (in place when write_f32; planes-only otherwise) (norm1/norm2 of nn.TransformerEncoderLayer,
 // eps = 1e-5, biased variance; torch transformer.py:951-956).  One wave per row, NV float4 per lane,
 // two-pass (mean, then centred sum of squares) entirely in registers.
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int rows, float eps,
-                                                        bf16_t* __restrict__ xh, bf16_t* __restrict__ xl) {
+                                                        bf16_t* __restrict__ xh, bf16_t* __restrict__ xl,
+                                                        int write_f32) {
   constexpr int D = 256 * NV;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -42,8 +43,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
     const float4 g = ld4(gamma + 256 * i + 4 * lane), b = ld4(beta + 256 * i + 4 * lane);
     const float4 o = make_float4(v[i].x * rstd * g.x + b.x, v[i].y * rstd * g.y + b.y, v[i].z * rstd * g.z + b.z,
                                  v[i].w * rstd * g.w + b.w);
-    st4(xr + 256 * i + 4 * lane, o);
-    if (xh != nullptr) {  // split planes for the next bf16x3 GEMM
+    if (write_f32) st4(xr + 256 * i + 4 * lane, o);
+    if (xh != nullptr) {  // split planes for the next bf16x3 GEMM (and, in that mode, the residual stream itself)
       const size_t off = (size_t)row * D + 256 * i + 4 * lane;
       split4_store(xh + off, xl + off, o);
     }

@@ -71,7 +71,9 @@ inline size_t x3_packed_weight_elems(int N, int K) { return (size_t)((N + 31) / 
 struct X3Epilogue {
   float* out;        // [M][ld] or null
   const float* bias;
-  const float* res;  // [M][ld] or null; may alias out
+  const float* res;  // RES == 1: fp32 residual [M][ld]; may alias out
+  const bf16_t* resh;  // RES == 2: the residual as hi/lo planes [M][ld] (value = hi + lo)
+  const bf16_t* resl;
   bf16_t* oh;        // [M][ld] split planes or null
   bf16_t* ol;
   int ld;
@@ -85,7 +87,11 @@ struct X3Epilogue {
 // and a 5-term Horner chain instead of the ~40-instruction libm erff; used only in this split-precision path.
 __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
+#ifdef MDM_EMU
   const float t = 1.0f / (1.0f + 0.3275911f * z);
+#else
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);  // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE divide
+#endif
   float p = 1.061405429f;
   p = p * t - 1.453152027f;
   p = p * t + 1.421413741f;
@@ -128,9 +134,10 @@ struct X3Cursor {
   uint32_t off[PIECES];
 };
 
+// RES: 0 = no residual, 1 = fp32 residual, 2 = residual held as bf16 hi/lo planes.
 // ABL (profiling experiments only, 0 in production): 1 = no epilogue stores, 2 = no loads after the prologue,
 // 4 = no MFMAs, 8 = loads issued but not waited for.
-template <int WAVES, int ACT, bool HAS_RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL>
+template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL>
 __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N,
                                                                      int K, int rows_per_tile, int tiles_n, int total) {
   MDM_DYN_SMEM(unsigned char, lds);
@@ -374,15 +381,33 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     } else {
       // residual tile: streamed two row sub-tiles ahead of its use through untracked loads (common.h gload16_async);
       // rows past the matrix are clamped (loaded, never stored)
-      f32x4 rr[3][4];
+      constexpr bool HAS_RES = RES != 0;
+      f32x4 rr[3][4];       // RES == 1
+      u32x2 rh[3][4], rl[3][4];  // RES == 2
       auto res_issue = [&](auto t_tag) __attribute__((always_inline)) {
         constexpr int t = decltype(t_tag)::value;
         if constexpr (HAS_RES && t < X3_MSUB) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int m = min(m0 + t * 32 + 8 * g + prow, M - 1);
-            gload16_async(rr[t % 3][g], ep.res + (size_t)m * ep.ld + (n4 < N ? n4 : 0));
+            const size_t o = (size_t)m * ep.ld + (n4 < N ? n4 : 0);
+            if constexpr (RES == 1) {
+              gload16_async(rr[t % 3][g], ep.res + o);
+            } else {
+              gload8_async(rh[t % 3][g], ep.resh + o);
+              gload8_async(rl[t % 3][g], ep.resl + o);
+            }
           }
+        }
+      };
+      auto res_wait = [&](auto t_tag) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_tag)::value;
+        constexpr int ahead = (X3_MSUB - 1 - t) < 2 ? (X3_MSUB - 1 - t) : 2;  // younger sub-tiles already requested
+        if constexpr (RES == 1) {
+          vmem_wait<4 * ahead>(rr[t % 3][0], rr[t % 3][1], rr[t % 3][2], rr[t % 3][3]);
+        } else if constexpr (RES == 2) {
+          vmem_wait<8 * ahead>(rh[t % 3][0], rh[t % 3][1], rh[t % 3][2], rh[t % 3][3], rl[t % 3][0], rl[t % 3][1],
+                               rl[t % 3][2], rl[t % 3][3]);
         }
       };
       if (!(ABL & 1)) {
@@ -410,8 +435,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
         if constexpr (HAS_RES && g == 0) {
           if (!(ABL & 1)) {
             res_issue(std::integral_constant<int, t + 2>{});
-            constexpr int younger = 4 * ((X3_MSUB - 1 - t) < 2 ? (X3_MSUB - 1 - t) : 2);
-            vmem_wait<younger>(rr[t % 3][0], rr[t % 3][1], rr[t % 3][2], rr[t % 3][3]);
+            res_wait(std::integral_constant<int, t>{});
           }
         }
         wave_lds_fence();
@@ -422,9 +446,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
           const int m = m0 + t * 32 + 8 * g + prow;
           if (m < m_end && n4 < N) {  // N % 4 == 0
             const size_t o = (size_t)m * ep.ld + n4;
-            if (HAS_RES) {
+            if constexpr (RES == 1) {
               const f32x4 q4 = rr[t % 3][g];
               v4.x += q4[0]; v4.y += q4[1]; v4.z += q4[2]; v4.w += q4[3];
+            } else if constexpr (RES == 2) {
+              const u32x2 a = rh[t % 3][g], b = rl[t % 3][g];
+              v4.x += bf16_bits_to_f32((bf16_t)(a[0] & 0xffffu)) + bf16_bits_to_f32((bf16_t)(b[0] & 0xffffu));
+              v4.y += bf16_bits_to_f32((bf16_t)(a[0] >> 16)) + bf16_bits_to_f32((bf16_t)(b[0] >> 16));
+              v4.z += bf16_bits_to_f32((bf16_t)(a[1] & 0xffffu)) + bf16_bits_to_f32((bf16_t)(b[1] & 0xffffu));
+              v4.w += bf16_bits_to_f32((bf16_t)(a[1] >> 16)) + bf16_bits_to_f32((bf16_t)(b[1] >> 16));
             }
             if (OUT_F32) st4(ep.out + o, v4);
             if (OUT_PLANES) split4_store(ep.oh + o, ep.ol + o, v4);
@@ -471,24 +501,24 @@ inline int& x3_waves_setting() {
   return waves;
 }
 
-template <int WAVES, int ACT, bool HAS_RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL>
+template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL>
 inline int launch_gemm_bf16x3_w(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                                 int rpt, hipStream_t stream) {
   constexpr int TN = x3_tn(WAVES);
   const int tiles_m = (M + rpt - 1) / rpt, tiles_n = (N + TN - 1) / TN;
   const int total = tiles_m * tiles_n;
-  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, HAS_RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>;
+  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>;
   const int grid = std::min(total, x3_grid_limit(WAVES == 4 ? 2 : 1));
   MDM_LAUNCH(kfn, dim3(grid), dim3(64 * WAVES), x3_lds_bytes(WAVES), stream, A, W, ep, M, N, K, rpt, tiles_n, total);
   return 0;
 }
 
-template <int ACT, bool HAS_RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL = 0>
+template <int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL = 0>
 inline int launch_gemm_bf16x3_t(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                                 int rpt, hipStream_t stream) {
   if (x3_waves_setting() == 8)
-    return launch_gemm_bf16x3_w<8, ACT, HAS_RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>(A, W, ep, M, N, K, rpt, stream);
-  return launch_gemm_bf16x3_w<4, ACT, HAS_RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>(A, W, ep, M, N, K, rpt, stream);
+    return launch_gemm_bf16x3_w<8, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>(A, W, ep, M, N, K, rpt, stream);
+  return launch_gemm_bf16x3_w<4, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>(A, W, ep, M, N, K, rpt, stream);
 }
 
 // runtime (act, res, outputs) -> one of the instantiations the encoder needs
@@ -496,24 +526,29 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Ep
                               int seq_len, hipStream_t s, int ablate = 0) {
   const bool res = ep.res != nullptr, f32 = ep.out != nullptr, pl = ep.oh != nullptr;
   const int rpt = x3_rows_per_tile(M, seq_len);
+  if (ep.resh != nullptr) {  // residual stream held as planes (the model's bf16x3 mode)
+    if (ablate == 0 && act == ACT_NONE && !res && f32 && !pl)
+      return launch_gemm_bf16x3_t<ACT_NONE, 2, true, false, false>(A, W, ep, M, N, K, rpt, s);
+    return -2;
+  }
   if (ablate != 0) {  // profiling experiments (mdm_debug_set): only the plain fp32-out variant is instantiated
     if (!(act == ACT_NONE && !res && f32 && !pl)) return -2;
     switch (ablate) {
-      case 1: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 1>(A, W, ep, M, N, K, rpt, s);
-      case 2: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 2>(A, W, ep, M, N, K, rpt, s);
-      case 3: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 3>(A, W, ep, M, N, K, rpt, s);
-      case 4: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 4>(A, W, ep, M, N, K, rpt, s);
-      case 8: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 8>(A, W, ep, M, N, K, rpt, s);
-      case 9: return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false, 9>(A, W, ep, M, N, K, rpt, s);
+      case 1: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 1>(A, W, ep, M, N, K, rpt, s);
+      case 2: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 2>(A, W, ep, M, N, K, rpt, s);
+      case 3: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 3>(A, W, ep, M, N, K, rpt, s);
+      case 4: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 4>(A, W, ep, M, N, K, rpt, s);
+      case 8: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 8>(A, W, ep, M, N, K, rpt, s);
+      case 9: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 9>(A, W, ep, M, N, K, rpt, s);
       default: return -2;
     }
   }
-  if (act == ACT_NONE && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_NONE, false, true, false, false>(A, W, ep, M, N, K, rpt, s);
-  if (act == ACT_NONE && res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_NONE, true, true, false, false>(A, W, ep, M, N, K, rpt, s);
-  if (act == ACT_GELU && !res && !f32 && pl) return launch_gemm_bf16x3_t<ACT_GELU, false, false, true, false>(A, W, ep, M, N, K, rpt, s);
-  if (act == ACT_GELU && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_GELU, false, true, false, false>(A, W, ep, M, N, K, rpt, s);
-  if (act == ACT_GELU && res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_GELU, true, true, false, false>(A, W, ep, M, N, K, rpt, s);
-  if (act == ACT_SILU && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_SILU, false, true, false, false>(A, W, ep, M, N, K, rpt, s);
+  if (act == ACT_NONE && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false>(A, W, ep, M, N, K, rpt, s);
+  if (act == ACT_NONE && res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_NONE, 1, true, false, false>(A, W, ep, M, N, K, rpt, s);
+  if (act == ACT_GELU && !res && !f32 && pl) return launch_gemm_bf16x3_t<ACT_GELU, 0, false, true, false>(A, W, ep, M, N, K, rpt, s);
+  if (act == ACT_GELU && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_GELU, 0, true, false, false>(A, W, ep, M, N, K, rpt, s);
+  if (act == ACT_GELU && res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_GELU, 1, true, false, false>(A, W, ep, M, N, K, rpt, s);
+  if (act == ACT_SILU && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_SILU, 0, true, false, false>(A, W, ep, M, N, K, rpt, s);
   return -2;
 }
 
@@ -521,7 +556,7 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Ep
 inline int launch_gemm_bf16x3_qkv(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int nseq, int S, int D,
                                   hipStream_t s) {
   if (S > X3_TM) return -2;
-  return launch_gemm_bf16x3_t<ACT_NONE, false, false, false, true>(A, W, ep, nseq * S, 3 * D, D, S, s);
+  return launch_gemm_bf16x3_t<ACT_NONE, 0, false, false, true>(A, W, ep, nseq * S, 3 * D, D, S, s);
 }
 
 }  // namespace mdm

@@ -162,14 +162,14 @@ Workspace carve(const mdm_model* m, int nseq, int T, void* base) {
 }
 
 int launch_layernorm(Profiler* pf, float* x, const float* g, const float* b, int rows, int D, bf16_t* xh, bf16_t* xl,
-                     hipStream_t s) {
+                     hipStream_t s, bool write_f32 = true) {
   ProfScope ps(pf, MDM_PROF_LAYERNORM, 0.0, s);
   const dim3 grid((rows + 3) / 4), block(256);
   switch (D / 256) {
-    case 1: { auto k = &layernorm_kernel<1>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl); break; }
-    case 2: { auto k = &layernorm_kernel<2>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl); break; }
-    case 3: { auto k = &layernorm_kernel<3>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl); break; }
-    case 4: { auto k = &layernorm_kernel<4>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl); break; }
+    case 1: { auto k = &layernorm_kernel<1>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl, (int)write_f32); break; }
+    case 2: { auto k = &layernorm_kernel<2>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl, (int)write_f32); break; }
+    case 3: { auto k = &layernorm_kernel<3>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl, (int)write_f32); break; }
+    case 4: { auto k = &layernorm_kernel<4>; MDM_LAUNCH(k, grid, block, 0, s, x, g, b, rows, 1e-5f, xh, xl, (int)write_f32); break; }
     default: return fail(MDM_EUNSUPPORTED, "layernorm: D must be 256, 512, 768 or 1024");
   }
   return rt_launch_status();
@@ -243,11 +243,11 @@ int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, cons
 // the M rows are token sequences of that length (tile = whole sequences).
 int launch_linear_x3(Profiler* pf, X3Operand a, X3Weights w, const float* bias, const float* res, float* out,
                      bf16_t* oh, bf16_t* ol, int M, int N, int K, int act, int scale_cols, float col_scale, int seq_len,
-                     hipStream_t s) {
+                     hipStream_t s, X3Operand res_planes = X3Operand{nullptr, nullptr}) {
   if (K % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 linear: K must be a multiple of 32");
   if (N % 4 != 0) return fail(MDM_EINVAL, "bf16x3 linear: N must be a multiple of 4");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
-  X3Epilogue ep{out, bias, res, oh, ol, N, scale_cols, col_scale, QkvPlanes{}, 0, 0};
+  X3Epilogue ep{out, bias, res, res_planes.hi, res_planes.lo, oh, ol, N, scale_cols, col_scale, QkvPlanes{}, 0, 0};
   const int rc = launch_gemm_bf16x3(a, w, ep, M, N, K, act, seq_len, s, g_x3_ablate);
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 linear: unsupported (activation, residual, output) combination");
   return rt_launch_status();
@@ -258,7 +258,7 @@ int launch_in_proj_x3(Profiler* pf, X3Operand a, X3Weights w, const float* bias,
                       int D, float qscale, hipStream_t s) {
   if (D % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 in_proj: latent_dim must be a multiple of 32");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * nseq * S * 3.0 * D * (double)D, s);
-  X3Epilogue ep{nullptr, bias, nullptr, nullptr, nullptr, 3 * D, D, qscale, qp, S, D};
+  X3Epilogue ep{nullptr, bias, nullptr, nullptr, nullptr, nullptr, nullptr, 3 * D, D, qscale, qp, S, D};
   const int rc = launch_gemm_bf16x3_qkv(a, w, ep, nseq, S, D, s);
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 in_proj: sequences longer than 224 tokens");
   return rt_launch_status();
@@ -316,14 +316,16 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
       const mdm_model::LayerPlanes& P = m->planes[l];
       if (int rc = launch_in_proj_x3(pf, tokp, P.in_proj, m->L(l, "self_attn.in_proj_bias"), ws.qp, nseq, S, D, qscale, s)) return rc;
       if (int rc = launch_attention_x3(pf, ws.qp, lengths, nseq, B, S, D, nullptr, ws.atth, ws.attl, s)) return rc;
-      if (int rc = launch_linear_x3(pf, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"), ws.tok, ws.tok, nullptr,
-                                    nullptr, M, D, D, ACT_NONE, 0, 1.f, S, s)) return rc;
-      if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, ws.tokh, ws.tokl, s)) return rc;
+      // the residual stream lives as planes only (value = hi + lo): the GEMM writes the pre-norm sum as fp32, LayerNorm
+      // turns it back into planes and does NOT write fp32 (one 103 MB stream less per LayerNorm)
+      if (int rc = launch_linear_x3(pf, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"), nullptr, ws.tok, nullptr,
+                                    nullptr, M, D, D, ACT_NONE, 0, 1.f, S, s, tokp)) return rc;
+      if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, ws.tokh, ws.tokl, s, false)) return rc;
       if (int rc = launch_linear_x3(pf, tokp, P.linear1, m->L(l, "linear1.bias"), nullptr, nullptr, ws.ffnh, ws.ffnl, M,
                                     FF, D, ACT_GELU, 0, 1.f, S, s)) return rc;
-      if (int rc = launch_linear_x3(pf, ffnp, P.linear2, m->L(l, "linear2.bias"), ws.tok, ws.tok, nullptr, nullptr, M, D,
-                                    FF, ACT_NONE, 0, 1.f, S, s)) return rc;
-      if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, ws.tokh, ws.tokl, s)) return rc;
+      if (int rc = launch_linear_x3(pf, ffnp, P.linear2, m->L(l, "linear2.bias"), nullptr, ws.tok, nullptr, nullptr, M, D,
+                                    FF, ACT_NONE, 0, 1.f, S, s, tokp)) return rc;
+      if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, ws.tokh, ws.tokl, s, false)) return rc;
     }
     return 0;
   }
