@@ -85,6 +85,31 @@ def cpu_baseline(state, T, dsteps, budget_s=15.0):
                       f"motions ({per * 1e3:.0f} ms per batch-step)"}
 
 
+# Mean ALGORITHMIC HBM bytes of one encoder-GEMM launch at the headline shape (256 sequences x 197 tokens, D=512, FF=1024;
+# DESIGN.md section 4): operand planes read once + weights once + output written once (+ residual planes), averaged over
+# the four GEMMs of a layer.  in_proj 103+3+352 MB, out_proj 103+1+103+103, linear1 103+2+207, linear2 207+2+103+103.
+ALGORITHMIC_GEMM_BYTES_PER_LAUNCH = int((458.9e6 + 310.9e6 + 311.9e6 + 415.2e6) / 4)
+
+
+def pmc_traffic_per_gemm_launch():
+    """HBM-side bytes per encoder-GEMM launch from the committed rocprofv3 PMC passes of THIS command
+    (profiles/r01_pmc.json, produced by tools/gpu_prof.sh + tools/pmc_to_json.py: FETCH_SIZE x2 per the gfx950 correction,
+    WRITE_SIZE as is; separate --pmc passes).  PMC collection needs rocprofv3 around the process, so the live run can
+    only quote the profile of the same build; None if the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if not os.path.isfile(path):
+        return None, None
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        w = {"gemm_bf16x3<in_proj -> Q/K/V^T planes>": 1, "gemm_bf16x3<out_proj | linear2, residual planes>": 2,
+             "gemm_bf16x3<linear1 + GELU -> planes>": 1}
+        tot = sum(d[k]["hbm_bytes"] * n for k, n in w.items())
+        return int(tot / sum(w.values())), "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command)"
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +173,7 @@ def main():
     eng.profile(False)
 
     if rank == 0:
+        traffic, traffic_src = pmc_traffic_per_gemm_launch()
         motions_s = GB * a.steps / dt
         lin = prof["linear"]
         ach = lin["flops"] / (lin["ms"] * 1e-3) / 1e12 if lin["ms"] > 0 else 0.0
@@ -170,7 +196,9 @@ def main():
                          "kernel": ("gemm_bf16x3_kernel<Linear>" if x3 else "gemm_f32_kernel<RowMajor,RowMajor,Linear>")
                          + " (encoder GEMMs: in_proj, out_proj, linear1, linear2)",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "traffic": None, "launches": lin["launches"],
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes": ALGORITHMIC_GEMM_BYTES_PER_LAUNCH if x3 else None,
+                         "launches": lin["launches"],
                          "avg_launch_us": round(lin["ms"] * 1e3 / max(lin["launches"], 1), 2),
                          "executed_mfma_tflops": round(ach * (3 if x3 else 1), 2),
                          "peak_basis": ("dense bf16 MFMA (v_mfma_f32_32x32x16_bf16) 2.5 PFLOP/s; `achieved` counts the "

@@ -201,6 +201,14 @@ size_t mdm_attention_bf16x3_scratch_bytes(int32_t nseq, int32_t S, int32_t D);
 int mdm_attention_bf16x3(const float* qkv_dev, float* out_dev, const int32_t* lengths_dev, int32_t nseq, int32_t B,
                          int32_t S, int32_t D, int32_t H, void* scratch_dev, size_t scratch_bytes, void* stream);
 
+/* Post-sampling transform of sample/generate.py:160-166, on the device:
+ *   data = x * std + mean                         (data_loaders/humanml/data/dataset.py:132-133 inv_transform)
+ *   recover_from_ric(data, joints)                (data_loaders/humanml/scripts/motion_process.py:437-452, :366-385)
+ * x_dev [B, njoints_feat, 1, T] (the sampler's output, normalised HumanML3D features: 263 wide, 22 joints; KIT 251 / 21),
+ * mean_dev / std_dev [njoints_feat], out_dev [B, joints, 3, T] -- the layout generate.py:166 produces by permute. */
+int mdm_recover_from_ric(const float* x_dev, const float* mean_dev, const float* std_dev, float* out_dev, int32_t B,
+                         int32_t T, int32_t njoints_feat, int32_t joints, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "mdm_abi_version", "mdm_last_error", "mdm_create", "mdm_destroy", "mdm_set_weight", "mdm_const_bytes",
     "mdm_prepare", "mdm_workspace_bytes", "mdm_forward", "mdm_sampler_step", "mdm_randn", "mdm_sample_loop",
     "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset", "mdm_set_precision", "mdm_linear_bf16x3",
-    "mdm_linear_bf16x3_scratch_bytes", "mdm_debug_set", "mdm_attention_bf16x3", "mdm_attention_bf16x3_scratch_bytes",
+    "mdm_linear_bf16x3_scratch_bytes", "mdm_debug_set", "mdm_attention_bf16x3", "mdm_attention_bf16x3_scratch_bytes", "mdm_recover_from_ric",
 ]
 
 
@@ -85,6 +85,7 @@ class MdmLib:
             "mdm_linear_bf16x3": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
             "mdm_attention_bf16x3_scratch_bytes": (sz, [i32, i32, i32]),
             "mdm_attention_bf16x3": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+            "mdm_recover_from_ric": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
             "mdm_profile_enable": (C.c_int, [vp, C.c_int]),
             "mdm_profile_read": (C.c_int, [vp, i32, P(C.c_double), P(i64), P(C.c_double)]),
             "mdm_profile_reset": (C.c_int, [vp]),

@@ -19,6 +19,7 @@
 #include "elementwise.h"
 #include "gemm_f32.h"
 #include "gemm_bf16x3.h"
+#include "motion_recover.h"
 
 using namespace mdm;
 
@@ -769,6 +770,17 @@ int mdm_attention_bf16x3(const float* qkv, float* out, const int32_t* lengths, i
   MDM_LAUNCH(qkv_pack_kernel, dim3(grid), dim3(256), 0, s, qkv, qp, nseq, S, D);
   if (int rc = rt_launch_status()) return rc;
   return launch_attention_x3(nullptr, qp, lengths, nseq, B, S, D, out, nullptr, nullptr, s);
+}
+
+int mdm_recover_from_ric(const float* x, const float* mean, const float* stdv, float* out, int32_t B, int32_t T,
+                         int32_t njoints_feat, int32_t joints, void* stream) {
+  if (!x || !mean || !stdv || !out || B <= 0 || T <= 0 || joints < 1) return fail(MDM_EINVAL, "mdm_recover_from_ric: bad argument");
+  if (njoints_feat < 4 + 3 * (joints - 1)) return fail(MDM_EINVAL, "mdm_recover_from_ric: feature width too small for the joint count");
+  if (T > 1024) return fail(MDM_EUNSUPPORTED, "mdm_recover_from_ric: at most 1024 frames");
+  auto k = &recover_from_ric_kernel;
+  MDM_LAUNCH(k, dim3(B), dim3(256), (size_t)3 * T * sizeof(float), static_cast<hipStream_t>(stream), x, mean, stdv, out, T,
+             njoints_feat, joints);
+  return rt_launch_status();
 }
 
 }  // extern "C"

@@ -118,3 +118,16 @@ def test_emulated_attention_bf16x3(lib, S, lengths):
         sc[s, :, :, 1 + int(lengths[s]):] = float("-inf")
     ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(nseq * S, D)
     assert maxabs(out, ref.numpy()) < 5e-5
+
+
+def test_emulated_recover_from_ric(lib):
+    """csrc/motion_recover.h (inv_transform + recover_from_ric + permute) against the oracle, ragged T and KIT width."""
+    from mdm_amd.motion_process import recover_from_ric
+    from oracle import motion_oracle as mo
+    from oracle.make_golden_motion import motion_inputs
+    for B, T, JF, J in [(2, 37, 263, 22), (1, 300, 251, 21)]:
+        sample, mean, std = motion_inputs(B, T, seed=B * 100 + T, JF=JF)
+        got = recover_from_ric(sample, mean, std, _native_lib=lib)
+        want = mo.recover_from_ric(sample.numpy(), mean.numpy(), std.numpy(), J)
+        assert got.shape == (B, J, 3, T)
+        assert maxabs(got, want) < 2e-6 * float(np.abs(want).max())

@@ -345,3 +345,27 @@ def test_errors_are_loud(sd):
         model(torch.zeros(2, 263, 1, 300, device=DEV), torch.zeros(2, dtype=torch.long, device=DEV), y=y)
     with pytest.raises(MdmError):          # CPU tensors never fall back to a CPU path
         model.cpu()(torch.zeros(2, 263, 1, 8), torch.zeros(2, dtype=torch.long), y=synth_y(2, 8, seed=0))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Post-sampling transform: inv_transform + recover_from_ric + permute, generate.py:160-166
+# ---------------------------------------------------------------------------------------------------
+def test_recover_from_ric_matches_reference_golden(golden_dir):
+    from mdm_amd.motion_process import recover_from_ric
+    from oracle.make_golden_motion import motion_inputs
+    g = _g(golden_dir, "recover_B3_T196")
+    sample, mean, std = motion_inputs(int(g["B"]), int(g["T"]), int(g["seed"]))
+    got = recover_from_ric(sample.to(DEV), mean.to(DEV), std.to(DEV))
+    assert got.shape == (3, 22, 3, 196) and got.is_cuda
+    assert maxabs(got.cpu(), g["out"]) < 2e-6 * float(np.abs(g["out"]).max())
+
+
+@pytest.mark.parametrize("B,T,JF,J", [(128, 196, 263, 22), (5, 1, 263, 22), (2, 1000, 251, 21)])
+def test_recover_from_ric_matches_oracle_shapes(B, T, JF, J):
+    from mdm_amd.motion_process import recover_from_ric
+    from oracle import motion_oracle as mo
+    from oracle.make_golden_motion import motion_inputs
+    sample, mean, std = motion_inputs(B, T, seed=7 * B + T, JF=JF)
+    got = recover_from_ric(sample.to(DEV), mean.to(DEV), std.to(DEV))
+    want = mo.recover_from_ric(sample.numpy(), mean.numpy(), std.numpy(), J)
+    assert maxabs(got.cpu(), want) < 3e-6 * float(np.abs(want).max())

@@ -118,3 +118,15 @@ def test_loop_golden_1000_steps(golden_dir, sd):
     g = _load(golden_dir, "loop1000_B1_T32")
     final, _ = _run_loop_case(g, sd)
     assert np.abs(final.numpy() - g["final"]).max() < TOL
+
+
+def test_motion_oracle_matches_reference_golden(golden_dir):
+    """oracle/motion_oracle.py (post-sampling transform) against the upstream functions' output."""
+    from oracle import motion_oracle as mo
+    from oracle.make_golden_motion import motion_inputs
+    g = np.load(os.path.join(golden_dir, "recover_B3_T196.npz"))
+    sample, mean, std = motion_inputs(int(g["B"]), int(g["T"]), int(g["seed"]))
+    got = mo.recover_from_ric(sample.numpy(), mean.numpy(), std.numpy(), int(g["joints"]))
+    assert got.shape == g["out"].shape == (3, 22, 3, 196)
+    # positions integrate 196 frames of root velocity (|out| up to ~1e2 here): fp32-rounding-level RELATIVE agreement
+    assert float(np.abs(got - g["out"]).max()) < 2e-6 * float(np.abs(g["out"]).max())
