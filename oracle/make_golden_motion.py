@@ -49,8 +49,10 @@ def main():
     np.savez_compressed(os.path.join(OUT, "recover_B3_T196.npz"), B=B, T=T, seed=seed, joints=22, out=ref.numpy())
     rp = os.path.join(OUT, "PIN_REPORT.json")
     report = json.load(open(rp)) if os.path.isfile(rp) else {}
-    report.setdefault("cases", {})["recover_B3_T196"] = {"oracle_vs_reference_maxabs": err,
-                                                         "out_absmax": float(np.abs(ref.numpy()).max())}
+    # kept out of "cases" (those are absolute max-abs on O(1) samples): positions integrate to ~1e2, the pin is relative
+    report["recover_B3_T196"] = {"oracle_vs_reference_maxabs": err, "out_absmax": float(np.abs(ref.numpy()).max()),
+                                 "relative": err / float(np.abs(ref.numpy()).max())}
+    report.get("cases", {}).pop("recover_B3_T196", None)
     json.dump(report, open(rp, "w"), indent=1, sort_keys=True)
     print("recover_B3_T196: oracle vs reference max-abs", err, "| |out|max", float(np.abs(ref.numpy()).max()))
 

@@ -30,6 +30,7 @@ def test_pin_report_is_tight(golden_dir):
         for k, v in rec.items():
             if k != "ref_absmax":
                 assert v < TOL, (name, k, v)
+    assert rep["recover_B3_T196"]["relative"] < 2e-6       # post-sampling transform (oracle/motion_oracle.py)
 
 
 @pytest.mark.parametrize("steps", [50, 1000])
