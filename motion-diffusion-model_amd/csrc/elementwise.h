@@ -170,6 +170,38 @@ __global__ __launch_bounds__(256) void outproj_finish_kernel(const float* __rest
   }
 }
 
+// LayerNorm folded into the linear layer that consumes it (mdm_prepare; gemm_bf16x3.h X3Epilogue):
+//   wf[n][k] = w[n][k] * gamma[k];  colsum[n] = sum_k wf[n][k];  biasf[n] = bias[n] + sum_k w[n][k] * beta[k]
+// so that  W.LN(x) + b = rstd * (Wf.x - mean * colsum) + biasf.  One wave per output row; rows N..Npad-1 of the
+// vectors are zeroed.  fp64 accumulation of the two sums (they are constants of the model).
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ bias, float* __restrict__ wf,
+                                                             float* __restrict__ colsum, float* __restrict__ biasf,
+                                                             int N, int K, int Npad) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= Npad) return;
+  if (n >= N) {
+    if (lane == 0) { colsum[n] = 0.f; biasf[n] = 0.f; }
+    return;
+  }
+  double cs = 0.0, bs = 0.0;
+  for (int k = lane; k < K; k += 64) {
+    const float wv = w[(size_t)n * K + k], f = wv * gamma[k];
+    wf[(size_t)n * K + k] = f;
+    cs += (double)f;
+    bs += (double)wv * (double)beta[k];
+  }
+  float csf = (float)cs, bsf = (float)bs;   // wave reduction in fp32 of the 64 fp64 partials (values are O(1))
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) {
+    csf += shfl_xor_f32(csf, msk);
+    bsf += shfl_xor_f32(bsf, msk);
+  }
+  if (lane == 0) { colsum[n] = csf; biasf[n] = bias[n] + bsf; }
+}
+
 // hi/lo bf16 planes of a fp32 array (weights at mdm_prepare; test inputs).  n must be a multiple of 4.
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi,
                                                            bf16_t* __restrict__ lo, size_t n4) {

@@ -52,7 +52,17 @@ constexpr int X3_A_STAGE = 2 * X3_A_BYTES;                       // Ah|Al: 28672
 constexpr int X3_A_RING = 2;
 constexpr int X3_PATCH_BASE = X3_A_RING * X3_A_STAGE;            // 57344
 constexpr int X3_PATCH_BYTES = 8 * 32 * 4;                       // per wave: 8 rows x 32 columns fp32
-constexpr int x3_lds_bytes(int waves) { return X3_PATCH_BASE + waves * X3_PATCH_BYTES; }  // 61440 (4 waves) / 65536 (8)
+constexpr int X3_TAB_BYTES = X3_TM * 8;                          // one (mean, rstd) table of the tile's rows
+// LDS after the patches: the (mean, rstd) table of the tile's rows (FOLD or RES == 3: a kernel has one of them) and the
+// raw partial sums it is built from (<= 4 partials per row: 7 KB, the LDS-DMA lands whole KBs), both double-buffered by
+// tile parity, then the per-wave partial sums of OSTAT
+constexpr int x3_tab_base(int waves) { return X3_PATCH_BASE + waves * X3_PATCH_BYTES; }
+constexpr int X3_RAW_BYTES = 7 * 1024;
+constexpr int x3_raw_base(int waves) { return x3_tab_base(waves) + 2 * X3_TAB_BYTES; }      // tables: 2 (tile parity)
+constexpr int x3_part_base(int waves) { return x3_raw_base(waves) + 2 * X3_RAW_BYTES; }    // raw partials: 2 (parity)
+constexpr int x3_lds_bytes(int waves, bool ln) {   // 61440 (4 waves) / 65536 (8); with the LayerNorm tables 87040 (8)
+  return ln ? x3_part_base(waves) + waves * X3_TAB_BYTES : x3_tab_base(waves);
+}
 constexpr int X3_A_GROUPS = X3_A_STAGE / 1024;                   // 28 LDS-DMA wave-instructions per stage
 constexpr int x3_a_pieces(int waves) { return (X3_A_GROUPS + waves - 1) / waves; }  // 7 (4 waves) / 4 (8 waves)
 
@@ -81,6 +91,20 @@ struct X3Epilogue {
   float col_scale;
   QkvPlanes qkv;     // OUT_QKV only
   int S, D;          // OUT_QKV only: tokens per sequence (= rows per tile), model width (N = 3 D)
+  // ---- LayerNorm folded into the GEMMs around it (no LayerNorm kernel, no normalised copy of the residual stream):
+  // the producer of a pre-norm sum x (out_proj / linear2, OSTAT) writes x as planes plus, per row and column tile, the
+  // partial sums (sum x, sum x^2) over its columns; every consumer rebuilds mean / rstd from those partials.
+  //   FOLD  the A operand is x itself and the weights were pre-multiplied by gamma (mdm_prepare), so
+  //         W.LN(x) + b = rstd * (W'.x - mean * colsum) + b'       with colsum[n] = sum_k W'[n][k], b' = b + W.beta
+  //   RES 3 the residual is LN(x) = (x - mean) * rstd * gamma + beta, rebuilt on the fly from x's planes
+  const float* astat;    // FOLD: partial sums of the A rows [M][stat_parts][2]
+  const float* colsum;   // FOLD: [N]
+  const float* rstat;    // RES == 3: partial sums of the residual rows [M][stat_parts][2]
+  const float* rgamma;   // RES == 3: [ld]
+  const float* rbeta;
+  float* ostat;          // OSTAT: [M][tiles_n][2] partial sums of the rows this launch writes
+  int stat_parts;        // partials per row in astat / rstat
+  float inv_dim;         // 1 / (normalised width) for astat / rstat
 };
 
 // exact-GELU with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, i.e. fp32-rounding class): one v_exp, one v_rcp
@@ -137,7 +161,9 @@ struct X3Cursor {
 // RES: 0 = no residual, 1 = fp32 residual, 2 = residual held as bf16 hi/lo planes.
 // ABL (profiling experiments only, 0 in production): 1 = no epilogue stores, 2 = no loads after the prologue,
 // 4 = no MFMAs, 8 = loads issued but not waited for.
-template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL>
+// FOLD / OSTAT / RES == 3: LayerNorm folded into the GEMMs (X3Epilogue).
+template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
+          bool OSTAT = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N,
                                                                      int K, int rows_per_tile, int tiles_n, int total) {
   MDM_DYN_SMEM(unsigned char, lds);
@@ -220,6 +246,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
   // Pipeline invariant: at the top of global step g the LDS holds A(g) [landed, visible] and the registers wh/wl hold
   // W(g).  During the step A(g+1) is issued into the other stage (its previous content A(g-1) was last read before the
   // barrier that ended step g-1) and W(g+1) is fetched into wnh/wnl; the step ends with vmcnt(0) + one barrier.
+  // LayerNorm row statistics: LDS-DMA of the producer's partial sums of the 224 rows starting at m0 (contiguous:
+  // [row][part][2] floats) into raw buffer `par`; waves 0..npieces-1 move 1 KB each
+  auto stats_dma = [&](int m0s, int par) {
+    const float* st = FOLD ? ep.astat : ep.rstat;
+    const int npieces = (X3_TM * ep.stat_parts * 8 + 1023) / 1024;
+    if (wid < npieces) {
+      const long long total_f = (long long)M * ep.stat_parts * 2;     // floats in the whole statistics buffer
+      long long fo = (long long)m0s * ep.stat_parts * 2 + 4LL * (64 * wid + lane);
+      if (fo > total_f - 4) fo = total_f - 4;                          // rows past the matrix: any valid address
+      glds16(st + fo, lds + x3_raw_base(WAVES) + par * X3_RAW_BYTES + wid * 1024);
+    }
+  };
+  if constexpr (FOLD || RES == 3) {
+    int m0f, n0f;
+    tile_origin(v, m0f, n0f);
+    stats_dma(m0f, 0);
+  }
   bf16x8 wh[2], wl[2], wnh[2], wnl[2];
 #pragma unroll
   for (int i = 0; i < X3_A_PIECES; ++i) piece_a(ca, i, 0);
@@ -229,7 +272,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
   wg_barrier();
 
   int abuf = 0;
-  for (; v < total; v += gstride) {
+  int tile_parity = 0;
+  for (; v < total; v += gstride, tile_parity ^= 1) {
     int m0, n0;
     tile_origin(v, m0, n0);
     f32x16 acc[X3_MSUB];
@@ -242,10 +286,41 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     const int ncol0 = n0 + wid * 32;                     // this wave's first column (wave-uniform)
     const int nc = ncol0 + r;                            // this lane's column in the accumulator layout
     float bias = (nc < N) ? ep.bias[nc] : 0.f;
+    float csum = 0.f;                                    // FOLD, accumulator layout (V^T path)
+    if constexpr (FOLD) csum = (nc < N) ? ep.colsum[nc] : 0.f;
 #ifndef MDM_EMU
-    asm volatile("" : "+v"(bias));
+    asm volatile("" : "+v"(bias), "+v"(csum));
 #endif
-
+    // row statistics (mean, rstd) of this tile's rows, built HERE -- where the accumulators are not live yet -- from the
+    // producer's partial sums, which an LDS-DMA issued one tile ago (or in the kernel prologue) has already landed; the
+    // next tile's partials are requested now and land under this tile's k-loop.  Tables and raw buffers alternate with
+    // the tile parity: a fast wave may build table j+1 while a slow one still reads table j in its epilogue.
+    constexpr bool LN_TABS = FOLD || RES == 3;
+    float2* const stab = reinterpret_cast<float2*>(lds + x3_tab_base(WAVES) + tile_parity * X3_TAB_BYTES);
+    if constexpr (LN_TABS) {
+      if (v + gstride < total) {
+        int m0n, n0n;
+        tile_origin(v + gstride, m0n, n0n);
+        stats_dma(m0n, tile_parity ^ 1);
+      }
+      if (tid < X3_TM) {
+        const float* sraw = reinterpret_cast<const float*>(lds + x3_raw_base(WAVES) + tile_parity * X3_RAW_BYTES);
+        float s1 = 0.f, s2 = 0.f;
+        for (int p = 0; p < ep.stat_parts; ++p) {
+          s1 += sraw[(tid * ep.stat_parts + p) * 2];
+          s2 += sraw[(tid * ep.stat_parts + p) * 2 + 1];
+        }
+        const float mean = s1 * ep.inv_dim;
+        const float var = fmaxf(s2 * ep.inv_dim - mean * mean, 0.f);
+#ifdef MDM_EMU
+        stab[tid] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+#else
+        stab[tid] = make_float2(mean, __builtin_amdgcn_rsqf(var + 1e-5f));   // v_rsq_f32, 1 ulp
+#endif
+      }
+    }
+    float2* const atab = stab;   // FOLD: statistics of the A rows;  RES == 3: of the residual rows (a kernel has one)
+    float2* const rtab = stab;
     for (int kt = 0; kt < nk; ++kt) {
       // W(g+1): advance the W stream and fetch (past the last tile: re-fetch, like the A stream)
       if (++wkk == nk) {
@@ -316,11 +391,44 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     // each wave transposes 8 rows x 32 columns at a time (accumulator registers 4g..4g+3 of both lane halves) through
     // its private 1 KB LDS patch -- disjoint from the A stages, which already hold the next tile's first stage
     // -- and writes 16 bytes per lane: lane -> (row = lane>>3, 4 consecutive columns).
-    const float mult = (nc < ep.scale_cols) ? ep.col_scale : 1.f;
     const int m_end = min(M, m0 + rows_per_tile);
     float* patch = reinterpret_cast<float*>(lds + X3_PATCH_BASE) + wid * (X3_PATCH_BYTES / 4);  // [8][32] fp32
     const int prow = lane >> 3, pc4 = (lane & 7) * 4;
     const int n4 = ncol0 + pc4;                          // first of this lane's 4 columns in the row layout
+    // per-lane column vectors of the row-major side: bias (or folded bias), Q scale, folded column sums, residual gamma/beta
+    const bool ncol_ok = n4 < N;                         // N % 4 == 0
+    const float4 b4 = ncol_ok ? ld4(ep.bias + n4) : zero4();
+    const float mult4 = (n4 < ep.scale_cols) ? ep.col_scale : 1.f;   // scale_cols is a multiple of the tile width
+    float4 c4 = zero4(), g4 = zero4(), be4 = zero4();
+    if constexpr (FOLD) c4 = ncol_ok ? ld4(ep.colsum + n4) : zero4();
+    if constexpr (RES == 3) {
+      g4 = ncol_ok ? ld4(ep.rgamma + n4) : zero4();
+      be4 = ncol_ok ? ld4(ep.rbeta + n4) : zero4();
+    }
+    // accumulator values of one round, row-major, -> the GEMM's value:  fold / bias, activation, Q scale
+    auto finish4 = [&](float4 v4, int row_in_tile) __attribute__((always_inline)) {
+      if constexpr (FOLD) {
+        const float2 st = atab[row_in_tile];
+        v4.x = st.y * (v4.x - st.x * c4.x) + b4.x; v4.y = st.y * (v4.y - st.x * c4.y) + b4.y;
+        v4.z = st.y * (v4.z - st.x * c4.z) + b4.z; v4.w = st.y * (v4.w - st.x * c4.w) + b4.w;
+      } else {
+        v4.x += b4.x; v4.y += b4.y; v4.z += b4.z; v4.w += b4.w;
+      }
+      if (ACT == ACT_GELU) { v4.x = gelu_erf_fast(v4.x); v4.y = gelu_erf_fast(v4.y); v4.z = gelu_erf_fast(v4.z); v4.w = gelu_erf_fast(v4.w); }
+      else if (ACT == ACT_SILU) { v4.x = silu(v4.x); v4.y = silu(v4.y); v4.z = silu(v4.z); v4.w = silu(v4.w); }
+      v4.x *= mult4; v4.y *= mult4; v4.z *= mult4; v4.w *= mult4;
+      return v4;
+    };
+    // 28 rounds (row sub-tile t, register group g): raw accumulators -> patch -> 16-byte row-major read.  Round j+1's
+    // patch writes are issued between round j's read and its stores, so the LDS round trip of one round hides under
+    // the VALU work of the next (a wave's LDS operations execute in order).
+    auto patch_write = [&](auto j_tag) __attribute__((always_inline)) {
+      constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
+      if constexpr (j < 4 * X3_MSUB) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = acc[t][4 * g + e];
+      }
+    };
 
     if (OUT_QKV) {
       // in_proj -> attention operand planes (attention_bf16x3.h).  rows_per_tile == S: tile row == token, tile_m == sequence.
@@ -343,7 +451,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
               for (int s2 = 0; s2 < 2; ++s2) {
                 float vv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vv[j] = acc[t][8 * s2 + j] + bias;
+                for (int j = 0; j < 8; ++j) {
+                  if constexpr (FOLD) {
+                    const float2 st = atab[32 * t + mfma_row(8 * s2 + j, h)];
+                    vv[j] = st.y * (acc[t][8 * s2 + j] - st.x * csum) + bias;
+                  } else {
+                    vv[j] = acc[t][8 * s2 + j] + bias;
+                  }
+                }
                 bf16x8 vh8, vl8;
                 split8(vv, vh8, vl8);
                 *reinterpret_cast<bf16x8*>(vhp + t * (AX_HD * 32) + 16 * s2) = vh8;
@@ -352,27 +467,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
             }
           }
         } else {
-          // Q / K rows: same pipelined patch rounds as the plain epilogue below (round j+1's patch writes sit between
-          // round j's patch read and its stores); one base pointer per plane, 32-bit offsets
+          // Q / K rows: one base pointer per plane, 32-bit offsets
           bf16_t* dh = (which == 0 ? ep.qkv.qh : ep.qkv.kh) + shq * SPq * AX_HD + d0 + pc4;
           bf16_t* dl = (which == 0 ? ep.qkv.ql : ep.qkv.kl) + shq * SPq * AX_HD + d0 + pc4;
           const int nkt = ep.qkv.NKT;
-          auto qk_write = [&](auto j_tag) __attribute__((always_inline)) {
-            constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
-            if constexpr (j < 4 * X3_MSUB) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = (acc[t][4 * g + e] + bias) * mult;
-            }
-          };
-          qk_write(std::integral_constant<int, 0>{});
+          patch_write(std::integral_constant<int, 0>{});
           static_for<4 * X3_MSUB>([&](auto j_tag) __attribute__((always_inline)) {
             constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
             wave_lds_fence();
             float4 v4 = ld4(&patch[prow * 32 + pc4]);
             wave_lds_fence();
-            qk_write(std::integral_constant<int, j + 1>{});
+            patch_write(std::integral_constant<int, j + 1>{});
             if (t < nkt) {
               const int tok = 32 * t + 8 * g + prow;
+              v4 = finish4(v4, tok);
               split4_store(dh + tok * AX_HD, dl + tok * AX_HD, v4);
             }
           });
@@ -382,8 +490,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       // residual tile: streamed two row sub-tiles ahead of its use through untracked loads (common.h gload16_async);
       // rows past the matrix are clamped (loaded, never stored)
       constexpr bool HAS_RES = RES != 0;
-      f32x4 rr[3][4];       // RES == 1
-      u32x2 rh[3][4], rl[3][4];  // RES == 2
+      constexpr bool RES_PLANES = RES == 2 || RES == 3;
+      constexpr int RR = (RES == 3) ? 2 : 3;   // residual sub-tiles in flight + in use (RES == 3 sits at the VGPR limit)
+      f32x4 rr[RR][4];       // RES == 1
+      u32x2 rh[RR][4], rl[RR][4];  // RES == 2 / 3
       auto res_issue = [&](auto t_tag) __attribute__((always_inline)) {
         constexpr int t = decltype(t_tag)::value;
         if constexpr (HAS_RES && t < X3_MSUB) {
@@ -392,49 +502,35 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
             const int m = min(m0 + t * 32 + 8 * g + prow, M - 1);
             const size_t o = (size_t)m * ep.ld + (n4 < N ? n4 : 0);
             if constexpr (RES == 1) {
-              gload16_async(rr[t % 3][g], ep.res + o);
+              gload16_async(rr[t % RR][g], ep.res + o);
             } else {
-              gload8_async(rh[t % 3][g], ep.resh + o);
-              gload8_async(rl[t % 3][g], ep.resl + o);
+              gload8_async(rh[t % RR][g], ep.resh + o);
+              gload8_async(rl[t % RR][g], ep.resl + o);
             }
           }
         }
       };
       auto res_wait = [&](auto t_tag) __attribute__((always_inline)) {
         constexpr int t = decltype(t_tag)::value;
-        constexpr int ahead = (X3_MSUB - 1 - t) < 2 ? (X3_MSUB - 1 - t) : 2;  // younger sub-tiles already requested
+        constexpr int ahead = (X3_MSUB - 1 - t) < (RR - 1) ? (X3_MSUB - 1 - t) : (RR - 1);  // younger sub-tiles requested
         if constexpr (RES == 1) {
-          vmem_wait<4 * ahead>(rr[t % 3][0], rr[t % 3][1], rr[t % 3][2], rr[t % 3][3]);
-        } else if constexpr (RES == 2) {
-          vmem_wait<8 * ahead>(rh[t % 3][0], rh[t % 3][1], rh[t % 3][2], rh[t % 3][3], rl[t % 3][0], rl[t % 3][1],
-                               rl[t % 3][2], rl[t % 3][3]);
+          vmem_wait<4 * ahead>(rr[t % RR][0], rr[t % RR][1], rr[t % RR][2], rr[t % RR][3]);
+        } else if constexpr (RES_PLANES) {
+          vmem_wait<8 * ahead>(rh[t % RR][0], rh[t % RR][1], rh[t % RR][2], rh[t % RR][3], rl[t % RR][0], rl[t % RR][1],
+                               rl[t % RR][2], rl[t % RR][3]);
         }
       };
       if (!(ABL & 1)) {
         res_issue(std::integral_constant<int, 0>{});
-        res_issue(std::integral_constant<int, 1>{});
+        if constexpr (RR == 3) res_issue(std::integral_constant<int, 1>{});
       }
-      // 28 rounds (row sub-tile t, register group g): patch write -> 16-byte patch read -> store.  Round j+1's patch
-      // writes (and the activation math feeding them) are issued between round j's read and its store, so the LDS round
-      // trip of one round hides under the VALU work of the next (a wave's LDS operations execute in order).
-      auto patch_write = [&](auto j_tag) __attribute__((always_inline)) {
-        constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
-        if constexpr (j < 4 * X3_MSUB) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = acc[t][4 * g + e] + bias;
-            if (ACT == ACT_GELU) x = gelu_erf_fast(x);
-            else if (ACT == ACT_SILU) x = silu(x);
-            patch[((e + 4 * h) << 5) + r] = x * mult;
-          }
-        }
-      };
+      float2* part = reinterpret_cast<float2*>(lds + x3_part_base(WAVES)) + wid * X3_TM;   // OSTAT: this wave's partials
       patch_write(std::integral_constant<int, 0>{});
       static_for<4 * X3_MSUB>([&](auto j_tag) __attribute__((always_inline)) {
         constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
         if constexpr (HAS_RES && g == 0) {
           if (!(ABL & 1)) {
-            res_issue(std::integral_constant<int, t + 2>{});
+            res_issue(std::integral_constant<int, t + RR - 1>{});
             res_wait(std::integral_constant<int, t>{});
           }
         }
@@ -442,25 +538,60 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
         float4 v4 = ld4(&patch[prow * 32 + pc4]);
         wave_lds_fence();
         patch_write(std::integral_constant<int, j + 1>{});
+        const int row_in_tile = t * 32 + 8 * g + prow;
+        v4 = finish4(v4, row_in_tile);
         if (!(ABL & 1)) {
-          const int m = m0 + t * 32 + 8 * g + prow;
+          if constexpr (RES == 1) {
+            const f32x4 q4 = rr[t % RR][g];
+            v4.x += q4[0]; v4.y += q4[1]; v4.z += q4[2]; v4.w += q4[3];
+          } else if constexpr (RES_PLANES) {
+            const u32x2 a = rh[t % RR][g], b = rl[t % RR][g];
+            float4 x4 = make_float4(
+                bf16_bits_to_f32((bf16_t)(a[0] & 0xffffu)) + bf16_bits_to_f32((bf16_t)(b[0] & 0xffffu)),
+                bf16_bits_to_f32((bf16_t)(a[0] >> 16)) + bf16_bits_to_f32((bf16_t)(b[0] >> 16)),
+                bf16_bits_to_f32((bf16_t)(a[1] & 0xffffu)) + bf16_bits_to_f32((bf16_t)(b[1] & 0xffffu)),
+                bf16_bits_to_f32((bf16_t)(a[1] >> 16)) + bf16_bits_to_f32((bf16_t)(b[1] >> 16)));
+            if constexpr (RES == 3) {   // the residual is LayerNorm(x), rebuilt from x's planes and its row statistics
+              const float2 st = rtab[row_in_tile];
+              x4.x = (x4.x - st.x) * st.y * g4.x + be4.x; x4.y = (x4.y - st.x) * st.y * g4.y + be4.y;
+              x4.z = (x4.z - st.x) * st.y * g4.z + be4.z; x4.w = (x4.w - st.x) * st.y * g4.w + be4.w;
+            }
+            v4.x += x4.x; v4.y += x4.y; v4.z += x4.z; v4.w += x4.w;
+          }
+        }
+        if constexpr (OSTAT) {   // partial (sum, sum of squares) of this row over the wave's 32 columns
+          float s1 = (v4.x + v4.y) + (v4.z + v4.w);
+          float s2 = (v4.x * v4.x + v4.y * v4.y) + (v4.z * v4.z + v4.w * v4.w);
+#pragma unroll
+          for (int msk = 1; msk <= 4; msk <<= 1) {
+            s1 += shfl_xor_f32(s1, msk);
+            s2 += shfl_xor_f32(s2, msk);
+          }
+          if ((lane & 7) == 0) part[row_in_tile] = make_float2(s1, s2);
+        }
+        if (!(ABL & 1)) {
+          const int m = m0 + row_in_tile;
           if (m < m_end && n4 < N) {  // N % 4 == 0
             const size_t o = (size_t)m * ep.ld + n4;
-            if constexpr (RES == 1) {
-              const f32x4 q4 = rr[t % 3][g];
-              v4.x += q4[0]; v4.y += q4[1]; v4.z += q4[2]; v4.w += q4[3];
-            } else if constexpr (RES == 2) {
-              const u32x2 a = rh[t % 3][g], b = rl[t % 3][g];
-              v4.x += bf16_bits_to_f32((bf16_t)(a[0] & 0xffffu)) + bf16_bits_to_f32((bf16_t)(b[0] & 0xffffu));
-              v4.y += bf16_bits_to_f32((bf16_t)(a[0] >> 16)) + bf16_bits_to_f32((bf16_t)(b[0] >> 16));
-              v4.z += bf16_bits_to_f32((bf16_t)(a[1] & 0xffffu)) + bf16_bits_to_f32((bf16_t)(b[1] & 0xffffu));
-              v4.w += bf16_bits_to_f32((bf16_t)(a[1] >> 16)) + bf16_bits_to_f32((bf16_t)(b[1] >> 16));
-            }
             if (OUT_F32) st4(ep.out + o, v4);
             if (OUT_PLANES) split4_store(ep.oh + o, ep.ol + o, v4);
           }
         }
       });
+      if constexpr (OSTAT) {   // rows x waves partials -> one (sum, sum^2) pair per row and column tile
+        wg_barrier();
+        if (tid < X3_TM && m0 + tid < m_end) {
+          const float2* pp = reinterpret_cast<const float2*>(lds + x3_part_base(WAVES));
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int w8 = 0; w8 < X3_WAVES; ++w8) {
+            const float2 v = pp[w8 * X3_TM + tid];
+            s1 += v.x;
+            s2 += v.y;
+          }
+          *reinterpret_cast<float2*>(ep.ostat + ((size_t)(m0 + tid) * tiles_n + n0 / X3_TN) * 2) = make_float2(s1, s2);
+        }
+      }
     }
   }
   wait_vmem_all();  // the stream's last (unused) LDS-DMA stage must land before this workgroup's LDS is released
@@ -501,16 +632,47 @@ inline int& x3_waves_setting() {
   return waves;
 }
 
-template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL>
+template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
+          bool OSTAT = false>
 inline int launch_gemm_bf16x3_w(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                                 int rpt, hipStream_t stream) {
   constexpr int TN = x3_tn(WAVES);
+  constexpr bool LN = FOLD || OSTAT || RES == 3;
   const int tiles_m = (M + rpt - 1) / rpt, tiles_n = (N + TN - 1) / TN;
   const int total = tiles_m * tiles_n;
-  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>;
+  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT>;
+#ifndef MDM_EMU
+  if (x3_lds_bytes(WAVES, LN) > 65536) {
+    static bool configured = false;  // per instantiation
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              x3_lds_bytes(WAVES, LN)) != hipSuccess)
+        return -1;
+      configured = true;
+    }
+  }
+#endif
   const int grid = std::min(total, x3_grid_limit(WAVES == 4 ? 2 : 1));
-  MDM_LAUNCH(kfn, dim3(grid), dim3(64 * WAVES), x3_lds_bytes(WAVES), stream, A, W, ep, M, N, K, rpt, tiles_n, total);
+  MDM_LAUNCH(kfn, dim3(grid), dim3(64 * WAVES), x3_lds_bytes(WAVES, LN), stream, A, W, ep, M, N, K, rpt, tiles_n, total);
   return 0;
+}
+
+// The GEMMs of the folded-LayerNorm encoder (8-wave workgroups only):
+//   kind 0  in_proj, A = pre-norm sum           FOLD -> attention operand planes
+//   kind 1  out_proj of layer 0                 residual = plain planes, writes planes + row statistics
+//   kind 2  out_proj (l >= 1) / linear2         residual = LayerNorm rebuilt from planes, writes planes + row statistics
+//   kind 3  linear1                             FOLD + GELU -> planes
+//   kind 4  OutputProcess                       FOLD -> fp32
+inline int launch_gemm_bf16x3_ln(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
+                                 int K, int rpt, hipStream_t s) {
+  switch (kind) {
+    case 0: return launch_gemm_bf16x3_w<8, ACT_NONE, 0, false, false, true, 0, true, false>(A, W, ep, M, N, K, rpt, s);
+    case 1: return launch_gemm_bf16x3_w<8, ACT_NONE, 2, false, true, false, 0, false, true>(A, W, ep, M, N, K, rpt, s);
+    case 2: return launch_gemm_bf16x3_w<8, ACT_NONE, 3, false, true, false, 0, false, true>(A, W, ep, M, N, K, rpt, s);
+    case 3: return launch_gemm_bf16x3_w<8, ACT_GELU, 0, false, true, false, 0, true, false>(A, W, ep, M, N, K, rpt, s);
+    case 4: return launch_gemm_bf16x3_w<8, ACT_NONE, 0, true, false, false, 0, true, false>(A, W, ep, M, N, K, rpt, s);
+    default: return -2;
+  }
 }
 
 template <int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL = 0>

@@ -109,6 +109,12 @@ struct mdm_model {
   int precision = MDM_PREC_BF16X3;
   struct LayerPlanes { X3Weights in_proj, out_proj, linear1, linear2; };
   std::vector<LayerPlanes> planes;  // fragment-ordered bf16 hi/lo planes of the encoder weights (mdm_prepare)
+  // LayerNorm folded into its consumers (gemm_bf16x3.h X3Epilogue): gamma-scaled weight planes, column sums, folded biases
+  struct LayerFold { X3Weights in_proj, linear1; float *c_qkv, *b_qkv, *c_1, *b_1; };
+  std::vector<LayerFold> fold;
+  X3Weights out_planes_f{nullptr, nullptr};
+  float *c_out = nullptr, *b_out = nullptr;
+  bool lnfold = false;                      // bf16x3 mode without LayerNorm kernels (set by mdm_prepare)
   X3Weights out_planes{nullptr, nullptr};  // poseFinal.weight, rows padded to jf_out (bf16x3 OutputProcess)
   float* out_bias_pad = nullptr;            // poseFinal.bias padded to jf_out
   int jf_out = 0;                           // njoints*nfeats rounded up to a multiple of 4
@@ -124,6 +130,8 @@ namespace {
 struct Workspace {
   float *tok, *qkv, *att, *ffn, *cond;
   QkvPlanes qp;         // bf16x3 mode: the in_proj epilogue writes Q/K/V^T planes over the qkv region
+  bf16_t *xah, *xal;    // folded-LayerNorm mode: planes of the post-attention pre-norm sum (alias tok)
+  float *stat1, *stat2; // folded-LayerNorm mode: per-row partial (sum, sum^2) of xa / of tokh|tokl
   bf16_t *tokh, *tokl;  // split planes of tok (bf16x3 mode)
   bf16_t *atth, *attl;  // alias att: the attention output is only consumed by the out_proj GEMM
   bf16_t *ffnh, *ffnl;  // alias ffn: the GELU output is only consumed by the linear2 GEMM
@@ -152,6 +160,11 @@ Workspace carve(const mdm_model* m, int nseq, int T, void* base) {
   w.attl = w.att ? w.atth + M * D : nullptr;
   w.ffnh = reinterpret_cast<bf16_t*>(w.ffn);
   w.ffnl = w.ffn ? w.ffnh + M * FF : nullptr;
+  w.xah = reinterpret_cast<bf16_t*>(w.tok);
+  w.xal = w.tok ? w.xah + M * D : nullptr;
+  const size_t parts = (D + 255) / 256;
+  w.stat1 = take(M * parts * 2);
+  w.stat2 = take(M * parts * 2);
   {
     const size_t plane = (size_t)nseq * SP * D;
     bf16_t* q = reinterpret_cast<bf16_t*>(w.qkv);
@@ -248,7 +261,8 @@ int launch_linear_x3(Profiler* pf, X3Operand a, X3Weights w, const float* bias, 
   if (K % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 linear: K must be a multiple of 32");
   if (N % 4 != 0) return fail(MDM_EINVAL, "bf16x3 linear: N must be a multiple of 4");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
-  X3Epilogue ep{out, bias, res, res_planes.hi, res_planes.lo, oh, ol, N, scale_cols, col_scale, QkvPlanes{}, 0, 0};
+  X3Epilogue ep{out, bias, res, res_planes.hi, res_planes.lo, oh, ol, N, scale_cols, col_scale, QkvPlanes{}, 0, 0,
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f};
   const int rc = launch_gemm_bf16x3(a, w, ep, M, N, K, act, seq_len, s, g_x3_ablate);
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 linear: unsupported (activation, residual, output) combination");
   return rt_launch_status();
@@ -259,9 +273,32 @@ int launch_in_proj_x3(Profiler* pf, X3Operand a, X3Weights w, const float* bias,
                       int D, float qscale, hipStream_t s) {
   if (D % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 in_proj: latent_dim must be a multiple of 32");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * nseq * S * 3.0 * D * (double)D, s);
-  X3Epilogue ep{nullptr, bias, nullptr, nullptr, nullptr, nullptr, nullptr, 3 * D, D, qscale, qp, S, D};
+  X3Epilogue ep{nullptr, bias, nullptr, nullptr, nullptr, nullptr, nullptr, 3 * D, D, qscale, qp, S, D,
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f};
   const int rc = launch_gemm_bf16x3_qkv(a, w, ep, nseq, S, D, s);
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 in_proj: sequences longer than 224 tokens");
+  return rt_launch_status();
+}
+
+// One GEMM of the folded-LayerNorm encoder (gemm_bf16x3.h launch_gemm_bf16x3_ln kinds)
+struct LnArgs {
+  const float* astat = nullptr; const float* colsum = nullptr;                                   // FOLD
+  X3Operand res{nullptr, nullptr}; const float* rstat = nullptr; const float* rgamma = nullptr; const float* rbeta = nullptr;  // residual
+  float* ostat = nullptr;                                                                       // OSTAT
+  int parts = 1; float inv_dim = 1.f;
+};
+int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w, const float* bias, const LnArgs& ln,
+                 float* out, bf16_t* oh, bf16_t* ol, const QkvPlanes* qp, int M, int N, int K, int S, int D,
+                 int scale_cols, float col_scale, hipStream_t s) {
+  if (K % X3_BK != 0 || N % 4 != 0) return fail(MDM_EINVAL, "bf16x3 linear: K % 32 and N % 4 must be 0");
+  if (ln.parts < 1 || ln.parts > 4) return fail(MDM_EUNSUPPORTED, "folded LayerNorm: at most 4 partial sums per row (D <= 1024)");
+  ProfScope ps(pf, prof_cat, 2.0 * M * (double)N * K, s);
+  X3Epilogue ep{out, bias, nullptr, ln.res.hi, ln.res.lo, oh, ol, N, scale_cols, col_scale, qp ? *qp : QkvPlanes{}, S, D,
+                ln.astat, ln.colsum, ln.rstat, ln.rgamma, ln.rbeta, ln.ostat, ln.parts, ln.inv_dim};
+  const int rpt = (kind == 0) ? S : x3_rows_per_tile(M, S);
+  const int rc = launch_gemm_bf16x3_ln(kind, a, w, ep, M, N, K, rpt, s);
+  if (rc == -1) return fail(MDM_EHIP, "bf16x3 linear: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 linear: unsupported folded-LayerNorm GEMM kind");
   return rt_launch_status();
 }
 
@@ -310,6 +347,44 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
   Profiler* pf = &m->prof;
   const int D = m->cfg.latent_dim, FF = m->cfg.ff_size, H = m->cfg.num_heads, M = nseq * S;
   const float qscale = 1.0f / sqrtf((float)(D / H));
+  if (m->precision == MDM_PREC_BF16X3 && m->lnfold && x3_waves_setting() == 8 && S <= X3_TM) {
+    // No LayerNorm kernels: xb = tokh|tokl holds the layer input / the post-FFN PRE-norm sum, xa the post-attention
+    // pre-norm sum, each with per-row partial (sum, sum^2) written by its producer; consumers fold the normalisation
+    // (gemm_bf16x3.h X3Epilogue).  Layer 0's input (the embedding) is not normalised: plain in_proj, plain residual.
+    const X3Operand xb{ws.tokh, ws.tokl}, xa{ws.xah, ws.xal}, attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
+    const int parts = (D + 255) / 256;
+    const float inv_dim = 1.0f / (float)D;
+    for (int l = 0; l < m->cfg.num_layers; ++l) {
+      const mdm_model::LayerPlanes& P = m->planes[l];
+      const mdm_model::LayerFold& F = m->fold[l];
+      if (l == 0) {
+        if (int rc = launch_in_proj_x3(pf, xb, P.in_proj, m->L(l, "self_attn.in_proj_bias"), ws.qp, nseq, S, D, qscale, s)) return rc;
+      } else {
+        LnArgs a; a.astat = ws.stat2; a.colsum = F.c_qkv; a.parts = parts; a.inv_dim = inv_dim;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, xb, F.in_proj, F.b_qkv, a, nullptr, nullptr, nullptr, &ws.qp, M,
+                                  3 * D, D, S, D, D, qscale, s)) return rc;
+      }
+      if (int rc = launch_attention_x3(pf, ws.qp, lengths, nseq, B, S, D, nullptr, ws.atth, ws.attl, s)) return rc;
+      {  // xa = att.Wo + bo + layer input (normalised on the fly for l >= 1), + row statistics
+        LnArgs a; a.res = xb; a.ostat = ws.stat1; a.parts = parts; a.inv_dim = inv_dim;
+        if (l >= 1) { a.rstat = ws.stat2; a.rgamma = m->L(l - 1, "norm2.weight"); a.rbeta = m->L(l - 1, "norm2.bias"); }
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, l == 0 ? 1 : 2, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"),
+                                  a, nullptr, ws.xah, ws.xal, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
+      }
+      {  // ffn = gelu(LN1(xa).W1 + b1), LN1 folded
+        LnArgs a; a.astat = ws.stat1; a.colsum = F.c_1; a.parts = parts; a.inv_dim = inv_dim;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 3, xa, F.linear1, F.b_1, a, nullptr, ws.ffnh, ws.ffnl, nullptr, M, FF,
+                                  D, S, D, 0, 1.f, s)) return rc;
+      }
+      {  // xb = ffn.W2 + b2 + LN1(xa), + row statistics
+        LnArgs a; a.res = xa; a.rstat = ws.stat1; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias");
+        a.ostat = ws.stat2; a.parts = parts; a.inv_dim = inv_dim;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, ffnp, P.linear2, m->L(l, "linear2.bias"), a, nullptr, ws.tokh,
+                                  ws.tokl, nullptr, M, D, FF, S, D, 0, 1.f, s)) return rc;
+      }
+    }
+    return 0;   // the encoder's output is LN2(L-1)(xb): folded into OutputProcess (outproj_x3)
+  }
   if (m->precision == MDM_PREC_BF16X3) {
     // tok (fp32, residual stream) travels with its split planes tokh/tokl; attention and GELU outputs exist only as planes
     const X3Operand tokp{ws.tokh, ws.tokl}, attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
@@ -354,8 +429,12 @@ int outproj_x3(mdm_model* m, const Workspace& ws, int nseq, int B, int T, const 
   const int D = m->cfg.latent_dim, S = T + 1, ldo = m->jf_out;
   float* out_tok = ws.qkv;
   ProfScope ps(&m->prof, MDM_PROF_OUTPROJ, 2.0 * nseq * T * (double)D * m->jf, s);
-  if (int rc = launch_linear_x3(nullptr, X3Operand{ws.tokh, ws.tokl}, m->out_planes, m->out_bias_pad, nullptr, out_tok,
-                                nullptr, nullptr, nseq * S, ldo, D, ACT_NONE, 0, 1.f, S, s)) return rc;
+  if (m->lnfold && x3_waves_setting() == 8 && S <= X3_TM) {   // the final LayerNorm is folded into this GEMM
+    LnArgs a; a.astat = ws.stat2; a.colsum = m->c_out; a.parts = (D + 255) / 256; a.inv_dim = 1.0f / (float)D;
+    if (int rc = launch_x3_ln(nullptr, MDM_PROF_OUTPROJ, 4, X3Operand{ws.tokh, ws.tokl}, m->out_planes_f, m->b_out, a,
+                              out_tok, nullptr, nullptr, nullptr, nseq * S, ldo, D, S, D, 0, 1.f, s)) return rc;
+  } else if (int rc = launch_linear_x3(nullptr, X3Operand{ws.tokh, ws.tokl}, m->out_planes, m->out_bias_pad, nullptr, out_tok,
+                                       nullptr, nullptr, nseq * S, ldo, D, ACT_NONE, 0, 1.f, S, s)) return rc;
   const int nb = (mode == 1) ? B : nseq;
   MDM_LAUNCH(outproj_finish_kernel, dim3((T + 31) / 32, (m->jf + 31) / 32, nb), dim3(256), 0, s, (const float*)out_tok,
              ldo, S, T, m->jf, B, scale, mode, out, x0_out, x_t, noise, inpaint_mask, inpaint_motion, co);
@@ -444,7 +523,13 @@ size_t mdm_const_bytes(const mdm_model_t* m) {
   const size_t per_layer = align_up(3 * D * D * 4, 256) + align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
   return align_up(D * m->jf_pad * sizeof(float), 256) + 2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) +
          (size_t)m->cfg.num_layers * per_layer + align_up(x3_packed_weight_elems(m->jf_out, (int)D) * 4, 256) +
-         align_up((size_t)m->jf_out * sizeof(float), 256);
+         align_up((size_t)m->jf_out * sizeof(float), 256) +
+         // folded-LayerNorm constants: per layer gamma-scaled in_proj / linear1 planes + 2 vectors each; OutputProcess;
+         // one fp32 scratch matrix for the scaled weights before they are packed
+         (size_t)m->cfg.num_layers * (align_up(3 * D * D * 4, 256) + align_up(FF * D * 4, 256) +
+                                      2 * align_up(3 * D * 4, 256) + 2 * align_up(FF * 4, 256)) +
+         align_up(x3_packed_weight_elems(m->jf_out, (int)D) * 4, 256) + 2 * align_up((size_t)32 * ((m->jf_out + 31) / 32) * 4, 256) +
+         align_up(std::max<size_t>(3 * D, FF) * D * 4, 256);
 }
 
 int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* stream) {
@@ -496,6 +581,38 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
   MDM_LAUNCH(pad_rows_kernel, dim3(1), dim3(256), 0, s, m->out_bias_pad, m->W("output_process.poseFinal.bias"), 1, m->jf,
              m->jf_out);
   if (int rc = rt_launch_status()) return rc;
+  // ---- LayerNorm folded into its consumers: in_proj(l >= 1) <- norm2(l-1), linear1(l) <- norm1(l), OutputProcess <- norm2(L-1)
+  {
+    const int L = m->cfg.num_layers;
+    float* scratch_w = reinterpret_cast<float*>(base);
+    base += align_up(std::max<size_t>(3 * (size_t)D, FF) * D * 4, 256);
+    auto take_vec = [&](size_t n) { float* p = reinterpret_cast<float*>(base); base += align_up(n * 4, 256); return p; };
+    auto fold_one = [&](const float* w, const float* bias, const float* gamma, const float* beta, int N, int Npad,
+                        X3Weights& op, float*& cvec, float*& bvec) -> int {
+      cvec = take_vec(Npad);
+      bvec = take_vec(Npad);
+      MDM_LAUNCH(fold_layernorm_kernel, dim3((Npad + 3) / 4), dim3(256), 0, s, w, gamma, beta, bias, scratch_w, cvec, bvec,
+                 N, D, Npad);
+      if (int rc = rt_launch_status()) return rc;
+      return make_planes(scratch_w, N, D, op);   // stream order: the pack kernel reads scratch_w after the fold kernel
+    };
+    m->fold.assign(L, mdm_model::LayerFold{});
+    for (int l = 0; l < L; ++l) {
+      mdm_model::LayerFold& F = m->fold[l];
+      if (l >= 1) {
+        if (int rc = fold_one(m->L(l, "self_attn.in_proj_weight"), m->L(l, "self_attn.in_proj_bias"),
+                              m->L(l - 1, "norm2.weight"), m->L(l - 1, "norm2.bias"), 3 * D, 3 * D, F.in_proj, F.c_qkv, F.b_qkv)) return rc;
+      }
+      if (int rc = fold_one(m->L(l, "linear1.weight"), m->L(l, "linear1.bias"), m->L(l, "norm1.weight"),
+                            m->L(l, "norm1.bias"), (int)FF, (int)FF, F.linear1, F.c_1, F.b_1)) return rc;
+    }
+    const int jf32 = (m->jf_out + 31) / 32 * 32;
+    if (int rc = fold_one(m->W("output_process.poseFinal.weight"), m->W("output_process.poseFinal.bias"),
+                          m->L(L - 1, "norm2.weight"), m->L(L - 1, "norm2.bias"), m->jf, jf32, m->out_planes_f, m->c_out,
+                          m->b_out)) return rc;
+    const char* e = getenv("MDM_LNFOLD");
+    m->lnfold = !(e != nullptr && e[0] == '0');
+  }
   m->prepared = true;
   return MDM_OK;
 }

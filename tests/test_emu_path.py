@@ -35,10 +35,12 @@ def test_emulated_cfg_loop_matches_oracle(lib, prec, tol):
     assert maxabs(got, want) < tol
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 1e-5), ("bf16x3", 1e-4)])
-def test_emulated_forward_branches(lib, prec, tol):
+@pytest.mark.parametrize("prec,tol,layers", [("f32", 1e-5, 1), ("bf16x3", 1e-4, 1), ("bf16x3", 1e-4, 2)])
+def test_emulated_forward_branches(lib, prec, tol, layers):
+    """layers = 2 reaches the GEMM kinds only a second layer uses: in_proj with the previous LayerNorm folded in, and
+    out_proj whose residual is a LayerNorm rebuilt from the pre-norm planes + row statistics."""
     B, T = 2, 33                                   # S = 34: two key tiles, ragged tail
-    sd = small_state_dict(num_layers=1)
+    sd = small_state_dict(num_layers=layers)
     model, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib, precision=prec)
     y = synth_y(B, T, seed=2, lengths=[33, 5])
     g = torch.Generator().manual_seed(0)
