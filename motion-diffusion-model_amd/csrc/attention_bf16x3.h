@@ -15,15 +15,14 @@
 //                                        with 16-byte stores and (b) the probabilities, which come out of phase 1 in
 //                                        accumulator registers, are already the matching B operand.  Pad keys: finite.
 //
-// One workgroup per (sequence, head); wave w owns queries [32w, 32w+32).  Everything is computed TRANSPOSED so the
+// Two workgroups per (sequence, head); a wave owns 32 queries.  Everything is computed TRANSPOSED so the
 // softmax axis is lane-local (cdna_hip_programming.md T12's "swapped QK^T"):
 //   phase 1  St[key][query] = K . Q^T    A = K fragments (LDS, XOR-swizzled 256-byte rows, conflict-free b128 reads)
 //                                        B = this wave's Q fragments (registers, loaded once)
 //   softmax  per lane over its 16 keys per tile x NKT tiles + ONE cross-half shuffle; normalisation deferred to O
 //   phase 2  Ot[d][query]  = V^T . P^T   A = V^T fragments (LDS, 64-byte rows swizzled like gemm_bf16x3.h)
 //                                        B = split(P) straight from the phase-1 registers
-// K and V^T arrive by global_load_lds_dwordx4 (no staging registers).  The first V^T key tiles are fetched into spare LDS
-// while phase 1 runs, the rest over the dead K planes while the softmax runs (LDS plan at the kernel).
+// K and V^T arrive by global_load_lds_dwordx4 (no staging registers) through a ring of LDS slots (see the kernel).
 #pragma once
 #include "common.h"
 
@@ -50,29 +49,25 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
   }
 }
 
-// LDS plan (bytes).  Region A = the two K planes (2 * SP * 256); region B = as many 16 KB V^T key tiles (hi 8 KB | lo 8 KB)
-// as still fit under 160 KB: they are fetched WHILE phase 1 runs.  The remaining V^T tiles are fetched into region A once
-// every wave is done with K (they land during the softmax and the first part of phase 2); finally the fp32 output tile
-// is staged over everything.
-constexpr int ax_plane_bytes(int nkt) { return nkt * 32 * 256; }
-constexpr int ax_early_tiles(int nkt) { return nkt < 3 ? nkt : 3; }  // 3 x 16 KB beside K(NKT = 7) = 160 KB; also keeps
-                                                                     // every ds_read immediate offset below 64 KB
-constexpr int ax_lds_bytes(int nkt) {
-  const int kv = 2 * ax_plane_bytes(nkt) + ax_early_tiles(nkt) * 16384, o = nkt * 32 * AX_OLD * 4;
-  return kv > o ? kv : o;
-}
+// Streaming form.  256 threads = 4 waves per workgroup, TWO workgroups per (sequence, head) -- query tiles 0-3 and 4-6 --
+// and two workgroups resident per CU (<= 68 KB of LDS, <= 256 VGPRs each), so that one workgroup's load / softmax /
+// store phases hide behind the other's MFMAs (the one-workgroup-per-CU predecessor held all of K in LDS and exposed a
+// 112 KB load at the start of each of its four back-to-back items: 152 us per launch for 456 MB).
+//   * K then V^T stream through a ring of four 16 KB LDS slots as 2*NKT uniform tiles (K tile: hi|lo [32 keys][256 B],
+//     V^T tile: hi|lo [128 d][64 B]); every wave issues 4 LDS-DMA pieces per tile, three tiles ahead; one counted
+//     vmcnt + one barrier per tile;
+//   * all NKT score tiles of a wave's 32 queries stay in registers, so the softmax is exact (no online rescaling).
+constexpr int AX_SLOT = 16384, AX_RING = 4;
+constexpr int ax_lds_bytes(int) { return 4 * 32 * AX_OLD * 4 > AX_RING * AX_SLOT ? 4 * 32 * AX_OLD * 4 : AX_RING * AX_SLOT; }
 
 template <int NKT>
-__global__ __launch_bounds__(64 * NKT) void attention_bf16x3_kernel(QkvPlanes P, const int* __restrict__ lengths,
-                                                                      int S, int D, int B, float* __restrict__ out,
-                                                                      bf16_t* __restrict__ oh, bf16_t* __restrict__ ol) {
+__global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, const int* __restrict__ lengths,
+                                                                    int S, int D, int B, float* __restrict__ out,
+                                                                    bf16_t* __restrict__ oh, bf16_t* __restrict__ ol,
+                                                                    int items) {
   MDM_DYN_SMEM(unsigned char, lds);
-  constexpr int NT = 64 * NKT;
   constexpr int SP = 32 * NKT;
-  constexpr int PLANE = ax_plane_bytes(NKT);
-  constexpr int NB = ax_early_tiles(NKT);   // V^T key tiles prefetched into region B during phase 1
-  constexpr int REGION_B = 2 * PLANE;
-  constexpr int LATE_PIECES = (16 * (NKT - NB)) / NKT;  // LDS-DMA pieces of the late tiles every wave issues at least
+  constexpr int NTILES = 2 * NKT;   // K tiles then V^T tiles
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -83,166 +78,170 @@ __global__ __launch_bounds__(64 * NKT) void attention_bf16x3_kernel(QkvPlanes P,
 #endif
   const int r = lane & 31, h = lane >> 5;
   const int H = P.H;
-  const int seq = blockIdx.x / H, head = blockIdx.x - seq * H;
+  // blocks b and b+8 run on the same XCD (block -> XCD b % 8): make them the two query halves of one (sequence, head)
+  const int bid = (int)blockIdx.x;
+  const int item = (bid >> 4) * 8 + (bid & 7), half = (bid >> 3) & 1;
+  if (item >= items) return;   // whole workgroup (uniform)
+  const int seq = item / H, head = item - seq * H;
   const size_t sh = (size_t)seq * H + head;
+  const int qt = 4 * half + w;            // this wave's query tile
+  const bool active = qt < NKT;           // (the second half has NKT - 4 tiles; idle waves still move data and sync)
 
   int nvalid = S;  // token 0 (the condition token) is never masked; frame j-1 must be < length (mdm.py:241-247)
   if (lengths != nullptr) nvalid = min(S, 1 + lengths[seq % B]);
 
-  // ---- K planes -> region A.  One LDS-DMA instruction = 1 KB = 4 rows of 256 B; lane -> (row = lane>>4, stored chunk =
-  // lane&15) fetches logical chunk (lane&15) ^ (row&15): the involution the fragment reads below repeat.
-  {
-    const bf16_t* kbase[2] = {P.kh + sh * SP * AX_HD, P.kl + sh * SP * AX_HD};
-    for (int i = w; i < 16 * NKT; i += NKT) {
-      const int plane = i / (8 * NKT), idx = i - plane * (8 * NKT);
-      const int row = 4 * idx + (lane >> 4);
-      const int chunk = (lane & 15) ^ (row & 15);
-      glds16(kbase[plane] + (size_t)row * AX_HD + chunk * 8, lds + plane * PLANE + idx * 1024);
+  // ---- tile t -> ring slot t & 3.  16 pieces of 1 KB per tile, wave w issues pieces 4w .. 4w+3 (piece = plane, idx):
+  // K tile kt: idx covers 4 keys x 256 B; lane -> (row = lane>>4, stored chunk = lane&15) fetches chunk ^ (key & 15);
+  // V^T tile kt: idx covers 16 d-rows x 64 B; lane -> (row = lane>>2, stored chunk = lane&3) fetches chunk ^ ((d>>2)&3).
+  const bf16_t* kbase[2] = {P.kh + sh * SP * AX_HD, P.kl + sh * SP * AX_HD};
+  const bf16_t* vbase[2] = {P.vh + sh * SP * AX_HD, P.vl + sh * SP * AX_HD};
+  auto issue_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * w + i, plane = j >> 3, idx = j & 7;
+      unsigned char* dst = lds + (t & (AX_RING - 1)) * AX_SLOT + plane * 8192 + idx * 1024;
+      if (t < NKT) {
+        const int key = 32 * t + 4 * idx + (lane >> 4);
+        glds16(kbase[plane] + (size_t)key * AX_HD + (((lane & 15) ^ (key & 15)) * 8), dst);
+      } else {
+        const int d = 16 * idx + (lane >> 2);
+        glds16(vbase[plane] + ((size_t)(t - NKT) * AX_HD + d) * 32 + (((lane & 3) ^ ((d >> 2) & 3)) * 8), dst);
+      }
     }
-  }
-  // ---- this wave's Q fragments: query q = 32w + r, k-step st covers d = 16 st + 8h .. +7
+  };
+
+  issue_tile(0);
+  // ---- this wave's Q fragments: query q = 32 qt + r, k-step st covers d = 16 st + 8h .. +7
   bf16x8 qh[8], ql[8];
   {
-    const size_t qo = (sh * SP + 32 * w + r) * AX_HD + 8 * h;
+    const size_t qo = (sh * SP + 32 * (active ? qt : 0) + r) * AX_HD + 8 * h;
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
       qh[st] = *reinterpret_cast<const bf16x8*>(P.qh + qo + 16 * st);
       ql[st] = *reinterpret_cast<const bf16x8*>(P.ql + qo + 16 * st);
     }
   }
-  wait_vmem_all();
-  wg_barrier();
+  wait_vmem_all();          // Q and tile 0 (hipcc would drain everything at the first use of Q anyway)
+  issue_tile(1);
+  if (NTILES > 2) issue_tile(2);
 
-  // ---- V^T tiles.  Per key tile 16 KB = hi [128 d][64 B] | lo [128 d][64 B]; one LDS-DMA instruction = 16 rows; lane ->
-  // (row = lane>>2, stored chunk = lane&3) fetches logical chunk (lane&3) ^ ((row>>2)&3).  Tile kt lives in region B
-  // (kt < NB) or, once K is dead, in region A.
-  const bf16_t* vbase[2] = {P.vh + sh * SP * AX_HD, P.vl + sh * SP * AX_HD};
-  auto v_tile_off = [&](int kt) { return kt < NB ? REGION_B + kt * 16384 : (kt - NB) * 16384; };
-  auto issue_v = [&](int kt_lo, int kt_hi) {
-    for (int i = 16 * kt_lo + w; i < 16 * kt_hi; i += NKT) {
-      const int kt = i >> 4, j = i & 15, plane = j >> 3, idx = j & 7;   // 8 pieces of 16 d-rows per plane
-      const int row = 16 * idx + (lane >> 2);                            // d
-      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-      glds16(vbase[plane] + ((size_t)kt * AX_HD + row) * 32 + chunk * 8, lds + v_tile_off(kt) + plane * 8192 + idx * 1024);
-    }
-  };
-  issue_v(0, NB);
-
-  // ---- phase 1: score tiles St[key][query], three products per 16-deep k step.  The 8*NKT (key tile, k step) units run as
-  // ONE software pipeline: fragment reads two units ahead through untracked ds_reads, counted waits (common.h).
   f32x16 p[NKT];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) p[kt][e] = 0.f;
-  {
-    // lane part of a K fragment address: row r of the tile, chunk h ^ (r & 15); k step st flips chunk bits 1..3
-    const uint32_t klane = (uint32_t)(r * 256 + ((h ^ (r & 15)) * 16));
-    bf16x8 kh[3], kl[3];
-    constexpr int NU1 = 8 * NKT;
+  f32x16 o[4];      // zeroed at the first V^T tile: must not be live (64 VGPRs) while the Q fragments are
+  float inv = 1.f;
+
+  // lane parts of the fragment addresses inside a slot: K row r, chunk h ^ (r & 15) (k step st flips chunk bits 1..3);
+  // V^T row r of a 32-d block, chunk h ^ ((r>>2)&3) (s2 flips chunk bit 1)
+  const uint32_t klane = (uint32_t)(r * 256 + ((h ^ (r & 15)) * 16));
+  const uint32_t vlane = (uint32_t)(r * 64 + ((h ^ ((r >> 2) & 3)) * 16));
+#ifndef MDM_EMU
+  const uint32_t lbase = lds_addr_of(lds);
+#endif
+
+  static_for<NTILES>([&](auto t_tag) __attribute__((always_inline)) {
+    constexpr int t = decltype(t_tag)::value;
+    constexpr int slot = t & (AX_RING - 1);
+    // tile t landed?  tiles t+1, t+2 (4 pieces each of this wave) may stay in flight; LDS-DMA retires in order
+    constexpr int ahead = (NTILES - 1 - t) < 2 ? (NTILES - 1 - t) : 2;
+#ifndef MDM_EMU
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (4 * ahead));
+#endif
+    wg_barrier();            // tile t visible to every wave; every wave is done with tile t-1 (whose slot is refilled now)
+    if constexpr (t + 3 < NTILES) issue_tile(t + 3);
+
+    if constexpr (t < NKT) {
+      // ---- phase 1, key tile t: St[key][query] += K . Q^T, three products per 16-deep k step
+      if (active) {
+        bf16x8 kh[3], kl[3];
 #ifdef MDM_EMU
-#define AX_RD_K(dst, plane, kt, st) lds_read16(dst, lds, (plane) * PLANE + (kt) * 8192 + (klane ^ ((st) << 5)))
+#define AX_RD_K(dst, plane, st) lds_read16(dst, lds, slot * AX_SLOT + (plane) * 8192 + (klane ^ ((st) << 5)))
 #else
-    const uint32_t kb0 = lds_addr_of(lds) + klane, kb1 = kb0 + PLANE;
-#define AX_RD_K(dst, plane, kt, st) lds_read16<(kt) * 8192>(dst, ((plane) ? kb1 : kb0) ^ (uint32_t)((st) << 5))
+        const uint32_t kb = lbase + klane;
+#define AX_RD_K(dst, plane, st) lds_read16<slot * AX_SLOT + (plane) * 8192>(dst, kb ^ (uint32_t)((st) << 5))
 #endif
-    static_for<NU1 + 2>([&](auto u_tag) __attribute__((always_inline)) {
-      constexpr int u = decltype(u_tag)::value;
-      if constexpr (u < NU1) {
-        AX_RD_K(kh[u % 3], 0, u / 8, u % 8);
-        AX_RD_K(kl[u % 3], 1, u / 8, u % 8);
-      }
-      if constexpr (u >= 2) {
-        constexpr int uv = u - 2, kt = uv / 8, st = uv % 8;
-        constexpr int younger = 2 * ((NU1 - 1 - uv) < 2 ? (NU1 - 1 - uv) : 2);
-        lds_wait<younger>(kh[uv % 3], kl[uv % 3]);
-#ifndef MDM_EMU
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        p[kt] = mfma_bf16(kl[uv % 3], qh[st], p[kt]);
-        p[kt] = mfma_bf16(kh[uv % 3], ql[st], p[kt]);
-        p[kt] = mfma_bf16(kh[uv % 3], qh[st], p[kt]);
-#ifndef MDM_EMU
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-      }
-    });
-#undef AX_RD_K
-  }
-
-  wg_barrier();          // every wave is done reading K
-  issue_v(NB, NKT);      // the late V^T tiles go over the K planes
-
-  // ---- softmax over keys: lane-local + one cross-half exchange; 1/sum is applied to the output
-  float mx = -INFINITY;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = kt * 32 + mfma_row(e, h);
-      const float sc = (key < nvalid) ? p[kt][e] : -INFINITY;
-      p[kt][e] = sc;
-      mx = fmaxf(mx, sc);
-    }
-  mx = fmaxf(mx, shfl_xor_f32(mx, 32));
-  float sum = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float pe = expf(p[kt][e] - mx);  // exp(-inf) = 0 for masked keys; key 0 is always valid
-      p[kt][e] = pe;
-      sum += pe;
-    }
-  sum += shfl_xor_f32(sum, 32);
-  const float inv = 1.0f / sum;
-
-  // the early tiles were issued before the late ones and LDS-DMA retires in order: allow the late pieces to stay in flight
-#ifndef MDM_EMU
-  if constexpr (NB < NKT) __builtin_amdgcn_s_waitcnt(0x0F70 | (LATE_PIECES & 15) | ((LATE_PIECES >> 4) << 14));
-  else __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
-  wg_barrier();
-
-  // ---- phase 2: Ot[d][query]; the B operand of k-step (kt, s2) is split(p[kt][8 s2 .. 8 s2 + 7]); units = (kt, s2, d tile)
-  f32x16 o[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
-  {
-    // lane part of a V^T fragment address: row r of a 32-d block, chunk h ^ ((r>>2)&3); s2 flips chunk bit 1
-    const uint32_t vlane = (uint32_t)(r * 64 + ((h ^ ((r >> 2) & 3)) * 16));
-    bf16x8 vh[3], vl[3];
-#ifdef MDM_EMU
-#define AX_RD_V(dst, plane, kt, s2, dt) \
-  lds_read16(dst, lds, ((kt) < NB ? REGION_B + (kt) * 16384 : ((kt) - NB) * 16384) + (plane) * 8192 + (dt) * 2048 + (vlane ^ ((s2) << 5)))
-#else
-    const uint32_t va = lds_addr_of(lds) + vlane, vb = va + REGION_B;
-#define AX_RD_V(dst, plane, kt, s2, dt) \
-  lds_read16<((kt) < NB ? (kt) * 16384 : ((kt) - NB) * 16384) + (plane) * 8192 + (dt) * 2048>(dst, ((kt) < NB ? vb : va) ^ (uint32_t)((s2) << 5))
-#endif
-    auto phase2 = [&](auto lo_tag, auto hi_tag) __attribute__((always_inline)) {
-      constexpr int KT_LO = decltype(lo_tag)::value, KT_HI = decltype(hi_tag)::value;
-      constexpr int NU2 = 8 * (KT_HI - KT_LO);   // units of this part: (kt, s2, dt)
-      if constexpr (NU2 > 0) {
-        bf16x8 ph, pl;
-        static_for<NU2 + 2>([&](auto u_tag) __attribute__((always_inline)) {
+        static_for<8 + 2>([&](auto u_tag) __attribute__((always_inline)) {
           constexpr int u = decltype(u_tag)::value;
-          if constexpr (u < NU2) {
-            constexpr int kt = KT_LO + u / 8, s2 = (u / 4) % 2, dt = u % 4;
-            AX_RD_V(vh[u % 3], 0, kt, s2, dt);
-            AX_RD_V(vl[u % 3], 1, kt, s2, dt);
+          if constexpr (u < 8) {
+            AX_RD_K(kh[u % 3], 0, u);
+            AX_RD_K(kl[u % 3], 1, u);
           }
           if constexpr (u >= 2) {
-            constexpr int uv = u - 2, kt = KT_LO + uv / 8, s2 = (uv / 4) % 2, dt = uv % 4;
+            constexpr int st = u - 2;
+            constexpr int younger = 2 * ((7 - st) < 2 ? (7 - st) : 2);
+            lds_wait<younger>(kh[st % 3], kl[st % 3]);
+#ifndef MDM_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            p[t] = mfma_bf16(kl[st % 3], qh[st], p[t]);
+            p[t] = mfma_bf16(kh[st % 3], ql[st], p[t]);
+            p[t] = mfma_bf16(kh[st % 3], qh[st], p[t]);
+#ifndef MDM_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+          }
+        });
+#undef AX_RD_K
+      }
+      if constexpr (t == NKT - 1) {
+        // ---- softmax over keys: lane-local + one cross-half exchange; 1/sum is applied to the output
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + mfma_row(e, h);
+            const float sc = (key < nvalid) ? p[kt][e] : -INFINITY;
+            p[kt][e] = sc;
+            mx = fmaxf(mx, sc);
+          }
+        mx = fmaxf(mx, shfl_xor_f32(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float pe = expf(p[kt][e] - mx);  // exp(-inf) = 0 for masked keys; key 0 is always valid
+            p[kt][e] = pe;
+            sum += pe;
+          }
+        sum += shfl_xor_f32(sum, 32);
+        inv = 1.0f / sum;
+      }
+    } else {
+      // ---- phase 2, key tile kt: Ot[d][query] += V^T . P^T; the B operand of k-step (kt, s2) is split(p[kt][8 s2 .. +7])
+      constexpr int kt = t - NKT;
+      if constexpr (kt == 0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+      }
+      if (active) {
+        bf16x8 vh[3], vl[3], ph, pl;
+#ifdef MDM_EMU
+#define AX_RD_V(dst, plane, s2, dt) lds_read16(dst, lds, slot * AX_SLOT + (plane) * 8192 + (dt) * 2048 + (vlane ^ ((s2) << 5)))
+#else
+        const uint32_t vb = lbase + vlane;
+#define AX_RD_V(dst, plane, s2, dt) lds_read16<slot * AX_SLOT + (plane) * 8192 + (dt) * 2048>(dst, vb ^ (uint32_t)((s2) << 5))
+#endif
+        static_for<8 + 2>([&](auto u_tag) __attribute__((always_inline)) {
+          constexpr int u = decltype(u_tag)::value;
+          if constexpr (u < 8) {
+            AX_RD_V(vh[u % 3], 0, u / 4, u % 4);
+            AX_RD_V(vl[u % 3], 1, u / 4, u % 4);
+          }
+          if constexpr (u >= 2) {
+            constexpr int uv = u - 2, s2 = uv / 4, dt = uv % 4;
             if constexpr (dt == 0) {
               float pv[8];
 #pragma unroll
               for (int j = 0; j < 8; ++j) pv[j] = p[kt][8 * s2 + j];
               split8(pv, ph, pl);
             }
-            constexpr int younger = 2 * ((NU2 - 1 - uv) < 2 ? (NU2 - 1 - uv) : 2);
+            constexpr int younger = 2 * ((7 - uv) < 2 ? (7 - uv) : 2);
             lds_wait<younger>(vh[uv % 3], vl[uv % 3]);
 #ifndef MDM_EMU
             __builtin_amdgcn_sched_barrier(0);
@@ -255,38 +254,35 @@ __global__ __launch_bounds__(64 * NKT) void attention_bf16x3_kernel(QkvPlanes P,
 #endif
           }
         });
-      }
-    };
-    phase2(std::integral_constant<int, 0>{}, std::integral_constant<int, NB>{});
-    if constexpr (NB < NKT) {
-      wait_vmem_all();
-      wg_barrier();
-      phase2(std::integral_constant<int, NB>{}, std::integral_constant<int, NKT>{});
-    }
 #undef AX_RD_V
-  }
-  wg_barrier();  // every wave is done reading V^T
-
-  // ---- stage O[q][d] (fp32, row stride AX_OLD) and store coalesced: rows mfma_row(4g..4g+3, h) are 4 consecutive d
-  float* so = reinterpret_cast<float*>(lds);
-  const int q = 32 * w + r;
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int d0 = dt * 32 + 8 * g + 4 * h;
-      st4(&so[q * AX_OLD + d0], make_float4(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
-                                            o[dt][4 * g + 3] * inv));
+      }
     }
-  wg_barrier();
-  const size_t obase = (size_t)seq * S * D + head * AX_HD;
-  for (int idx = tid; idx < SP * 32; idx += NT) {
-    const int qq = idx >> 5, c4 = idx & 31;
-    if (qq < S) {
-      const float4 v = ld4(&so[qq * AX_OLD + 4 * c4]);
-      const size_t oo = obase + (size_t)qq * D + 4 * c4;
-      if (out != nullptr) st4(out + oo, v);
-      if (oh != nullptr) split4_store(oh + oo, ol + oo, v);  // planes for the out_proj bf16x3 GEMM
+  });
+  wg_barrier();  // every wave is done reading the ring: it becomes the output staging area
+
+  // ---- stage this wave's O[32 queries][128 d] (fp32, row stride AX_OLD, wave-private) and store coalesced:
+  // accumulator rows mfma_row(4g..4g+3, h) are 4 consecutive d
+  float* so = reinterpret_cast<float*>(lds) + w * (32 * AX_OLD);
+  if (active) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = dt * 32 + 8 * g + 4 * h;
+        st4(&so[r * AX_OLD + d0], make_float4(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
+                                              o[dt][4 * g + 3] * inv));
+      }
+    wave_lds_fence();
+    const size_t obase = (size_t)seq * S * D + head * AX_HD;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 2 * i + h, qq = 32 * qt + row, c4 = r;   // lane -> (row parity = h, 4 consecutive d at 4 r)
+      if (qq < S) {
+        const float4 v = ld4(&so[row * AX_OLD + 4 * c4]);
+        const size_t oo = obase + (size_t)qq * D + 4 * c4;
+        if (out != nullptr) st4(out + oo, v);
+        if (oh != nullptr) split4_store(oh + oo, ol + oo, v);  // planes for the out_proj bf16x3 GEMM
+      }
     }
   }
 }

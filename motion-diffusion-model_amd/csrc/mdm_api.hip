@@ -221,7 +221,10 @@ int launch_attention_x3_t(const QkvPlanes& qp, const int* lengths, int nseq, int
   auto k = &attention_bf16x3_kernel<NKT>;
   const size_t lds = attention_x3_lds_bytes(NKT);
   if (int rc = rt_allow_lds(k, lds)) return rc;
-  MDM_LAUNCH(k, dim3(nseq * qp.H), dim3(64 * NKT), lds, s, qp, lengths, S, D, B, out, oh, ol);
+  // two workgroups (query halves) per (sequence, head); the item <-> block mapping pairs blocks b and b + 8 (same XCD),
+  // so the number of items is rounded up to a multiple of 8 and surplus workgroups exit
+  const int items = nseq * qp.H, groups = (items + 7) / 8;
+  MDM_LAUNCH(k, dim3(groups * 16), dim3(256), lds, s, qp, lengths, S, D, B, out, oh, ol, items);
   return rt_launch_status();
 }
 
