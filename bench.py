@@ -102,8 +102,9 @@ def pmc_traffic_per_gemm_launch():
     try:
         with open(path) as f:
             d = json.load(f)
-        w = {"gemm_bf16x3<in_proj -> Q/K/V^T planes>": 1, "gemm_bf16x3<out_proj | linear2, residual planes>": 2,
-             "gemm_bf16x3<linear1 + GELU -> planes>": 1}
+        w = {"gemm_bf16x3<in_proj (LayerNorm folded) -> Q/K/V^T planes>": 1,
+             "gemm_bf16x3<out_proj | linear2, LayerNorm residual, planes + row stats>": 2,
+             "gemm_bf16x3<linear1 (LayerNorm folded) + GELU -> planes>": 1}
         tot = sum(d[k]["hbm_bytes"] * n for k, n in w.items())
         return int(tot / sum(w.values())), "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command)"
     except (KeyError, ValueError, OSError):
