@@ -203,7 +203,11 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
+#ifdef MDM_EMU
             const float pe = expf(p[kt][e] - mx);  // exp(-inf) = 0 for masked keys; key 0 is always valid
+#else
+            const float pe = __expf(p[kt][e] - mx);  // v_exp_f32 of a non-positive argument (2 instructions, ~2 ulp)
+#endif
             p[kt][e] = pe;
             sum += pe;
           }

@@ -170,6 +170,28 @@ __global__ __launch_bounds__(256) void outproj_finish_kernel(const float* __rest
   }
 }
 
+// InputProcess operand for the split-precision GEMM: poses x [B][JF][T] (frames contiguous) -> bf16 hi/lo planes
+// [B*T][KP] (row = (b, t), features contiguous, zero-padded from JF to KP) -- the permute of mdm.py:345 as a 32x32 LDS
+// tile transpose.  grid (ceil(T/32), KP/32, B), 256 threads.
+__global__ __launch_bounds__(256) void pose_to_planes_kernel(const float* __restrict__ x, bf16_t* __restrict__ ph,
+                                                             bf16_t* __restrict__ pl, int T, int JF, int KP) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int t0 = blockIdx.x * 32, j0 = blockIdx.y * 32, b = blockIdx.z;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = j0 + ty + 8 * i, t = t0 + tx;
+    tile[ty + 8 * i][tx] = (j < JF && t < T) ? x[((size_t)b * JF + j) * T + t] : 0.f;
+  }
+  __syncthreads();
+  const int tl = threadIdx.x >> 3, jq = (threadIdx.x & 7) * 4;
+  const int t = t0 + tl;
+  if (t < T) {
+    const size_t o = ((size_t)b * T + t) * KP + j0 + jq;
+    split4_store(ph + o, pl + o, make_float4(tile[jq + 0][tl], tile[jq + 1][tl], tile[jq + 2][tl], tile[jq + 3][tl]));
+  }
+}
+
 // LayerNorm folded into the linear layer that consumes it (mdm_prepare; gemm_bf16x3.h X3Epilogue):
 //   wf[n][k] = w[n][k] * gamma[k];  colsum[n] = sum_k wf[n][k];  biasf[n] = bias[n] + sum_k w[n][k] * beta[k]
 // so that  W.LN(x) + b = rstd * (Wf.x - mean * colsum) + biasf.  One wave per output row; rows N..Npad-1 of the

@@ -105,6 +105,9 @@ struct X3Epilogue {
   float* ostat;          // OSTAT: [M][tiles_n][2] partial sums of the rows this launch writes
   int stat_parts;        // partials per row in astat / rstat
   float inv_dim;         // 1 / (normalised width) for astat / rstat
+  // ---- EMBED (InputProcess, mdm.py:343-349 + :251-252): GEMM row m = (b, t) of [B*T]; the value gets the positional row
+  // res[(1 + t) * ld + n] added and is written, as planes, to token row b*S + 1 + t of every branch (S = emb_T + 1)
+  int emb_T, emb_B, emb_nbranch;
 };
 
 // exact-GELU with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, i.e. fp32-rounding class): one v_exp, one v_rcp
@@ -163,7 +166,7 @@ struct X3Cursor {
 // 4 = no MFMAs, 8 = loads issued but not waited for.
 // FOLD / OSTAT / RES == 3: LayerNorm folded into the GEMMs (X3Epilogue).
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
-          bool OSTAT = false>
+          bool OSTAT = false, bool EMBED = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N,
                                                                      int K, int rows_per_tile, int tiles_n, int total) {
   MDM_DYN_SMEM(unsigned char, lds);
@@ -200,13 +203,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       const int q = min(wid + X3_WAVES * i, X3_A_GROUPS - 1);
       const int ga = (q < 14) ? q : q - 14;
       const int arow = min(m0 + ga * 16 + (lane >> 2), M - 1);
-      c.off[i] = (uint32_t)arow * (uint32_t)K + schunk * 8;
+      if constexpr ((ABL & 16) != 0) {
+        // timing experiment: a k-BLOCKED plane layout ([row/16][k/32][16 rows][32 k]) would make every piece one
+        // contiguous KB; the data fetched here is wrong, only the address pattern is representative
+        c.off[i] = (uint32_t)(arow >> 4) * (uint32_t)(K / 32) * 512u + (uint32_t)(arow & 15) * 32u + schunk * 8;
+      } else {
+        c.off[i] = (uint32_t)arow * (uint32_t)K + schunk * 8;
+      }
     }
   };
   auto piece_a = [&](const Cursor& c, int i, int buf) {
     const int q = wid + X3_WAVES * i;
     if (q < X3_A_GROUPS)
-      glds16(((q < 14) ? A.hi : A.lo) + c.off[i] + c.k * X3_BK, lds + buf * X3_A_STAGE + q * 1024);
+      glds16(((q < 14) ? A.hi : A.lo) + c.off[i] + c.k * ((ABL & 16) ? 512 : X3_BK), lds + buf * X3_A_STAGE + q * 1024);
   };
   // past its last tile the stream simply re-fetches that tile (one wasted stage per workgroup): no "anything left to
   // load" branches in the step body
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int m = min(m0 + t * 32 + 8 * g + prow, M - 1);
-            const size_t o = (size_t)m * ep.ld + (n4 < N ? n4 : 0);
+            const size_t o = (size_t)(EMBED ? 1 + m % ep.emb_T : m) * ep.ld + (n4 < N ? n4 : 0);   // EMBED: positional row
             if constexpr (RES == 1) {
               gload16_async(rr[t % RR][g], ep.res + o);
             } else {
@@ -572,9 +581,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
         if (!(ABL & 1)) {
           const int m = m0 + row_in_tile;
           if (m < m_end && n4 < N) {  // N % 4 == 0
-            const size_t o = (size_t)m * ep.ld + n4;
-            if (OUT_F32) st4(ep.out + o, v4);
-            if (OUT_PLANES) split4_store(ep.oh + o, ep.ol + o, v4);
+            if constexpr (EMBED) {
+              const int bb = m / ep.emb_T, tt = m - bb * ep.emb_T;
+              for (int br = 0; br < ep.emb_nbranch; ++br) {
+                const size_t o = ((size_t)(br * ep.emb_B + bb) * (ep.emb_T + 1) + 1 + tt) * ep.ld + n4;
+                split4_store(ep.oh + o, ep.ol + o, v4);
+              }
+            } else {
+              const size_t o = (size_t)m * ep.ld + n4;
+              if (OUT_F32) st4(ep.out + o, v4);
+              if (OUT_PLANES) split4_store(ep.oh + o, ep.ol + o, v4);
+            }
           }
         }
       });
@@ -633,14 +650,14 @@ inline int& x3_waves_setting() {
 }
 
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
-          bool OSTAT = false>
+          bool OSTAT = false, bool EMBED = false>
 inline int launch_gemm_bf16x3_w(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                                 int rpt, hipStream_t stream) {
   constexpr int TN = x3_tn(WAVES);
   constexpr bool LN = FOLD || OSTAT || RES == 3;
   const int tiles_m = (M + rpt - 1) / rpt, tiles_n = (N + TN - 1) / TN;
   const int total = tiles_m * tiles_n;
-  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT>;
+  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED>;
 #ifndef MDM_EMU
   if (x3_lds_bytes(WAVES, LN) > 65536) {
     static bool configured = false;  // per instantiation
@@ -663,6 +680,7 @@ inline int launch_gemm_bf16x3_w(const X3Operand& A, const X3Weights& W, const X3
 //   kind 2  out_proj (l >= 1) / linear2         residual = LayerNorm rebuilt from planes, writes planes + row statistics
 //   kind 3  linear1                             FOLD + GELU -> planes
 //   kind 4  OutputProcess                       FOLD -> fp32
+//   kind 5  InputProcess                        + positional rows, planes to the token rows of every branch (EMBED)
 inline int launch_gemm_bf16x3_ln(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
                                  int K, int rpt, hipStream_t s) {
   switch (kind) {
@@ -671,6 +689,7 @@ inline int launch_gemm_bf16x3_ln(int kind, const X3Operand& A, const X3Weights& 
     case 2: return launch_gemm_bf16x3_w<8, ACT_NONE, 3, false, true, false, 0, false, true>(A, W, ep, M, N, K, rpt, s);
     case 3: return launch_gemm_bf16x3_w<8, ACT_GELU, 0, false, true, false, 0, true, false>(A, W, ep, M, N, K, rpt, s);
     case 4: return launch_gemm_bf16x3_w<8, ACT_NONE, 0, true, false, false, 0, true, false>(A, W, ep, M, N, K, rpt, s);
+    case 5: return launch_gemm_bf16x3_w<8, ACT_NONE, 1, false, true, false, 0, false, false, true>(A, W, ep, M, N, K, rpt, s);
     default: return -2;
   }
 }
@@ -701,6 +720,7 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Ep
       case 3: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 3>(A, W, ep, M, N, K, rpt, s);
       case 4: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 4>(A, W, ep, M, N, K, rpt, s);
       case 8: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 8>(A, W, ep, M, N, K, rpt, s);
+      case 16: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 16>(A, W, ep, M, N, K, rpt, s);
       case 9: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 9>(A, W, ep, M, N, K, rpt, s);
       default: return -2;
     }

@@ -112,6 +112,8 @@ struct mdm_model {
   // LayerNorm folded into its consumers (gemm_bf16x3.h X3Epilogue): gamma-scaled weight planes, column sums, folded biases
   struct LayerFold { X3Weights in_proj, linear1; float *c_qkv, *b_qkv, *c_1, *b_1; };
   std::vector<LayerFold> fold;
+  X3Weights in_planes{nullptr, nullptr};   // poseEmbedding.weight, K zero-padded to jf_k (bf16x3 InputProcess)
+  int jf_k = 0;                             // njoints*nfeats rounded up to a multiple of 32
   X3Weights out_planes_f{nullptr, nullptr};
   float *c_out = nullptr, *b_out = nullptr;
   bool lnfold = false;                      // bf16x3 mode without LayerNorm kernels (set by mdm_prepare)
@@ -265,7 +267,7 @@ int launch_linear_x3(Profiler* pf, X3Operand a, X3Weights w, const float* bias, 
   if (N % 4 != 0) return fail(MDM_EINVAL, "bf16x3 linear: N must be a multiple of 4");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
   X3Epilogue ep{out, bias, res, res_planes.hi, res_planes.lo, oh, ol, N, scale_cols, col_scale, QkvPlanes{}, 0, 0,
-                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f};
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1};
   const int rc = launch_gemm_bf16x3(a, w, ep, M, N, K, act, seq_len, s, g_x3_ablate);
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 linear: unsupported (activation, residual, output) combination");
   return rt_launch_status();
@@ -277,7 +279,7 @@ int launch_in_proj_x3(Profiler* pf, X3Operand a, X3Weights w, const float* bias,
   if (D % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 in_proj: latent_dim must be a multiple of 32");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * nseq * S * 3.0 * D * (double)D, s);
   X3Epilogue ep{nullptr, bias, nullptr, nullptr, nullptr, nullptr, nullptr, 3 * D, D, qscale, qp, S, D,
-                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f};
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1};
   const int rc = launch_gemm_bf16x3_qkv(a, w, ep, nseq, S, D, s);
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 in_proj: sequences longer than 224 tokens");
   return rt_launch_status();
@@ -289,6 +291,7 @@ struct LnArgs {
   X3Operand res{nullptr, nullptr}; const float* rstat = nullptr; const float* rgamma = nullptr; const float* rbeta = nullptr;  // residual
   float* ostat = nullptr;                                                                       // OSTAT
   int parts = 1; float inv_dim = 1.f;
+  const float* res_f32 = nullptr; int emb_T = 1, emb_B = 1, emb_nbranch = 1;                     // EMBED (kind 5)
 };
 int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w, const float* bias, const LnArgs& ln,
                  float* out, bf16_t* oh, bf16_t* ol, const QkvPlanes* qp, int M, int N, int K, int S, int D,
@@ -296,9 +299,10 @@ int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w,
   if (K % X3_BK != 0 || N % 4 != 0) return fail(MDM_EINVAL, "bf16x3 linear: K % 32 and N % 4 must be 0");
   if (ln.parts < 1 || ln.parts > 4) return fail(MDM_EUNSUPPORTED, "folded LayerNorm: at most 4 partial sums per row (D <= 1024)");
   ProfScope ps(pf, prof_cat, 2.0 * M * (double)N * K, s);
-  X3Epilogue ep{out, bias, nullptr, ln.res.hi, ln.res.lo, oh, ol, N, scale_cols, col_scale, qp ? *qp : QkvPlanes{}, S, D,
-                ln.astat, ln.colsum, ln.rstat, ln.rgamma, ln.rbeta, ln.ostat, ln.parts, ln.inv_dim};
-  const int rpt = (kind == 0) ? S : x3_rows_per_tile(M, S);
+  X3Epilogue ep{out, bias, ln.res_f32, ln.res.hi, ln.res.lo, oh, ol, N, scale_cols, col_scale, qp ? *qp : QkvPlanes{}, S, D,
+                ln.astat, ln.colsum, ln.rstat, ln.rgamma, ln.rbeta, ln.ostat, ln.parts, ln.inv_dim, ln.emb_T, ln.emb_B,
+                ln.emb_nbranch};
+  const int rpt = (kind == 0) ? S : x3_rows_per_tile(M, kind == 5 ? ln.emb_T : S);
   const int rc = launch_gemm_bf16x3_ln(kind, a, w, ep, M, N, K, rpt, s);
   if (rc == -1) return fail(MDM_EHIP, "bf16x3 linear: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 linear: unsupported folded-LayerNorm GEMM kind");
@@ -322,6 +326,25 @@ int launch_split(const float* src, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t
   return rt_launch_status();
 }
 
+// InputProcess in split precision (8-wave kernel): poses -> planes [B*T][jf_k] (in the dead ffn region) -> GEMM whose epilogue
+// adds the positional rows and writes the frame tokens of every branch as planes.
+int embed_frames_x3(mdm_model* m, const Workspace& ws, const float* x, int B, int T, int nbranch, hipStream_t s) {
+  const int D = m->cfg.latent_dim, KP = m->jf_k;
+  ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
+  bf16_t* ph = reinterpret_cast<bf16_t*>(ws.ffn);
+  bf16_t* pl = ph + (size_t)B * T * KP;
+  MDM_LAUNCH(pose_to_planes_kernel, dim3((T + 31) / 32, KP / 32, B), dim3(256), 0, s, x, ph, pl, T, m->jf, KP);
+  if (int rc = rt_launch_status()) return rc;
+  LnArgs a;
+  a.res_f32 = m->W("sequence_pos_encoder.pe");
+  a.emb_T = T; a.emb_B = B; a.emb_nbranch = nbranch;
+  return launch_x3_ln(nullptr, MDM_PROF_EMBED, 5, X3Operand{ph, pl}, m->in_planes, m->W("input_process.poseEmbedding.bias"), a,
+                      nullptr, ws.tokh, ws.tokl, nullptr, B * T, D, KP, T + 1, D, 0, 1.f, s);
+}
+inline bool use_embed_x3(const mdm_model* m, int T) {
+  return m->precision == MDM_PREC_BF16X3 && x3_waves_setting() == 8 && T + 1 <= X3_TM;
+}
+
 // Tokens for every sequence: frame tokens via the InputProcess GEMM, token 0 via cond_token_kernel.
 int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long long* timesteps,
                  long long t_uniform_unused, const float* cond_emb, int B, int T, int nbranch,
@@ -333,7 +356,9 @@ int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long l
   const bool x3 = m->precision == MDM_PREC_BF16X3;
   EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D,
                    nbranch, x3 ? ws.tokh : nullptr, x3 ? ws.tokl : nullptr};
-  {
+  if (use_embed_x3(m, T)) {
+    if (int rc = embed_frames_x3(m, ws, x, B, T, nbranch, s)) return rc;
+  } else {
     ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
     launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
   }
@@ -472,6 +497,7 @@ int mdm_create(const mdm_config_t* cfg, mdm_model_t** out) {
   m->jf = cfg->njoints * cfg->nfeats;
   m->jf_pad = (m->jf + 3) / 4 * 4;
   m->jf_out = m->jf_pad;
+  m->jf_k = (m->jf + 31) / 32 * 32;
   const int64_t d = D, ff = cfg->ff_size, jf = m->jf;
   auto& e = m->expect;
   e["input_process.poseEmbedding.weight"] = d * jf;
@@ -532,7 +558,7 @@ size_t mdm_const_bytes(const mdm_model_t* m) {
          (size_t)m->cfg.num_layers * (align_up(3 * D * D * 4, 256) + align_up(FF * D * 4, 256) +
                                       2 * align_up(3 * D * 4, 256) + 2 * align_up(FF * 4, 256)) +
          align_up(x3_packed_weight_elems(m->jf_out, (int)D) * 4, 256) + 2 * align_up((size_t)32 * ((m->jf_out + 31) / 32) * 4, 256) +
-         align_up(std::max<size_t>(3 * D, FF) * D * 4, 256);
+         align_up(std::max<size_t>(3 * D, FF) * D * 4, 256) + align_up((size_t)D * m->jf_k * 4, 256);
 }
 
 int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* stream) {
@@ -613,6 +639,17 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
     if (int rc = fold_one(m->W("output_process.poseFinal.weight"), m->W("output_process.poseFinal.bias"),
                           m->L(L - 1, "norm2.weight"), m->L(L - 1, "norm2.bias"), m->jf, jf32, m->out_planes_f, m->c_out,
                           m->b_out)) return rc;
+    // InputProcess in split precision: weight [D][jf] zero-padded along K to jf_k, then fragment-ordered planes
+    MDM_LAUNCH(pad_rows_kernel, dim3(256), dim3(256), 0, s, scratch_w, m->W("input_process.poseEmbedding.weight"), D, m->jf,
+               m->jf_k);
+    if (int rc = rt_launch_status()) return rc;
+    {
+      const size_t n = x3_packed_weight_elems(D, m->jf_k);
+      bf16_t* hi = reinterpret_cast<bf16_t*>(base);
+      base += align_up(n * 4, 256);
+      m->in_planes = X3Weights{hi, hi + n};
+      if (int rc = launch_pack_weights(scratch_w, hi, hi + n, D, m->jf_k, s)) return rc;
+    }
     const char* e = getenv("MDM_LNFOLD");
     m->lnfold = !(e != nullptr && e[0] == '0');
   }
@@ -736,7 +773,9 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
       const bool x3 = m->precision == MDM_PREC_BF16X3;
       EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D, nbranch,
                        x3 ? ws.tokh : nullptr, x3 ? ws.tokl : nullptr};
-      {
+      if (use_embed_x3(m, T)) {
+        if (int rc = embed_frames_x3(m, ws, x, B, T, nbranch, s)) return rc;
+      } else {
         ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
         launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
       }
