@@ -55,6 +55,22 @@ __device__ __forceinline__ float shfl_xor_f32(float v, int mask) {
 #endif
 }
 
+// Sum over the 8 consecutive lanes that share lane>>3 (every lane gets the total): three DPP moves (quad_perm xor 1,
+// quad_perm xor 2, row_half_mirror) at VALU speed; __shfl_xor lowers to ds_bpermute_b32, an LDS round trip per step.
+__device__ __forceinline__ float sum_lanes8(float v) {
+#ifdef MDM_EMU
+  v += shfl_xor_f32(v, 1);
+  v += shfl_xor_f32(v, 2);
+  v += shfl_xor_f32(v, 4);
+  return v;
+#else
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  return v;
+#endif
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }

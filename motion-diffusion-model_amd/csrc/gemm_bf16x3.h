@@ -367,7 +367,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
 #ifndef MDM_EMU
           __builtin_amdgcn_sched_barrier(0);  // the MFMAs below must not be hoisted above the wait (rule 18)
 #endif
-          if constexpr ((ABL & 4) != 0) {
+          if constexpr ((ABL & 4) != 0 || ((ABL & 32) != 0 && uv == NU - 1)) {
+            // 4: no MFMAs at all; 32: timing experiment -- one unit of 14 skipped = the MFMA work a 16-row last sub-tile
+            // (208 instead of 224 rows per tile) would save
 #ifndef MDM_EMU
             asm volatile("" ::"v"(al[uv % RING]), "v"(ah[uv % RING]), "v"(wh[ks]), "v"(wl[ks]));
 #endif
@@ -571,11 +573,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
         if constexpr (OSTAT) {   // partial (sum, sum of squares) of this row over the wave's 32 columns
           float s1 = (v4.x + v4.y) + (v4.z + v4.w);
           float s2 = (v4.x * v4.x + v4.y * v4.y) + (v4.z * v4.z + v4.w * v4.w);
-#pragma unroll
-          for (int msk = 1; msk <= 4; msk <<= 1) {
-            s1 += shfl_xor_f32(s1, msk);
-            s2 += shfl_xor_f32(s2, msk);
-          }
+          s1 = sum_lanes8(s1);
+          s2 = sum_lanes8(s2);
           if ((lane & 7) == 0) part[row_in_tile] = make_float2(s1, s2);
         }
         if (!(ABL & 1)) {
@@ -721,6 +720,7 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Ep
       case 4: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 4>(A, W, ep, M, N, K, rpt, s);
       case 8: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 8>(A, W, ep, M, N, K, rpt, s);
       case 16: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 16>(A, W, ep, M, N, K, rpt, s);
+      case 32: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 32>(A, W, ep, M, N, K, rpt, s);
       case 9: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 9>(A, W, ep, M, N, K, rpt, s);
       default: return -2;
     }

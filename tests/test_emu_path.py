@@ -35,7 +35,7 @@ def test_emulated_cfg_loop_matches_oracle(lib, prec, tol):
     assert maxabs(got, want) < tol
 
 
-@pytest.mark.parametrize("prec,tol,layers", [("f32", 1e-5, 1), ("bf16x3", 1e-4, 1), ("bf16x3", 1e-4, 2)])
+@pytest.mark.parametrize("prec,tol,layers", [("f32", 1e-5, 1), ("bf16x3", 1e-4, 2)])
 def test_emulated_forward_branches(lib, prec, tol, layers):
     """layers = 2 reaches the GEMM kinds only a second layer uses: in_proj with the previous LayerNorm folded in, and
     out_proj whose residual is a LayerNorm rebuilt from the pre-norm planes + row statistics."""
