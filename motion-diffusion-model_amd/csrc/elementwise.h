@@ -127,13 +127,13 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, con
 // reference's [.., JF, T] pose layout (mdm.py:385) and fuses, per element, what OutProjEpilogue fuses in the fp32 path:
 // mode 0 plain model output for every sequence; mode 1 classifier-free-guidance combine of the two branches
 // (utils/sampler_util.py:34 -- here AFTER the projection, which is linear), inpainting blend, clamp, posterior /
-// DDIM update with this step's noise (gaussian_diffusion.py:300-304, :347-353, :525-540).
+// DDIM update with this step's noise -- injected, or drawn inline from the counter-based stream, bit-identical to
+// randn_kernel's values (gaussian_diffusion.py:300-304, :347-353, :525-540).
 // grid (ceil(T/32), ceil(JF/32), sequences or samples), 256 threads = 32 x 8.
 __global__ __launch_bounds__(256) void outproj_finish_kernel(const float* __restrict__ out_tok, int ldo, int S, int T,
                                                              int JF, int B, const float* __restrict__ scale, int mode,
                                                              float* __restrict__ out, float* __restrict__ x0_out,
-                                                             const float* __restrict__ x_t,
-                                                             const float* __restrict__ noise,
+                                                             const float* __restrict__ x_t, NoiseSource ns,
                                                              const unsigned char* __restrict__ inpaint_mask,
                                                              const float* __restrict__ inpaint_motion, StepCoefs co) {
   __shared__ float tile[32][33];
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void outproj_finish_kernel(const float* __rest
       if (inpaint_mask != nullptr && inpaint_mask[off]) x0 = inpaint_motion[off];
       if (co.clip_denoised) x0 = fminf(1.f, fmaxf(-1.f, x0));
       float v = co.a_x0 * x0 + co.a_xt * x_t[off];
-      if (noise != nullptr) v += co.sigma * noise[off];
+      if (co.sigma != 0.f) v += co.sigma * ns.get(b, (uint32_t)(j * T + t), off);   // injected, or the Philox stream inline
       if (x0_out != nullptr) x0_out[off] = x0;
       out[off] = v;
     }

@@ -452,7 +452,7 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
 // OutputProcess, split precision: every sequence's tokens x poseFinal -> fp32 rows in the (dead) qkv region, then the
 // transposing / fusing tail kernel (elementwise.h outproj_finish_kernel).
 int outproj_x3(mdm_model* m, const Workspace& ws, int nseq, int B, int T, const float* scale, int mode, float* out,
-               float* x0_out, const float* x_t, const float* noise, const unsigned char* inpaint_mask,
+               float* x0_out, const float* x_t, NoiseSource noise, const unsigned char* inpaint_mask,
                const float* inpaint_motion, StepCoefs co, hipStream_t s) {
   const int D = m->cfg.latent_dim, S = T + 1, ldo = m->jf_out;
   float* out_tok = ws.qkv;
@@ -694,7 +694,7 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
   if (int rc = encoder(m, ws, nseq, B, S, len, s)) return rc;
   // OutputProcess, plain: every branch's tokens -> [nseq, JF, T]
   if (m->precision == MDM_PREC_BF16X3)
-    return outproj_x3(m, ws, nseq, B, T, nullptr, 0, out, nullptr, nullptr, nullptr, nullptr, nullptr, StepCoefs{}, s);
+    return outproj_x3(m, ws, nseq, B, T, nullptr, 0, out, nullptr, nullptr, NoiseSource{}, nullptr, nullptr, StepCoefs{}, s);
   RowMajorLoader al{m->W("output_process.poseFinal.weight"), D, m->jf, D};
   CfgTokenLoader bl{ws.tok, nullptr, nseq, T, S, D, nseq * T};
   OutProjEpilogue ep{};
@@ -788,11 +788,13 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
       if (int rc = rt_launch_status()) return rc;
     }
     if (int rc = encoder(m, ws, nseq, B, S, len, s)) return rc;
-    // this step's eps: injected, or drawn from the counter-based stream into the (now dead) attention buffer
+    // this step's eps: injected, or the counter-based stream -- drawn inline by the split-precision tail kernel, into the
+    // (now dead) attention buffer for the exact-fp32 OutputProcess epilogue
+    const bool x3mode = m->precision == MDM_PREC_BF16X3;
     const float* step_noise = nullptr;
     if (p->sigma[i] != 0.f) {
       if (p->noise_dev != nullptr) step_noise = p->noise_dev + (size_t)k * B * per_sample;
-      else {
+      else if (!x3mode) {
         ProfScope ps(&m->prof, MDM_PROF_ELEMENTWISE, 0.0, s);
         if (int rc = mdm_randn(ws.att, nullptr, nullptr, 0.f, 1.f, B, (int)per_sample, p->seed, p->sample_base,
                                (uint32_t)(1 + k), stream)) return rc;
@@ -800,9 +802,10 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
       }
     }
     // OutputProcess + CFG combine + sampler update, in place on x
-    if (m->precision == MDM_PREC_BF16X3) {
+    if (x3mode) {
       if (int rc = outproj_x3(m, ws, nseq, B, T, cfg ? p->scale_dev : nullptr, 1, x, (i == 0) ? p->x0_dev : nullptr, x,
-                              step_noise, p->inpaint_mask_dev, p->inpaint_motion_dev,
+                              NoiseSource{step_noise, p->seed, p->sample_base, (uint32_t)(1 + k)}, p->inpaint_mask_dev,
+                              p->inpaint_motion_dev,
                               StepCoefs{p->a_x0[i], p->a_xt[i], p->sigma[i], p->clip_denoised}, s)) return rc;
     } else {
       RowMajorLoader al{m->W("output_process.poseFinal.weight"), D, m->jf, D};
