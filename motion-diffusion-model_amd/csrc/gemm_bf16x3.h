@@ -5,26 +5,30 @@
 // Why: the reference computes these `addmm`s in fp32 (model/mdm.py:77-84 -> torch TransformerEncoderLayer) and
 // BASELINE's parity bar is 1e-3 max-abs over a 50-step guided trajectory.  gfx950 has no TF32; exact-fp32 MFMA
 // peaks at 157 TFLOP/s, bf16 MFMA at 2.5 PFLOP/s, so three bf16 passes carry a ~2^-16-relative fp32 product at up to
-// ~5x the fp32 rate (measured trajectory error ~3e-5).  Replaces in_proj / out_proj / linear1 /
-// linear2; the 263-wide input/output projections stay on the exact-fp32 kernel (gemm_f32.h).
+// ~5x the fp32 rate.  Replaces in_proj / out_proj / linear1 / linear2 and,
+// with K / N padded, InputProcess and OutputProcess (rows a12, a16); the LayerNorms between them are folded into the
+// epilogues (X3Epilogue).  The exact-fp32 kernel (gemm_f32.h) remains the `f32` mode.
 //
 // Data layout.  Activations: two bf16 planes [rows][K] (hi, lo), K contiguous, written by the PRODUCING kernel's
-// epilogue (LayerNorm, attention, GELU).  Weights: split ONCE (mdm_prepare) and stored in MFMA-FRAGMENT order
+// epilogue.  Weights: split ONCE (mdm_prepare) and stored in MFMA-FRAGMENT order
 //     Wp[plane][n/32][k/16][lane 0..63][8]      lane = (n%32) + 32*((k%16)/8),  element j = k%8
 // so the B-operand fragment of one wave for one 16-deep k sub-step is ONE contiguous, perfectly coalesced 1 KB
 // global_load_dwordx4 -- weights never pass through LDS (a wave's 32 output columns are private to it, so staging them
 // in LDS bought nothing and cost an LDS-DMA write plus an LDS read per byte).
 //
-// Machine mapping (gfx950).  256 threads = 4 waves per workgroup, TWO PERSISTENT workgroups per CU (60 KB of LDS and
-// <= 256 VGPRs each), so every SIMD hosts one wave of each workgroup and the two workgroups -- which share nothing and
-// drift apart in phase -- hide each other's non-MFMA time: the per-step barrier, the LDS-DMA latency, the epilogue's
-// VALU / LDS-transpose / store-issue work.  (Measured on the one-workgroup-per-CU predecessor: MFMA-only 141 us +
-// epilogue stores 40 + fragment reads/barriers 18 + loads 32 = 230 us for in_proj, i.e. the parts ADD when all eight
-// waves of a CU march in lock-step; no instruction-order or wave-priority variant moved that by more than 0.3 %.)
-//   * block tile = up to 224 rows x 128 columns; the row extent is a whole number of token sequences (S = 197 -> one
-//     sequence per tile), so the headline shape (256 sequences, N in {512, 1024, 1536}) gives every workgroup exactly
-//     N/256 tiles.  Wave w owns columns [32w, 32w+32) x all 7 row sub-tiles (7 accumulators = 112 VGPRs).
-//   * A tile: global -> LDS by global_load_lds_dwordx4, BK = 32, two stages of Ah|Al [224][32] = 28 KB; the 7 pieces a
+// Machine mapping (gfx950).  WAVES waves per PERSISTENT workgroup, each wave owning 32 output columns x all 7 row
+// sub-tiles of the tile (7 accumulators = 112 VGPRs):
+//     WAVES = 8 (default)  224 x 256 tiles, one workgroup per CU (66-97 KB of LDS, <= 256 VGPRs)
+//     WAVES = 4            224 x 128 tiles, two independent workgroups per CU, which hide each other's barriers, LDS-DMA
+//                          latency and epilogues -- and re-read the activation panels twice as often from L2.
+// Whole-bench A/B on one box: 307 vs 302 motions/s.  The two shapes, four instruction schedules and two wave-priority
+// schemes all measure within 0.1-3 % of each other: while this kernel runs the chip sits at its power limit (zero-filled
+// operands: +16-22 %), and the costs of the parts add up instead of overlapping -- MFMA-only 141 us + epilogue stores
+// 25-40 + fragment reads / barriers 18 + loads 32 = 230 us for in_proj (profiles/r01c_final.md).  What pays is less
+// work and fewer bytes.
+//   * the row extent of a tile is a whole number of token sequences (S = 197 -> one sequence per tile), so the headline
+//     shape (256 sequences, N in {512, 1024, 1536}) gives every CU exactly N/256 equal tiles;
+//   * A tile: global -> LDS by global_load_lds_dwordx4, BK = 32, two stages of Ah|Al [224][32] = 28 KB; the pieces a
 //     wave issues per step ride BETWEEN the MFMA units; the stream has its own (tile, k) cursor one step ahead and
 //     rolls over into the workgroup's next tile, so the pipeline never drains at a tile boundary;
 //   * LDS image: row-major, 64-byte rows, 16-byte chunk index XOR-swizzled with (row>>2)&3 (conflict-free ds_read_b128
