@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
 
   int nvalid = S;  // token 0 (the condition token) is never masked; frame j-1 must be < length (mdm.py:241-247)
   if (lengths != nullptr) nvalid = min(S, 1 + lengths[seq % B]);
+  const bool last_group = S > 32 * (NKT - 1) + 16;   // does the sequence reach into the last 16-key group?
 
   // ---- tile t -> ring slot t & 3.  16 pieces of 1 KB per tile, wave w issues pieces 4w .. 4w+3 (piece = plane, idx):
   // K tile kt: idx covers 4 keys x 256 B; lane -> (row = lane>>4, stored chunk = lane&15) fetches chunk ^ (key & 15);
@@ -250,9 +251,13 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
 #ifndef MDM_EMU
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            o[dt] = mfma_bf16(vl[uv % 3], ph, o[dt]);
-            o[dt] = mfma_bf16(vh[uv % 3], pl, o[dt]);
-            o[dt] = mfma_bf16(vh[uv % 3], ph, o[dt]);
+            // a 16-key group wholly past the sequence (only the last one can be) has p == 0 and V^T rows that the in_proj
+            // GEMM's 208-row tiles never wrote: skipped, not multiplied
+            if (kt < NKT - 1 || s2 == 0 || last_group) {
+              o[dt] = mfma_bf16(vl[uv % 3], ph, o[dt]);
+              o[dt] = mfma_bf16(vh[uv % 3], pl, o[dt]);
+              o[dt] = mfma_bf16(vh[uv % 3], ph, o[dt]);
+            }
 #ifndef MDM_EMU
             __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -44,6 +44,54 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 #endif
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x32_bf16: lane l supplies 8 consecutive-k bf16 of row/col (l&15), k-block (l>>4) (k = 8*(l>>4)+e);
+// D[reg] is row 4*(l>>4) + reg, column l&15.
+__device__ __forceinline__ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+#ifdef MDM_EMU
+  return emu::mfma_f32_16x16x32_bf16(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// Two v_mfma_f32_32x32x16_bf16 operand fragments of the same 32 rows -- w0: k 0-15, w1: k 16-31 -- become the two
+// v_mfma_f32_16x16x32_bf16 fragments over the same 32 k -- w0: rows 0-15, w1: rows 16-31.  As rows of 16 lanes,
+//   in   w0 = [r0-15 k0-7 | r16-31 k0-7 | r0-15 k8-15 | r16-31 k8-15]    w1 = the same with k + 16
+//   v_permlane32_swap (lanes 32-63 of w0 <-> lanes 0-31 of w1), then v_permlane16_swap (odd rows of w0 <-> even rows of w1)
+//   out  w0 = [r0-15 k0-7 | r0-15 k8-15 | r0-15 k16-23 | r0-15 k24-31]   w1 = the same for r16-31
+__device__ __forceinline__ void frag32_to_frag16(bf16x8& w0, bf16x8& w1) {
+  u32x4 a = __builtin_bit_cast(u32x4, w0), b = __builtin_bit_cast(u32x4, w1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t x = a[i], y = b[i];
+#ifdef MDM_EMU
+    emu::permlane32_swap(x, y);
+    emu::permlane16_swap(x, y);
+#else
+    auto s32 = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    auto s16 = __builtin_amdgcn_permlane16_swap(s32[0], s32[1], false, false);
+    x = s16[0];
+    y = s16[1];
+#endif
+    a[i] = x;
+    b[i] = y;
+  }
+  w0 = __builtin_bit_cast(bf16x8, a);
+  w1 = __builtin_bit_cast(bf16x8, b);
+}
+
+// value of `v` in lane `src_lane` (wave-uniform control flow required)
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {
+#ifdef MDM_EMU
+  return emu::shfl_f32(v, src_lane);
+#else
+  return __shfl(v, src_lane, 64);
+#endif
+}
+
 // row of accumulator register `reg` inside a 32x32 MFMA tile, for lane-half h = lane>>5
 __device__ __forceinline__ int mfma_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -180,7 +228,6 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 // every tracked global load with vmcnt(0), i.e. one full memory latency per load.  The GEMM epilogue streams its
 // residual tile through these instead, two row sub-tiles ahead, retired by a counted vmem_wait<N> where N = number of
 // LOADS issued after the ones awaited (loads return in order; stores in between can only make the wait stricter).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef MDM_EMU
 __device__ __forceinline__ void gload16_async(f32x4& dst, const float* p) {
   dst = f32x4{p[0], p[1], p[2], p[3]};

@@ -156,6 +156,15 @@ __global__ __launch_bounds__(256) void pack_weight_planes_kernel(const float* __
   }
 }
 
+// epilogue rounds (8 rows each) of row sub-tile t: 4, or 2 for the 16-row last sub-tile; and how many rounds' worth of
+// residual loads are younger than sub-tile t's when RR sub-tiles are kept in flight + in use
+constexpr int x3_res_rounds(int t, bool t16) { return (t16 && t == X3_MSUB - 1) ? 2 : 4; }
+constexpr int x3_res_younger_rounds(int t, int rr, bool t16) {
+  int n = 0;
+  for (int q = t + 1; q <= t + rr - 1 && q < X3_MSUB; ++q) n += x3_res_rounds(q, t16);
+  return n;
+}
+
 // The A load stream: which tile of this workgroup and which k step it fetches next, and the per-lane source element
 // offsets of the wave's seven LDS-DMA pieces for that tile.
 template <int PIECES>
@@ -169,12 +178,18 @@ struct X3Cursor {
 // ABL (profiling experiments only, 0 in production): 1 = no epilogue stores, 2 = no loads after the prologue,
 // 4 = no MFMAs, 8 = loads issued but not waited for.
 // FOLD / OSTAT / RES == 3: LayerNorm folded into the GEMMs (X3Epilogue).
+// T16: the tile is 208 rows -- six 32-row sub-tiles plus ONE 16-row sub-tile (rows 192-207) on v_mfma_f32_16x16x32_bf16 --
+// for row extents <= 208 (S = 197: 11 pad rows instead of 27, i.e. 6.5 of 7 units of matrix work and 13 of 14 A groups).
+// The 16-row sub-tile needs the wave's W fragments in the 16x16x32 operand layout; they are derived from the 32x32x16
+// fragments in registers by two lane swaps per dword (common.h frag32_to_frag16), not fetched a second time.
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
-          bool OSTAT = false, bool EMBED = false>
+          bool OSTAT = false, bool EMBED = false, bool T16 = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N,
                                                                      int K, int rows_per_tile, int tiles_n, int total) {
   MDM_DYN_SMEM(unsigned char, lds);
   constexpr int X3_WAVES = WAVES, X3_TN = x3_tn(WAVES), X3_A_PIECES = x3_a_pieces(WAVES);
+  constexpr int NT32 = T16 ? X3_MSUB - 1 : X3_MSUB;     // 32-row sub-tiles
+  constexpr int NROUNDS = 4 * NT32 + (T16 ? 2 : 0);     // epilogue rounds of 8 rows
   using Cursor = X3Cursor<X3_A_PIECES>;
 
   const int tid = threadIdx.x;
@@ -218,7 +233,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
   };
   auto piece_a = [&](const Cursor& c, int i, int buf) {
     const int q = wid + X3_WAVES * i;
-    if (q < X3_A_GROUPS)
+    if (q < X3_A_GROUPS && !(T16 && (q == 13 || q == 27)))   // T16: rows 208-223 of the stage are never read
       glds16(((q < 14) ? A.hi : A.lo) + c.off[i] + c.k * ((ABL & 16) ? 512 : X3_BK), lds + buf * X3_A_STAGE + q * 1024);
   };
   // past its last tile the stream simply re-fetches that tile (one wasted stage per workgroup): no "anything left to
@@ -246,6 +261,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
   // ---- fragment read offsets (bytes inside a plane tile): row*64 + ((ksub*2 + h) ^ sw)*16, sw = (row>>2)&3
   const int sw = (r >> 2) & 3;
   const int fa = r * 64;                 // + t*2048 per row sub-tile
+  // 16-row sub-tile (T16): lane -> (row 192 + (lane&15), k chunk lane>>4)
+  const int r16 = lane & 15, g16 = lane >> 4;
+  const int fa16 = (192 + r16) * 64 + ((g16 ^ ((r16 >> 2) & 3)) * 16);
 #ifndef MDM_EMU
   const uint32_t lds_base = lds_addr_of(lds);
 #endif
@@ -265,7 +283,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     const float* st = FOLD ? ep.astat : ep.rstat;
     const int npieces = (X3_TM * ep.stat_parts * 8 + 1023) / 1024;
     if (wid < npieces) {
-      const long long total_f = (long long)M * ep.stat_parts * 2;     // floats in the whole statistics buffer
+      // floats in the whole statistics buffer, rounded up to the 16-byte unit of the transfer (M odd with one partial per
+      // row ends on an 8-byte boundary; the workspace carves these buffers in 256-byte units, so the tail is addressable)
+      const long long total_f = ((long long)M * ep.stat_parts * 2 + 3) / 4 * 4;
       long long fo = (long long)m0s * ep.stat_parts * 2 + 4LL * (64 * wid + lane);
       if (fo > total_f - 4) fo = total_f - 4;                          // rows past the matrix: any valid address
       glds16(st + fo, lds + x3_raw_base(WAVES) + par * X3_RAW_BYTES + wid * 1024);
@@ -289,11 +309,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
   for (; v < total; v += gstride, tile_parity ^= 1) {
     int m0, n0;
     tile_origin(v, m0, n0);
-    f32x16 acc[X3_MSUB];
+    f32x16 acc[NT32];
 #pragma unroll
-    for (int t = 0; t < X3_MSUB; ++t)
+    for (int t = 0; t < NT32; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // T16: rows 192-207 x columns 0-15 / 16-31 of the wave
     // this lane's bias, fetched (and its wait retired: hipcc waits vmcnt(0) for a tracked load) at the START of the tile,
     // so that the epilogue's untracked residual loads are not drained by it
     const int ncol0 = n0 + wid * 32;                     // this wave's first column (wave-uniform)
@@ -355,19 +376,37 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       const uint32_t aaddr[2] = {sa0 + ((h ^ sw) * 16), sa0 + (((2 + h) ^ sw) * 16)};
 #define X3_RD_A(dst, plane, t, ks) lds_read16<(plane) * X3_A_BYTES + (t) * 2048>(dst, aaddr[ks])
 #endif
-      constexpr int NU = 2 * X3_MSUB;  // units per stage
+      // T16: the 16-row sub-tile's A fragments (one per plane covers the whole 32-deep step) are read FIRST, so they are
+      // older than every unit's reads and retired by unit 0's wait; its W fragments come from wh / wl by lane swaps
+      bf16x8 a16h, a16l, w16h[2], w16l[2];
+      if constexpr (T16) {
+#ifdef MDM_EMU
+        lds_read16(a16h, sa, fa16);
+        lds_read16(a16l, sa, X3_A_BYTES + fa16);
+#else
+        const uint32_t a16addr = lds_base + abuf * X3_A_STAGE + fa16;
+        lds_read16<0>(a16h, a16addr);
+        lds_read16<X3_A_BYTES>(a16l, a16addr);
+#endif
+        w16h[0] = wh[0]; w16h[1] = wh[1];
+        w16l[0] = wl[0]; w16l[1] = wl[1];
+        frag32_to_frag16(w16h[0], w16h[1]);
+        frag32_to_frag16(w16l[0], w16l[1]);
+      }
+      constexpr int NU = 2 * NT32;  // units per stage
       static_for<NU + DEPTH>([&](auto u_tag) __attribute__((always_inline)) {
         constexpr int u = decltype(u_tag)::value;
         if constexpr (u < NU) {
-          constexpr int ks = u / X3_MSUB, t = u - ks * X3_MSUB;
+          constexpr int ks = u / NT32, t = u - ks * NT32;
           X3_RD_A(ah[u % RING], 0, t, ks);
           X3_RD_A(al[u % RING], 1, t, ks);
         }
         if constexpr (u >= DEPTH) {
-          constexpr int uv = u - DEPTH, ks = uv / X3_MSUB, t = uv - ks * X3_MSUB;
+          constexpr int uv = u - DEPTH, ks = uv / NT32, t = uv - ks * NT32;
           // reads allowed to stay in flight: those of the (up to) DEPTH younger units
           constexpr int younger = 2 * ((NU - 1 - uv) < DEPTH ? (NU - 1 - uv) : DEPTH);
-          lds_wait<younger>(ah[uv % RING], al[uv % RING]);
+          if constexpr (T16 && uv == 0) lds_wait<younger>(ah[uv % RING], al[uv % RING], a16h, a16l);
+          else lds_wait<younger>(ah[uv % RING], al[uv % RING]);
 #ifndef MDM_EMU
           __builtin_amdgcn_sched_barrier(0);  // the MFMAs below must not be hoisted above the wait (rule 18)
 #endif
@@ -381,6 +420,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
             acc[t] = mfma_bf16(al[uv % RING], wh[ks], acc[t]);
             acc[t] = mfma_bf16(ah[uv % RING], wl[ks], acc[t]);
             acc[t] = mfma_bf16(ah[uv % RING], wh[ks], acc[t]);
+            if constexpr (T16 && uv == 0) {
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) {
+                acc16[cb] = mfma16_bf16(a16l, w16h[cb], acc16[cb]);
+                acc16[cb] = mfma16_bf16(a16h, w16l[cb], acc16[cb]);
+                acc16[cb] = mfma16_bf16(a16h, w16h[cb], acc16[cb]);
+              }
+            }
           }
 #ifndef MDM_EMU
           __builtin_amdgcn_sched_barrier(0);  // keep the same-accumulator triple back to back (no filler inside)
@@ -439,9 +486,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     // the VALU work of the next (a wave's LDS operations execute in order).
     auto patch_write = [&](auto j_tag) __attribute__((always_inline)) {
       constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
-      if constexpr (j < 4 * X3_MSUB) {
+      if constexpr (j < 4 * NT32) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = acc[t][4 * g + e];
+      } else if constexpr (T16 && j < NROUNDS) {
+        // 16-row sub-tile, rows 8g .. 8g+7 = accumulator rows 4*(lane>>4) + e of the lanes with lane>>5 == g
+        if (h == g) {
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) patch[((e + 4 * (g16 & 1)) << 5) + 16 * cb + r16] = acc16[cb][e];
+        }
       }
     };
 
@@ -460,7 +515,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
           bf16_t* vlp = ep.qkv.vl + ((shq * ep.qkv.NKT) * AX_HD + d0 + r) * 32 + 8 * h;
           const int nkt = ep.qkv.NKT;
 #pragma unroll
-          for (int t = 0; t < X3_MSUB; ++t) {
+          for (int t = 0; t < NT32; ++t) {
             if (t < nkt) {
 #pragma unroll
               for (int s2 = 0; s2 < 2; ++s2) {
@@ -481,13 +536,37 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
               }
             }
           }
+          if constexpr (T16) {
+            // keys 192 + 4*(lane>>4) + e of key tile 6, 16-key group 0: positions 4*((g16>>1) + 2*(g16&1)) + e; the group-1
+            // half of the tile (keys 208-223) is never written -- the attention kernel skips it
+            if (NT32 < nkt) {
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) {
+                const int cl = 16 * cb + r16;                      // this lane's column inside the wave's 32
+                const float b16 = lane_bcast(bias, cl);
+                const float c16 = FOLD ? lane_bcast(csum, cl) : 0.f;
+                float vv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  if constexpr (FOLD) {
+                    const float2 st = atab[192 + 4 * g16 + e];
+                    vv[e] = st.y * (acc16[cb][e] - st.x * c16) + b16;
+                  } else {
+                    vv[e] = acc16[cb][e] + b16;
+                  }
+                }
+                const size_t o = ((shq * ep.qkv.NKT + NT32) * AX_HD + d0 + cl) * 32 + 4 * ((g16 >> 1) + 2 * (g16 & 1));
+                split4_store(ep.qkv.vh + o, ep.qkv.vl + o, make_float4(vv[0], vv[1], vv[2], vv[3]));
+              }
+            }
+          }
         } else {
           // Q / K rows: one base pointer per plane, 32-bit offsets
           bf16_t* dh = (which == 0 ? ep.qkv.qh : ep.qkv.kh) + shq * SPq * AX_HD + d0 + pc4;
           bf16_t* dl = (which == 0 ? ep.qkv.ql : ep.qkv.kl) + shq * SPq * AX_HD + d0 + pc4;
           const int nkt = ep.qkv.NKT;
           patch_write(std::integral_constant<int, 0>{});
-          static_for<4 * X3_MSUB>([&](auto j_tag) __attribute__((always_inline)) {
+          static_for<NROUNDS>([&](auto j_tag) __attribute__((always_inline)) {
             constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
             wave_lds_fence();
             float4 v4 = ld4(&patch[prow * 32 + pc4]);
@@ -513,7 +592,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
         constexpr int t = decltype(t_tag)::value;
         if constexpr (HAS_RES && t < X3_MSUB) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
+          for (int g = 0; g < x3_res_rounds(t, T16); ++g) {
             const int m = min(m0 + t * 32 + 8 * g + prow, M - 1);
             const size_t o = (size_t)(EMBED ? 1 + m % ep.emb_T : m) * ep.ld + (n4 < N ? n4 : 0);   // EMBED: positional row
             if constexpr (RES == 1) {
@@ -527,11 +606,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       };
       auto res_wait = [&](auto t_tag) __attribute__((always_inline)) {
         constexpr int t = decltype(t_tag)::value;
-        constexpr int ahead = (X3_MSUB - 1 - t) < (RR - 1) ? (X3_MSUB - 1 - t) : (RR - 1);  // younger sub-tiles requested
+        // loads of the younger sub-tiles already requested (the only ones allowed to stay in flight)
+        constexpr int ahead = x3_res_younger_rounds(t, RR, T16);
         if constexpr (RES == 1) {
-          vmem_wait<4 * ahead>(rr[t % RR][0], rr[t % RR][1], rr[t % RR][2], rr[t % RR][3]);
+          vmem_wait<ahead>(rr[t % RR][0], rr[t % RR][1], rr[t % RR][2], rr[t % RR][3]);
         } else if constexpr (RES_PLANES) {
-          vmem_wait<8 * ahead>(rh[t % RR][0], rh[t % RR][1], rh[t % RR][2], rh[t % RR][3], rl[t % RR][0], rl[t % RR][1],
+          vmem_wait<2 * ahead>(rh[t % RR][0], rh[t % RR][1], rh[t % RR][2], rh[t % RR][3], rl[t % RR][0], rl[t % RR][1],
                                rl[t % RR][2], rl[t % RR][3]);
         }
       };
@@ -541,7 +621,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       }
       float2* part = reinterpret_cast<float2*>(lds + x3_part_base(WAVES)) + wid * X3_TM;   // OSTAT: this wave's partials
       patch_write(std::integral_constant<int, 0>{});
-      static_for<4 * X3_MSUB>([&](auto j_tag) __attribute__((always_inline)) {
+      static_for<NROUNDS>([&](auto j_tag) __attribute__((always_inline)) {
         constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
         if constexpr (HAS_RES && g == 0) {
           if (!(ABL & 1)) {
@@ -653,14 +733,15 @@ inline int& x3_waves_setting() {
 }
 
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
-          bool OSTAT = false, bool EMBED = false>
+          bool OSTAT = false, bool EMBED = false, bool T16 = false>
 inline int launch_gemm_bf16x3_w(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                                 int rpt, hipStream_t stream) {
   constexpr int TN = x3_tn(WAVES);
   constexpr bool LN = FOLD || OSTAT || RES == 3;
   const int tiles_m = (M + rpt - 1) / rpt, tiles_n = (N + TN - 1) / TN;
   const int total = tiles_m * tiles_n;
-  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED>;
+  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16>;
+  if (T16 && rpt > X3_TM - 16) return -2;
 #ifndef MDM_EMU
   if (x3_lds_bytes(WAVES, LN) > 65536) {
     static bool configured = false;  // per instantiation
@@ -684,17 +765,31 @@ inline int launch_gemm_bf16x3_w(const X3Operand& A, const X3Weights& W, const X3
 //   kind 3  linear1                             FOLD + GELU -> planes
 //   kind 4  OutputProcess                       FOLD -> fp32
 //   kind 5  InputProcess                        + positional rows, planes to the token rows of every branch (EMBED)
-inline int launch_gemm_bf16x3_ln(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
-                                 int K, int rpt, hipStream_t s) {
+template <bool T16>
+inline int launch_gemm_bf16x3_ln_t(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
+                                   int K, int rpt, hipStream_t s) {
   switch (kind) {
-    case 0: return launch_gemm_bf16x3_w<8, ACT_NONE, 0, false, false, true, 0, true, false>(A, W, ep, M, N, K, rpt, s);
-    case 1: return launch_gemm_bf16x3_w<8, ACT_NONE, 2, false, true, false, 0, false, true>(A, W, ep, M, N, K, rpt, s);
-    case 2: return launch_gemm_bf16x3_w<8, ACT_NONE, 3, false, true, false, 0, false, true>(A, W, ep, M, N, K, rpt, s);
-    case 3: return launch_gemm_bf16x3_w<8, ACT_GELU, 0, false, true, false, 0, true, false>(A, W, ep, M, N, K, rpt, s);
-    case 4: return launch_gemm_bf16x3_w<8, ACT_NONE, 0, true, false, false, 0, true, false>(A, W, ep, M, N, K, rpt, s);
-    case 5: return launch_gemm_bf16x3_w<8, ACT_NONE, 1, false, true, false, 0, false, false, true>(A, W, ep, M, N, K, rpt, s);
+    case 0: return launch_gemm_bf16x3_w<8, ACT_NONE, 0, false, false, true, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
+    case 1: return launch_gemm_bf16x3_w<8, ACT_NONE, 2, false, true, false, 0, false, true, false, T16>(A, W, ep, M, N, K, rpt, s);
+    case 2: return launch_gemm_bf16x3_w<8, ACT_NONE, 3, false, true, false, 0, false, true, false, T16>(A, W, ep, M, N, K, rpt, s);
+    case 3: return launch_gemm_bf16x3_w<8, ACT_GELU, 0, false, true, false, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
+    case 4: return launch_gemm_bf16x3_w<8, ACT_NONE, 0, true, false, false, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
+    case 5: return launch_gemm_bf16x3_w<8, ACT_NONE, 1, false, true, false, 0, false, false, true, T16>(A, W, ep, M, N, K, rpt, s);
     default: return -2;
   }
+}
+// 208-row tiles (T16) whenever the row extent of a tile fits (S = 197 does); MDM_X3_T16=0 keeps 224-row tiles (A/B runs)
+inline bool x3_t16_setting() {
+  static const bool on = [] {
+    const char* e = getenv("MDM_X3_T16");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
+}
+inline int launch_gemm_bf16x3_ln(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
+                                 int K, int rpt, hipStream_t s) {
+  if (rpt <= X3_TM - 16 && x3_t16_setting()) return launch_gemm_bf16x3_ln_t<true>(kind, A, W, ep, M, N, K, rpt, s);
+  return launch_gemm_bf16x3_ln_t<false>(kind, A, W, ep, M, N, K, rpt, s);
 }
 
 template <int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL = 0>

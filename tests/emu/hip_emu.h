@@ -8,6 +8,7 @@
 //       v_mfma_f32_32x32x2_f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
 //                                D[reg]: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5); k-ordered fmaf chain
 //       v_mfma_f32_32x32x16_bf16: A/B 8 bf16 per lane, k = 8*(l>>5)+e ; same D layout, fp32 accumulate
+//       v_mfma_f32_16x16x32_bf16, v_permlane32_swap / v_permlane16_swap (the GEMM's 16-row last sub-tile)
 // It validates index math / masking / epilogues, NOT timing, and is never part of the product path.
 #pragma once
 #include <ucontext.h>
@@ -58,6 +59,7 @@ struct Fiber {
 struct WaveBuf {
   float fa[64], fb[64];
   bf16x8 ha[64], hb[64];
+  uint32_t ua[64], ub[64];
   int arrive = 0;
   unsigned gen = 0;
 };
@@ -149,6 +151,55 @@ inline f32x16 mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   }
   wave_barrier();
   return c;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x32_bf16: A row / B column = l&15, k = 8*(l>>4)+e; D[reg]: row 4*(l>>4)+reg, column l&15
+inline f32x4 mfma_f32_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  WaveBuf& w = blk().waves[wave_id()];
+  int l = lane_id();
+  w.ha[l] = a;
+  w.hb[l] = b;
+  wave_barrier();
+  int j = l & 15, g = l >> 4;
+  for (int r = 0; r < 4; ++r) {
+    int i = 4 * g + r;
+    float acc = c[r];
+    for (int kg = 0; kg < 4; ++kg)
+      for (int e = 0; e < 8; ++e)
+        acc = fmaf(bf16_to_f32(w.ha[i + 16 * kg][e]), bf16_to_f32(w.hb[j + 16 * kg][e]), acc);
+    c[r] = acc;
+  }
+  wave_barrier();
+  return c;
+}
+
+// v_permlane32_swap_b32: lanes 32-63 of vdst <-> lanes 0-31 of src
+inline void permlane32_swap(uint32_t& vdst, uint32_t& src) {
+  WaveBuf& w = blk().waves[wave_id()];
+  int l = lane_id();
+  w.ua[l] = vdst;
+  w.ub[l] = src;
+  wave_barrier();
+  uint32_t nv = (l < 32) ? w.ua[l] : w.ub[l - 32];
+  uint32_t ns = (l < 32) ? w.ua[l + 32] : w.ub[l];
+  wave_barrier();
+  vdst = nv;
+  src = ns;
+}
+// v_permlane16_swap_b32: odd 16-lane rows of vdst <-> even rows of src
+inline void permlane16_swap(uint32_t& vdst, uint32_t& src) {
+  WaveBuf& w = blk().waves[wave_id()];
+  int l = lane_id();
+  w.ua[l] = vdst;
+  w.ub[l] = src;
+  wave_barrier();
+  bool odd = (l >> 4) & 1;
+  uint32_t nv = odd ? w.ub[l - 16] : w.ua[l];
+  uint32_t ns = odd ? w.ub[l] : w.ua[l + 16];
+  wave_barrier();
+  vdst = nv;
+  src = ns;
 }
 
 inline void fiber_entry() {

@@ -35,16 +35,21 @@ def test_emulated_cfg_loop_matches_oracle(lib, prec, tol):
     assert maxabs(got, want) < tol
 
 
-@pytest.mark.parametrize("prec,tol,layers", [("f32", 1e-5, 1), ("bf16x3", 1e-4, 2)])
-def test_emulated_forward_branches(lib, prec, tol, layers):
+@pytest.mark.parametrize("prec,tol,layers,B,T,lengths", [
+    ("f32", 1e-5, 1, 2, 33, [33, 5]),
+    ("bf16x3", 1e-4, 2, 2, 33, [33, 5]),        # S = 34: two key tiles, ragged tail; six sequences per 208-row GEMM tile
+    ("bf16x3", 1e-4, 2, 1, 196, [150]),         # S = 197 (headline): one sequence per 208-row tile, 16-row last sub-tile
+    ("bf16x3", 1e-4, 1, 1, 207, [207]),         # S = 208: the 16-row sub-tile completely used
+    ("bf16x3", 1e-4, 1, 1, 208, [208]),         # S = 209: does not fit 208 rows -> the 224-row (7 x 32) form
+])
+def test_emulated_forward_branches(lib, prec, tol, layers, B, T, lengths):
     """layers = 2 reaches the GEMM kinds only a second layer uses: in_proj with the previous LayerNorm folded in, and
     out_proj whose residual is a LayerNorm rebuilt from the pre-norm planes + row statistics."""
-    B, T = 2, 33                                   # S = 34: two key tiles, ragged tail
     sd = small_state_dict(num_layers=layers)
     model, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib, precision=prec)
-    y = synth_y(B, T, seed=2, lengths=[33, 5])
+    y = synth_y(B, T, seed=2, lengths=lengths)
     g = torch.Generator().manual_seed(0)
-    x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 0])
+    x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 0][:B])
     assert maxabs(model(x, t, y=dict(y)), orc.mdm_forward(sd, x, t, y, num_heads=2)) < tol
     yu = {**y, "uncond": True}
     assert maxabs(model(x, t, y=yu), orc.mdm_forward(sd, x, t, yu, num_heads=2)) < tol
