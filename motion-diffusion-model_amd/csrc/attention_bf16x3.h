@@ -7,7 +7,7 @@
 // the key-padding mask of mdm.py:241-247.  The exact-fp32 kernel (attention_f32.h) remains the `f32` mode.
 //
 // Operand planes (all bf16, hi and lo; SP = tokens padded to a multiple of 32, NKT = SP/32):
-//   Q, K   [nseq][H][SP][128]            row = token, Q pre-scaled by 1/sqrt(128); pad rows: any FINITE values
+//   Q, K   [nseq][H][SP][128]            row = token, Q pre-scaled by 1/sqrt(128); pad rows (>= S): never read
 //   V^T    [nseq][H][NKT][128][32]       per 32-key tile: row = d, 32 keys of that tile in MFMA ORDER: inside each
 //                                        group of 16 keys, position p holds key (p&3) + 8*((p>>2)&1) + 4*(p>>3).
 //                                        That is the order in which a lane of a 32x32 MFMA accumulator holds its 16
@@ -60,7 +60,9 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
 constexpr int AX_SLOT = 16384, AX_RING = 4;
 constexpr int ax_lds_bytes(int) { return 4 * 32 * AX_OLD * 4 > AX_RING * AX_SLOT ? 4 * 32 * AX_OLD * 4 : AX_RING * AX_SLOT; }
 
-template <int NKT>
+// ABL (timing experiments only, 0 in production; results are garbage): 1 = no MFMAs, 2 = no LDS fragment reads,
+// 4 = no softmax, 8 = no output staging / stores, 16 = no K / V^T streaming after the prologue, 32 = no per-tile barrier.
+template <int NKT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, const int* __restrict__ lengths,
                                                                     int S, int D, int B, float* __restrict__ out,
                                                                     bf16_t* __restrict__ oh, bf16_t* __restrict__ ol,
@@ -102,8 +104,10 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
       const int j = 4 * w + i, plane = j >> 3, idx = j & 7;
       unsigned char* dst = lds + (t & (AX_RING - 1)) * AX_SLOT + plane * 8192 + idx * 1024;
       if (t < NKT) {
+        // pad keys (>= S) are fetched from the last real row instead: finite, cache-resident, and no HBM traffic for rows
+        // nobody wrote; the swizzle still follows the LDS row
         const int key = 32 * t + 4 * idx + (lane >> 4);
-        glds16(kbase[plane] + (size_t)key * AX_HD + (((lane & 15) ^ (key & 15)) * 8), dst);
+        glds16(kbase[plane] + (size_t)min(key, S - 1) * AX_HD + (((lane & 15) ^ (key & 15)) * 8), dst);
       } else {
         const int d = 16 * idx + (lane >> 2);
         glds16(vbase[plane] + ((size_t)(t - NKT) * AX_HD + d) * 32 + (((lane & 3) ^ ((d >> 2) & 3)) * 8), dst);
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
   // ---- this wave's Q fragments: query q = 32 qt + r, k-step st covers d = 16 st + 8h .. +7
   bf16x8 qh[8], ql[8];
   {
-    const size_t qo = (sh * SP + 32 * (active ? qt : 0) + r) * AX_HD + 8 * h;
+    const size_t qo = (sh * SP + min(32 * (active ? qt : 0) + r, S - 1)) * AX_HD + 8 * h;   // pad queries: last real row
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
       qh[st] = *reinterpret_cast<const bf16x8*>(P.qh + qo + 16 * st);
@@ -148,10 +152,10 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
     // tile t landed?  tiles t+1, t+2 (4 pieces each of this wave) may stay in flight; LDS-DMA retires in order
     constexpr int ahead = (NTILES - 1 - t) < 2 ? (NTILES - 1 - t) : 2;
 #ifndef MDM_EMU
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (4 * ahead));
+    if constexpr (!(ABL & 16)) __builtin_amdgcn_s_waitcnt(0x0F70 | (4 * ahead));
 #endif
-    wg_barrier();            // tile t visible to every wave; every wave is done with tile t-1 (whose slot is refilled now)
-    if constexpr (t + 3 < NTILES) issue_tile(t + 3);
+    if constexpr (!(ABL & 32)) wg_barrier();  // tile t visible to every wave; every wave is done with tile t-1 (whose slot is refilled now)
+    if constexpr (t + 3 < NTILES && !(ABL & 16)) issue_tile(t + 3);
 
     if constexpr (t < NKT) {
       // ---- phase 1, key tile t: St[key][query] += K . Q^T, three products per 16-deep k step
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
 #endif
         static_for<8 + 2>([&](auto u_tag) __attribute__((always_inline)) {
           constexpr int u = decltype(u_tag)::value;
-          if constexpr (u < 8) {
+          if constexpr (u < 8 && !(ABL & 2)) {
             AX_RD_K(kh[u % 3], 0, u);
             AX_RD_K(kl[u % 3], 1, u);
           }
@@ -176,9 +180,15 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
 #ifndef MDM_EMU
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            p[t] = mfma_bf16(kl[st % 3], qh[st], p[t]);
-            p[t] = mfma_bf16(kh[st % 3], ql[st], p[t]);
-            p[t] = mfma_bf16(kh[st % 3], qh[st], p[t]);
+            if constexpr (ABL & 1) {
+#ifndef MDM_EMU
+              asm volatile("" ::"v"(kl[st % 3]), "v"(kh[st % 3]), "v"(qh[st]), "v"(ql[st]));
+#endif
+            } else {
+              p[t] = mfma_bf16(kl[st % 3], qh[st], p[t]);
+              p[t] = mfma_bf16(kh[st % 3], ql[st], p[t]);
+              p[t] = mfma_bf16(kh[st % 3], qh[st], p[t]);
+            }
 #ifndef MDM_EMU
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
         });
 #undef AX_RD_K
       }
-      if constexpr (t == NKT - 1) {
+      if constexpr (t == NKT - 1 && !(ABL & 4)) {
         // ---- softmax over keys: lane-local + one cross-half exchange; 1/sum is applied to the output
         float mx = -INFINITY;
 #pragma unroll
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
 #endif
         static_for<8 + 2>([&](auto u_tag) __attribute__((always_inline)) {
           constexpr int u = decltype(u_tag)::value;
-          if constexpr (u < 8) {
+          if constexpr (u < 8 && !(ABL & 2)) {
             AX_RD_V(vh[u % 3], 0, u / 4, u % 4);
             AX_RD_V(vl[u % 3], 1, u / 4, u % 4);
           }
@@ -253,7 +263,11 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
 #endif
             // a 16-key group wholly past the sequence (only the last one can be) has p == 0 and V^T rows that the in_proj
             // GEMM's 208-row tiles never wrote: skipped, not multiplied
-            if (kt < NKT - 1 || s2 == 0 || last_group) {
+            if constexpr (ABL & 1) {
+#ifndef MDM_EMU
+              asm volatile("" ::"v"(vl[uv % 3]), "v"(vh[uv % 3]), "v"(ph), "v"(pl));
+#endif
+            } else if (kt < NKT - 1 || s2 == 0 || last_group) {
               o[dt] = mfma_bf16(vl[uv % 3], ph, o[dt]);
               o[dt] = mfma_bf16(vh[uv % 3], pl, o[dt]);
               o[dt] = mfma_bf16(vh[uv % 3], ph, o[dt]);
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
   // ---- stage this wave's O[32 queries][128 d] (fp32, row stride AX_OLD, wave-private) and store coalesced:
   // accumulator rows mfma_row(4g..4g+3, h) are 4 consecutive d
   float* so = reinterpret_cast<float*>(lds) + w * (32 * AX_OLD);
-  if (active) {
+  if (active && !(ABL & 8)) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -294,6 +308,14 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
       }
     }
   }
+#ifndef MDM_EMU
+  if constexpr ((ABL & 8) != 0) {   // keep the computation alive without the staging / stores
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) asm volatile("" ::"v"(o[dt]));
+    asm volatile("" ::"v"(inv));
+  }
+#endif
+  if constexpr ((ABL & 16) != 0) wait_vmem_all();   // experiment: the prologue's unawaited LDS-DMA must land before exit
 }
 
 inline size_t attention_x3_lds_bytes(int nkt) { return (size_t)ax_lds_bytes(nkt); }

@@ -176,7 +176,7 @@ struct X3Cursor {
 
 // RES: 0 = no residual, 1 = fp32 residual, 2 = residual held as bf16 hi/lo planes.
 // ABL (profiling experiments only, 0 in production): 1 = no epilogue stores, 2 = no loads after the prologue,
-// 4 = no MFMAs, 8 = loads issued but not waited for.
+// 4 = no MFMAs, 8 = loads issued but not waited for, 16 / 32 / 64 = timing probes described where they are used.
 // FOLD / OSTAT / RES == 3: LayerNorm folded into the GEMMs (X3Epilogue).
 // T16: the tile is 208 rows -- six 32-row sub-tiles plus ONE 16-row sub-tile (rows 192-207) on v_mfma_f32_16x16x32_bf16 --
 // for row extents <= 208 (S = 197: 11 pad rows instead of 27, i.e. 6.5 of 7 units of matrix work and 13 of 14 A groups).
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       constexpr int NU = 2 * NT32;  // units per stage
       static_for<NU + DEPTH>([&](auto u_tag) __attribute__((always_inline)) {
         constexpr int u = decltype(u_tag)::value;
-        if constexpr (u < NU) {
+        if constexpr (u < NU && (!(ABL & 64) || u % 2 == 0)) {   // 64: timing experiment -- half the fragment reads
           constexpr int ks = u / NT32, t = u - ks * NT32;
           X3_RD_A(ah[u % RING], 0, t, ks);
           X3_RD_A(al[u % RING], 1, t, ks);
@@ -502,12 +502,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
 
     if (OUT_QKV) {
       // in_proj -> attention operand planes (attention_bf16x3.h).  rows_per_tile == S: tile row == token, tile_m == sequence.
-      // Pad tokens (S <= token < SP) are written with whatever finite values the clamped / neighbouring activation rows
-      // produce: the attention kernel selects -inf for their scores (p == 0 exactly) and never stores their queries, so
-      // they only need to be finite -- masking them here cost 112 hoisted lane masks (280 spilled SGPRs).
+      // Pad tokens (S <= token < SP): V^T pads are written with whatever finite values the neighbouring activation rows
+      // produce (the attention kernel multiplies them by p == 0 exactly); Q / K pad rows are never read by it and are not
+      // stored in the last sub-tile (masking every round cost 112 hoisted lane masks, 280 spilled SGPRs).
       const int Dm = ep.D, SPq = ep.qkv.SP, Hq = ep.qkv.H;
-      const int which = ncol0 / Dm, hcol = ncol0 - which * Dm, head = hcol >> 7, d0 = hcol & 127;
-      const size_t shq = (size_t)(m0 / rows_per_tile) * Hq + head;
+      int ncol_e = ncol0, m0_e = m0;
+#ifndef MDM_EMU
+      // opaque copies: keeps hipcc from computing the epilogue's 64-bit store addresses BEFORE the k-loop and carrying
+      // them (spilled) across it
+      asm volatile("" : "+s"(ncol_e), "+s"(m0_e));
+#endif
+      const int which = ncol_e / Dm, hcol = ncol_e - which * Dm, head = hcol >> 7, d0 = hcol & 127;
+      const size_t shq = (size_t)(m0_e / rows_per_tile) * Hq + head;
       if (ncol0 < N && !(ABL & 1)) {
         if (which == 2) {
           // V^T: accumulator registers 8 s2 .. 8 s2 + 7 of a lane ARE positions 8h .. 8h+7 of 16-key group s2
@@ -575,7 +581,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
             if (t < nkt) {
               const int tok = 32 * t + 8 * g + prow;
               v4 = finish4(v4, tok);
-              split4_store(dh + tok * AX_HD, dl + tok * AX_HD, v4);
+              // tokens past the sequence (only the last sub-tile can hold any when the tile is one sequence of more than
+              // 192 tokens) are not stored: the attention kernel never reads Q / K pad rows
+              if (t < X3_MSUB - 1 || tok < ep.S) split4_store(dh + tok * AX_HD, dl + tok * AX_HD, v4);
             }
           });
         }
@@ -820,6 +828,7 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Ep
       case 8: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 8>(A, W, ep, M, N, K, rpt, s);
       case 16: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 16>(A, W, ep, M, N, K, rpt, s);
       case 32: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 32>(A, W, ep, M, N, K, rpt, s);
+      case 64: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 64>(A, W, ep, M, N, K, rpt, s);
       case 9: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 9>(A, W, ep, M, N, K, rpt, s);
       default: return -2;
     }
@@ -837,6 +846,9 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Ep
 inline int launch_gemm_bf16x3_qkv(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int nseq, int S, int D,
                                   hipStream_t s) {
   if (S > X3_TM) return -2;
+  if (x3_waves_setting() == 8 && S <= X3_TM - 16 && x3_t16_setting())
+    return launch_gemm_bf16x3_w<8, ACT_NONE, 0, false, false, true, 0, false, false, false, true>(A, W, ep, nseq * S, 3 * D, D,
+                                                                                                 S, s);
   return launch_gemm_bf16x3_t<ACT_NONE, 0, false, false, true>(A, W, ep, nseq * S, 3 * D, D, S, s);
 }
 

@@ -217,10 +217,11 @@ int launch_attention(Profiler* pf, const float* qkv, float* out, const int* leng
   }
 }
 
-template <int NKT>
+int g_ax_ablate = 0;   // mdm_debug_set(3, code): timing experiments on the NKT = 7 attention kernel (attention_bf16x3.h ABL)
+template <int NKT, int ABL = 0>
 int launch_attention_x3_t(const QkvPlanes& qp, const int* lengths, int nseq, int B, int S, int D, float* out, bf16_t* oh,
                           bf16_t* ol, hipStream_t s) {
-  auto k = &attention_bf16x3_kernel<NKT>;
+  auto k = &attention_bf16x3_kernel<NKT, ABL>;
   const size_t lds = attention_x3_lds_bytes(NKT);
   if (int rc = rt_allow_lds(k, lds)) return rc;
   // two workgroups (query halves) per (sequence, head); the item <-> block mapping pairs blocks b and b + 8 (same XCD),
@@ -243,7 +244,19 @@ int launch_attention_x3(Profiler* pf, const QkvPlanes& qp, const int* lengths, i
     case 4: return launch_attention_x3_t<4>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
     case 5: return launch_attention_x3_t<5>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
     case 6: return launch_attention_x3_t<6>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-    default: return launch_attention_x3_t<7>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+    default:
+      switch (g_ax_ablate) {
+        case 1: return launch_attention_x3_t<7, 1>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 2: return launch_attention_x3_t<7, 2>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 3: return launch_attention_x3_t<7, 3>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 4: return launch_attention_x3_t<7, 4>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 8: return launch_attention_x3_t<7, 8>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 16: return launch_attention_x3_t<7, 16>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 32: return launch_attention_x3_t<7, 32>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 48: return launch_attention_x3_t<7, 48>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 63: return launch_attention_x3_t<7, 63>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        default: return launch_attention_x3_t<7>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+      }
   }
 }
 
@@ -836,6 +849,7 @@ int mdm_debug_set(int what, int value) {
   if (what == 0) g_x3_ablate = value;
   if (what == 1) g_x3_reuse_planes = value;
   if (what == 2 && (value == 4 || value == 8)) x3_waves_setting() = value;
+  if (what == 3) g_ax_ablate = value;
   return MDM_OK;
 }
 
@@ -929,8 +943,10 @@ int mdm_attention_bf16x3(const float* qkv, float* out, const int32_t* lengths, i
   bf16_t* q = static_cast<bf16_t*>(scratch);
   QkvPlanes qp{q, q + plane, q + 2 * plane, q + 3 * plane, q + 4 * plane, q + 5 * plane, SP, NKT, H};
   const int grid = (int)std::min<size_t>((plane + 255) / 256, 4096);
-  MDM_LAUNCH(qkv_pack_kernel, dim3(grid), dim3(256), 0, s, qkv, qp, nseq, S, D);
-  if (int rc = rt_launch_status()) return rc;
+  if (!g_x3_reuse_planes) {   // mdm_debug_set(1, 1): kernel-only timing, the planes of the previous call are reused
+    MDM_LAUNCH(qkv_pack_kernel, dim3(grid), dim3(256), 0, s, qkv, qp, nseq, S, D);
+    if (int rc = rt_launch_status()) return rc;
+  }
   return launch_attention_x3(nullptr, qp, lengths, nseq, B, S, D, out, nullptr, nullptr, s);
 }
 
