@@ -33,11 +33,14 @@ extern "C" {
 #define MDM_EHIP (-4)     /* a HIP runtime call failed                         */
 #define MDM_EUNSUPPORTED (-5)
 
-#define MDM_ABI_VERSION 1
+#define MDM_ABI_VERSION 2
 
 typedef struct mdm_model mdm_model_t;
 
-/* Hyper-parameters of model/mdm.py:11-135 (arch='trans_enc', data_rep='hml_vec', cond_mode='text'). */
+#define MDM_ARCH_TRANS_ENC 0  /* model/mdm.py:75-84: nn.TransformerEncoder, condition token in front of the frames   */
+#define MDM_ARCH_TRANS_DEC 1  /* model/mdm.py:85-93: nn.TransformerDecoder over a text-token memory (DiP, DiP.md)    */
+
+/* Hyper-parameters of model/mdm.py:11-135 (data_rep='hml_vec', cond_mode='text'). */
 typedef struct mdm_config {
   int32_t njoints;      /* 263  (utils/model_util.py:43)                        */
   int32_t nfeats;       /* 1                                                    */
@@ -48,6 +51,10 @@ typedef struct mdm_config {
   int32_t clip_dim;     /* 512: width of y['text_embed']                        */
   int32_t max_len;      /* rows of the positional table `sequence_pos_encoder.pe` (5000) */
   int32_t mask_frames;  /* args.mask_frames (model/mdm.py:48, :243)             */
+  int32_t arch;         /* MDM_ARCH_TRANS_ENC (0, default) | MDM_ARCH_TRANS_DEC  */
+  int32_t context_len;  /* trans_dec: prefix frames of the completion task (model/mdm.py:59, :203-206); 0 otherwise.
+                         * With MDM_ARCH_TRANS_DEC, clip_dim is the width of the text-token embeddings (768, DistilBERT:
+                         * model/mdm.py:121-127), emb_policy is 'add' and emb_trans_dec is False (the DiP configuration) */
 } mdm_config_t;
 
 int mdm_abi_version(void);
@@ -100,6 +107,22 @@ size_t mdm_workspace_bytes(const mdm_model_t* m, int32_t nseq, int32_t nframes);
 int mdm_forward(mdm_model_t* m, const float* x_dev, const int64_t* timesteps_dev, const float* text_embed_dev,
                 const int32_t* lengths_dev, int32_t B, int32_t T, int32_t branches, float* out_dev, void* ws_dev,
                 size_t ws_bytes, void* stream);
+
+/* MDM.forward for MDM_ARCH_TRANS_DEC (model/mdm.py:189-283 with is_prefix_comp, text_encoder_type='bert'): exact fp32.
+ *   x_dev            [B, njoints, nfeats, pred_len]      the window being denoised
+ *   prefix_dev       [B, njoints, nfeats, context_len]   y['prefix'] (NULL iff context_len == 0)
+ *   timesteps_dev    [B] int64
+ *   text_tokens_dev  [ntok, B, clip_dim]  = y['text_embed'][0] (DistilBERT last_hidden_state, token-major as
+ *                    bert_encode_text returns it, model/mdm.py:180-187); may be NULL for MDM_BRANCH_UNCOND
+ *   text_lengths_dev [B] int32: tokens of each prompt (y['text_embed'][1] is a suffix pad mask: the tokenizer pads on the
+ *                    right, model/BERT/BERT_encoder.py:28-30) -- the memory_key_padding_mask of mdm.py:265
+ *   lengths_dev      [B] int32 valid frames of the context_len + pred_len window (tgt_key_padding_mask), or NULL
+ *   out_dev          [B or 2B, njoints, nfeats, pred_len]  the completed suffix (mdm.py:278-279)              */
+size_t mdm_workspace_bytes_dec(const mdm_model_t* m, int32_t nseq, int32_t pred_len, int32_t ntok);
+int mdm_forward_dec(mdm_model_t* m, const float* x_dev, const float* prefix_dev, const int64_t* timesteps_dev,
+                    const float* text_tokens_dev, const int32_t* text_lengths_dev, const int32_t* lengths_dev, int32_t B,
+                    int32_t pred_len, int32_t ntok, int32_t branches, float* out_dev, void* ws_dev, size_t ws_bytes,
+                    void* stream);
 
 /* One fused sampler update given model outputs (the tail of GaussianDiffusion.p_sample / ddim_sample,
  * diffusion/gaussian_diffusion.py:489-541, :729-779, incl. ClassifierFreeSampleModel's combine

@@ -104,6 +104,25 @@ class Engine:
                                             self.stream()), "mdm_forward")
         return out
 
+    # ---- MDM.forward, trans_dec (DiP) ----------------------------------------------------------
+    def forward_dec(self, x, prefix, timesteps, text_tokens, text_lengths, lengths, branches):
+        """x [B,J,F,pred_len], prefix [B,J,F,context_len] | None, text_tokens [ntok,B,dim],
+        text_lengths [B] int32, lengths [B] int32 | None  ->  [B or 2B, J, F, pred_len]."""
+        B, J, Fe, P = x.shape
+        self._check_device(x)
+        ntok = int(text_tokens.shape[0])        # also sizes the (bias + time) memory of the unconditional branch
+        nb = 2 if branches == nat.BRANCH_BOTH else 1
+        out = torch.empty((nb * B, J, Fe, P), dtype=torch.float32, device=x.device)
+        need = self.lib.mdm_workspace_bytes_dec(self.handle, nb * B, P, ntok)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.lib.check(self.lib.mdm_forward_dec(self.handle, x.data_ptr(), _ptr(prefix), timesteps.data_ptr(),
+                                                _ptr(text_tokens), text_lengths.data_ptr(), _ptr(lengths), B, P, ntok,
+                                                branches, out.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                                self.stream()), "mdm_forward_dec")
+        return out
+
     # ---- fused sampler pieces -----------------------------------------------------------------
     def sampler_step(self, x_t, out_cond, out_uncond, scale, inpaint_mask, inpaint_motion, noise, a_x0, a_xt, sigma,
                      clip_denoised=False, seed=0, sample_base=0, draw=0, want_x0=False):

@@ -22,12 +22,15 @@ EXPORTED_SYMBOLS = [
     "mdm_prepare", "mdm_workspace_bytes", "mdm_forward", "mdm_sampler_step", "mdm_randn", "mdm_sample_loop",
     "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset", "mdm_set_precision", "mdm_linear_bf16x3",
     "mdm_linear_bf16x3_scratch_bytes", "mdm_debug_set", "mdm_attention_bf16x3", "mdm_attention_bf16x3_scratch_bytes", "mdm_recover_from_ric",
+    "mdm_workspace_bytes_dec", "mdm_forward_dec",
 ]
+ABI_VERSION = 2
+ARCH = {"trans_enc": 0, "trans_dec": 1}
 
 
 class MdmConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("njoints", "nfeats", "latent_dim", "ff_size", "num_layers", "num_heads",
-                                         "clip_dim", "max_len", "mask_frames")]
+                                         "clip_dim", "max_len", "mask_frames", "arch", "context_len")]
 
 
 class MdmStep(C.Structure):
@@ -86,6 +89,8 @@ class MdmLib:
             "mdm_attention_bf16x3_scratch_bytes": (sz, [i32, i32, i32]),
             "mdm_attention_bf16x3": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
             "mdm_recover_from_ric": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+            "mdm_workspace_bytes_dec": (sz, [vp, i32, i32, i32]),
+            "mdm_forward_dec": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
             "mdm_profile_enable": (C.c_int, [vp, C.c_int]),
             "mdm_profile_read": (C.c_int, [vp, i32, P(C.c_double), P(i64), P(C.c_double)]),
             "mdm_profile_reset": (C.c_int, [vp]),
@@ -94,8 +99,8 @@ class MdmLib:
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.mdm_abi_version() != 1:
-            raise MdmError(f"{path}: ABI version {lib.mdm_abi_version()} != 1")
+        if lib.mdm_abi_version() != ABI_VERSION:
+            raise MdmError(f"{path}: ABI version {lib.mdm_abi_version()} != {ABI_VERSION}")
 
     def check(self, rc, what):
         if rc != MDM_OK:

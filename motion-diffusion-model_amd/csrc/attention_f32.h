@@ -5,6 +5,7 @@
 // :253) and the key-padding mask of mdm.py:241-247.
 //
 //   qkv  [nseq*S, 3*D]  row = (sequence, token);  Q cols [0,D) already scaled by 1/sqrt(hd), K [D,2D), V [2D,3D)
+//        (or separate query / key / value sources with their own lengths: AttnF32Args)
 //   out  [nseq*S, D]    head h occupies cols [h*hd, (h+1)*hd)
 //
 // One workgroup per (sequence, head); hd = 128; S <= 32*NKT <= 224.  Wave w owns query rows
@@ -28,45 +29,59 @@ namespace mdm {
 constexpr int ATT_HD = 128;
 constexpr int ATT_KLD = ATT_HD + 4;  // K / O staging row stride (floats)
 
+// Operands.  Self-attention of the encoder: q = qkv, k = qkv + D, v = qkv + 2D, ldq = ldkv = 3D, Sq = Sk = S, lead = 1
+// (token 0, the condition token, is never masked; frame j-1 must be < length: mdm.py:241-247).  DiP decoder
+// (mdm.py:255-270): the same with lead = 0 for its self-attention, and for the cross-attention over the text memory
+// q = projected tokens [nseq*Sq][D], k / v = the two halves of the projected memory [nseq*Sk][2D], lengths = text
+// token counts (memory_key_padding_mask).
+struct AttnF32Args {
+  const float* q;
+  int ldq;
+  const float* k;
+  const float* v;
+  int ldkv;
+  int Sq, Sk;
+  const int* lengths;  // [B] or null: valid keys = min(Sk, lead + lengths[seq % B])
+  int lead;
+  int B;
+};
+
+// blockDim.x = 64 * ceil(Sq / 32): wave w owns query rows [32w, 32w + 32); NKT = ceil(Sk / 32) key tiles.
 template <int NKT>
-__global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float* __restrict__ qkv,
-                                                                   float* __restrict__ out,
-                                                                   const int* __restrict__ lengths,  // [B] or null
-                                                                   int S, int D, int H, int B,
-                                                                   bf16_t* __restrict__ oh, bf16_t* __restrict__ ol) {
-  MDM_DYN_SMEM(float, smem);  // NKT*32 rows x ATT_KLD floats
-  constexpr int NT = 64 * NKT;
+__global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float* __restrict__ out, int D, int H,
+                                                             bf16_t* __restrict__ oh, bf16_t* __restrict__ ol) {
+  MDM_DYN_SMEM(float, smem);  // max(NKT, query tiles) * 32 rows x ATT_KLD floats
+  const int NT = (int)blockDim.x;
   constexpr int ROWS = 32 * NKT;
+  const int S = a.Sk, Sq = a.Sq;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int seq = blockIdx.x / H, head = blockIdx.x - seq * H;
-  const int ld = 3 * D;
-  const float* base = qkv + (size_t)seq * S * ld + head * ATT_HD;
+  const int ld = a.ldkv;
+  const float* qbase = a.q + (size_t)seq * Sq * a.ldq + head * ATT_HD;
+  const float* kbase = a.k + (size_t)seq * S * ld + head * ATT_HD;
+  const float* vbase = a.v + (size_t)seq * S * ld + head * ATT_HD;
 
-  // number of valid keys: token 0 (the condition token) is never masked; frame j-1 must be < length
   int nvalid = S;
-  if (lengths != nullptr) {
-    const int len = lengths[seq % B];
-    nvalid = min(S, 1 + len);
-  }
+  if (a.lengths != nullptr) nvalid = min(S, a.lead + a.lengths[seq % a.B]);
 
   // ---- Q fragment: query row q = 32w + r, this lane-half's 64 d's
   const int q = 32 * w + r;
   float qf[64];
   {
-    const float* qp = base + (size_t)q * ld + 64 * h;
+    const float* qp = qbase + (size_t)q * a.ldq + 64 * h;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      float4 v = (q < S) ? ld4(qp + 4 * j) : zero4();
+      float4 v = (q < Sq) ? ld4(qp + 4 * j) : zero4();
       qf[4 * j + 0] = v.x; qf[4 * j + 1] = v.y; qf[4 * j + 2] = v.z; qf[4 * j + 3] = v.w;
     }
   }
   // ---- stage K (rows >= S zero-filled)
   for (int idx = tid; idx < ROWS * 32; idx += NT) {
     const int key = idx >> 5, c4 = idx & 31;
-    float4 v = (key < S) ? ld4(base + (size_t)key * ld + D + 4 * c4) : zero4();
+    float4 v = (key < S) ? ld4(kbase + (size_t)key * ld + 4 * c4) : zero4();
     st4(&smem[key * ATT_KLD + 4 * c4], v);
   }
   __syncthreads();
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float* __
   // ---- stage V into the same buffer, row stride ATT_HD (rows >= S zero-filled)
   for (int idx = tid; idx < ROWS * 32; idx += NT) {
     const int key = idx >> 5, c4 = idx & 31;
-    float4 v = (key < S) ? ld4(base + (size_t)key * ld + 2 * D + 4 * c4) : zero4();
+    float4 v = (key < S) ? ld4(vbase + (size_t)key * ld + 4 * c4) : zero4();
     st4(&smem[key * ATT_HD + 4 * c4], v);
   }
   __syncthreads();
@@ -154,10 +169,10 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float* __
       st4(&smem[q * ATT_KLD + d0], make_float4(o[dt][4 * g + 0], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]));
     }
   __syncthreads();
-  const size_t obase = (size_t)seq * S * D + head * ATT_HD;
-  for (int idx = tid; idx < ROWS * 32; idx += NT) {
+  const size_t obase = (size_t)seq * Sq * D + head * ATT_HD;
+  for (int idx = tid; idx < NT / 2 * 32; idx += NT) {   // NT / 2 = 32 * query tiles rows
     const int qq = idx >> 5, c4 = idx & 31;
-    if (qq < S) {
+    if (qq < Sq) {
       const float4 v = ld4(&smem[qq * ATT_KLD + 4 * c4]);
       const size_t o = obase + (size_t)qq * D + 4 * c4;
       if (out != nullptr) st4(out + o, v);
@@ -166,6 +181,6 @@ __global__ __launch_bounds__(64 * NKT) void attention_f32_kernel(const float* __
   }
 }
 
-inline size_t attention_lds_bytes(int nkt) { return (size_t)nkt * 32 * ATT_KLD * sizeof(float); }
+inline size_t attention_lds_bytes(int nkt, int nqt) { return (size_t)(nkt > nqt ? nkt : nqt) * 32 * ATT_KLD * sizeof(float); }
 
 }  // namespace mdm

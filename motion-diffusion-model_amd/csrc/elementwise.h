@@ -77,6 +77,27 @@ __global__ __launch_bounds__(256) void cond_token_kernel(float* __restrict__ tok
   }
 }
 
+// Text memory of the DiP decoder (mdm.py:217-219, emb_policy 'add'): mem[seq][j] = embed_text(enc_text[j][b]) + time_emb[b]
+// for the conditional branch, bias + time_emb[b] for the unconditional one (mask_cond zeroes the input, mdm.py:155-156).
+// `proj` [ntok*B][D] holds embed_text(enc_text) token-major (row j*B + b), as bert_encode_text lays the tokens out.
+// Grid = nbranch*B*ntok blocks; each thread 4 consecutive channels.
+__global__ __launch_bounds__(256) void text_memory_kernel(float* __restrict__ mem, const float* __restrict__ proj,
+                                                          const float* __restrict__ text_bias,
+                                                          const float* __restrict__ time_table,
+                                                          const long long* __restrict__ timesteps, int B, int ntok, int D,
+                                                          int uncond_from_branch, int table_rows) {
+  const int row = blockIdx.x, seq = row / ntok, j = row - seq * ntok, b = seq % B, br = seq / B;
+  long long t = timesteps[b];
+  if (t < 0) t = 0;
+  if (t >= table_rows) t = table_rows - 1;
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+    const float4 e = (br >= uncond_from_branch || proj == nullptr) ? ld4(text_bias + c)
+                                                                  : ld4(proj + ((size_t)j * B + b) * D + c);
+    const float4 tt = ld4(time_table + (size_t)t * D + c);
+    st4(mem + (size_t)row * D + c, make_float4(e.x + tt.x, e.y + tt.y, e.z + tt.z, e.w + tt.w));
+  }
+}
+
 // Stand-alone fused sampler update: classifier-free-guidance combine
 // (utils/sampler_util.py:34), inpainting blend (gaussian_diffusion.py:300-304), optional clamp (:347-353),
 // posterior mean / DDIM mean with host-folded coefficients, noise add with the t != 0 mask folded into

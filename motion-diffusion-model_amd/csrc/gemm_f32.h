@@ -50,18 +50,24 @@ struct RowMajorLoader {
 
 // A-operand of InputProcess: logical row m = b*T + t, logical k = feature jf in [0, J*F):
 // element = x[b][jf][t] of the contiguous [B, J*F, T] pose tensor (mdm.py:345 permute+reshape fused away).
+// Prefix completion (mdm.py:203-206, DiP): the first C of the T frames of a row batch come from `prefix` [B, J*F, C],
+// the remaining T - C from x [B, J*F, T - C] -- the torch.cat along the frame axis is fused away.
 struct PoseGatherLoader {
   static constexpr bool kColumnStaging = true;
   const float* x;
   int T, JF, rows;
+  const float* prefix = nullptr;
+  int C = 0;
   __device__ __forceinline__ float4 load4(int row, int k) const {
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (row < rows) {
       const int b = row / T, t = row - b * T;
-      const float* base = x + ((size_t)b * JF) * T + t;
+      const bool in_prefix = t < C;
+      const int Tx = in_prefix ? C : T - C;
+      const float* base = (in_prefix ? prefix : x) + ((size_t)b * JF) * Tx + (in_prefix ? t : t - C);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (k + i < JF) v[i] = base[(size_t)(k + i) * T];
+        if (k + i < JF) v[i] = base[(size_t)(k + i) * Tx];
     }
     return make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -77,12 +83,14 @@ struct CfgTokenLoader {
   const float* tok;    // [nbranch*B*S, D]
   const float* scale;  // [B] or nullptr (single branch)
   int B, T, S, D, rows;
+  int lead = 1;        // tokens of a sequence in front of the T output frames: the condition token (trans_enc), or the
+                       // context_len prefix frames of the DiP decoder (mdm.py:278-279)
   __device__ __forceinline__ float4 load4(int row, int k) const {
     if (row >= rows || k >= D) return zero4();
     const int b = row / T, t = row - b * T;
-    const float4 c = ld4(tok + ((size_t)b * S + 1 + t) * D + k);
+    const float4 c = ld4(tok + ((size_t)b * S + lead + t) * D + k);
     if (scale == nullptr) return c;
-    const float4 u = ld4(tok + ((size_t)(B + b) * S + 1 + t) * D + k);
+    const float4 u = ld4(tok + ((size_t)(B + b) * S + lead + t) * D + k);
     const float s = scale[b];
     return make_float4(u.x + s * (c.x - u.x), u.y + s * (c.y - u.y), u.z + s * (c.z - u.z), u.w + s * (c.w - u.w));
   }
@@ -133,11 +141,12 @@ struct EmbedEpilogue {
   int B, T, S, D, nbranch;
   bf16_t* th;          // optional split planes of tok (bf16x3 mode)
   bf16_t* tl;
+  int lead = 1;        // token rows in front of the frames: 1 (condition token, trans_enc) or 0 (trans_dec: S == T)
   struct Row { size_t tok_off, pe_off; };
   struct Col { int n; float bias; };
   __device__ __forceinline__ Row row(int m) const {
     const int b = m / T, t = m - b * T;
-    return Row{((size_t)b * S + 1 + t) * D, (size_t)(1 + t) * D};
+    return Row{((size_t)b * S + lead + t) * D, (size_t)(lead + t) * D};
   }
   __device__ __forceinline__ Col col(int n) const { return Col{n, bias[n]}; }
   __device__ __forceinline__ void store(const Row& r, const Col& c, float acc) const {

@@ -123,7 +123,8 @@ struct mdm_model {
 
   const float* W(const std::string& k) const { return w.at(k); }
   const float* L(int layer, const char* suffix) const {
-    return w.at("seqTransEncoder.layers." + std::to_string(layer) + "." + suffix);
+    return w.at((cfg.arch == MDM_ARCH_TRANS_DEC ? "seqTransDecoder.layers." : "seqTransEncoder.layers.") +
+                std::to_string(layer) + "." + suffix);
   }
 };
 
@@ -192,29 +193,38 @@ int launch_layernorm(Profiler* pf, float* x, const float* g, const float* b, int
 }
 
 template <int NKT>
-int launch_attention_t(const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D, int H,
-                       bf16_t* oh, bf16_t* ol, hipStream_t s) {
+int launch_attention_t(const AttnF32Args& a, float* out, int nseq, int D, int H, bf16_t* oh, bf16_t* ol, hipStream_t s) {
   auto k = &attention_f32_kernel<NKT>;
-  const size_t lds = attention_lds_bytes(NKT);
+  const int nqt = (a.Sq + 31) / 32;
+  const size_t lds = attention_lds_bytes(NKT, nqt);
   if (int rc = rt_allow_lds(k, lds)) return rc;
-  MDM_LAUNCH(k, dim3(nseq * H), dim3(64 * NKT), lds, s, qkv, out, lengths, S, D, H, B, oh, ol);
+  MDM_LAUNCH(k, dim3(nseq * H), dim3(64 * nqt), lds, s, a, out, D, H, oh, ol);
   return rt_launch_status();
 }
 
-int launch_attention(Profiler* pf, const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D,
-                     int H, bf16_t* oh, bf16_t* ol, hipStream_t s) {
-  ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * H * (double)S * S * ATT_HD, s);
+// exact-fp32 attention with separate query / key-value sources (attention_f32.h AttnF32Args)
+int launch_attention_args(Profiler* pf, const AttnF32Args& a, float* out, int nseq, int D, int H, bf16_t* oh, bf16_t* ol,
+                          hipStream_t s) {
+  ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * H * (double)a.Sq * a.Sk * ATT_HD, s);
   if (D != H * ATT_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
-  if (S < 1 || S > 224) return fail(MDM_EUNSUPPORTED, "attention: 1 <= S <= 224 tokens (T <= 223 frames)");
-  switch ((S + 31) / 32) {
-    case 1: return launch_attention_t<1>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
-    case 2: return launch_attention_t<2>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
-    case 3: return launch_attention_t<3>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
-    case 4: return launch_attention_t<4>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
-    case 5: return launch_attention_t<5>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
-    case 6: return launch_attention_t<6>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
-    default: return launch_attention_t<7>(qkv, out, lengths, nseq, B, S, D, H, oh, ol, s);
+  if (a.Sq < 1 || a.Sq > 224 || a.Sk < 1 || a.Sk > 224)
+    return fail(MDM_EUNSUPPORTED, "attention: 1 <= tokens <= 224 on both sides (T <= 223 frames)");
+  switch ((a.Sk + 31) / 32) {
+    case 1: return launch_attention_t<1>(a, out, nseq, D, H, oh, ol, s);
+    case 2: return launch_attention_t<2>(a, out, nseq, D, H, oh, ol, s);
+    case 3: return launch_attention_t<3>(a, out, nseq, D, H, oh, ol, s);
+    case 4: return launch_attention_t<4>(a, out, nseq, D, H, oh, ol, s);
+    case 5: return launch_attention_t<5>(a, out, nseq, D, H, oh, ol, s);
+    case 6: return launch_attention_t<6>(a, out, nseq, D, H, oh, ol, s);
+    default: return launch_attention_t<7>(a, out, nseq, D, H, oh, ol, s);
   }
+}
+
+// self-attention over packed qkv rows [nseq*S][3D]; `lead` tokens in front of the frames are never masked
+int launch_attention(Profiler* pf, const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D,
+                     int H, bf16_t* oh, bf16_t* ol, hipStream_t s, int lead = 1) {
+  const AttnF32Args a{qkv, 3 * D, qkv + D, qkv + 2 * D, 3 * D, S, S, lengths, lead, B};
+  return launch_attention_args(pf, a, out, nseq, D, H, oh, ol, s);
 }
 
 int g_ax_ablate = 0;   // mdm_debug_set(3, code): timing experiments on the NKT = 7 attention kernel (attention_bf16x3.h ABL)
@@ -504,6 +514,9 @@ int mdm_create(const mdm_config_t* cfg, mdm_model_t** out) {
   if (cfg->clip_dim <= 0 || cfg->clip_dim % 4) return fail(MDM_EUNSUPPORTED, "clip_dim must be a positive multiple of 4");
   if (cfg->njoints <= 0 || cfg->nfeats <= 0 || cfg->num_layers <= 0 || cfg->max_len < 2)
     return fail(MDM_EINVAL, "mdm_create: non-positive dimension");
+  if (cfg->arch != MDM_ARCH_TRANS_ENC && cfg->arch != MDM_ARCH_TRANS_DEC) return fail(MDM_EUNSUPPORTED, "arch must be trans_enc or trans_dec");
+  if (cfg->context_len < 0 || (cfg->arch == MDM_ARCH_TRANS_ENC && cfg->context_len != 0))
+    return fail(MDM_EUNSUPPORTED, "context_len (prefix completion) belongs to the trans_dec (DiP) configuration");
   mdm_model* m = new (std::nothrow) mdm_model();
   if (m == nullptr) return fail(MDM_EINVAL, "out of host memory");
   m->cfg = *cfg;
@@ -516,7 +529,16 @@ int mdm_create(const mdm_config_t* cfg, mdm_model_t** out) {
   e["input_process.poseEmbedding.weight"] = d * jf;
   e["input_process.poseEmbedding.bias"] = d;
   for (int l = 0; l < cfg->num_layers; ++l) {
-    const std::string p = "seqTransEncoder.layers." + std::to_string(l) + ".";
+    const std::string p = (cfg->arch == MDM_ARCH_TRANS_DEC ? "seqTransDecoder.layers." : "seqTransEncoder.layers.") +
+                          std::to_string(l) + ".";
+    if (cfg->arch == MDM_ARCH_TRANS_DEC) {   // nn.TransformerDecoderLayer: + cross-attention over the memory, + norm3
+      e[p + "multihead_attn.in_proj_weight"] = 3 * d * d;
+      e[p + "multihead_attn.in_proj_bias"] = 3 * d;
+      e[p + "multihead_attn.out_proj.weight"] = d * d;
+      e[p + "multihead_attn.out_proj.bias"] = d;
+      e[p + "norm3.weight"] = d;
+      e[p + "norm3.bias"] = d;
+    }
     e[p + "self_attn.in_proj_weight"] = 3 * d * d;
     e[p + "self_attn.in_proj_bias"] = 3 * d;
     e[p + "self_attn.out_proj.weight"] = d * d;
@@ -598,6 +620,11 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
                              m->W("embed_timestep.time_embed.2.bias"), nullptr, m->time_table, R, D, D, ACT_NONE, 0,
                              1.f, s))
     return rc;
+  if (m->cfg.arch == MDM_ARCH_TRANS_DEC) {   // the DiP decoder runs in exact fp32: no operand planes
+    m->precision = MDM_PREC_F32;
+    m->prepared = true;
+    return MDM_OK;
+  }
   // bf16 hi/lo planes of the encoder weights (always built: the precision mode can be switched afterwards)
   base += align_up((size_t)R * D * sizeof(float), 256);
   const size_t FF = m->cfg.ff_size;
@@ -675,6 +702,8 @@ int mdm_set_precision(mdm_model_t* m, int32_t mode) {
   if (mode != MDM_PREC_F32 && mode != MDM_PREC_BF16X3) return fail(MDM_EINVAL, "mdm_set_precision: unknown mode");
   if (mode == MDM_PREC_BF16X3 && (m->cfg.latent_dim % X3_BK != 0 || m->cfg.ff_size % X3_BK != 0))
     return fail(MDM_EUNSUPPORTED, "bf16x3 needs latent_dim and ff_size to be multiples of 32");
+  if (mode == MDM_PREC_BF16X3 && m->cfg.arch == MDM_ARCH_TRANS_DEC)
+    return fail(MDM_EUNSUPPORTED, "the trans_dec (DiP) denoiser runs in exact fp32 only");
   m->precision = mode;
   return MDM_OK;
 }
@@ -688,6 +717,7 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
                 const int32_t* lengths, int32_t B, int32_t T, int32_t branches, float* out, void* ws_dev,
                 size_t ws_bytes, void* stream) {
   if (int rc = check_ready(m)) return rc;
+  if (m->cfg.arch != MDM_ARCH_TRANS_ENC) return fail(MDM_ESTATE, "mdm_forward: trans_dec models go through mdm_forward_dec");
   if (x == nullptr || timesteps == nullptr || out == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_forward: null pointer");
   if (B <= 0 || T <= 0 || T + 1 > 224) return fail(MDM_EINVAL, "mdm_forward: need B >= 1 and 1 <= T <= 223");
   if (branches < 0 || branches > 2) return fail(MDM_EINVAL, "mdm_forward: bad branches");
@@ -716,6 +746,122 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
   ep.T = T; ep.JF = m->jf; ep.mode = 0;
   ProfScope ps(&m->prof, MDM_PROF_OUTPROJ, 2.0 * nseq * T * (double)D * m->jf, s);
   launch_gemm_f32(al, bl, ep, m->jf, nseq * T, D, s);
+  return rt_launch_status();
+}
+
+// ---- DiP: trans_dec denoiser, exact fp32 -----------------------------------------------------------
+namespace {
+struct DecWorkspace {
+  float *tok, *qkv, *att, *ffn, *mem, *kv, *proj;
+  size_t bytes;
+};
+DecWorkspace carve_dec(const mdm_model* m, int nseq, int S, int ntok, int B, void* base) {
+  const size_t D = m->cfg.latent_dim, FF = m->cfg.ff_size, M = (size_t)nseq * S, Mm = (size_t)nseq * ntok;
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    size_t o = off;
+    off += align_up(floats * sizeof(float), 256);
+    return base ? reinterpret_cast<float*>(static_cast<char*>(base) + o) : nullptr;
+  };
+  DecWorkspace w;
+  w.tok = take(M * D);
+  w.qkv = take(M * 3 * D);        // self-attention: packed q|k|v rows; cross-attention: the projected queries [M][D]
+  w.att = take(M * D);
+  w.ffn = take(M * FF);
+  w.mem = take(Mm * D);           // text memory [nseq][ntok][D]
+  w.kv = take(Mm * 2 * D);        // its key | value projections of the current layer
+  w.proj = take((size_t)ntok * B * D);   // embed_text(enc_text), token-major
+  w.bytes = off;
+  return w;
+}
+}  // namespace
+
+size_t mdm_workspace_bytes_dec(const mdm_model_t* m, int32_t nseq, int32_t pred_len, int32_t ntok) {
+  if (m == nullptr || nseq <= 0 || pred_len <= 0 || ntok <= 0) return 0;
+  return carve_dec(m, nseq, m->cfg.context_len + pred_len, ntok, nseq, nullptr).bytes;
+}
+
+int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const int64_t* timesteps, const float* text_tokens,
+                    const int32_t* text_lengths, const int32_t* lengths, int32_t B, int32_t pred_len, int32_t ntok,
+                    int32_t branches, float* out, void* ws_dev, size_t ws_bytes, void* stream) {
+  if (int rc = check_ready(m)) return rc;
+  if (m->cfg.arch != MDM_ARCH_TRANS_DEC) return fail(MDM_ESTATE, "mdm_forward_dec: the model was created as trans_enc");
+  const int C = m->cfg.context_len, S = C + pred_len, D = m->cfg.latent_dim, H = m->cfg.num_heads, FF = m->cfg.ff_size;
+  if (x == nullptr || timesteps == nullptr || out == nullptr || ws_dev == nullptr || text_lengths == nullptr)
+    return fail(MDM_EINVAL, "mdm_forward_dec: null pointer");
+  if ((C > 0) != (prefix != nullptr)) return fail(MDM_EINVAL, "mdm_forward_dec: prefix must be given iff context_len > 0");
+  if (B <= 0 || pred_len <= 0 || S > 224) return fail(MDM_EINVAL, "mdm_forward_dec: need B >= 1 and context_len + pred_len <= 224");
+  if (ntok <= 0 || ntok > 224) return fail(MDM_EINVAL, "mdm_forward_dec: 1 <= text tokens <= 224");
+  if (S > m->cfg.max_len) return fail(MDM_EINVAL, "mdm_forward_dec: window longer than the positional table");
+  if (branches < 0 || branches > 2) return fail(MDM_EINVAL, "mdm_forward_dec: bad branches");
+  if (branches != MDM_BRANCH_UNCOND && text_tokens == nullptr) return fail(MDM_EINVAL, "mdm_forward_dec: text tokens required");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nbranch = (branches == MDM_BRANCH_BOTH) ? 2 : 1;
+  const int nseq = nbranch * B, M = nseq * S, Mm = nseq * ntok;
+  DecWorkspace ws = carve_dec(m, nseq, S, ntok, B, ws_dev);
+  if (ws_bytes < ws.bytes) return fail(MDM_ENOSPC, "mdm_forward_dec: workspace too small");
+  Profiler* pf = &m->prof;
+  const int* len = m->cfg.mask_frames ? lengths : nullptr;
+  const float qscale = 1.0f / sqrtf((float)ATT_HD);
+
+  // ---- text memory: embed_text over every token (cond branch), + time embedding (mdm.py:217-219)
+  if (branches != MDM_BRANCH_UNCOND)
+    if (int rc = launch_linear(nullptr, text_tokens, m->cfg.clip_dim, m->W("embed_text.weight"), m->W("embed_text.bias"),
+                               nullptr, ws.proj, ntok * B, D, m->cfg.clip_dim, ACT_NONE, 0, 1.f, s)) return rc;
+  {
+    ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
+    MDM_LAUNCH(text_memory_kernel, dim3(Mm), dim3(128), 0, s, ws.mem, (const float*)ws.proj, m->W("embed_text.bias"),
+               (const float*)m->time_table, reinterpret_cast<const long long*>(timesteps), B, ntok, D,
+               (branches == MDM_BRANCH_UNCOND) ? 0 : 1, (int)m->cfg.max_len);
+    if (int rc = rt_launch_status()) return rc;
+  }
+  // ---- tgt tokens: InputProcess over cat(prefix, x) + positional rows (mdm.py:203-206, :239, :259-260); both branches
+  {
+    PoseGatherLoader al{x, S, m->jf, B * S, prefix, C};
+    RowMajorLoader bl{m->w_in_pad, m->jf_pad, D, m->jf_pad};
+    EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, S, S, D, nbranch,
+                     nullptr, nullptr, 0};
+    ProfScope ps(pf, MDM_PROF_EMBED, 2.0 * B * S * (double)D * m->jf, s);
+    launch_gemm_f32(al, bl, ep, B * S, D, m->jf_pad, s);
+    if (int rc = rt_launch_status()) return rc;
+  }
+  // ---- nn.TransformerDecoder (mdm.py:265; post-norm layers, no final norm)
+  for (int l = 0; l < m->cfg.num_layers; ++l) {
+    // x = norm1(x + self_attn(x))
+    if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "self_attn.in_proj_weight"), m->L(l, "self_attn.in_proj_bias"), nullptr,
+                               ws.qkv, M, 3 * D, D, ACT_NONE, D, qscale, s)) return rc;
+    if (int rc = launch_attention(pf, ws.qkv, ws.att, len, nseq, B, S, D, H, nullptr, nullptr, s, /*lead=*/0)) return rc;
+    if (int rc = launch_linear(pf, ws.att, D, m->L(l, "self_attn.out_proj.weight"), m->L(l, "self_attn.out_proj.bias"),
+                               ws.tok, ws.tok, M, D, D, ACT_NONE, 0, 1.f, s)) return rc;
+    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, nullptr, nullptr, s)) return rc;
+    // x = norm2(x + multihead_attn(x, memory, memory)): q from the tokens, k | v from the memory (packed in_proj rows)
+    const float* wc = m->L(l, "multihead_attn.in_proj_weight");
+    const float* bc = m->L(l, "multihead_attn.in_proj_bias");
+    if (int rc = launch_linear(pf, ws.tok, D, wc, bc, nullptr, ws.qkv, M, D, D, ACT_NONE, D, qscale, s)) return rc;
+    if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s)) return rc;
+    {
+      const AttnF32Args a{ws.qkv, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
+      if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s)) return rc;
+    }
+    if (int rc = launch_linear(pf, ws.att, D, m->L(l, "multihead_attn.out_proj.weight"), m->L(l, "multihead_attn.out_proj.bias"),
+                               ws.tok, ws.tok, M, D, D, ACT_NONE, 0, 1.f, s)) return rc;
+    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, nullptr, nullptr, s)) return rc;
+    // x = norm3(x + linear2(gelu(linear1(x))))
+    if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "linear1.weight"), m->L(l, "linear1.bias"), nullptr, ws.ffn, M, FF, D,
+                               ACT_GELU, 0, 1.f, s)) return rc;
+    if (int rc = launch_linear(pf, ws.ffn, FF, m->L(l, "linear2.weight"), m->L(l, "linear2.bias"), ws.tok, ws.tok, M, D, FF,
+                               ACT_NONE, 0, 1.f, s)) return rc;
+    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm3.weight"), m->L(l, "norm3.bias"), M, D, nullptr, nullptr, s)) return rc;
+  }
+  // ---- OutputProcess over the completed suffix (mdm.py:278-282): token rows context_len .. S-1 of every sequence
+  RowMajorLoader al{m->W("output_process.poseFinal.weight"), D, m->jf, D};
+  CfgTokenLoader bl{ws.tok, nullptr, nseq, pred_len, S, D, nseq * pred_len, C};
+  OutProjEpilogue ep{};
+  ep.bias = m->W("output_process.poseFinal.bias");
+  ep.out = out;
+  ep.T = pred_len; ep.JF = m->jf; ep.mode = 0;
+  ProfScope ps(pf, MDM_PROF_OUTPROJ, 2.0 * nseq * pred_len * (double)D * m->jf, s);
+  launch_gemm_f32(al, bl, ep, m->jf, nseq * pred_len, D, s);
   return rt_launch_status();
 }
 
@@ -749,6 +895,7 @@ int mdm_randn(float* out, const float* init, const float* eps, float a, float s,
 int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void* ws_dev, size_t ws_bytes,
                     void* stream) {
   if (int rc = check_ready(m)) return rc;
+  if (m->cfg.arch != MDM_ARCH_TRANS_ENC) return fail(MDM_ESTATE, "mdm_sample_loop: the fused loop drives the trans_enc denoiser");
   if (p == nullptr || x == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop: null pointer");
   const int B = p->B, T = p->T;
   if (B <= 0 || T <= 0 || T + 1 > 224) return fail(MDM_EINVAL, "mdm_sample_loop: need B >= 1 and 1 <= T <= 223");

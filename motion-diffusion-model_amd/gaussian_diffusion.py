@@ -276,6 +276,9 @@ class GaussianDiffusion:
         if 'text' in y.keys() and 'text_embed' not in y.keys():
             # encoding once instead of each iteration (gaussian_diffusion.py:633-635); caches into the caller's dict
             y['text_embed'] = model.encode_text(y['text'])
+        if mdm.arch == 'trans_dec':
+            return self._loop_stepwise(model, mdm, shape, coefs, noise, clip_denoised, model_kwargs, device,
+                                       skip_timesteps, init_image, dump_steps, noise_sequence, seed)
 
         eng = mdm.engine()
         with torch.no_grad():
@@ -328,6 +331,40 @@ class GaussianDiffusion:
         if dump_steps is not None:      # the reference appends in loop order (:654-657)
             return [dumps[j] for j in range(len(kept))] if kept else []
         return out
+
+    def _loop_stepwise(self, model, mdm, shape, coefs, noise, clip_denoised, model_kwargs, device, skip_timesteps,
+                       init_image, dump_steps, noise_sequence, seed):
+        """The same loop, one native forward + one fused step kernel per iteration: the DiP decoder (10 steps x 60 tokens
+        per window) is not in the fused trans_enc loop of mdm_sample_loop."""
+        eng = mdm.engine()
+        with torch.no_grad():
+            seed = self.reseed(seed)
+            base = self.sample_base
+            start = self.num_timesteps - 1 - int(skip_timesteps)
+            if noise is not None:
+                img = noise.to(device=device, dtype=torch.float32).contiguous().clone()
+            elif noise_sequence is not None:
+                img = noise_sequence[0].to(device=device, dtype=torch.float32).contiguous().clone()
+            else:
+                img = None
+            if skip_timesteps and init_image is None:
+                init_image = torch.zeros(shape, dtype=torch.float32, device=device)
+            if init_image is not None:
+                img = eng.randn(shape, device, seed, base, 0,
+                                init=init_image.to(device=device, dtype=torch.float32).contiguous(), eps=img,
+                                a=float(np.float32(self.sqrt_alphas_cumprod[start])),
+                                s=float(np.float32(self.sqrt_one_minus_alphas_cumprod[start])))
+            elif img is None:
+                img = eng.randn(shape, device, seed, base, 0)
+            dumps = []
+            for k, i in enumerate(range(start, -1, -1)):
+                t = torch.full((shape[0],), i, device=device, dtype=torch.long)
+                nz = None if noise_sequence is None else noise_sequence[1 + k]
+                out = self._step(model, img, t, coefs, clip_denoised, None, None, model_kwargs, nz, draw=1 + k)
+                img = out["sample"]
+                if dump_steps is not None and i in dump_steps:
+                    dumps.append(img.clone())
+        return dumps if dump_steps is not None else img
 
     # ---- progressive generators (the reference yields per step; kept for callers that iterate) ---------
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,

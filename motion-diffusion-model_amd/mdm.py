@@ -6,7 +6,9 @@ keys, so `utils/model_util.py:18-21 create_model_and_diffusion` a
 sub-modules below exist only to hold parameters under the reference's names.
 
 Scope: arch='trans_enc', text conditioning with a cached `y['text_embed']`
-(or no conditioning), inference only.  Everything else raises NotImplementedError loudly.
+(or no conditioning), inference only; and (DiP) arch='trans_dec' with prefix completion
+and a cached token-level text embedding (DistilBERT) or a single CLIP token as the decoder memory, in exact
+fp32.  Everything else raises NotImplementedError loudly.
 """
 import math
 import os
@@ -108,26 +110,43 @@ class MDM(nn.Module):
         # arithmetic of the encoder GEMMs (include/mdm_hip.h mdm_set_precision): 'bf16x3' | 'f32'
         self.precision = kargs.get('precision', os.environ.get('MDM_PRECISION', 'bf16x3'))
 
-        if arch != 'trans_enc':
-            raise NotImplementedError(f"arch={arch!r}: only the trans_enc denoiser is on the MI355X hot path (SURVEY.md 8f)")
+        if arch not in ('trans_enc', 'trans_dec'):
+            raise NotImplementedError(f"arch={arch!r}: trans_enc and trans_dec (DiP) only (SURVEY.md 8f)")
         if activation != "gelu":
             raise NotImplementedError("only activation='gelu' (the reference's fixed choice, utils/model_util.py:64)")
-        if data_rep == 'rot_vel' or self.is_prefix_comp or self.multi_target_cond or self.emb_policy != 'add':
-            raise NotImplementedError("rot_vel / prefix completion / target conditioning / emb_policy!='add' are out of scope")
+        if data_rep == 'rot_vel' or self.multi_target_cond or self.emb_policy != 'add':
+            raise NotImplementedError("rot_vel / target conditioning / emb_policy!='add' are out of scope")
         if self.cond_mode not in ('no_cond', 'text'):
             raise NotImplementedError(f"cond_mode={self.cond_mode!r}: text or no_cond only")
-        if self.text_encoder_type != 'clip' and 'text' in self.cond_mode:
-            raise NotImplementedError("text_encoder_type='bert' belongs to the DiP (trans_dec) path")
+        if arch == 'trans_enc':
+            if self.is_prefix_comp:
+                raise NotImplementedError("prefix completion belongs to the DiP (trans_dec) path")
+            if self.text_encoder_type != 'clip' and 'text' in self.cond_mode:
+                raise NotImplementedError("text_encoder_type='bert' belongs to the DiP (trans_dec) path")
+        else:
+            if emb_trans_dec or 'text' not in self.cond_mode:
+                raise NotImplementedError("trans_dec: emb_trans_dec=False with text conditioning (the DiP configuration)")
+            if self.text_encoder_type not in ('clip', 'bert'):
+                raise ValueError('We only support [CLIP, BERT] text encoders')
+            if self.text_encoder_type == 'bert':
+                self.clip_dim = clip_dim = 768          # model/mdm.py:127
+            self.precision = 'f32'                       # the decoder path is exact fp32 (include/mdm_hip.h)
 
         self.input_process = InputProcess(data_rep, self.input_feats, latent_dim)
         self.sequence_pos_encoder = PositionalEncoding(latent_dim, dropout, max_len=kargs.get('pos_embed_max_len', 5000))
-        layer = nn.TransformerEncoderLayer(d_model=latent_dim, nhead=num_heads, dim_feedforward=ff_size,
-                                           dropout=dropout, activation=activation)
-        self.seqTransEncoder = nn.TransformerEncoder(layer, num_layers=num_layers, enable_nested_tensor=False)
+        if arch == 'trans_enc':
+            layer = nn.TransformerEncoderLayer(d_model=latent_dim, nhead=num_heads, dim_feedforward=ff_size,
+                                               dropout=dropout, activation=activation)
+            self.seqTransEncoder = nn.TransformerEncoder(layer, num_layers=num_layers, enable_nested_tensor=False)
+        else:
+            layer = nn.TransformerDecoderLayer(d_model=latent_dim, nhead=num_heads, dim_feedforward=ff_size,
+                                               dropout=dropout, activation=activation)
+            self.seqTransDecoder = nn.TransformerDecoder(layer, num_layers=num_layers)
         self.embed_timestep = TimestepEmbedder(latent_dim, self.sequence_pos_encoder)
         if 'text' in self.cond_mode:
             self.embed_text = nn.Linear(clip_dim, latent_dim)
-            self.clip_model = self._try_load_clip(clip_version)
+            # the text encoder itself (CLIP / DistilBERT) is outside the hot path: callers cache y['text_embed']
+            self.clip_model = self._try_load_clip(clip_version) if self.text_encoder_type == 'clip' else None
         self.output_process = OutputProcess(data_rep, self.input_feats, latent_dim, njoints, nfeats)
         self.rot2xyz = _IdentityRot2xyz()
         self._engine = None
@@ -147,7 +166,10 @@ class MDM(nn.Module):
         return model
 
     def encode_text(self, raw_text):
-        """model/mdm.py:163-178 clip_encode_text."""
+        """model/mdm.py:163-178 clip_encode_text (bert_encode_text :180-187 needs DistilBERT weights: cache instead)."""
+        if self.text_encoder_type == 'bert':
+            raise RuntimeError("DistilBERT is not available in this environment: pass the cached embedding as "
+                               "y['text_embed'] = (last_hidden_state [Ntok, B, 768], pad_mask [B, Ntok])")
         if getattr(self, 'clip_model', None) is None:
             raise RuntimeError("CLIP is not available in this environment: pass the cached embedding as "
                                "y['text_embed'] ([1, B, clip_dim]); see sample/generate.py:130-132")
@@ -188,7 +210,8 @@ class MDM(nn.Module):
         if self._engine is None or self._engine_key != key:
             cfg = dict(njoints=self.njoints, nfeats=self.nfeats, latent_dim=self.latent_dim, ff_size=self.ff_size,
                        num_layers=self.num_layers, num_heads=self.num_heads, clip_dim=self.clip_dim,
-                       max_len=self.sequence_pos_encoder.pe.shape[0], mask_frames=int(bool(self.mask_frames)))
+                       max_len=self.sequence_pos_encoder.pe.shape[0], mask_frames=int(bool(self.mask_frames)),
+                       arch=nat.ARCH[self.arch], context_len=int(self.context_len) if self.arch == 'trans_dec' else 0)
             eng = Engine(cfg, lib=self._native_lib, precision=self.precision)
             eng.bind(self._native_state(), p.device)
             self._engine, self._engine_key = eng, key
@@ -215,12 +238,58 @@ class MDM(nn.Module):
             raise NotImplementedError("token-level (BERT) text embeddings belong to the DiP path")
         return enc.to(device=device, dtype=torch.float32).reshape(-1, self.clip_dim).contiguous()
 
+    # ---- trans_dec (DiP) inputs -------------------------------------------------------------------------
+    def _dec_inputs(self, x, y):
+        """-> (prefix | None, text tokens [Ntok, B, dim], text lengths [B] int32, frame lengths [B] int32 | None)
+        from the reference's `y` contract (model/mdm.py:203-216, :242-244)."""
+        dev, bs = x.device, x.shape[0]
+        prefix = None
+        if self.context_len > 0:
+            prefix = y['prefix'].to(device=dev, dtype=torch.float32).contiguous()
+            assert prefix.shape == (bs, self.njoints, self.nfeats, self.context_len), prefix.shape
+        enc = y['text_embed'] if 'text_embed' in y.keys() else self.encode_text(y['text'])
+        if isinstance(enc, tuple):
+            enc, pad = enc                                   # [Ntok, B, 768], [B or 1, Ntok] True = no token
+            pad = pad.to(dev)
+            if pad.shape[0] == 1 and bs > 1:
+                pad = pad.repeat_interleave(bs, dim=0)       # single prompt for all (mdm.py:215-216)
+            tl = (~pad).sum(dim=1)
+            # the tokenizer pads on the right (BERT_encoder.py:28): the mask is a suffix mask <=> lengths describe it
+            if not bool((pad == (torch.arange(pad.shape[1], device=dev)[None, :] >= tl[:, None])).all()):
+                raise NotImplementedError("text pad masks must be suffix masks (right-padded prompts)")
+        else:                                                # CLIP: one memory token per sample (mdm.py:262)
+            tl = torch.ones(bs, dtype=torch.int64, device=dev)
+        enc = enc.to(device=dev, dtype=torch.float32).contiguous()
+        assert enc.dim() == 3 and enc.shape[1] == bs and enc.shape[2] == self.clip_dim, enc.shape
+        lengths = None
+        mask = y.get('mask', None)
+        if self.mask_frames and mask is not None and mask.shape[-1] > 1:
+            lengths = (self.context_len + mask[..., :x.shape[-1]].reshape(bs, -1).sum(dim=1)).to(device=dev, dtype=torch.int32)
+            m2 = mask[..., :x.shape[-1]].reshape(bs, -1).to(dev)
+            if not bool((m2 == (torch.arange(m2.shape[1], device=dev)[None, :] < m2.sum(dim=1)[:, None])).all()):
+                raise NotImplementedError("frame masks must be prefix masks (data_loaders/tensors.py:3-8)")
+            lengths = lengths.contiguous()
+        return prefix, enc, tl.to(torch.int32).contiguous(), lengths
+
+    def _forward_dec(self, x, timesteps, y, branches):
+        for k in ('target_cond', 'action'):
+            if k in y:
+                raise NotImplementedError(f"y[{k!r}] is outside the MI355X hot path")
+        x = x.to(torch.float32).contiguous()
+        assert x.shape[1] == self.njoints and x.shape[2] == self.nfeats
+        ts = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
+        prefix, enc, tl, lengths = self._dec_inputs(x, y)
+        return self.engine().forward_dec(x, prefix, ts, enc, tl, lengths, branches)
+
     # ---- the seam ----------------------------------------------------------------------------------
     def forward(self, x, timesteps, y=None):
         """x: [bs, njoints, nfeats, nframes]; timesteps: [bs] int; y: dict (model/mdm.py:189-194)."""
         if self.training:
             raise NotImplementedError("inference only: call .eval() (sample/generate.py:96)")
         y = {} if y is None else y
+        if self.arch == 'trans_dec':
+            uncond = bool(y.get('uncond', False))
+            return self._forward_dec(x, timesteps, y, nat.BRANCH_UNCOND if uncond else nat.BRANCH_COND)
         for k in ('target_cond', 'prefix', 'action'):
             if k in y:
                 raise NotImplementedError(f"y[{k!r}] is outside the MI355X hot path")
@@ -241,6 +310,9 @@ class MDM(nn.Module):
     def forward_both(self, x, timesteps, y):
         """cond and uncond branches batched through one native call -> (out_cond, out_uncond)."""
         bs = x.shape[0]
+        if self.arch == 'trans_dec':
+            out = self._forward_dec(x, timesteps, y, nat.BRANCH_BOTH)
+            return out[:bs], out[bs:]
         eng = self.engine()
         x = x.to(torch.float32).contiguous()
         ts = timesteps.to(device=x.device, dtype=torch.int64).contiguous()

@@ -14,12 +14,16 @@ import mdm_amd  # noqa: E402,F401
 from mdm_amd import model_util  # noqa: E402
 from mdm_amd.cfg_sampler import ClassifierFreeSampleModel  # noqa: E402
 from oracle import mdm_oracle as orc  # noqa: E402
-from oracle.synth import synth_state_dict, synth_y  # noqa: E402
+from oracle import dip_oracle as dip  # noqa: E402
+from oracle.synth import synth_dip_state_dict, synth_dip_y, synth_state_dict, synth_y  # noqa: E402
 
 
 def make_pair(sd, steps, device, guided=True, native_lib=None, precision="bf16x3", **arg_over):
     """(model, diffusion) exactly as sample/generate.py:85-96 assembles them."""
-    layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("seqTransEncoder.layers."))
+    dec = any(k.startswith("seqTransDecoder.layers.") for k in sd)
+    layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith(("seqTransEncoder.layers.", "seqTransDecoder.layers.")))
+    if dec:   # DiP: `--arch trans_dec --text_encoder_type bert --context_len 20 --pred_len 40` (DiP.md)
+        arg_over = {"arch": "trans_dec", "text_encoder_type": "bert", "mask_frames": False, **arg_over}
     d = sd["input_process.poseEmbedding.weight"].shape[0]
     args = model_util.default_args(diffusion_steps=steps, layers=layers, latent_dim=d, **arg_over)
     model, diffusion = model_util.create_model_and_diffusion(args, _native_lib=native_lib, num_heads=d // 128,
@@ -69,3 +73,24 @@ def small_state_dict(seed=0, latent_dim=256, num_layers=2, ff_size=1024):
 
 def maxabs(a, b):
     return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+DIP_CONTEXT, DIP_PRED = 20, 40
+
+
+def dip_small_state_dict(seed=0, latent_dim=256, num_layers=1, ff_size=1024):
+    """A shallow/narrow DiP decoder for the CPU emulator."""
+    return synth_dip_state_dict(seed=seed, latent_dim=latent_dim, ff_size=ff_size, num_layers=num_layers)
+
+
+def to_dev(y, device):
+    """model_kwargs['y'] with its tensors (and the (embedding, mask) tuple of DiP) moved to `device`."""
+    out = {}
+    for k, v in y.items():
+        if isinstance(v, tuple):
+            out[k] = tuple(t.to(device) for t in v)
+        elif torch.is_tensor(v):
+            out[k] = v.to(device)
+        else:
+            out[k] = v
+    return out

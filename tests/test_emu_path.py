@@ -12,7 +12,8 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
 
 from emu_lib import emu, f32, ptr  # noqa: E402
-from helpers import make_pair, maxabs, orc, small_state_dict, synth_y  # noqa: E402
+from helpers import (dip, dip_small_state_dict, make_pair, maxabs, orc, small_state_dict, synth_dip_y,  # noqa: E402
+                     synth_y)
 
 
 @pytest.fixture(scope="module")
@@ -138,3 +139,19 @@ def test_emulated_recover_from_ric(lib):
         want = mo.recover_from_ric(sample.numpy(), mean.numpy(), std.numpy(), J)
         assert got.shape == (B, J, 3, T)
         assert maxabs(got, want) < 2e-6 * float(np.abs(want).max())
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_emulated_dip_decoder_forward(lib, masked):
+    """trans_dec denoiser: prefix completion, token-level text memory with ragged lengths, cross-attention
+    with a different key count than queries, both CFG branches, through MDM.forward / ClassifierFreeSampleModel."""
+    B, C, P = 2, 5, 12
+    sd = dip_small_state_dict(num_layers=2)
+    model, _ = make_pair(sd, 10, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, mask_frames=masked)
+    y = synth_dip_y(B, P, C, seed=3, text_lengths=[6, 3], lengths=[12, 7] if masked else None, scale=2.5)
+    x = torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([9, 0])
+    kw = dict(context_len=C, num_heads=2, mask_frames=masked)
+    assert maxabs(model.model(x, t, y=dict(y)), dip.dip_forward(sd, x, t, y, **kw)) < 2e-5
+    assert maxabs(model.model(x, t, y={**y, "uncond": True}), dip.dip_forward(sd, x, t, {**y, "uncond": True}, **kw)) < 2e-5
+    assert maxabs(model(x, t, y=dict(y)), dip.dip_cfg_forward(sd, x, t, y, **kw)) < 5e-5

@@ -16,8 +16,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (ClassifierFreeSampleModel, golden_loop_inputs, make_pair, maxabs, orc, run_product_loop,
-                     synth_state_dict, synth_y)
+from helpers import (ClassifierFreeSampleModel, dip, golden_loop_inputs, make_pair, maxabs, orc, run_product_loop,
+                     synth_dip_state_dict, synth_dip_y, synth_state_dict, synth_y, to_dev)
 
 pytestmark = pytest.mark.gpu
 
@@ -369,3 +369,86 @@ def test_recover_from_ric_matches_oracle_shapes(B, T, JF, J):
     got = recover_from_ric(sample.to(DEV), mean.to(DEV), std.to(DEV))
     want = mo.recover_from_ric(sample.numpy(), mean.numpy(), std.numpy(), J)
     assert maxabs(got.cpu(), want) < 3e-6 * float(np.abs(want).max())
+
+
+# ---- DiP: trans_dec denoiser + prefix completion + AutoRegressiveSampler, exact fp32 ----------------
+TOL_DIP_FWD, TOL_DIP_AR = 2e-5, 2e-4     # AR: CFG scale 7.5, 3 windows x 10 steps (reference-vs-oracle floor: 1.8e-5)
+
+
+@pytest.fixture(scope="module")
+def sd_dip():
+    return synth_dip_state_dict(seed=0)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_dip_forward_matches_reference_golden(golden_dir, sd_dip, masked):
+    g = np.load(os.path.join(golden_dir, "dip_fwd_masked_B3.npz" if masked else "dip_fwd_B3.npz"))
+    B = 3
+    model, _ = make_pair(sd_dip, 10, DEV, guided=True, context_len=20, pred_len=40, mask_frames=masked)
+    y = to_dev(synth_dip_y(B, 40, 20, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]),
+                           lengths=list(g["lengths"]) if masked else None), DEV)
+    x = torch.randn(B, 263, 1, 40, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV)
+    t = torch.from_numpy(g["t"]).to(DEV)
+    assert maxabs(model.model(x, t, y=dict(y)).cpu(), g["out_cond"]) < TOL_DIP_FWD
+    if not masked:
+        assert maxabs(model.model(x, t, y={**y, "uncond": True}).cpu(), g["out_uncond"]) < TOL_DIP_FWD
+        assert maxabs(model(x, t, y=dict(y)).cpu(), g["out_cfg"]) < 5e-5
+
+
+@pytest.mark.parametrize("B,C,P,text_lengths,lengths", [(5, 20, 40, [1, 9, 33, 17, 40], None),
+                                                         (2, 0, 64, [70, 3], [64, 31]),
+                                                         (3, 8, 100, [5, 5, 12], [100, 2, 57])])
+def test_dip_forward_matches_oracle_shapes(sd_dip, B, C, P, text_lengths, lengths):
+    """other window / memory shapes than the shipped 20 + 40: no prefix, long text (3 key tiles), ragged frame masks"""
+    masked = lengths is not None
+    model, _ = make_pair(sd_dip, 10, DEV, guided=False, context_len=C, pred_len=P, mask_frames=masked)
+    y = synth_dip_y(B, P, max(C, 1), seed=B, text_lengths=text_lengths, lengths=lengths)
+    if C == 0:
+        y.pop("prefix")
+    else:
+        y["prefix"] = y["prefix"][..., :C].contiguous()
+    x = torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(P))
+    t = torch.arange(B) % 10
+    want = dip.dip_forward(sd_dip, x, t, y, context_len=C, mask_frames=masked)
+    assert maxabs(model(x.to(DEV), t.to(DEV), y=to_dev(y, DEV)).cpu(), want) < TOL_DIP_FWD
+
+
+def test_dip_autoregressive_matches_reference_golden(golden_dir, sd_dip):
+    """AutoRegressiveSampler over SpacedDiffusion.p_sample_loop over ClassifierFreeSampleModel(MDM trans_dec), with the
+    reference's CPU noise stream injected window by window, against the reference's own 100-frame output."""
+    from mdm_amd.sampler_util import AutoRegressiveSampler
+    from types import SimpleNamespace
+    g = np.load(os.path.join(golden_dir, "dip_ar10_B2_F100.npz"))
+    steps, B, frames, seed = int(g["steps"]), int(g["B"]), int(g["frames"]), int(g["seed"])
+    model, diffusion = make_pair(sd_dip, steps, DEV, guided=True, context_len=20, pred_len=40)
+    y = to_dev(synth_dip_y(B, 40, 20, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]), scale=float(g["scale"])), DEV)
+    chunks = iter(dip.make_noise_chunks((B, 263, 1, 40), steps, seed, 3))
+
+    def sample_fn(mdl, shape, **kw):
+        x_T, eps = next(chunks)
+        return diffusion.p_sample_loop(mdl, shape, noise_sequence=[x_T] + [e.contiguous() for e in eps], **kw)
+
+    args = SimpleNamespace(pred_len=40, context_len=20, autoregressive_include_prefix=False)
+    out = AutoRegressiveSampler(args, sample_fn, frames).sample(
+        model, (B, 263, 1, frames), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, init_image=None,
+        progress=False, dump_steps=None, noise=None, const_noise=False)
+    assert out.shape == (B, 263, 1, frames)
+    assert maxabs(out.cpu(), g["final"]) < TOL_DIP_AR
+
+
+def test_dip_autoregressive_philox_is_deterministic(sd_dip):
+    from mdm_amd.sampler_util import AutoRegressiveSampler
+    from types import SimpleNamespace
+    B, frames = 4, 196
+    model, diffusion = make_pair(sd_dip, 10, DEV, guided=True, context_len=20, pred_len=40)
+    y = to_dev(synth_dip_y(B, 40, 20, seed=5, text_lengths=[4, 11, 25, 8]), DEV)
+    args = SimpleNamespace(pred_len=40, context_len=20, autoregressive_include_prefix=True)
+    outs = []
+    for _ in range(2):
+        seeds = iter(range(100, 110))
+        fn = lambda mdl, shape, **kw: diffusion.p_sample_loop(mdl, shape, seed=next(seeds), **kw)   # noqa: E731
+        outs.append(AutoRegressiveSampler(args, fn, frames).sample(model, (B, 263, 1, frames), clip_denoised=False,
+                                                                   model_kwargs={"y": y}))
+    assert outs[0].shape == (B, 263, 1, frames) and torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0][..., :20], y["prefix"])            # autoregressive_include_prefix (sampler_util.py:54-55)

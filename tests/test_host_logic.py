@@ -104,9 +104,19 @@ def test_wrapper_and_scope_errors():
         from mdm_amd.cfg_sampler import ClassifierFreeSampleModel
         m0, _ = model_util.create_model_and_diffusion(model_util.default_args(cond_mask_prob=0.0, layers=1))
         ClassifierFreeSampleModel(m0)
-    for kw in (dict(arch="trans_dec"), dict(arch="gru")):
+    for kw in (dict(arch="trans_dec", emb_trans_dec=True), dict(arch="gru"), dict(context_len=20, pred_len=40),
+               dict(text_encoder_type="bert")):
         with pytest.raises(NotImplementedError):
             model_util.create_model_and_diffusion(model_util.default_args(**kw))
+    # DiP configuration (DiP.md): constructs, keeps the reference's state-dict keys, runs in exact fp32
+    md, _ = model_util.create_model_and_diffusion(model_util.default_args(
+        arch="trans_dec", text_encoder_type="bert", context_len=20, pred_len=40, layers=1))
+    assert md.clip_dim == 768 and md.precision == "f32" and md.is_prefix_comp
+    keys = set(md.state_dict().keys())
+    assert "seqTransDecoder.layers.0.multihead_attn.in_proj_weight" in keys and "seqTransDecoder.layers.0.norm3.bias" in keys
+    assert md.embed_text.weight.shape == (512, 768)
+    with pytest.raises(RuntimeError):
+        md.encode_text(["a person walks"])         # DistilBERT is not on the path: the embedding must be cached
     with pytest.raises(NotImplementedError):
         diffusion.p_sample_loop(model, (1, 263, 1, 8), cond_fn=lambda *a: None, model_kwargs={"y": {}})
     with pytest.raises(NotImplementedError):

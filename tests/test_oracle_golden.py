@@ -131,3 +131,51 @@ def test_motion_oracle_matches_reference_golden(golden_dir):
     assert got.shape == g["out"].shape == (3, 22, 3, 196)
     # positions integrate 196 frames of root velocity (|out| up to ~1e2 here): fp32-rounding-level RELATIVE agreement
     assert float(np.abs(got - g["out"]).max()) < 2e-6 * float(np.abs(g["out"]).max())
+
+
+# ---- DiP: oracle/dip_oracle.py against the upstream reference's own outputs (oracle/make_golden_dip.py)
+DIP_TOL_FWD, DIP_TOL_AR = 2e-5, 1e-4    # CFG scale 7.5 over 3 windows x 10 steps amplifies the fp32 reorder floor
+
+
+def test_dip_pin_report_is_tight(golden_dir):
+    rep = json.load(open(os.path.join(golden_dir, "PIN_REPORT.json")))["dip"]
+    assert max(rep["fwd_B3"][k] for k in ("cond", "uncond", "cfg")) < DIP_TOL_FWD
+    assert rep["fwd_masked_B3"]["cond"] < DIP_TOL_FWD
+    assert rep["ar10_B2_F100"]["final"] < DIP_TOL_AR
+
+
+def test_dip_forward_golden(golden_dir):
+    from oracle import dip_oracle as dip
+    from oracle.synth import synth_dip_state_dict, synth_dip_y
+    sdd = synth_dip_state_dict(seed=0)
+    for name, masked in (("dip_fwd_B3", False), ("dip_fwd_masked_B3", True)):
+        g = _load(golden_dir, name)
+        B = 3
+        y = synth_dip_y(B, 40, 20, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]),
+                        lengths=list(g["lengths"]) if masked else None)
+        x = torch.randn(B, 263, 1, 40, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+        t = torch.from_numpy(g["t"])
+        kw = dict(context_len=20, mask_frames=masked)
+        assert np.abs(dip.dip_forward(sdd, x, t, y, **kw).numpy() - g["out_cond"]).max() < DIP_TOL_FWD
+        if not masked:
+            assert np.abs(dip.dip_forward(sdd, x, t, {**y, "uncond": True}, **kw).numpy() - g["out_uncond"]).max() < DIP_TOL_FWD
+            assert np.abs(dip.dip_cfg_forward(sdd, x, t, y, **kw).numpy() - g["out_cfg"]).max() < DIP_TOL_FWD
+    # the frames mask matters for the padded samples only, the text mask for every sample with pad tokens
+    gm, g0 = _load(golden_dir, "dip_fwd_masked_B3"), _load(golden_dir, "dip_fwd_B3")
+    d = np.abs(gm["out_cond"] - g0["out_cond"]).reshape(3, -1).max(1)
+    assert d[0] == 0.0 and d[1] > 1e-3 and d[2] > 1e-3
+
+
+def test_dip_autoregressive_golden(golden_dir):
+    from oracle import dip_oracle as dip
+    from oracle.synth import synth_dip_state_dict, synth_dip_y
+    g = _load(golden_dir, "dip_ar10_B2_F100")
+    steps, B, frames, seed = int(g["steps"]), int(g["B"]), int(g["frames"]), int(g["seed"])
+    sdd = synth_dip_state_dict(seed=0)
+    y = synth_dip_y(B, 40, 20, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]), scale=float(g["scale"]))
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    chunks = dip.make_noise_chunks((B, 263, 1, 40), steps, seed, 3)
+    out = dip.autoregressive_sample(sdd, tab, (B, 263, 1, frames), y, chunks, context_len=20, pred_len=40,
+                                    required_frames=frames, cfg=True)
+    assert out.shape == (B, 263, 1, frames)
+    assert np.abs(out.numpy() - g["final"]).max() < DIP_TOL_AR
