@@ -146,7 +146,7 @@ def test_emulated_dip_decoder_forward(lib, masked):
     """trans_dec denoiser: prefix completion, token-level text memory with ragged lengths, cross-attention
     with a different key count than queries, both CFG branches, through MDM.forward / ClassifierFreeSampleModel."""
     B, C, P = 2, 5, 12
-    sd = dip_small_state_dict(num_layers=2)
+    sd = dip_small_state_dict(num_layers=1 if masked else 2)
     model, _ = make_pair(sd, 10, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, mask_frames=masked)
     y = synth_dip_y(B, P, C, seed=3, text_lengths=[6, 3], lengths=[12, 7] if masked else None, scale=2.5)
     x = torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(1))
