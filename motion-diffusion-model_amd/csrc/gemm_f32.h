@@ -215,11 +215,16 @@ struct OutProjEpilogue {
 };
 
 // ------------------------------------------------------------------------------------------------
-template <class AL, class BL, class EP>
+// BT = block tile edge: 128 (wave tile 64x64 = 2x2 accumulators) or 64 (wave tile 32x32, one accumulator) -- the small
+// tile exists for problems whose 128x128 tiling leaves most of the 256 CUs idle (the DiP decoder's 3840-row GEMMs).
+template <class AL, class BL, class EP, int BT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl, EP ep, int M, int N, int K,
                                                                     int tiles_n) {
-  __shared__ __attribute__((aligned(16))) float As[GEMM_BM * GEMM_LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[GEMM_BN * GEMM_LDS_LD];
+  constexpr int WT = BT / 2;          // wave tile edge
+  constexpr int NA = WT / 32;         // 32x32 accumulators per wave tile edge
+  constexpr int NST = BT / 32;        // float4 per operand per thread while staging
+  __shared__ __attribute__((aligned(16))) float As[BT * GEMM_LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BT * GEMM_LDS_LD];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -228,29 +233,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
 
   const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
-  const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
+  const int m0 = tile_m * BT, n0 = tile_n * BT;
 
-  // staging coordinates: 4 float4 per operand per thread
-  int a_row[4], a_k[4], b_row[4], b_k[4];
+  // staging coordinates: NST float4 per operand per thread
+  int a_row[NST], a_k[NST], b_row[NST], b_k[NST];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (AL::kColumnStaging) { a_row[i] = tid & 127; a_k[i] = ((tid >> 7) + 2 * i) * 4; }
+  for (int i = 0; i < NST; ++i) {
+    if (AL::kColumnStaging) { a_row[i] = tid & (BT - 1); a_k[i] = (tid / BT + (256 / BT) * i) * 4; }
     else { a_row[i] = (tid >> 3) + 32 * i; a_k[i] = (tid & 7) * 4; }
-    if (BL::kColumnStaging) { b_row[i] = tid & 127; b_k[i] = ((tid >> 7) + 2 * i) * 4; }
+    if (BL::kColumnStaging) { b_row[i] = tid & (BT - 1); b_k[i] = (tid / BT + (256 / BT) * i) * 4; }
     else { b_row[i] = (tid >> 3) + 32 * i; b_k[i] = (tid & 7) * 4; }
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[NA][NA];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NA; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NA; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[4], rb[4];
+  float4 ra[NST], rb[NST];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NST; ++i) {
     ra[i] = al.load4(m0 + a_row[i], a_k[i]);
     rb[i] = bl.load4(n0 + b_row[i], b_k[i]);
   }
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
   const int nk = (K + GEMM_BK - 1) / GEMM_BK;
   for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NST; ++i) {
       st4(&As[a_row[i] * GEMM_LDS_LD + a_k[i]], ra[i]);
       st4(&Bs[b_row[i] * GEMM_LDS_LD + b_k[i]], rb[i]);
     }
@@ -266,23 +271,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
     if (kt + 1 < nk) {
       const int kb = (kt + 1) * GEMM_BK;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NST; ++i) {
         ra[i] = al.load4(m0 + a_row[i], kb + a_k[i]);
         rb[i] = bl.load4(n0 + b_row[i], kb + b_k[i]);
       }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {  // 4 chunks of 4 k-pairs each
-      float4 fa[2], fb[2];
+      float4 fa[NA], fb[NA];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        fa[t] = ld4(&As[(wm * 64 + t * 32 + r) * GEMM_LDS_LD + 16 * h + 4 * c]);
-        fb[t] = ld4(&Bs[(wn * 64 + t * 32 + r) * GEMM_LDS_LD + 16 * h + 4 * c]);
+      for (int t = 0; t < NA; ++t) {
+        fa[t] = ld4(&As[(wm * WT + t * 32 + r) * GEMM_LDS_LD + 16 * h + 4 * c]);
+        fb[t] = ld4(&Bs[(wn * WT + t * 32 + r) * GEMM_LDS_LD + 16 * h + 4 * c]);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NA; ++j) {
           acc[i][j] = mfma_f32(fa[i].x, fb[j].x, acc[i][j]);
           acc[i][j] = mfma_f32(fa[i].y, fb[j].y, acc[i][j]);
           acc[i][j] = mfma_f32(fa[i].z, fb[j].z, acc[i][j]);
@@ -292,32 +297,39 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
     __syncthreads();
   }
 
-  typename EP::Col cc[2];
-  bool nv[2];
+  typename EP::Col cc[NA];
+  bool nv[NA];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + r;
+  for (int j = 0; j < NA; ++j) {
+    const int n = n0 + wn * WT + j * 32 + r;
     nv[j] = n < N;
     cc[j] = ep.col(nv[j] ? n : 0);
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NA; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int m = m0 + wm * 64 + i * 32 + mfma_row(e, h);
+      const int m = m0 + wm * WT + i * 32 + mfma_row(e, h);
       if (m < M) {
         const typename EP::Row rc = ep.row(m);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NA; ++j)
           if (nv[j]) ep.store(rc, cc[j], acc[i][j][e]);
       }
     }
 }
 
+// 128x128 tiles unless they would leave more than half of the chip's workgroup slots (2 per CU) empty
 template <class AL, class BL, class EP>
 inline void launch_gemm_f32(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream) {
   const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-  auto kfn = &gemm_f32_kernel<AL, BL, EP>;
+  if (tiles_m * tiles_n < 256 && (size_t)M * N >= 64 * 64 * 4) {
+    const int tm = (M + 63) / 64, tn = (N + 63) / 64;
+    auto kfn = &gemm_f32_kernel<AL, BL, EP, 64>;
+    MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K, tn);
+    return;
+  }
+  auto kfn = &gemm_f32_kernel<AL, BL, EP, 128>;
   MDM_LAUNCH(kfn, dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K, tiles_n);
 }
 
