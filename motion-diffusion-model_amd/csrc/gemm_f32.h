@@ -323,7 +323,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
 template <class AL, class BL, class EP>
 inline void launch_gemm_f32(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream) {
   const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-  if (tiles_m * tiles_n < 256 && (size_t)M * N >= 64 * 64 * 4) {
+  if (tiles_m * tiles_n < 512 && (size_t)M * N >= 64 * 64 * 4) {
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
     auto kfn = &gemm_f32_kernel<AL, BL, EP, 64>;
     MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K, tn);

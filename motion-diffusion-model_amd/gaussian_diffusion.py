@@ -178,11 +178,11 @@ class GaussianDiffusion:
             raise NotImplementedError("per-sample timesteps inside one sampler step are not supported")
         return i
 
-    def _step(self, model, x, t, coefs, clip_denoised, denoised_fn, cond_fn, model_kwargs, noise, draw):
+    def _step(self, model, x, t, coefs, clip_denoised, denoised_fn, cond_fn, model_kwargs, noise, draw, index=None):
         if denoised_fn is not None or cond_fn is not None:
             raise NotImplementedError("denoised_fn / cond_fn guidance is outside the MI355X hot path (no live caller)")
         y = (model_kwargs or {}).get('y', {})
-        i = self._uniform_index(t)
+        i = self._uniform_index(t) if index is None else index   # (a loop knows its index: no device round trip)
         oc, ou, scale, eng = self._model_x0_parts(model, x, t, model_kwargs)
         im = y.get('inpainting_mask', None)
         imo = y.get('inpainted_motion', None)
@@ -360,7 +360,7 @@ class GaussianDiffusion:
             for k, i in enumerate(range(start, -1, -1)):
                 t = torch.full((shape[0],), i, device=device, dtype=torch.long)
                 nz = None if noise_sequence is None else noise_sequence[1 + k]
-                out = self._step(model, img, t, coefs, clip_denoised, None, None, model_kwargs, nz, draw=1 + k)
+                out = self._step(model, img, t, coefs, clip_denoised, None, None, model_kwargs, nz, draw=1 + k, index=i)
                 img = out["sample"]
                 if dump_steps is not None and i in dump_steps:
                     dumps.append(img.clone())

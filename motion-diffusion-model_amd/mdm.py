@@ -248,28 +248,37 @@ class MDM(nn.Module):
             prefix = y['prefix'].to(device=dev, dtype=torch.float32).contiguous()
             assert prefix.shape == (bs, self.njoints, self.nfeats, self.context_len), prefix.shape
         enc = y['text_embed'] if 'text_embed' in y.keys() else self.encode_text(y['text'])
-        if isinstance(enc, tuple):
-            enc, pad = enc                                   # [Ntok, B, 768], [B or 1, Ntok] True = no token
-            pad = pad.to(dev)
-            if pad.shape[0] == 1 and bs > 1:
-                pad = pad.repeat_interleave(bs, dim=0)       # single prompt for all (mdm.py:215-216)
-            tl = (~pad).sum(dim=1)
-            # the tokenizer pads on the right (BERT_encoder.py:28): the mask is a suffix mask <=> lengths describe it
-            if not bool((pad == (torch.arange(pad.shape[1], device=dev)[None, :] >= tl[:, None])).all()):
-                raise NotImplementedError("text pad masks must be suffix masks (right-padded prompts)")
-        else:                                                # CLIP: one memory token per sample (mdm.py:262)
-            tl = torch.ones(bs, dtype=torch.int64, device=dev)
-        enc = enc.to(device=dev, dtype=torch.float32).contiguous()
-        assert enc.dim() == 3 and enc.shape[1] == bs and enc.shape[2] == self.clip_dim, enc.shape
-        lengths = None
         mask = y.get('mask', None)
-        if self.mask_frames and mask is not None and mask.shape[-1] > 1:
-            lengths = (self.context_len + mask[..., :x.shape[-1]].reshape(bs, -1).sum(dim=1)).to(device=dev, dtype=torch.int32)
-            m2 = mask[..., :x.shape[-1]].reshape(bs, -1).to(dev)
-            if not bool((m2 == (torch.arange(m2.shape[1], device=dev)[None, :] < m2.sum(dim=1)[:, None])).all()):
-                raise NotImplementedError("frame masks must be prefix masks (data_loaders/tensors.py:3-8)")
-            lengths = lengths.contiguous()
-        return prefix, enc, tl.to(torch.int32).contiguous(), lengths
+        use_mask = self.mask_frames and mask is not None and mask.shape[-1] > 1
+        # the derived token counts / frame counts (and the host-synchronising validity checks of the masks) are computed
+        # once per (embedding, mask) pair: a sampling loop calls forward with the same y every step
+        e0 = enc[0] if isinstance(enc, tuple) else enc
+        key = (e0.data_ptr(), e0._version, tuple(e0.shape), str(dev), bs, x.shape[-1],
+               (enc[1].data_ptr(), enc[1]._version) if isinstance(enc, tuple) else None,
+               (mask.data_ptr(), mask._version) if use_mask else None)
+        if getattr(self, '_dec_cache', (None,))[0] != key:
+            if isinstance(enc, tuple):
+                tok, pad = enc                               # [Ntok, B, 768], [B or 1, Ntok] True = no token
+                pad = pad.to(dev)
+                if pad.shape[0] == 1 and bs > 1:
+                    pad = pad.repeat_interleave(bs, dim=0)   # single prompt for all (mdm.py:215-216)
+                tl = (~pad).sum(dim=1)
+                # the tokenizer pads on the right (BERT_encoder.py:28): the mask is a suffix mask <=> lengths describe it
+                if not bool((pad == (torch.arange(pad.shape[1], device=dev)[None, :] >= tl[:, None])).all()):
+                    raise NotImplementedError("text pad masks must be suffix masks (right-padded prompts)")
+            else:                                            # CLIP: one memory token per sample (mdm.py:262)
+                tok, tl = enc, torch.ones(bs, dtype=torch.int64, device=dev)
+            tok = tok.to(device=dev, dtype=torch.float32).contiguous()
+            assert tok.dim() == 3 and tok.shape[1] == bs and tok.shape[2] == self.clip_dim, tok.shape
+            lengths = None
+            if use_mask:
+                m2 = mask[..., :x.shape[-1]].reshape(bs, -1).to(dev)
+                if not bool((m2 == (torch.arange(m2.shape[1], device=dev)[None, :] < m2.sum(dim=1)[:, None])).all()):
+                    raise NotImplementedError("frame masks must be prefix masks (data_loaders/tensors.py:3-8)")
+                lengths = (self.context_len + m2.sum(dim=1)).to(torch.int32).contiguous()
+            self._dec_cache = (key, (tok, tl.to(torch.int32).contiguous(), lengths))
+        tok, tl, lengths = self._dec_cache[1]
+        return prefix, tok, tl, lengths
 
     def _forward_dec(self, x, timesteps, y, branches):
         for k in ('target_cond', 'action'):
