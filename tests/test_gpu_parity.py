@@ -452,3 +452,37 @@ def test_dip_autoregressive_philox_is_deterministic(sd_dip):
     assert outs[0].shape == (B, 263, 1, frames) and torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0][..., :20], y["prefix"])            # autoregressive_include_prefix (sampler_util.py:54-55)
+
+
+def test_eval_caller_call_sequence(sd):
+    """the second production caller, CompMDMGeneratedDataset (data_loaders/humanml/motion_loaders/
+    comp_v6_model_dataset.py:148-257): batches of 32 variable-length motions, `scale` added to y by the caller, the exact
+    keyword set of its sample_fn call, repeated calls on the same model_kwargs (multimodality repeats).  The datasets are not
+    reachable here, so the batch is synthetic; two of the 32 samples are replayed through the oracle with the same noise
+    (samples are independent chains), which exercises the key-padding mask path at the caller's size."""
+    B, T, steps, scale = 32, 196, 50, 2.5
+    model, diffusion = make_pair(sd, steps, DEV, guided=True)
+    g = torch.Generator().manual_seed(77)
+    lengths = torch.randint(40, T + 1, (B,), generator=g)
+    lengths[0], lengths[1] = T, 40
+    y = synth_y(B, T, seed=78, lengths=lengths.tolist(), scale=1.0)
+    y.pop("scale")
+    y["text"] = ["synthetic caption"] * B                      # present in eval batches; the embedding is cached below
+    y["tokens"] = ["sos/OTHER_eos/OTHER"] * B
+    model_kwargs = {"y": {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in y.items()}}
+    model_kwargs["y"]["scale"] = torch.ones(B, device=DEV) * scale          # comp_v6_model_dataset.py:197-199
+    shape = (B, 263, 1, T)
+    x_T, noises = orc.make_noise(shape, steps, 79)
+    seq = [x_T] + [n.contiguous() for n in noises]
+    outs = []
+    for rep in range(2):                                                     # mm_num_repeats-style repeated calls
+        outs.append(diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs=model_kwargs, skip_timesteps=0,
+                                            init_image=None, progress=False, dump_steps=None, noise=None,
+                                            const_noise=False, noise_sequence=seq))
+    assert torch.equal(outs[0], outs[1])
+    for b in (1, 17):
+        yb = {"mask": y["mask"][b:b + 1], "lengths": y["lengths"][b:b + 1], "text_embed": y["text_embed"][:, b:b + 1],
+              "scale": torch.ones(1) * scale}
+        want = orc.sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), (1, 263, 1, T), yb, x_T[b:b + 1],
+                               [n[b:b + 1] for n in noises], cfg=True)
+        assert maxabs(outs[0][b:b + 1].cpu(), want) < TOL_LOOP["bf16x3"]
