@@ -57,8 +57,13 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
 //     V^T tile: hi|lo [128 d][64 B]); every wave issues 4 LDS-DMA pieces per tile, three tiles ahead; one counted
 //     vmcnt + one barrier per tile;
 //   * all NKT score tiles of a wave's 32 queries stay in registers, so the softmax is exact (no online rescaling).
+//   * the workgroups are PERSISTENT (grid = two per CU): a workgroup walks over its items, and while it finishes item i
+//     (last V^T tile, output) the first key tile and the Q fragments of item i+1 are already on their way -- the load
+//     latency at the start of an item and the output phase at its end were 26 + 19 of the kernel's 105 us otherwise.
 constexpr int AX_SLOT = 16384, AX_RING = 4;
-constexpr int ax_lds_bytes(int) { return 4 * 32 * AX_OLD * 4 > AX_RING * AX_SLOT ? 4 * 32 * AX_OLD * 4 : AX_RING * AX_SLOT; }
+constexpr int AX_OST = 64 + 4;   // output staging row stride (floats): 32 queries x 64 d per wave and pass, in ring slots 1-3
+constexpr int ax_lds_bytes(int) { return AX_RING * AX_SLOT; }
+static_assert(AX_SLOT + 4 * 32 * AX_OST * 4 <= AX_RING * AX_SLOT, "output staging must fit behind ring slot 0");
 
 // ABL (timing experiments only, 0 in production; results are garbage): 1 = no MFMAs, 2 = no LDS fragment reads,
 // 4 = no softmax, 8 = no output staging / stores, 16 = no K / V^T streaming after the prologue, 32 = no per-tile barrier.
@@ -80,25 +85,23 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
 #endif
   const int r = lane & 31, h = lane >> 5;
   const int H = P.H;
-  // blocks b and b+8 run on the same XCD (block -> XCD b % 8): make them the two query halves of one (sequence, head)
-  const int bid = (int)blockIdx.x;
-  const int item = (bid >> 4) * 8 + (bid & 7), half = (bid >> 3) & 1;
-  if (item >= items) return;   // whole workgroup (uniform)
-  const int seq = item / H, head = item - seq * H;
-  const size_t sh = (size_t)seq * H + head;
+  // virtual blocks vb and vb+8 run on the same XCD (block -> XCD b % 8; the grid is a multiple of 16): they are the two query
+  // halves of one (sequence, head), so the second reader of K / V^T hits L2
+  int vb = (int)blockIdx.x;
+  const int vb_total = (items + 7) / 8 * 16, vb_step = (int)gridDim.x;
+  const int half = (vb >> 3) & 1;          // the same for every item of this workgroup (vb_step % 16 == 0)
+  auto item_of = [](int b) { return (b >> 4) * 8 + (b & 7); };
+  if (item_of(vb) >= items) return;   // whole workgroup (uniform); only the last group of 8 items can be ragged
   const int qt = 4 * half + w;            // this wave's query tile
   const bool active = qt < NKT;           // (the second half has NKT - 4 tiles; idle waves still move data and sync)
-
-  int nvalid = S;  // token 0 (the condition token) is never masked; frame j-1 must be < length (mdm.py:241-247)
-  if (lengths != nullptr) nvalid = min(S, 1 + lengths[seq % B]);
   const bool last_group = S > 32 * (NKT - 1) + 16;   // does the sequence reach into the last 16-key group?
 
   // ---- tile t -> ring slot t & 3.  16 pieces of 1 KB per tile, wave w issues pieces 4w .. 4w+3 (piece = plane, idx):
   // K tile kt: idx covers 4 keys x 256 B; lane -> (row = lane>>4, stored chunk = lane&15) fetches chunk ^ (key & 15);
   // V^T tile kt: idx covers 16 d-rows x 64 B; lane -> (row = lane>>2, stored chunk = lane&3) fetches chunk ^ ((d>>2)&3).
-  const bf16_t* kbase[2] = {P.kh + sh * SP * AX_HD, P.kl + sh * SP * AX_HD};
-  const bf16_t* vbase[2] = {P.vh + sh * SP * AX_HD, P.vl + sh * SP * AX_HD};
-  auto issue_tile = [&](int t) {
+  // `lv` = the lane id, re-laundered per item (see the item loop): the per-lane source offsets of the 4 * NTILES pieces are
+  // the same for every item, and hipcc otherwise hoists all of them out of the item loop and spills them (120 VGPRs)
+  auto issue_tile = [&](size_t sh, int t, int lv) {   // tile t of (sequence, head) sh
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int j = 4 * w + i, plane = j >> 3, idx = j & 7;
@@ -106,29 +109,45 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
       if (t < NKT) {
         // pad keys (>= S) are fetched from the last real row instead: finite, cache-resident, and no HBM traffic for rows
         // nobody wrote; the swizzle still follows the LDS row
-        const int key = 32 * t + 4 * idx + (lane >> 4);
-        glds16(kbase[plane] + (size_t)min(key, S - 1) * AX_HD + (((lane & 15) ^ (key & 15)) * 8), dst);
+        const int key = 32 * t + 4 * idx + (lv >> 4);
+        glds16((plane ? P.kl : P.kh) + (sh * SP + (size_t)min(key, S - 1)) * AX_HD + (((lv & 15) ^ (key & 15)) * 8), dst);
       } else {
-        const int d = 16 * idx + (lane >> 2);
-        glds16(vbase[plane] + ((size_t)(t - NKT) * AX_HD + d) * 32 + (((lane & 3) ^ ((d >> 2) & 3)) * 8), dst);
+        const int d = 16 * idx + (lv >> 2);
+        glds16((plane ? P.vl : P.vh) + ((sh * NKT + (size_t)(t - NKT)) * AX_HD + d) * 32 + (((lv & 3) ^ ((d >> 2) & 3)) * 8),
+               dst);
       }
     }
   };
-
-  issue_tile(0);
   // ---- this wave's Q fragments: query q = 32 qt + r, k-step st covers d = 16 st + 8h .. +7
   bf16x8 qh[8], ql[8];
-  {
+  auto load_q = [&](size_t sh) {
     const size_t qo = (sh * SP + min(32 * (active ? qt : 0) + r, S - 1)) * AX_HD + 8 * h;   // pad queries: last real row
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
       qh[st] = *reinterpret_cast<const bf16x8*>(P.qh + qo + 16 * st);
       ql[st] = *reinterpret_cast<const bf16x8*>(P.ql + qo + 16 * st);
     }
-  }
-  wait_vmem_all();          // Q and tile 0 (hipcc would drain everything at the first use of Q anyway)
-  issue_tile(1);
-  if (NTILES > 2) issue_tile(2);
+  };
+  issue_tile((size_t)item_of(vb), 0, lane);
+  load_q((size_t)item_of(vb));
+
+  for (;;) {   // ---- one item = one (sequence, head); vb advances by the grid size
+  const int item = item_of(vb);
+  const int seq = item / H, head = item - seq * H;
+  const size_t sh = (size_t)item;   // == seq * H + head
+  const int vb_next = vb + vb_step;
+  const bool has_next = vb_next < vb_total && item_of(vb_next) < items;
+  int nvalid = S;  // token 0 (the condition token) is never masked; frame j-1 must be < length (mdm.py:241-247)
+  if (lengths != nullptr) nvalid = min(S, 1 + lengths[seq % B]);
+  int lv = lane;
+#ifndef MDM_EMU
+  asm volatile("" : "+v"(lv));   // opaque per item: nothing derived from it is hoisted out of the item loop
+#endif
+
+  wait_vmem_all();          // Q and tile 0 of this item (requested under the previous item), the previous item's stores
+  wg_barrier();             // every wave is done with the previous item's output staging (ring slots 1-3)
+  if (NTILES > 1) issue_tile(sh, 1, lv);
+  if (NTILES > 2) issue_tile(sh, 2, lv);
 
   f32x16 p[NKT];
 #pragma unroll
@@ -155,7 +174,15 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
     if constexpr (!(ABL & 16)) __builtin_amdgcn_s_waitcnt(0x0F70 | (4 * ahead));
 #endif
     if constexpr (!(ABL & 32)) wg_barrier();  // tile t visible to every wave; every wave is done with tile t-1 (whose slot is refilled now)
-    if constexpr (t + 3 < NTILES && !(ABL & 16)) issue_tile(t + 3);
+    if constexpr (t + 3 < NTILES && !(ABL & 16)) issue_tile(sh, t + 3, lv);
+    if constexpr (t == NTILES - 1) {
+      // the next item's first key tile (slot 0: its last tenant, tile NTILES-2 or earlier, is consumed) and Q fragments
+      // (their registers have been dead since phase 1) travel under this item's last V^T tile and its output phase
+      // (the Q load is unconditional -- the last item re-fetches its own -- so that the old fragments are dead after phase 1
+      // on every path; conditionally kept, they would stay live through phase 2: 64 VGPRs, 120 spilled)
+      if (has_next) issue_tile((size_t)item_of(vb_next), 0, lv);
+      load_q(has_next ? (size_t)item_of(vb_next) : sh);
+    }
 
     if constexpr (t < NKT) {
       // ---- phase 1, key tile t: St[key][query] += K . Q^T, three products per 16-deep k step
@@ -281,31 +308,35 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
       }
     }
   });
-  wg_barrier();  // every wave is done reading the ring: it becomes the output staging area
+  wg_barrier();  // every wave is done reading the ring: slots 1-3 become the output staging area (slot 0 is being refilled)
 
-  // ---- stage this wave's O[32 queries][128 d] (fp32, row stride AX_OLD, wave-private) and store coalesced:
-  // accumulator rows mfma_row(4g..4g+3, h) are 4 consecutive d
-  float* so = reinterpret_cast<float*>(lds) + w * (32 * AX_OLD);
+  // ---- stage this wave's O[32 queries][128 d] in two passes of 64 d (fp32, row stride AX_OST, wave-private) and store
+  // coalesced: accumulator rows mfma_row(4g..4g+3, h) are 4 consecutive d
+  float* so = reinterpret_cast<float*>(lds + AX_SLOT) + w * (32 * AX_OST);
   if (active && !(ABL & 8)) {
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = dt * 32 + 8 * g + 4 * h;
-        st4(&so[r * AX_OLD + d0], make_float4(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv,
-                                              o[dt][4 * g + 3] * inv));
-      }
-    wave_lds_fence();
     const size_t obase = (size_t)seq * S * D + head * AX_HD;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = 2 * i + h, qq = 32 * qt + row, c4 = r;   // lane -> (row parity = h, 4 consecutive d at 4 r)
-      if (qq < S) {
-        const float4 v = ld4(&so[row * AX_OLD + 4 * c4]);
-        const size_t oo = obase + (size_t)qq * D + 4 * c4;
-        if (out != nullptr) st4(out + oo, v);
-        if (oh != nullptr) split4_store(oh + oo, ol + oo, v);  // planes for the out_proj bf16x3 GEMM
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dt = 2 * pass + dd;
+          st4(&so[r * AX_OST + dd * 32 + 8 * g + 4 * h],
+              make_float4(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv));
+        }
+      wave_lds_fence();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + (lv >> 4), qq = 32 * qt + row, c4 = lv & 15;   // lane -> (row % 4, 4 consecutive d)
+        if (qq < S) {
+          const float4 v = ld4(&so[row * AX_OST + 4 * c4]);
+          const size_t oo = obase + (size_t)qq * D + 64 * pass + 4 * c4;
+          if (out != nullptr) st4(out + oo, v);
+          if (oh != nullptr) split4_store(oh + oo, ol + oo, v);  // planes for the out_proj bf16x3 GEMM
+        }
       }
+      wave_lds_fence();
     }
   }
 #ifndef MDM_EMU
@@ -315,7 +346,10 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
     asm volatile("" ::"v"(inv));
   }
 #endif
-  if constexpr ((ABL & 16) != 0) wait_vmem_all();   // experiment: the prologue's unawaited LDS-DMA must land before exit
+  if (!has_next) break;
+  vb = vb_next;
+  }   // item loop
+  wait_vmem_all();   // nothing of this workgroup may still be in flight towards its LDS when it is released
 }
 
 inline size_t attention_x3_lds_bytes(int nkt) { return (size_t)ax_lds_bytes(nkt); }

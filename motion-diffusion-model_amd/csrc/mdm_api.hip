@@ -236,8 +236,10 @@ int launch_attention_x3_t(const QkvPlanes& qp, const int* lengths, int nseq, int
   if (int rc = rt_allow_lds(k, lds)) return rc;
   // two workgroups (query halves) per (sequence, head); the item <-> block mapping pairs blocks b and b + 8 (same XCD),
   // so the number of items is rounded up to a multiple of 8 and surplus workgroups exit
+  // persistent workgroups, two per CU (the grid stays a multiple of 16 so that a workgroup keeps its query half)
   const int items = nseq * qp.H, groups = (items + 7) / 8;
-  MDM_LAUNCH(k, dim3(groups * 16), dim3(256), lds, s, qp, lengths, S, D, B, out, oh, ol, items);
+  const int grid = std::min(groups * 16, std::max(16, x3_grid_limit(2) / 16 * 16));
+  MDM_LAUNCH(k, dim3(grid), dim3(256), lds, s, qp, lengths, S, D, B, out, oh, ol, items);
   return rt_launch_status();
 }
 
