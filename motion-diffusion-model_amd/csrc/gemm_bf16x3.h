@@ -468,9 +468,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       be4 = ncol_ok ? ld4(ep.rbeta + n4) : zero4();
     }
     // accumulator values of one round, row-major, -> the GEMM's value:  fold / bias, activation, Q scale
-    auto finish4 = [&](float4 v4, int row_in_tile) __attribute__((always_inline)) {
+    auto finish4 = [&](float4 v4, float2 st) __attribute__((always_inline)) {
       if constexpr (FOLD) {
-        const float2 st = atab[row_in_tile];
         v4.x = st.y * (v4.x - st.x * c4.x) + b4.x; v4.y = st.y * (v4.y - st.x * c4.y) + b4.y;
         v4.z = st.y * (v4.z - st.x * c4.z) + b4.z; v4.w = st.y * (v4.w - st.x * c4.w) + b4.w;
       } else {
@@ -480,6 +479,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       else if (ACT == ACT_SILU) { v4.x = silu(v4.x); v4.y = silu(v4.y); v4.z = silu(v4.z); v4.w = silu(v4.w); }
       v4.x *= mult4; v4.y *= mult4; v4.z *= mult4; v4.w *= mult4;
       return v4;
+    };
+    // row statistics of the rows a lane finishes in round j (FOLD: of the A rows, RES == 3: of the residual rows).  Read ONE
+    // ROUND AHEAD, next to the patch read: fetched where it is used, each round paid a second, exposed LDS round trip
+    // (the wave-level fences keep it behind the next round's patch writes)
+    auto row_stats = [&](auto j_tag) __attribute__((always_inline)) {
+      constexpr int j = decltype(j_tag)::value;
+      if constexpr (LN_TABS && j < NROUNDS) return stab[(j / 4) * 32 + 8 * (j % 4) + prow];
+      else return make_float2(0.f, 1.f);
     };
     // 28 rounds (row sub-tile t, register group g): raw accumulators -> patch -> 16-byte row-major read.  Round j+1's
     // patch writes are issued between round j's read and its stores, so the LDS round trip of one round hides under
@@ -572,15 +579,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
           bf16_t* dl = (which == 0 ? ep.qkv.ql : ep.qkv.kl) + shq * SPq * AX_HD + d0 + pc4;
           const int nkt = ep.qkv.NKT;
           patch_write(std::integral_constant<int, 0>{});
+          float2 st_cur = row_stats(std::integral_constant<int, 0>{});
           static_for<NROUNDS>([&](auto j_tag) __attribute__((always_inline)) {
             constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
             wave_lds_fence();
             float4 v4 = ld4(&patch[prow * 32 + pc4]);
+            const float2 st_next = row_stats(std::integral_constant<int, j + 1>{});
             wave_lds_fence();
             patch_write(std::integral_constant<int, j + 1>{});
+            const float2 st = st_cur;
+            st_cur = st_next;
             if (t < nkt) {
               const int tok = 32 * t + 8 * g + prow;
-              v4 = finish4(v4, tok);
+              v4 = finish4(v4, st);
               // tokens past the sequence (only the last sub-tile can hold any when the tile is one sequence of more than
               // 192 tokens) are not stored: the attention kernel never reads Q / K pad rows
               if (t < X3_MSUB - 1 || tok < ep.S) split4_store(dh + tok * AX_HD, dl + tok * AX_HD, v4);
@@ -629,6 +640,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       }
       float2* part = reinterpret_cast<float2*>(lds + x3_part_base(WAVES)) + wid * X3_TM;   // OSTAT: this wave's partials
       patch_write(std::integral_constant<int, 0>{});
+      float2 st_cur = row_stats(std::integral_constant<int, 0>{});
       static_for<NROUNDS>([&](auto j_tag) __attribute__((always_inline)) {
         constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
         if constexpr (HAS_RES && g == 0) {
@@ -639,10 +651,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
         }
         wave_lds_fence();
         float4 v4 = ld4(&patch[prow * 32 + pc4]);
+        const float2 st_next = row_stats(std::integral_constant<int, j + 1>{});
         wave_lds_fence();
         patch_write(std::integral_constant<int, j + 1>{});
+        const float2 st = st_cur;
+        st_cur = st_next;
         const int row_in_tile = t * 32 + 8 * g + prow;
-        v4 = finish4(v4, row_in_tile);
+        v4 = finish4(v4, st);
         if (!(ABL & 1)) {
           if constexpr (RES == 1) {
             const f32x4 q4 = rr[t % RR][g];
@@ -655,7 +670,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
                 bf16_bits_to_f32((bf16_t)(a[1] & 0xffffu)) + bf16_bits_to_f32((bf16_t)(b[1] & 0xffffu)),
                 bf16_bits_to_f32((bf16_t)(a[1] >> 16)) + bf16_bits_to_f32((bf16_t)(b[1] >> 16)));
             if constexpr (RES == 3) {   // the residual is LayerNorm(x), rebuilt from x's planes and its row statistics
-              const float2 st = rtab[row_in_tile];
               x4.x = (x4.x - st.x) * st.y * g4.x + be4.x; x4.y = (x4.y - st.x) * st.y * g4.y + be4.y;
               x4.z = (x4.z - st.x) * st.y * g4.z + be4.z; x4.w = (x4.w - st.x) * st.y * g4.w + be4.w;
             }
