@@ -64,8 +64,12 @@ constexpr int x3_tab_base(int waves) { return X3_PATCH_BASE + waves * X3_PATCH_B
 constexpr int X3_RAW_BYTES = 7 * 1024;
 constexpr int x3_raw_base(int waves) { return x3_tab_base(waves) + 2 * X3_TAB_BYTES; }      // tables: 2 (tile parity)
 constexpr int x3_part_base(int waves) { return x3_raw_base(waves) + 2 * X3_RAW_BYTES; }    // raw partials: 2 (parity)
-constexpr int x3_lds_bytes(int waves, bool ln) {   // 61440 (4 waves) / 65536 (8); with the LayerNorm tables 87040 (8)
-  return ln ? x3_part_base(waves) + waves * X3_TAB_BYTES : x3_tab_base(waves);
+// last: the epilogue's per-column vectors of the tile (bias, folded column sums, residual gamma, beta: 4 x 256 floats),
+// fetched by LDS-DMA one tile ahead, double-buffered by tile parity
+constexpr int X3_CVEC_BYTES = 4 * 1024;
+constexpr int x3_cvec_base(int waves, bool ln) { return ln ? x3_part_base(waves) + waves * X3_TAB_BYTES : x3_tab_base(waves); }
+constexpr int x3_lds_bytes(int waves, bool ln) {   // 69632 (4 waves) / 73728 (8); with the LayerNorm tables 95232 (8)
+  return x3_cvec_base(waves, ln) + 2 * X3_CVEC_BYTES;
 }
 constexpr int X3_A_GROUPS = X3_A_STAGE / 1024;                   // 28 LDS-DMA wave-instructions per stage
 constexpr int x3_a_pieces(int waves) { return (X3_A_GROUPS + waves - 1) / waves; }  // 7 (4 waves) / 4 (8 waves)
@@ -291,10 +295,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       glds16(st + fo, lds + x3_raw_base(WAVES) + par * X3_RAW_BYTES + wid * 1024);
     }
   };
-  if constexpr (FOLD || RES == 3) {
+  // the epilogue's per-column vectors of the tile starting at column n0c -> LDS buffer `par`: wave 0 bias, wave 1 folded
+  // column sums (FOLD), waves 2 / 3 residual gamma / beta (RES == 3); 1 KB = the tile's 256 columns each (columns past N:
+  // clamped source, never stored)
+  constexpr bool LN_ANY = FOLD || OSTAT || RES == 3;
+  auto cvec_dma = [&](int n0c, int par) {
+    const float* src = nullptr;
+    if (wid == 0) src = ep.bias;
+    if constexpr (FOLD) { if (wid == 1) src = ep.colsum; }
+    if constexpr (RES == 3) { if (wid == 2) src = ep.rgamma; if (wid == 3) src = ep.rbeta; }
+    if (src != nullptr) glds16(src + min(n0c + 4 * lane, N - 4), lds + x3_cvec_base(WAVES, LN_ANY) + par * X3_CVEC_BYTES + wid * 1024);
+  };
+  {
     int m0f, n0f;
     tile_origin(v, m0f, n0f);
-    stats_dma(m0f, 0);
+    if constexpr (FOLD || RES == 3) stats_dma(m0f, 0);
+    cvec_dma(n0f, 0);
   }
   bf16x8 wh[2], wl[2], wnh[2], wnl[2];
 #pragma unroll
@@ -315,16 +331,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // T16: rows 192-207 x columns 0-15 / 16-31 of the wave
-    // this lane's bias, fetched (and its wait retired: hipcc waits vmcnt(0) for a tracked load) at the START of the tile,
-    // so that the epilogue's untracked residual loads are not drained by it
     const int ncol0 = n0 + wid * 32;                     // this wave's first column (wave-uniform)
-    const int nc = ncol0 + r;                            // this lane's column in the accumulator layout
-    float bias = (nc < N) ? ep.bias[nc] : 0.f;
-    float csum = 0.f;                                    // FOLD, accumulator layout (V^T path)
-    if constexpr (FOLD) csum = (nc < N) ? ep.colsum[nc] : 0.f;
-#ifndef MDM_EMU
-    asm volatile("" : "+v"(bias), "+v"(csum));
-#endif
+    // this tile's per-column epilogue vectors are in LDS buffer `tile_parity` (requested one tile ago / in the prologue: no
+    // global-load latency in front of the epilogue); the next tile's are requested now and land under this tile's k-loop
+    const float* const cvec = reinterpret_cast<const float*>(lds + x3_cvec_base(WAVES, LN_ANY) + tile_parity * X3_CVEC_BYTES);
+    if (v + gstride < total) {
+      int m0n, n0n;
+      tile_origin(v + gstride, m0n, n0n);
+      cvec_dma(n0n, tile_parity ^ 1);
+    }
     // row statistics (mean, rstd) of this tile's rows, built HERE -- where the accumulators are not live yet -- from the
     // producer's partial sums, which an LDS-DMA issued one tile ago (or in the kernel prologue) has already landed; the
     // next tile's partials are requested now and land under this tile's k-loop.  Tables and raw buffers alternate with
@@ -458,15 +473,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     const int prow = lane >> 3, pc4 = (lane & 7) * 4;
     const int n4 = ncol0 + pc4;                          // first of this lane's 4 columns in the row layout
     // per-lane column vectors of the row-major side: bias (or folded bias), Q scale, folded column sums, residual gamma/beta
-    const bool ncol_ok = n4 < N;                         // N % 4 == 0
-    const float4 b4 = ncol_ok ? ld4(ep.bias + n4) : zero4();
+    const int cl4 = wid * 32 + pc4;                      // this lane's first column inside the tile
+    const float4 b4 = ld4(cvec + cl4);
     const float mult4 = (n4 < ep.scale_cols) ? ep.col_scale : 1.f;   // scale_cols is a multiple of the tile width
     float4 c4 = zero4(), g4 = zero4(), be4 = zero4();
-    if constexpr (FOLD) c4 = ncol_ok ? ld4(ep.colsum + n4) : zero4();
+    if constexpr (FOLD) c4 = ld4(cvec + 256 + cl4);
     if constexpr (RES == 3) {
-      g4 = ncol_ok ? ld4(ep.rgamma + n4) : zero4();
-      be4 = ncol_ok ? ld4(ep.rbeta + n4) : zero4();
+      g4 = ld4(cvec + 512 + cl4);
+      be4 = ld4(cvec + 768 + cl4);
     }
+    // the same in the accumulator layout (lane -> column r of the wave's 32): V^T path
+    const float bias = cvec[wid * 32 + r];
+    float csum = 0.f;
+    if constexpr (FOLD) csum = cvec[256 + wid * 32 + r];
     // accumulator values of one round, row-major, -> the GEMM's value:  fold / bias, activation, Q scale
     auto finish4 = [&](float4 v4, float2 st) __attribute__((always_inline)) {
       if constexpr (FOLD) {
