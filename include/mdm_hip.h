@@ -201,6 +201,8 @@ int mdm_profile_reset(mdm_model_t* m);
  * (gemm_bf16x3.h ABL); what = 1: mdm_linear_bf16x3 reuses the operand planes already in scratch (kernel-only timing); what = 2: waves per
  * bf16x3 GEMM workgroup, 8 (default: 224x256 tiles, one workgroup per CU) or 4 (224x128 tiles, two per CU). */
 int mdm_debug_set(int what, int value);
+/* Timing experiments only: cycle counters of the split-precision GEMM's ablation build (idx 0..7; idx < 0 resets). */
+int mdm_debug_get(int idx, double* out);
 
 /* Building blocks, exported for the parity tests and for callers that compose their own layers.
  *   mdm_linear:    out[M,N] = act(in[M,K] . w[N,K]^T + bias) (+ res)     act: 0 none, 1 gelu(erf), 2 silu

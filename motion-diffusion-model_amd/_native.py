@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "mdm_prepare", "mdm_workspace_bytes", "mdm_forward", "mdm_sampler_step", "mdm_randn", "mdm_sample_loop",
     "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset", "mdm_set_precision", "mdm_linear_bf16x3",
     "mdm_linear_bf16x3_scratch_bytes", "mdm_debug_set", "mdm_attention_bf16x3", "mdm_attention_bf16x3_scratch_bytes", "mdm_recover_from_ric",
-    "mdm_workspace_bytes_dec", "mdm_forward_dec",
+    "mdm_workspace_bytes_dec", "mdm_forward_dec", "mdm_debug_get",
 ]
 ABI_VERSION = 2
 ARCH = {"trans_enc": 0, "trans_dec": 1}
@@ -84,6 +84,7 @@ class MdmLib:
             "mdm_attention": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
             "mdm_set_precision": (C.c_int, [vp, i32]),
             "mdm_debug_set": (C.c_int, [C.c_int, C.c_int]),
+            "mdm_debug_get": (C.c_int, [C.c_int, P(C.c_double)]),
             "mdm_linear_bf16x3_scratch_bytes": (sz, [i32, i32, i32]),
             "mdm_linear_bf16x3": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
             "mdm_attention_bf16x3_scratch_bytes": (sz, [i32, i32, i32]),

@@ -169,6 +169,14 @@ constexpr int x3_res_younger_rounds(int t, int rr, bool t16) {
   return n;
 }
 
+// ABL & 128 (timing experiment): cycles (s_memtime) wave 0 of every workgroup spends [0] in the end-of-step vmcnt(0) of a
+// tile's FIRST k step -- which also drains the previous tile's epilogue stores --, [1] in the same wait of all other steps,
+// [2] in whole k-loops, [3] in whole epilogues; [4] tiles, [5] k steps.  Read with mdm_debug_get.
+#ifndef MDM_EMU
+__device__ unsigned long long g_x3_dbg[8];
+__device__ __forceinline__ unsigned long long x3_now() { return __builtin_readcyclecounter(); }
+#endif
+
 // The A load stream: which tile of this workgroup and which k step it fetches next, and the per-lane source element
 // offsets of the wave's seven LDS-DMA pieces for that tile.
 template <int PIECES>
@@ -370,6 +378,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     }
     float2* const atab = stab;   // FOLD: statistics of the A rows;  RES == 3: of the residual rows (a kernel has one)
     float2* const rtab = stab;
+#ifndef MDM_EMU
+    unsigned long long dbg_t0 = 0, dbg_w0 = 0, dbg_w1 = 0, dbg_bar = 0;
+    if constexpr ((ABL & 128) != 0) dbg_t0 = x3_now();
+#endif
     for (int kt = 0; kt < nk; ++kt) {
       // W(g+1): advance the W stream and fetch (past the last tile: re-fetch, like the A stream)
       if (++wkk == nk) {
@@ -455,7 +467,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       });
 #undef X3_RD_A
       advance_a(ca);
+#ifndef MDM_EMU
+      if constexpr ((ABL & 128) != 0) {
+        const unsigned long long a0 = x3_now();
+        wait_vmem_all();
+        const unsigned long long a1 = x3_now();
+        if (kt == 0) dbg_w0 += a1 - a0; else dbg_w1 += a1 - a0;
+      }
+#endif
       if (!(ABL & 8)) wait_vmem_all();   // 8: experiment -- loads issued but never waited for (results are garbage)
+#ifndef MDM_EMU
+      if constexpr ((ABL & 128) != 0) {
+        const unsigned long long b0 = x3_now();
+        wg_barrier();
+        dbg_bar += x3_now() - b0;
+      }
+#endif
       wg_barrier();
       abuf ^= 1;
       if (!(ABL & 2)) {
@@ -468,6 +495,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     // each wave transposes 8 rows x 32 columns at a time (accumulator registers 4g..4g+3 of both lane halves) through
     // its private 1 KB LDS patch -- disjoint from the A stages, which already hold the next tile's first stage
     // -- and writes 16 bytes per lane: lane -> (row = lane>>3, 4 consecutive columns).
+#ifndef MDM_EMU
+    unsigned long long dbg_t1 = 0;
+    if constexpr ((ABL & 128) != 0) dbg_t1 = x3_now();
+#endif
     const int m_end = min(M, m0 + rows_per_tile);
     float* patch = reinterpret_cast<float*>(lds + X3_PATCH_BASE) + wid * (X3_PATCH_BYTES / 4);  // [8][32] fp32
     const int prow = lane >> 3, pc4 = (lane & 7) * 4;
@@ -734,6 +765,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
         }
       }
     }
+#ifndef MDM_EMU
+    if constexpr ((ABL & 128) != 0) {
+      const unsigned long long t2 = x3_now();
+      if (tid == 0) {
+        atomicAdd(&g_x3_dbg[0], dbg_w0); atomicAdd(&g_x3_dbg[1], dbg_w1); atomicAdd(&g_x3_dbg[2], dbg_t1 - dbg_t0);
+        atomicAdd(&g_x3_dbg[3], t2 - dbg_t1); atomicAdd(&g_x3_dbg[4], 1ULL); atomicAdd(&g_x3_dbg[5], (unsigned long long)nk); atomicAdd(&g_x3_dbg[6], dbg_bar);
+      }
+    }
+#endif
   }
   wait_vmem_all();  // the stream's last (unused) LDS-DMA stage must land before this workgroup's LDS is released
 }
@@ -862,6 +902,7 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Ep
       case 16: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 16>(A, W, ep, M, N, K, rpt, s);
       case 32: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 32>(A, W, ep, M, N, K, rpt, s);
       case 64: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 64>(A, W, ep, M, N, K, rpt, s);
+      case 128: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 128>(A, W, ep, M, N, K, rpt, s);
       case 9: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 9>(A, W, ep, M, N, K, rpt, s);
       default: return -2;
     }

@@ -1002,6 +1002,20 @@ int mdm_debug_set(int what, int value) {
   return MDM_OK;
 }
 
+int mdm_debug_get(int idx, double* out) {   // ABL & 128 cycle counters of gemm_bf16x3.h; idx < 0 resets them
+#ifndef MDM_EMU
+  unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (idx < 0) return hipMemcpyToSymbol(HIP_SYMBOL(g_x3_dbg), v, sizeof(v)) == hipSuccess ? MDM_OK : fail(MDM_EHIP, "mdm_debug_get: reset failed");
+  if (idx >= 8 || out == nullptr) return fail(MDM_EINVAL, "mdm_debug_get: bad argument");
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_x3_dbg), sizeof(v)) != hipSuccess) return fail(MDM_EHIP, "mdm_debug_get: read failed");
+  *out = (double)v[idx];
+#else
+  if (out != nullptr) *out = 0.0;
+  (void)idx;
+#endif
+  return MDM_OK;
+}
+
 int mdm_profile_enable(mdm_model_t* m, int on) {
   if (m == nullptr) return fail(MDM_EINVAL, "mdm_profile_enable: null model");
   m->prof.on = on != 0;
