@@ -341,13 +341,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // T16: rows 192-207 x columns 0-15 / 16-31 of the wave
     const int ncol0 = n0 + wid * 32;                     // this wave's first column (wave-uniform)
     // this tile's per-column epilogue vectors are in LDS buffer `tile_parity` (requested one tile ago / in the prologue: no
-    // global-load latency in front of the epilogue); the next tile's are requested now and land under this tile's k-loop
+    // global-load latency in front of the epilogue); the next tile's are requested in this tile's SECOND k step (below),
+    // i.e. behind a workgroup barrier every wave reaches only after its epilogue of the previous tile -- whose vectors
+    // live in the buffer being refilled -- and land under the rest of this tile's k-loop
     const float* const cvec = reinterpret_cast<const float*>(lds + x3_cvec_base(WAVES, LN_ANY) + tile_parity * X3_CVEC_BYTES);
-    if (v + gstride < total) {
-      int m0n, n0n;
-      tile_origin(v + gstride, m0n, n0n);
-      cvec_dma(n0n, tile_parity ^ 1);
-    }
+    const int kt_cvec = nk > 1 ? 1 : 0;
+    if (nk == 1) wg_barrier();   // single-step contractions: no k-step barrier in front of the request
     // row statistics (mean, rstd) of this tile's rows, built HERE -- where the accumulators are not live yet -- from the
     // producer's partial sums, which an LDS-DMA issued one tile ago (or in the kernel prologue) has already landed; the
     // next tile's partials are requested now and land under this tile's k-loop.  Tables and raw buffers alternate with
@@ -383,6 +382,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     if constexpr ((ABL & 128) != 0) dbg_t0 = x3_now();
 #endif
     for (int kt = 0; kt < nk; ++kt) {
+      if (kt == kt_cvec && v + gstride < total) {
+        int m0n, n0n;
+        tile_origin(v + gstride, m0n, n0n);
+        cvec_dma(n0n, tile_parity ^ 1);
+      }
       // W(g+1): advance the W stream and fetch (past the last tile: re-fetch, like the A stream)
       if (++wkk == nk) {
         wkk = 0;
