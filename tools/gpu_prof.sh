@@ -6,10 +6,12 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$PWD
+if [ "${SKIP_TRACE:-0}" != "1" ]; then   # SKIP_TRACE=1: PMC passes only (tools/gpu_round.sh already took the kernel trace)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o trace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/$OUT/prof_bench.json 2> $R/$OUT/prof.err)
 DB=$(find $OUT/prof -name '*.db' | head -1)
 if [ -n "$DB" ]; then python tools/rocpd_summary.py $DB > $OUT/kernel_stats.md; cat $OUT/kernel_stats.md | cut -c1-200 | head -16; rm -f $DB; fi
 find $OUT/prof -name '*.csv' -size +2M -delete
+fi
 if [ "${2:-}" = "pmc" ]; then
   # counters in their own passes (no trace domains besides --kernel-trace): HBM bytes, MFMA busy, LDS conflicts
   i=0
