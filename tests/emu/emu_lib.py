@@ -6,7 +6,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SO = os.path.join(ROOT, "build", "libmdm_emu.so")
+SO = os.environ.get("MDM_EMU_SO", os.path.join(ROOT, "build", "libmdm_emu.so"))
 SRC_DIR = os.path.join(ROOT, "motion-diffusion-model_amd", "csrc")
 _lib = None
 
