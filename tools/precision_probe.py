@@ -1,0 +1,117 @@
+"""CPU probe (no GPU): trajectory error of candidate GEMM operand decompositions on the oracle's 50-step guided loop.
+
+The production `bf16x3` GEMM carries an fp32 product by three bf16 MFMA passes (ah*wh + ah*wl + al*wh).  This probe
+patches torch.nn.functional.linear inside the oracle (test infrastructure) with emulations of cheaper schemes and reports
+the max-abs trajectory error against the fp32 oracle on the same weights / noise -- the figure BASELINE's 1e-3 bar is on:
+
+  bf16x3     the production scheme (reference point)
+  f16x3      fp16 hi/lo split, three passes
+  f16+f8x2   fp16 main term + the two cross terms on FP8 (e4m3) operands with power-of-two block scales over 32 k
+             (the MX block format of gfx950's v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 MFMA rate: 2 passes' worth)
+  bf16+f8x2  same with a bf16 main term
+  f16+f6x2   cross terms on MX-FP6 (E2M3) operands: four times the fp16 MFMA rate (1.5 passes' worth);  f16+f4x2: MX-FP4
+Usage: python tools/precision_probe.py [B] [steps]"""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import mdm_oracle as orc  # noqa: E402
+from oracle.synth import synth_state_dict, synth_y  # noqa: E402
+
+_real_linear = F.linear
+
+
+def split(x, dt):
+    hi = x.to(dt).float()
+    return hi, x - hi
+
+
+def f8_block(x, block=32):
+    """round to e4m3 with one power-of-two scale per `block` consecutive k (last dim)"""
+    sh = x.shape
+    k = sh[-1]
+    pad = (-k) % block
+    xp = F.pad(x, (0, pad)).reshape(*sh[:-1], -1, block)
+    amax = xp.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    scale = torch.exp2(torch.floor(torch.log2(448.0 / amax)))          # e8m0-style scale: a power of two
+    q = (xp * scale).to(torch.float8_e4m3fn).float() / scale
+    return q.reshape(*sh[:-1], -1)[..., :k]
+
+
+def mx_block(x, fmt, block=32):
+    """round to an MX element format (OCP Microscaling v1.0) with one power-of-two scale per `block` consecutive k:
+    fp6 = E2M3 (max 7.5, 3 mantissa bits), fp4 = E2M1 (max 6, 1 mantissa bit); round-to-nearest, saturating"""
+    mbits, emax_val, emax = {"fp6": (3, 7.5, 2), "fp4": (1, 6.0, 2)}[fmt]
+    sh = x.shape
+    k = sh[-1]
+    pad = (-k) % block
+    xp = F.pad(x, (0, pad)).reshape(*sh[:-1], -1, block)
+    amax = xp.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    # MX convention: shared exponent = floor(log2(amax)) - emax_elem  (elements may saturate slightly above 2^emax * 1.x)
+    scale = torch.exp2(emax - torch.floor(torch.log2(amax)))
+    v = (xp * scale).clamp(-emax_val, emax_val)
+    e = torch.floor(torch.log2(v.abs().clamp_min(1e-30))).clamp(min=0.0)      # exponent of the binade; subnormals share e = 0
+    step = torch.exp2(e - mbits)
+    q = torch.round(v / step) * step
+    q = q.clamp(-emax_val, emax_val) / scale
+    return q.reshape(*sh[:-1], -1)[..., :k]
+
+
+def make_linear(scheme):
+    def lin(x, w, b=None):
+        if scheme == "f32":
+            return _real_linear(x, w, b)
+        main_dt = torch.bfloat16 if scheme.startswith("bf16") else torch.float16
+        ah, al = split(x, main_dt)
+        wh, wl = split(w, main_dt)
+        if scheme in ("bf16x3", "f16x3"):
+            al, wl = al.to(main_dt).float(), wl.to(main_dt).float()
+            y = _real_linear(ah, wh) + _real_linear(ah, wl) + _real_linear(al, wh)
+        elif scheme in ("f16+f8x2", "bf16+f8x2"):
+            y = _real_linear(ah, wh) + _real_linear(f8_block(ah), f8_block(wl)) + _real_linear(f8_block(al), f8_block(wh))
+        elif scheme in ("f16+f6x2", "f16+f4x2"):
+            fmt = "fp6" if "f6" in scheme else "fp4"
+            y = _real_linear(ah, wh) + _real_linear(mx_block(ah, fmt), mx_block(wl, fmt)) + \
+                _real_linear(mx_block(al, fmt), mx_block(wh, fmt))
+        elif scheme == "f16+f8a.f6w":   # activations-side operands fp8, weight-side operands fp6 (mixed formats are allowed)
+            y = _real_linear(ah, wh) + _real_linear(f8_block(ah), mx_block(wl, "fp6")) + \
+                _real_linear(f8_block(al), mx_block(wh, "fp6"))
+        elif scheme in ("f16x1", "bf16x1"):
+            y = _real_linear(ah, wh)
+        else:
+            raise ValueError(scheme)
+        return y if b is None else y + b
+    return lin
+
+
+def run(scheme, sd, tab, shape, y, x_T, noises):
+    F.linear = make_linear(scheme)
+    try:
+        return orc.sample_loop(sd, tab, shape, y, x_T, noises, cfg=True)
+    finally:
+        F.linear = _real_linear
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    T = 196
+    sd = synth_state_dict(seed=0)
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    shape = (B, 263, 1, T)
+    y = synth_y(B, T, seed=7, lengths=[T, T - 50][:B] + [T] * max(0, B - 2))
+    x_T, noises = orc.make_noise(shape, steps, seed=3)
+    with torch.no_grad():
+        ref = run("f32", sd, tab, shape, y, x_T, noises)
+        print(f"|x0| max {ref.abs().max().item():.3f}", flush=True)
+        for scheme in ("bf16x3", "f16x3", "f16+f8x2", "f16+f6x2", "f16+f8a.f6w", "f16+f4x2", "bf16+f8x2", "f16x1"):
+            got = run(scheme, sd, tab, shape, y, x_T, noises)
+            print(f"{scheme:10s} max-abs vs fp32 oracle: {(got - ref).abs().max().item():.3e}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
