@@ -33,7 +33,7 @@ extern "C" {
 #define MDM_EHIP (-4)     /* a HIP runtime call failed                         */
 #define MDM_EUNSUPPORTED (-5)
 
-#define MDM_ABI_VERSION 2
+#define MDM_ABI_VERSION 3
 
 typedef struct mdm_model mdm_model_t;
 
@@ -217,6 +217,14 @@ size_t mdm_linear_bf16x3_scratch_bytes(int32_t M, int32_t N, int32_t K);
 int mdm_linear_bf16x3(const float* in_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
                       float* out_dev, int32_t M, int32_t N, int32_t K, int32_t act, void* scratch_dev,
                       size_t scratch_bytes, void* stream);
+/*   mdm_linear_f16f6: the same contract (res may be null) on the SEED of the next split-precision GEMM (csrc/gemm_f16f6.h:
+ *                      one fp16 MFMA pass + two cross terms on block-scaled MX-FP6 operands, K % 64 == 0), through a
+ *                      reference kernel -- exported so that the quantiser, the plane layout and the instruction semantics are
+ *                      under parity tests before the model's GEMMs move to it; `scratch_dev` receives both operands' planes. */
+size_t mdm_linear_f16f6_scratch_bytes(int32_t M, int32_t N, int32_t K);
+int mdm_linear_f16f6(const float* in_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
+                     float* out_dev, int32_t M, int32_t N, int32_t K, int32_t act, void* scratch_dev,
+                     size_t scratch_bytes, void* stream);
 int mdm_layernorm(float* x_dev, const float* gamma_dev, const float* beta_dev, int32_t rows, int32_t D, void* stream);
 int mdm_attention(const float* qkv_dev, float* out_dev, const int32_t* lengths_dev, int32_t nseq, int32_t B,
                   int32_t S, int32_t D, int32_t H, void* stream);

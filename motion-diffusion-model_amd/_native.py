@@ -20,11 +20,11 @@ PROF_CLASSES = ("linear", "attention", "layernorm", "embed", "outproj", "element
 EXPORTED_SYMBOLS = [
     "mdm_abi_version", "mdm_last_error", "mdm_create", "mdm_destroy", "mdm_set_weight", "mdm_const_bytes",
     "mdm_prepare", "mdm_workspace_bytes", "mdm_forward", "mdm_sampler_step", "mdm_randn", "mdm_sample_loop",
-    "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset", "mdm_set_precision", "mdm_linear_bf16x3",
+    "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset", "mdm_set_precision", "mdm_linear_bf16x3", "mdm_linear_f16f6", "mdm_linear_f16f6_scratch_bytes",
     "mdm_linear_bf16x3_scratch_bytes", "mdm_debug_set", "mdm_attention_bf16x3", "mdm_attention_bf16x3_scratch_bytes", "mdm_recover_from_ric",
     "mdm_workspace_bytes_dec", "mdm_forward_dec", "mdm_debug_get",
 ]
-ABI_VERSION = 2
+ABI_VERSION = 3
 ARCH = {"trans_enc": 0, "trans_dec": 1}
 
 
@@ -87,6 +87,8 @@ class MdmLib:
             "mdm_debug_get": (C.c_int, [C.c_int, P(C.c_double)]),
             "mdm_linear_bf16x3_scratch_bytes": (sz, [i32, i32, i32]),
             "mdm_linear_bf16x3": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+            "mdm_linear_f16f6_scratch_bytes": (sz, [i32, i32, i32]),
+            "mdm_linear_f16f6": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
             "mdm_attention_bf16x3_scratch_bytes": (sz, [i32, i32, i32]),
             "mdm_attention_bf16x3": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
             "mdm_recover_from_ric": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

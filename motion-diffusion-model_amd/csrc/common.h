@@ -44,6 +44,30 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 #endif
 }
 
+// ---- the instructions of the "f16f6" seed GEMM (gemm_f16f6.h)
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// v_mfma_f32_32x32x16_f16: operand / result layout of mfma_bf16 above, fp16 elements.
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
+#ifdef MDM_EMU
+  return emu::mfma_f32_32x32x16_f16(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+// v_mfma_scale_f32_32x32x64_f8f6f4 with both operands FP6 E2M3 (cbsz = blgp = 2): lane l supplies the 32 consecutive k of
+// k-block (l>>5) of row / column (l&31) as 32 six-bit codes (element j at bit 6j of dwords 0-5; dwords 6-7 unused) and that
+// block's E8M0 scale (2^(byte - 127)) in byte 0 of scale_a / scale_b; D layout as above.  Semantics verified on the MI355X
+// against a host reference (tools/mx/mx_probe.hip part A, profiles/r01h_mx_probe.txt).
+__device__ __forceinline__ f32x16 mfma_mx_fp6(i32x8 a, i32x8 b, f32x16 c, int scale_a, int scale_b) {
+#ifdef MDM_EMU
+  return emu::mfma_scale_f32_32x32x64_fp6(a, b, c, scale_a, scale_b);
+#else
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 2, 2, 0, scale_a, 0, scale_b);
+#endif
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 

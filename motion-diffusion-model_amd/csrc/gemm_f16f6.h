@@ -1,0 +1,154 @@
+// SEED of the next split-precision GEMM ("f16f6"), NOT used by the model yet:
+//     C[m][n] = sum_k A[m][k] * W[n][k],   a*w ~ ah*wh + q6(ah)*q6(wl) + q6(al)*q6(wh)
+// ah = fp16(a), al = a - ah (same for w); q6 = MX-FP6 (OCP Microscaling E2M3) with one power-of-two scale (E8M0) per 32
+// consecutive k.  The main term is ONE v_mfma_f32_32x32x16_f16 pass; the two cross terms -- 2^-11 of it, so ~5 bits do -- run on
+// v_mfma_scale_f32_32x32x64_f8f6f4, which gfx950 executes at four times the fp16 rate: 1.5 pass-equivalents instead of the
+// three bf16 passes of gemm_bf16x3.h (measured at the matrix pipe: 1.75x; 50-step trajectory error 9.8e-5 vs 4.4e-5, bar 1e-3:
+// tools/precision_probe.py, tools/mx/, profiles/r01h_*).  Replaces nothing in the reference that gemm_bf16x3.h does not
+// already replace (the `addmm`s of model/mdm.py:77-84).
+//
+// This file pins down what the production kernel will be built on and is exercised by the emulator and GPU parity tests
+// through mdm_linear_f16f6: the quantiser, the operand plane layout, the fragment <-> plane mapping of both instructions,
+// and a REFERENCE kernel (one wave per 32x32 output tile, fragments straight from global memory -- correct, not fast).
+//
+// Operand planes of a matrix X [R][K] (K % 64 == 0):
+//     h16 [R][K]             fp16 hi
+//     rec [R][K/32][16 dw]   one 64-byte record per row and 32-k block: dwords 0-5 FP6 codes of hi (element j at bit 6j),
+//                            6-11 FP6 codes of lo, dword 12 = scale bytes (byte 0: hi block, byte 1: lo block; 127 + e), 13-15 pad
+// i.e. 2 + 2 bytes per element, the byte geometry of gemm_bf16x3.h's hi / lo planes (its LDS-DMA staging carries over).
+// Fragments: fp16 MFMA, k sub-step s of a 64-deep step: lane (r = lane & 31, h = lane >> 5) holds k = 16 s + 8 h .. + 7 of
+// row (column) r; scaled MFMA: the lane holds the 32 k of block h of row (column) r and that block's scale in byte 0.
+#pragma once
+#include "common.h"
+#include "gemm_f32.h"  // ACT_* enums
+
+namespace mdm {
+
+struct F6Planes {
+  f16_t* h16;
+  uint32_t* rec;
+};
+inline size_t f6_align256(size_t v) { return (v + 255) / 256 * 256; }
+inline size_t f6_plane_bytes(int R, int K) { return f6_align256((size_t)R * K * 2) + f6_align256((size_t)R * (K / 32) * 64); }
+inline F6Planes f6_carve(void* base, int R, int K) {
+  return F6Planes{static_cast<f16_t*>(base),
+                  reinterpret_cast<uint32_t*>(static_cast<char*>(base) + f6_align256((size_t)R * K * 2))};
+}
+
+// shared exponent e of an MX block with maximum magnitude amax: elements are x * 2^-e with |.| < 8 (E2M3 tops out at 7.5)
+__host__ __device__ inline int mx_block_exp(float amax) {
+  if (!(amax > 0.f)) return 0;
+  int ex;
+  frexpf(amax, &ex);          // amax = f * 2^ex, f in [0.5, 1): floor(log2 amax) = ex - 1
+  return (ex - 1) - 2;        // E2M3's largest binade is [4, 8)
+}
+// FP6 E2M3 (1 sign, 2 exponent bits with bias 1, 3 mantissa bits; no inf / nan): round to nearest even, saturate at 7.5
+__host__ __device__ inline uint32_t fp6_e2m3_encode(float x) {
+  const uint32_t s = x < 0.f ? 1u : 0u;
+  float v = fminf(fabsf(x), 7.5f);
+  const int ex = v >= 4.f ? 2 : (v >= 2.f ? 1 : 0);          // [0, 2) shares the step 1/8 (subnormals + first binade)
+  const float step = ex == 2 ? 0.5f : (ex == 1 ? 0.25f : 0.125f);
+  const float q = fminf(rintf(v / step) * step, 7.5f);       // may land on the first value of the next binade
+  uint32_t code;
+  if (q < 1.f) code = (uint32_t)(q * 8.f);
+  else {
+    const int e2 = q >= 4.f ? 2 : (q >= 2.f ? 1 : 0);
+    const float m = q * (e2 == 2 ? 0.25f : (e2 == 1 ? 0.5f : 1.f)) - 1.f;
+    code = ((uint32_t)(e2 + 1) << 3) | (uint32_t)(m * 8.f);
+  }
+  return (s << 5) | code;
+}
+__host__ __device__ inline float fp6_e2m3_decode(uint32_t code) {
+  const uint32_t s = (code >> 5) & 1u, e = (code >> 3) & 3u, m = code & 7u;
+  const float v = (e == 0) ? m * 0.125f : (1.f + m * 0.125f) * (e == 1 ? 1.f : (e == 2 ? 2.f : 4.f));
+  return s ? -v : v;
+}
+
+// fp32 [R][K] -> planes; one thread per (row, 32-k block).  (The production path will never run this: its planes are written
+// by the producing GEMM's epilogue, where a wave's 32 output columns are exactly one block.)
+__global__ __launch_bounds__(256) void pack_f16f6_kernel(const float* __restrict__ x, F6Planes p, int R, int K) {
+  const int nb = K / 32;
+  const int blk = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (blk >= R * nb) return;
+  const int row = blk / nb, b = blk - row * nb;
+  const float* src = x + (size_t)row * K + b * 32;
+  f16_t* dst = p.h16 + (size_t)row * K + b * 32;
+  float mh = 0.f, ml = 0.f;
+  for (int j = 0; j < 32; ++j) {
+    const f16_t hv = (f16_t)src[j];
+    dst[j] = hv;
+    mh = fmaxf(mh, fabsf((float)hv));
+    ml = fmaxf(ml, fabsf(src[j] - (float)hv));
+  }
+  const int eh = mx_block_exp(mh), el = mx_block_exp(ml);
+  uint32_t wh[7] = {0, 0, 0, 0, 0, 0, 0}, wl[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < 32; ++j) {
+    const float hv = (float)dst[j];
+    const uint32_t ch = fp6_e2m3_encode(ldexpf(hv, -eh)), cl = fp6_e2m3_encode(ldexpf(src[j] - hv, -el));
+    const int bit = 6 * j, w = bit >> 5, o = bit & 31;
+    wh[w] |= ch << o;
+    wl[w] |= cl << o;
+    if (o > 26) {
+      wh[w + 1] |= ch >> (32 - o);
+      wl[w + 1] |= cl >> (32 - o);
+    }
+  }
+  uint32_t* rec = p.rec + (size_t)blk * 16;
+  for (int w = 0; w < 6; ++w) {
+    rec[w] = wh[w];
+    rec[6 + w] = wl[w];
+  }
+  rec[12] = (uint32_t)(127 + eh) | ((uint32_t)(127 + el) << 8);
+  rec[13] = rec[14] = rec[15] = 0;
+}
+
+// REFERENCE kernel: one wave per 32x32 tile of out = act(A.W^T + bias) (+ res); ragged M / N: clamped loads, masked stores
+template <int ACT>
+__global__ __launch_bounds__(64) void gemm_f16f6_ref_kernel(F6Planes A, F6Planes W, const float* __restrict__ bias,
+                                                            const float* res, float* out, int M, int N, int K) {
+  const int lane = (int)threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int m0 = (int)blockIdx.y * 32, n0 = (int)blockIdx.x * 32;
+  const int nb = K / 32;
+  const size_t ar = (size_t)min(m0 + r, M - 1), wr = (size_t)min(n0 + r, N - 1);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f16x8 a = *reinterpret_cast<const f16x8*>(A.h16 + ar * K + k0 + 16 * s + 8 * h);
+      const f16x8 w = *reinterpret_cast<const f16x8*>(W.h16 + wr * K + k0 + 16 * s + 8 * h);
+      acc = mfma_f16(a, w, acc);
+    }
+    const uint32_t* ra = A.rec + (ar * nb + (k0 >> 5) + h) * 16;
+    const uint32_t* rw = W.rec + (wr * nb + (k0 >> 5) + h) * 16;
+    i32x8 ah6, al6, wh6, wl6;
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+      ah6[w] = (int)ra[w];
+      al6[w] = (int)ra[6 + w];
+      wh6[w] = (int)rw[w];
+      wl6[w] = (int)rw[6 + w];
+    }
+    ah6[6] = ah6[7] = al6[6] = al6[7] = wh6[6] = wh6[7] = wl6[6] = wl6[7] = 0;
+    const uint32_t sa = ra[12], sw = rw[12];
+    acc = mfma_mx_fp6(ah6, wl6, acc, (int)(sa & 255u), (int)((sw >> 8) & 255u));   // q6(ah) * q6(wl)
+    acc = mfma_mx_fp6(al6, wh6, acc, (int)((sa >> 8) & 255u), (int)(sw & 255u));   // q6(al) * q6(wh)
+  }
+  const int n = n0 + r;
+  if (n >= N) return;
+  const float bv = bias[n];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (m < M) {
+      float v = acc[i] + bv;
+      if constexpr (ACT == ACT_GELU) v = gelu_erf(v);
+      if constexpr (ACT == ACT_SILU) v = silu(v);
+      if (res != nullptr) v += res[(size_t)m * N + n];
+      out[(size_t)m * N + n] = v;
+    }
+  }
+}
+
+}  // namespace mdm

@@ -19,6 +19,7 @@
 #include "elementwise.h"
 #include "gemm_f32.h"
 #include "gemm_bf16x3.h"
+#include "gemm_f16f6.h"
 #include "motion_recover.h"
 
 using namespace mdm;
@@ -1076,6 +1077,31 @@ int mdm_linear_bf16x3(const float* in, const float* w, const float* bias, const 
   }
   return launch_linear_x3(nullptr, X3Operand{ah, al}, X3Weights{wh, wl}, bias, res, out, nullptr, nullptr, M, N, K, act, 0,
                           1.f, 0, s);
+}
+
+size_t mdm_linear_f16f6_scratch_bytes(int32_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 64 != 0) return 0;
+  return f6_plane_bytes(M, K) + f6_plane_bytes(N, K);
+}
+
+int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M,
+                     int32_t N, int32_t K, int32_t act, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!in || !w || !bias || !out || !scratch || M <= 0 || N <= 0 || K <= 0) return fail(MDM_EINVAL, "mdm_linear_f16f6: bad argument");
+  if (K % 64 != 0) return fail(MDM_EINVAL, "mdm_linear_f16f6: K must be a multiple of 64");
+  if (act != ACT_NONE && act != ACT_GELU && act != ACT_SILU) return fail(MDM_EINVAL, "mdm_linear_f16f6: bad activation");
+  if (scratch_bytes < mdm_linear_f16f6_scratch_bytes(M, N, K)) return fail(MDM_ENOSPC, "mdm_linear_f16f6: scratch too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const F6Planes pa = f6_carve(scratch, M, K);
+  const F6Planes pw = f6_carve(static_cast<char*>(scratch) + f6_plane_bytes(M, K), N, K);
+  MDM_LAUNCH(pack_f16f6_kernel, dim3((M * (K / 32) + 255) / 256), dim3(256), 0, s, in, pa, M, K);
+  if (int rc = rt_launch_status()) return rc;
+  MDM_LAUNCH(pack_f16f6_kernel, dim3((N * (K / 32) + 255) / 256), dim3(256), 0, s, w, pw, N, K);
+  if (int rc = rt_launch_status()) return rc;
+  const dim3 grid((N + 31) / 32, (M + 31) / 32);
+  if (act == ACT_GELU) MDM_LAUNCH(gemm_f16f6_ref_kernel<ACT_GELU>, grid, dim3(64), 0, s, pa, pw, bias, res, out, M, N, K);
+  else if (act == ACT_SILU) MDM_LAUNCH(gemm_f16f6_ref_kernel<ACT_SILU>, grid, dim3(64), 0, s, pa, pw, bias, res, out, M, N, K);
+  else MDM_LAUNCH(gemm_f16f6_ref_kernel<ACT_NONE>, grid, dim3(64), 0, s, pa, pw, bias, res, out, M, N, K);
+  return rt_launch_status();
 }
 
 int mdm_layernorm(float* x, const float* gamma, const float* beta, int32_t rows, int32_t D, void* stream) {

@@ -56,10 +56,15 @@ struct Fiber {
   dim3 tid;
 };
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 struct WaveBuf {
   float fa[64], fb[64];
   bf16x8 ha[64], hb[64];
   uint32_t ua[64], ub[64];
+  i32x8 qa[64], qb[64];      // scaled-MFMA operands
+  int sa[64], sb[64];        // and their scale registers
   int arrive = 0;
   unsigned gen = 0;
 };
@@ -147,6 +152,63 @@ inline f32x16 mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     for (int g = 0; g < 2; ++g)
       for (int e = 0; e < 8; ++e)
         acc = fmaf(bf16_to_f32(w.ha[i + 32 * g][e]), bf16_to_f32(w.hb[j + 32 * g][e]), acc);
+    c[r] = acc;
+  }
+  wave_barrier();
+  return c;
+}
+
+// v_mfma_f32_32x32x16_f16: the bf16 form's layout with fp16 elements
+inline f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
+  WaveBuf& w = blk().waves[wave_id()];
+  int l = lane_id();
+  w.ha[l] = __builtin_bit_cast(bf16x8, a);
+  w.hb[l] = __builtin_bit_cast(bf16x8, b);
+  wave_barrier();
+  int j = l & 31, h = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+    float acc = c[r];
+    for (int g = 0; g < 2; ++g) {
+      const f16x8 fa = __builtin_bit_cast(f16x8, w.ha[i + 32 * g]), fb = __builtin_bit_cast(f16x8, w.hb[j + 32 * g]);
+      for (int e = 0; e < 8; ++e) acc = fmaf((float)fa[e], (float)fb[e], acc);
+    }
+    c[r] = acc;
+  }
+  wave_barrier();
+  return c;
+}
+
+// v_mfma_scale_f32_32x32x64_f8f6f4, both operands FP6 E2M3: lane l holds 32 six-bit codes (element j at bit 6j) of k-block
+// l>>5 of row / column l&31 and the block's E8M0 scale in byte 0 of its scale register (semantics checked on the MI355X:
+// tools/mx/mx_probe.hip part A)
+inline float fp6_e2m3_value(const i32x8& v, int j) {
+  const int bit = 6 * j, w = bit >> 5, o = bit & 31;
+  uint32_t code = ((uint32_t)v[w]) >> o;
+  if (o > 26) code |= ((uint32_t)v[w + 1]) << (32 - o);
+  code &= 63u;
+  const uint32_t s = code >> 5, e = (code >> 3) & 3u, m = code & 7u;
+  const float x = (e == 0) ? m * 0.125f : ldexpf(1.0f + m * 0.125f, (int)e - 1);
+  return s ? -x : x;
+}
+inline f32x16 mfma_scale_f32_32x32x64_fp6(i32x8 a, i32x8 b, f32x16 c, int scale_a, int scale_b) {
+  WaveBuf& w = blk().waves[wave_id()];
+  int l = lane_id();
+  w.qa[l] = a;
+  w.qb[l] = b;
+  w.sa[l] = scale_a;
+  w.sb[l] = scale_b;
+  wave_barrier();
+  int j = l & 31, h = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+    float acc = c[r];
+    for (int g = 0; g < 2; ++g) {
+      const float s = ldexpf(1.0f, ((w.sa[i + 32 * g] & 255) - 127) + ((w.sb[j + 32 * g] & 255) - 127));
+      float part = 0.f;
+      for (int e = 0; e < 32; ++e) part = fmaf(fp6_e2m3_value(w.qa[i + 32 * g], e), fp6_e2m3_value(w.qb[j + 32 * g], e), part);
+      acc = fmaf(part, s, acc);
+    }
     c[r] = acc;
   }
   wave_barrier();

@@ -89,6 +89,48 @@ def test_emulated_linear_bf16x3(lib, M, N, K, act, res):
     assert maxabs(out, ref.numpy()) < 6e-5
 
 
+def _f16f6_reference(a, w):
+    """numpy restatement of csrc/gemm_f16f6.h's operand decomposition: fp16 hi + MX-FP6 (E2M3, power-of-two scale per 32 k)
+    of hi and lo; returns sum_k ah*wh + q6(ah)*q6(wl) + q6(al)*q6(wh) in float64."""
+    def q6(x):
+        R, K = x.shape
+        b = x.reshape(R, K // 32, 32).astype(np.float64)
+        amax = np.abs(b).max(-1, keepdims=True)
+        e = np.where(amax > 0, np.floor(np.log2(np.where(amax > 0, amax, 1.0))) - 2, 0.0)
+        v = np.clip(b / 2.0 ** e, -7.5, 7.5)
+        av = np.abs(v)
+        step = np.where(av >= 4, 0.5, np.where(av >= 2, 0.25, 0.125))
+        q = np.clip(np.round(v / step) * step, -7.5, 7.5)         # np.round = round-half-even, as rintf
+        return (q * 2.0 ** e).reshape(R, K)
+    ah, wh = a.astype(np.float16).astype(np.float64), w.astype(np.float16).astype(np.float64)
+    al, wl = a.astype(np.float64) - ah, w.astype(np.float64) - wh
+    return ah @ wh.T + q6(ah) @ q6(wl).T + q6(al) @ q6(wh).T
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(70, 40, 64, 0, True), (33, 96, 128, 1, False)])
+def test_emulated_linear_f16f6(lib, M, N, K, act, res):
+    """Seed of the next GEMM (fp16 pass + two MX-FP6 cross terms): device quantiser, plane records, fragment mapping of both
+    instructions (emulated) against the numpy restatement of the decomposition and against the exact product."""
+    rng = np.random.default_rng(M)
+    a, w = f32(rng.standard_normal((M, K))), f32(rng.standard_normal((N, K)) / np.sqrt(K))
+    a[::7, ::5] *= 9.0                                            # outliers inside MX blocks
+    a[3, 32:64] = 0.0                                             # an all-zero block
+    b = f32(rng.standard_normal(N))
+    r = f32(rng.standard_normal((M, N))) if res else None
+    out = np.full((M, N), np.nan, np.float32)
+    nb = lib.mdm_linear_f16f6_scratch_bytes(M, N, K)
+    scratch = np.zeros(nb, np.uint8)
+    lib.check(lib.mdm_linear_f16f6(ptr(a), ptr(w), ptr(b), ptr(r) if res else None, ptr(out), M, N, K, act,
+                                   ptr(scratch), nb, None), "linear_f16f6")
+
+    def finish(c):
+        c = torch.from_numpy(c) + torch.from_numpy(b).double()
+        c = torch.nn.functional.gelu(c) if act == 1 else c
+        return (c + torch.from_numpy(r).double() if res else c).numpy()
+    assert maxabs(out, finish(_f16f6_reference(a, w))) < 2e-5      # the scheme itself: fp32 accumulation order only
+    assert maxabs(out, finish(a.astype(np.float64) @ w.astype(np.float64).T)) < 3e-4   # vs the exact product
+
+
 def test_emulated_attention_mask(lib):
     nseq, B, S, D, H, hd = 2, 2, 37, 256, 2, 128
     rng = np.random.default_rng(0)

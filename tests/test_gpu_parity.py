@@ -265,6 +265,34 @@ def test_mdm_linear_bf16x3(M, N, K, act, res):
     assert err < 6e-5, err
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(197 * 4, 512, 512, 0, True), (333, 1024, 512, 1, False), (197 * 2, 512, 1024, 0, True)])
+def test_mdm_linear_f16f6(M, N, K, act, res):
+    """Seed of the next GEMM (csrc/gemm_f16f6.h) on the real instructions: one v_mfma_f32_32x32x16_f16 pass + two
+    v_mfma_scale_f32_32x32x64_f8f6f4 (MX-FP6) cross terms against fp64; the error budget is ~3x bf16x3's (1.2e-5 of rms)."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g)
+    a[::5, ::9] *= 10.0
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+    rd = r.cuda() if res else None
+    out = torch.full((M, N), float("nan"), device="cuda")
+    nb = lib.mdm_linear_f16f6_scratch_bytes(M, N, K)
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    lib.check(lib.mdm_linear_f16f6(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if res else None,
+                                   out.data_ptr(), M, N, K, act, scratch.data_ptr(), nb, _stream()), "mdm_linear_f16f6")
+    torch.cuda.synchronize()
+    ref = a.double() @ w.double().t() + b.double()
+    ref = torch.nn.functional.gelu(ref) if act == 1 else ref
+    if res:
+        ref = ref + r.double()
+    err = (out.cpu().double() - ref).abs()
+    assert err.max().item() < 5e-4, err.max().item()
+    assert (err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item() < 4e-5
+
+
 @pytest.mark.parametrize("rows,D", [(1, 512), (1001, 512), (64, 256), (33, 1024)])
 def test_mdm_layernorm(rows, D):
     g = torch.Generator().manual_seed(rows)
