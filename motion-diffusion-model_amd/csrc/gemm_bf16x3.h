@@ -188,7 +188,7 @@ struct X3Cursor {
 
 // RES: 0 = no residual, 1 = fp32 residual, 2 = residual held as bf16 hi/lo planes.
 // ABL (profiling experiments only, 0 in production): 1 = no epilogue stores, 2 = no loads after the prologue,
-// 4 = no MFMAs, 8 = loads issued but not waited for, 16 / 32 / 64 = timing probes described where they are used.
+// 4 = no MFMAs, 8 = loads issued but not waited for, 16 / 32 / 64 / 256 = timing probes described where they are used.
 // FOLD / OSTAT / RES == 3: LayerNorm folded into the GEMMs (X3Epilogue).
 // T16: the tile is 208 rows -- six 32-row sub-tiles plus ONE 16-row sub-tile (rows 192-207) on v_mfma_f32_16x16x32_bf16 --
 // for row extents <= 208 (S = 197: 11 pad rows instead of 27, i.e. 6.5 of 7 units of matrix work and 13 of 14 A groups).
@@ -446,6 +446,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
             // (208 instead of 224 rows per tile) would save
 #ifndef MDM_EMU
             asm volatile("" ::"v"(al[uv % RING]), "v"(ah[uv % RING]), "v"(wh[ks]), "v"(wl[ks]));
+#endif
+          } else if constexpr ((ABL & 256) != 0) {
+            // 256: timing experiment -- the INSTRUCTION MIX of the f16f6 scheme (gemm_f16f6.h) inside this kernel's skeleton:
+            // per row sub-tile and 32 k, two main-term MFMAs (fp16 and bf16 run at the same rate) and ONE scaled MX-FP6 MFMA
+            // (both cross terms of 32 k fill its K = 64); loads, LDS traffic and barriers as in production (the planned plane
+            // records have the bytes of today's lo plane).  Operands of the scaled MFMA are whatever bits the lo fragments
+            // hold: results are garbage, only the time is representative.
+            acc[t] = mfma_bf16(ah[uv % RING], wh[ks], acc[t]);
+#ifndef MDM_EMU
+            if constexpr (ks == 0) {
+              const u32x4 qa0 = __builtin_bit_cast(u32x4, al[uv % RING]), qa1 = __builtin_bit_cast(u32x4, ah[uv % RING]);
+              const u32x4 qb0 = __builtin_bit_cast(u32x4, wl[0]), qb1 = __builtin_bit_cast(u32x4, wl[1]);
+              const i32x8 qa = {(int)qa0[0], (int)qa0[1], (int)qa0[2], (int)qa0[3], (int)qa1[0], (int)qa1[1], 0, 0};
+              const i32x8 qb = {(int)qb0[0], (int)qb0[1], (int)qb0[2], (int)qb0[3], (int)qb1[0], (int)qb1[1], 0, 0};
+              acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa, qb, acc[t], 2, 2, 0, 120 + (lane & 7), 0, 121 + (lane & 3));
+            }
 #endif
           } else {
             acc[t] = mfma_bf16(al[uv % RING], wh[ks], acc[t]);
@@ -907,6 +923,7 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Ep
       case 32: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 32>(A, W, ep, M, N, K, rpt, s);
       case 64: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 64>(A, W, ep, M, N, K, rpt, s);
       case 128: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 128>(A, W, ep, M, N, K, rpt, s);
+      case 256: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 256>(A, W, ep, M, N, K, rpt, s);
       case 9: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 9>(A, W, ep, M, N, K, rpt, s);
       default: return -2;
     }
