@@ -924,6 +924,11 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Ep
       case 64: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 64>(A, W, ep, M, N, K, rpt, s);
       case 128: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 128>(A, W, ep, M, N, K, rpt, s);
       case 256: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 256>(A, W, ep, M, N, K, rpt, s);
+      // decomposition of the no-MFMA floor: 5 = 4|1 (also no stores), 6 = 4|2 (also no loads), 7 = 4|2|1, 68 = 4|64 (half the reads)
+      case 5: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 5>(A, W, ep, M, N, K, rpt, s);
+      case 6: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 6>(A, W, ep, M, N, K, rpt, s);
+      case 7: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 7>(A, W, ep, M, N, K, rpt, s);
+      case 68: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 68>(A, W, ep, M, N, K, rpt, s);
       case 9: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 9>(A, W, ep, M, N, K, rpt, s);
       default: return -2;
     }
