@@ -218,7 +218,7 @@ int mdm_linear_bf16x3(const float* in_dev, const float* w_dev, const float* bias
                       float* out_dev, int32_t M, int32_t N, int32_t K, int32_t act, void* scratch_dev,
                       size_t scratch_bytes, void* stream);
 /*   mdm_linear_f16f6: the same contract (res may be null) on the SEED of the next split-precision GEMM (csrc/gemm_f16f6.h:
- *                      one fp16 MFMA pass + two cross terms on block-scaled MX-FP6 operands, K % 64 == 0), through a
+ *                      one fp16 MFMA pass + two cross terms on block-scaled MX-FP6 operands, K % 32 == 0), through a
  *                      reference kernel -- exported so that the quantiser, the plane layout and the instruction semantics are
  *                      under parity tests before the model's GEMMs move to it; `scratch_dev` receives both operands' planes. */
 size_t mdm_linear_f16f6_scratch_bytes(int32_t M, int32_t N, int32_t K);

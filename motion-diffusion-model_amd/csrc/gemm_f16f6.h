@@ -11,13 +11,14 @@
 // through mdm_linear_f16f6: the quantiser, the operand plane layout, the fragment <-> plane mapping of both instructions,
 // and a REFERENCE kernel (one wave per 32x32 output tile, fragments straight from global memory -- correct, not fast).
 //
-// Operand planes of a matrix X [R][K] (K % 64 == 0):
+// Operand planes of a matrix X [R][K] (K % 32 == 0):
 //     h16 [R][K]             fp16 hi
 //     rec [R][K/32][16 dw]   one 64-byte record per row and 32-k block: dwords 0-5 FP6 codes of hi (element j at bit 6j),
 //                            6-11 FP6 codes of lo, dword 12 = scale bytes (byte 0: hi block, byte 1: lo block; 127 + e), 13-15 pad
 // i.e. 2 + 2 bytes per element, the byte geometry of gemm_bf16x3.h's hi / lo planes (its LDS-DMA staging carries over).
-// Fragments: fp16 MFMA, k sub-step s of a 64-deep step: lane (r = lane & 31, h = lane >> 5) holds k = 16 s + 8 h .. + 7 of
-// row (column) r; scaled MFMA: the lane holds the 32 k of block h of row (column) r and that block's scale in byte 0.
+// Fragments, per 32-k block: fp16 MFMA, k sub-step s in {0, 1}: lane (r = lane & 31, h = lane >> 5) holds k = 16 s + 8 h .. + 7 of
+// row (column) r; scaled MFMA (K = 64 = both cross terms of the block): A lane (r, h) holds the block's 32 codes of hi (h = 0) /
+// lo (h = 1) and that part's scale in byte 0; B lane (c, h) holds the codes of lo (h = 0) / hi (h = 1) of column c.
 #pragma once
 #include "common.h"
 #include "gemm_f32.h"  // ACT_* enums
@@ -113,27 +114,27 @@ __global__ __launch_bounds__(64) void gemm_f16f6_ref_kernel(F6Planes A, F6Planes
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += 64) {
+  // One 32-k block per iteration -- the production kernel's k step (gemm_bf16x3.h stages are 32 deep): two fp16 MFMAs for the
+  // main term and ONE scaled MFMA whose K = 64 holds BOTH cross terms of the block: lane half 0 supplies q6(ah) (A) against
+  // q6(wl) (B), lane half 1 supplies q6(al) against q6(wh); the K reduction adds the two.
+  for (int kb = 0; kb < nb; ++kb) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const f16x8 a = *reinterpret_cast<const f16x8*>(A.h16 + ar * K + k0 + 16 * s + 8 * h);
-      const f16x8 w = *reinterpret_cast<const f16x8*>(W.h16 + wr * K + k0 + 16 * s + 8 * h);
+    for (int s = 0; s < 2; ++s) {
+      const f16x8 a = *reinterpret_cast<const f16x8*>(A.h16 + ar * K + kb * 32 + 16 * s + 8 * h);
+      const f16x8 w = *reinterpret_cast<const f16x8*>(W.h16 + wr * K + kb * 32 + 16 * s + 8 * h);
       acc = mfma_f16(a, w, acc);
     }
-    const uint32_t* ra = A.rec + (ar * nb + (k0 >> 5) + h) * 16;
-    const uint32_t* rw = W.rec + (wr * nb + (k0 >> 5) + h) * 16;
-    i32x8 ah6, al6, wh6, wl6;
+    const uint32_t* ra = A.rec + (ar * nb + kb) * 16;
+    const uint32_t* rw = W.rec + (wr * nb + kb) * 16;
+    i32x8 a6, w6;
 #pragma unroll
     for (int w = 0; w < 6; ++w) {
-      ah6[w] = (int)ra[w];
-      al6[w] = (int)ra[6 + w];
-      wh6[w] = (int)rw[w];
-      wl6[w] = (int)rw[6 + w];
+      a6[w] = (int)ra[6 * h + w];          // h = 0: codes of hi, h = 1: codes of lo
+      w6[w] = (int)rw[6 * (1 - h) + w];    // h = 0: codes of lo, h = 1: codes of hi
     }
-    ah6[6] = ah6[7] = al6[6] = al6[7] = wh6[6] = wh6[7] = wl6[6] = wl6[7] = 0;
+    a6[6] = a6[7] = w6[6] = w6[7] = 0;
     const uint32_t sa = ra[12], sw = rw[12];
-    acc = mfma_mx_fp6(ah6, wl6, acc, (int)(sa & 255u), (int)((sw >> 8) & 255u));   // q6(ah) * q6(wl)
-    acc = mfma_mx_fp6(al6, wh6, acc, (int)((sa >> 8) & 255u), (int)(sw & 255u));   // q6(al) * q6(wh)
+    acc = mfma_mx_fp6(a6, w6, acc, (int)((sa >> (8 * h)) & 255u), (int)((sw >> (8 * (1 - h))) & 255u));
   }
   const int n = n0 + r;
   if (n >= N) return;

@@ -1080,14 +1080,14 @@ int mdm_linear_bf16x3(const float* in, const float* w, const float* bias, const 
 }
 
 size_t mdm_linear_f16f6_scratch_bytes(int32_t M, int32_t N, int32_t K) {
-  if (M <= 0 || N <= 0 || K <= 0 || K % 64 != 0) return 0;
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0) return 0;
   return f6_plane_bytes(M, K) + f6_plane_bytes(N, K);
 }
 
 int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M,
                      int32_t N, int32_t K, int32_t act, void* scratch, size_t scratch_bytes, void* stream) {
   if (!in || !w || !bias || !out || !scratch || M <= 0 || N <= 0 || K <= 0) return fail(MDM_EINVAL, "mdm_linear_f16f6: bad argument");
-  if (K % 64 != 0) return fail(MDM_EINVAL, "mdm_linear_f16f6: K must be a multiple of 64");
+  if (K % 32 != 0) return fail(MDM_EINVAL, "mdm_linear_f16f6: K must be a multiple of 32");
   if (act != ACT_NONE && act != ACT_GELU && act != ACT_SILU) return fail(MDM_EINVAL, "mdm_linear_f16f6: bad activation");
   if (scratch_bytes < mdm_linear_f16f6_scratch_bytes(M, N, K)) return fail(MDM_ENOSPC, "mdm_linear_f16f6: scratch too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
