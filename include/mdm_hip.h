@@ -199,7 +199,8 @@ int mdm_profile_read(mdm_model_t* m, int32_t category, double* total_ms, int64_t
 int mdm_profile_reset(mdm_model_t* m);
 /* Switches for profiling experiments; value 0 = production behaviour.  what = 0: bf16x3 GEMM ablation code
  * (gemm_bf16x3.h ABL); what = 1: mdm_linear_bf16x3 reuses the operand planes already in scratch (kernel-only timing); what = 2: waves per
- * bf16x3 GEMM workgroup, 8 (default: 224x256 tiles, one workgroup per CU) or 4 (224x128 tiles, two per CU). */
+ * bf16x3 GEMM workgroup, 8 (default: 224x256 tiles, one workgroup per CU) or 4 (224x128 tiles, two per CU); what = 3: attention
+ * ablation code; what = 4: mdm_linear_f16f6 on its reference kernel. */
 int mdm_debug_set(int what, int value);
 /* Timing experiments only: cycle counters of the split-precision GEMM's ablation build (idx 0..7; idx < 0 resets). */
 int mdm_debug_get(int idx, double* out);
@@ -219,8 +220,10 @@ int mdm_linear_bf16x3(const float* in_dev, const float* w_dev, const float* bias
                       size_t scratch_bytes, void* stream);
 /*   mdm_linear_f16f6: the same contract (res may be null) on the SEED of the next split-precision GEMM (csrc/gemm_f16f6.h:
  *                      one fp16 MFMA pass + two cross terms on block-scaled MX-FP6 operands, K % 32 == 0), through a
- *                      reference kernel -- exported so that the quantiser, the plane layout and the instruction semantics are
- *                      under parity tests before the model's GEMMs move to it; `scratch_dev` receives both operands' planes. */
+ *                      production GEMM skeleton with the f16f6 k-loop (N % 4 == 0; act none with or without res, gelu without)
+ *                      or a one-wave-per-tile reference kernel (otherwise, or after mdm_debug_set(4, 1)) -- exported so that
+ *                      the quantiser, the plane layout and the k-loop are under parity tests before the model's GEMMs move
+ *                      to it; `scratch_dev` receives both operands' planes. */
 size_t mdm_linear_f16f6_scratch_bytes(int32_t M, int32_t N, int32_t K);
 int mdm_linear_f16f6(const float* in_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
                      float* out_dev, int32_t M, int32_t N, int32_t K, int32_t act, void* scratch_dev,

@@ -194,8 +194,11 @@ struct X3Cursor {
 // for row extents <= 208 (S = 197: 11 pad rows instead of 27, i.e. 6.5 of 7 units of matrix work and 13 of 14 A groups).
 // The 16-row sub-tile needs the wave's W fragments in the 16x16x32 operand layout; they are derived from the 32x32x16
 // fragments in registers by two lane swaps per dword (common.h frag32_to_frag16), not fetched a second time.
+// F6: the k-loop runs the "f16f6" arithmetic of gemm_f16f6.h on the same skeleton -- plane 0 holds fp16 values, plane 1 the MX-FP6
+// records, the weight planes come from pack_weight_f16f6_kernel; units are ordered sub-tile-major so that a sub-tile's two
+// 16-byte record reads (k sub-steps 0 and 1) meet in ONE scaled MFMA; 2 + 1 MFMAs per sub-tile and step instead of 6.
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
-          bool OSTAT = false, bool EMBED = false, bool T16 = false>
+          bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N,
                                                                      int K, int rows_per_tile, int tiles_n, int total) {
   MDM_DYN_SMEM(unsigned char, lds);
@@ -425,15 +428,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
         frag32_to_frag16(w16l[0], w16l[1]);
       }
       constexpr int NU = 2 * NT32;  // units per stage
+      bf16x8 f6_hold = {0, 0, 0, 0, 0, 0, 0, 0};   // F6 only
       static_for<NU + DEPTH>([&](auto u_tag) __attribute__((always_inline)) {
         constexpr int u = decltype(u_tag)::value;
         if constexpr (u < NU && (!(ABL & 64) || u % 2 == 0)) {   // 64: timing experiment -- half the fragment reads
-          constexpr int ks = u / NT32, t = u - ks * NT32;
+          constexpr int ks = F6 ? (u & 1) : u / NT32, t = F6 ? (u >> 1) : u - ks * NT32;
           X3_RD_A(ah[u % RING], 0, t, ks);
           X3_RD_A(al[u % RING], 1, t, ks);
         }
         if constexpr (u >= DEPTH) {
-          constexpr int uv = u - DEPTH, ks = uv / NT32, t = uv - ks * NT32;
+          constexpr int uv = u - DEPTH, ks = F6 ? (uv & 1) : uv / NT32, t = F6 ? (uv >> 1) : uv - ks * NT32;
           // reads allowed to stay in flight: those of the (up to) DEPTH younger units
           constexpr int younger = 2 * ((NU - 1 - uv) < DEPTH ? (NU - 1 - uv) : DEPTH);
           if constexpr (T16 && uv == 0) lds_wait<younger>(ah[uv % RING], al[uv % RING], a16h, a16l);
@@ -447,6 +451,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
 #ifndef MDM_EMU
             asm volatile("" ::"v"(al[uv % RING]), "v"(ah[uv % RING]), "v"(wh[ks]), "v"(wl[ks]));
 #endif
+          } else if constexpr (F6) {
+            // main term on fp16; the record's first 16 bytes (code dwords c0-c3) wait in f6_hold for the second read
+            // (c4, c5, scale) of the same sub-tile, then ONE scaled MFMA adds both cross terms of the 32-k block
+            if constexpr (ks == 0) {
+              f6_hold = al[uv % RING];
+              acc[t] = mfma_f16(__builtin_bit_cast(f16x8, ah[uv % RING]), __builtin_bit_cast(f16x8, wh[0]), acc[t]);
+            } else {
+              acc[t] = mfma_f16(__builtin_bit_cast(f16x8, ah[uv % RING]), __builtin_bit_cast(f16x8, wh[1]), acc[t]);
+              const u32x4 c0 = __builtin_bit_cast(u32x4, f6_hold), c1 = __builtin_bit_cast(u32x4, al[uv % RING]);
+              const u32x4 w0 = __builtin_bit_cast(u32x4, wl[0]), w1 = __builtin_bit_cast(u32x4, wl[1]);
+              const i32x8 a6 = {(int)c0[0], (int)c0[1], (int)c0[2], (int)c0[3], (int)c1[0], (int)c1[1], 0, 0};
+              const i32x8 w6 = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], 0, 0};
+              acc[t] = mfma_mx_fp6(a6, w6, acc[t], (int)c1[2], (int)w1[2]);
+            }
           } else if constexpr ((ABL & 256) != 0) {
             // 256: timing experiment -- the INSTRUCTION MIX of the f16f6 scheme (gemm_f16f6.h) inside this kernel's skeleton:
             // per row sub-tile and 32 k, two main-term MFMAs (fp16 and bf16 run at the same rate) and ONE scaled MX-FP6 MFMA
@@ -834,14 +852,15 @@ inline int& x3_waves_setting() {
 }
 
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
-          bool OSTAT = false, bool EMBED = false, bool T16 = false>
+          bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false>
 inline int launch_gemm_bf16x3_w(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                                 int rpt, hipStream_t stream) {
   constexpr int TN = x3_tn(WAVES);
   constexpr bool LN = FOLD || OSTAT || RES == 3;
   const int tiles_m = (M + rpt - 1) / rpt, tiles_n = (N + TN - 1) / TN;
   const int total = tiles_m * tiles_n;
-  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16>;
+  static_assert(!(F6 && T16), "the f16f6 k-loop has no 16-row sub-tile yet");
+  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16, F6>;
   if (T16 && rpt > X3_TM - 16) return -2;
 #ifndef MDM_EMU
   if (x3_lds_bytes(WAVES, LN) > 65536) {
@@ -939,6 +958,19 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Ep
   if (act == ACT_GELU && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_GELU, 0, true, false, false>(A, W, ep, M, N, K, rpt, s);
   if (act == ACT_GELU && res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_GELU, 1, true, false, false>(A, W, ep, M, N, K, rpt, s);
   if (act == ACT_SILU && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_SILU, 0, true, false, false>(A, W, ep, M, N, K, rpt, s);
+  return -2;
+}
+
+// The f16f6 building block (mdm_linear_f16f6): plain fp32-out epilogues on the F6 k-loop, 224-row tiles
+inline int launch_gemm_f16f6(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K, int act,
+                             hipStream_t s) {
+  const bool res = ep.res != nullptr;
+  if (act == ACT_NONE && !res)
+    return launch_gemm_bf16x3_w<8, ACT_NONE, 0, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
+  if (act == ACT_NONE && res)
+    return launch_gemm_bf16x3_w<8, ACT_NONE, 1, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
+  if (act == ACT_GELU && !res)
+    return launch_gemm_bf16x3_w<8, ACT_GELU, 0, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
   return -2;
 }
 

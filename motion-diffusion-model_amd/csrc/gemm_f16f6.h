@@ -13,8 +13,10 @@
 //
 // Operand planes of a matrix X [R][K] (K % 32 == 0):
 //     h16 [R][K]             fp16 hi
-//     rec [R][K/32][16 dw]   one 64-byte record per row and 32-k block: dwords 0-5 FP6 codes of hi (element j at bit 6j),
-//                            6-11 FP6 codes of lo, dword 12 = scale bytes (byte 0: hi block, byte 1: lo block; 127 + e), 13-15 pad
+//     rec [R][K/32][16 dw]   one 64-byte record per row and 32-k block, in four 16-byte chunks (element j of a part's code
+//                            string at bit 6j of its dwords c0..c5):  [hi c0-c3 | lo c0-c3 | hi c4 c5, hi scale (127 + e), 0 |
+//                            lo c4 c5, lo scale, 0] -- lane half h of the production k-loop reads chunk h in k sub-step 0 and
+//                            chunk 2 + h in sub-step 1, exactly the two 16-byte reads it issues on today's lo plane
 // i.e. 2 + 2 bytes per element, the byte geometry of gemm_bf16x3.h's hi / lo planes (its LDS-DMA staging carries over).
 // Fragments, per 32-k block: fp16 MFMA, k sub-step s in {0, 1}: lane (r = lane & 31, h = lane >> 5) holds k = 16 s + 8 h .. + 7 of
 // row (column) r; scaled MFMA (K = 64 = both cross terms of the block): A lane (r, h) holds the block's 32 codes of hi (h = 0) /
@@ -95,12 +97,60 @@ __global__ __launch_bounds__(256) void pack_f16f6_kernel(const float* __restrict
     }
   }
   uint32_t* rec = p.rec + (size_t)blk * 16;
-  for (int w = 0; w < 6; ++w) {
+  for (int w = 0; w < 4; ++w) {
     rec[w] = wh[w];
-    rec[6 + w] = wl[w];
+    rec[4 + w] = wl[w];
   }
-  rec[12] = (uint32_t)(127 + eh) | ((uint32_t)(127 + el) << 8);
-  rec[13] = rec[14] = rec[15] = 0;
+  rec[8] = wh[4]; rec[9] = wh[5]; rec[10] = (uint32_t)(127 + eh); rec[11] = 0;
+  rec[12] = wl[4]; rec[13] = wl[5]; rec[14] = (uint32_t)(127 + el); rec[15] = 0;
+}
+
+// Weights fp32 [N][K] -> the fragment-ordered planes the production k-loop streams straight into registers (gemm_bf16x3.h
+// header: [n/32][k/16][lane][16 B], rows >= N zero): plane `hi` holds fp16 values where bf16x3 holds bf16; plane `lo` holds,
+// per 32-k block, for B-operand lane half 0 the codes of LO and for half 1 the codes of HI (the scaled MFMA pairs them with
+// the A operand's hi / lo codes): k16 slot 2 kb: code dwords c0-c3, slot 2 kb + 1: [c4, c5, scale, 0].  One thread per (n, block).
+__global__ __launch_bounds__(256) void pack_weight_f16f6_kernel(const float* __restrict__ w, bf16_t* __restrict__ hi,
+                                                                bf16_t* __restrict__ lo, int N, int K) {
+  const int npad = (N + 31) / 32 * 32, nb = K / 32;
+  const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (idx >= npad * nb) return;
+  const int n = idx / nb, kb = idx - n * nb;
+  float hv[32], lv[32], mh = 0.f, ml = 0.f;
+  for (int j = 0; j < 32; ++j) {
+    const float x = (n < N) ? w[(size_t)n * K + kb * 32 + j] : 0.f;
+    hv[j] = (float)(f16_t)x;
+    lv[j] = x - hv[j];
+    mh = fmaxf(mh, fabsf(hv[j]));
+    ml = fmaxf(ml, fabsf(lv[j]));
+  }
+  const int eh = mx_block_exp(mh), el = mx_block_exp(ml);
+  uint32_t ch[7] = {0, 0, 0, 0, 0, 0, 0}, cl[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < 32; ++j) {
+    const uint32_t a = fp6_e2m3_encode(ldexpf(hv[j], -eh)), b = fp6_e2m3_encode(ldexpf(lv[j], -el));
+    const int bit = 6 * j, q = bit >> 5, o = bit & 31;
+    ch[q] |= a << o;
+    cl[q] |= b << o;
+    if (o > 26) {
+      ch[q + 1] |= a >> (32 - o);
+      cl[q + 1] |= b >> (32 - o);
+    }
+  }
+  const size_t wk16 = (size_t)(K / 16);
+  for (int k8 = 0; k8 < 4; ++k8) {           // fp16 hi values: 8 consecutive k -> one 16-byte fragment piece
+    const int lane = (n & 31) + 32 * (k8 & 1);
+    const size_t o = (((size_t)(n >> 5) * wk16 + (size_t)(2 * kb + (k8 >> 1))) * 64 + lane) * 8;
+    f16_t* dst = reinterpret_cast<f16_t*>(hi + o);
+    for (int j = 0; j < 8; ++j) dst[j] = (f16_t)hv[8 * k8 + j];
+  }
+  for (int half = 0; half < 2; ++half) {
+    const uint32_t* c = half == 0 ? cl : ch;
+    const uint32_t sc = (uint32_t)(127 + (half == 0 ? el : eh));
+    const int lane = (n & 31) + 32 * half;
+    uint32_t* d0 = reinterpret_cast<uint32_t*>(lo + (((size_t)(n >> 5) * wk16 + (size_t)(2 * kb)) * 64 + lane) * 8);
+    uint32_t* d1 = reinterpret_cast<uint32_t*>(lo + (((size_t)(n >> 5) * wk16 + (size_t)(2 * kb + 1)) * 64 + lane) * 8);
+    d0[0] = c[0]; d0[1] = c[1]; d0[2] = c[2]; d0[3] = c[3];
+    d1[0] = c[4]; d1[1] = c[5]; d1[2] = sc; d1[3] = 0;
+  }
 }
 
 // REFERENCE kernel: one wave per 32x32 tile of out = act(A.W^T + bias) (+ res); ragged M / N: clamped loads, masked stores
@@ -127,14 +177,16 @@ __global__ __launch_bounds__(64) void gemm_f16f6_ref_kernel(F6Planes A, F6Planes
     const uint32_t* ra = A.rec + (ar * nb + kb) * 16;
     const uint32_t* rw = W.rec + (wr * nb + kb) * 16;
     i32x8 a6, w6;
+    const int pa = h, pw = 1 - h;            // A: h = 0 codes of hi, h = 1 of lo;  W: h = 0 codes of lo, h = 1 of hi
 #pragma unroll
-    for (int w = 0; w < 6; ++w) {
-      a6[w] = (int)ra[6 * h + w];          // h = 0: codes of hi, h = 1: codes of lo
-      w6[w] = (int)rw[6 * (1 - h) + w];    // h = 0: codes of lo, h = 1: codes of hi
+    for (int w = 0; w < 4; ++w) {
+      a6[w] = (int)ra[4 * pa + w];
+      w6[w] = (int)rw[4 * pw + w];
     }
+    a6[4] = (int)ra[8 + 4 * pa]; a6[5] = (int)ra[9 + 4 * pa];
+    w6[4] = (int)rw[8 + 4 * pw]; w6[5] = (int)rw[9 + 4 * pw];
     a6[6] = a6[7] = w6[6] = w6[7] = 0;
-    const uint32_t sa = ra[12], sw = rw[12];
-    acc = mfma_mx_fp6(a6, w6, acc, (int)((sa >> (8 * h)) & 255u), (int)((sw >> (8 * (1 - h))) & 255u));
+    acc = mfma_mx_fp6(a6, w6, acc, (int)ra[10 + 4 * pa], (int)rw[10 + 4 * pw]);
   }
   const int n = n0 + r;
   if (n >= N) return;

@@ -29,6 +29,7 @@ namespace {
 thread_local std::string g_err;
 int g_x3_ablate = 0;  // profiling experiments only (mdm_debug_set)
 int g_x3_reuse_planes = 0;  // probes only: mdm_linear_bf16x3 skips the operand split and reuses the planes in scratch
+int g_f6_reference = 0;     // tests / probes: mdm_linear_f16f6 on the one-wave-per-tile reference kernel
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -1000,6 +1001,7 @@ int mdm_debug_set(int what, int value) {
   if (what == 1) g_x3_reuse_planes = value;
   if (what == 2 && (value == 4 || value == 8)) x3_waves_setting() = value;
   if (what == 3) g_ax_ablate = value;
+  if (what == 4) g_f6_reference = value;
   return MDM_OK;
 }
 
@@ -1081,7 +1083,8 @@ int mdm_linear_bf16x3(const float* in, const float* w, const float* bias, const 
 
 size_t mdm_linear_f16f6_scratch_bytes(int32_t M, int32_t N, int32_t K) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0) return 0;
-  return f6_plane_bytes(M, K) + f6_plane_bytes(N, K);
+  // A planes | W as fragment-ordered planes (fast kernel) | W as row-major planes (reference kernel)
+  return f6_plane_bytes(M, K) + 2 * align_up(x3_packed_weight_elems(N, K) * 2, 256) + f6_plane_bytes(N, K);
 }
 
 int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M,
@@ -1091,12 +1094,33 @@ int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const f
   if (act != ACT_NONE && act != ACT_GELU && act != ACT_SILU) return fail(MDM_EINVAL, "mdm_linear_f16f6: bad activation");
   if (scratch_bytes < mdm_linear_f16f6_scratch_bytes(M, N, K)) return fail(MDM_ENOSPC, "mdm_linear_f16f6: scratch too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const F6Planes pa = f6_carve(scratch, M, K);
-  const F6Planes pw = f6_carve(static_cast<char*>(scratch) + f6_plane_bytes(M, K), N, K);
-  MDM_LAUNCH(pack_f16f6_kernel, dim3((M * (K / 32) + 255) / 256), dim3(256), 0, s, in, pa, M, K);
-  if (int rc = rt_launch_status()) return rc;
-  MDM_LAUNCH(pack_f16f6_kernel, dim3((N * (K / 32) + 255) / 256), dim3(256), 0, s, w, pw, N, K);
-  if (int rc = rt_launch_status()) return rc;
+  char* base = static_cast<char*>(scratch);
+  const F6Planes pa = f6_carve(base, M, K);
+  bf16_t* wfh = reinterpret_cast<bf16_t*>(base + f6_plane_bytes(M, K));
+  bf16_t* wfl = reinterpret_cast<bf16_t*>(base + f6_plane_bytes(M, K) + align_up(x3_packed_weight_elems(N, K) * 2, 256));
+  const F6Planes pw = f6_carve(base + f6_plane_bytes(M, K) + 2 * align_up(x3_packed_weight_elems(N, K) * 2, 256), N, K);
+  // the production skeleton (gemm_bf16x3_kernel<..., F6>) where its epilogues exist; else the one-wave-per-tile reference
+  const bool fast = !g_f6_reference && N % 4 == 0 && ((act == ACT_NONE) || (act == ACT_GELU && res == nullptr));
+  if (!g_x3_reuse_planes) {
+    MDM_LAUNCH(pack_f16f6_kernel, dim3((M * (K / 32) + 255) / 256), dim3(256), 0, s, in, pa, M, K);
+    if (int rc = rt_launch_status()) return rc;
+    if (fast) {
+      const int npad = (N + 31) / 32 * 32;
+      MDM_LAUNCH(pack_weight_f16f6_kernel, dim3((npad * (K / 32) + 255) / 256), dim3(256), 0, s, w, wfh, wfl, N, K);
+    } else {
+      MDM_LAUNCH(pack_f16f6_kernel, dim3((N * (K / 32) + 255) / 256), dim3(256), 0, s, w, pw, N, K);
+    }
+    if (int rc = rt_launch_status()) return rc;
+  }
+  if (fast) {
+    X3Epilogue ep{out, bias, res, nullptr, nullptr, nullptr, nullptr, N, 0, 1.f, QkvPlanes{}, 0, 0,
+                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1};
+    const X3Operand a{reinterpret_cast<const bf16_t*>(pa.h16), reinterpret_cast<const bf16_t*>(pa.rec)};
+    const int rc = launch_gemm_f16f6(a, X3Weights{wfh, wfl}, ep, M, N, K, act, s);
+    if (rc == -1) return fail(MDM_EHIP, "mdm_linear_f16f6: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    if (rc == -2) return fail(MDM_EUNSUPPORTED, "mdm_linear_f16f6: unsupported (activation, residual) combination");
+    return rt_launch_status();
+  }
   const dim3 grid((N + 31) / 32, (M + 31) / 32);
   if (act == ACT_GELU) MDM_LAUNCH(gemm_f16f6_ref_kernel<ACT_GELU>, grid, dim3(64), 0, s, pa, pw, bias, res, out, M, N, K);
   else if (act == ACT_SILU) MDM_LAUNCH(gemm_f16f6_ref_kernel<ACT_SILU>, grid, dim3(64), 0, s, pa, pw, bias, res, out, M, N, K);

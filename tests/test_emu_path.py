@@ -107,8 +107,9 @@ def _f16f6_reference(a, w):
     return ah @ wh.T + q6(ah) @ q6(wl).T + q6(al) @ q6(wh).T
 
 
-@pytest.mark.parametrize("M,N,K,act,res", [(70, 40, 96, 0, True), (33, 96, 128, 1, False)])
-def test_emulated_linear_f16f6(lib, M, N, K, act, res):
+@pytest.mark.parametrize("M,N,K,act,res,ref_kernel", [(70, 40, 96, 0, True, True), (33, 96, 128, 1, False, True),
+                                                      (230, 264, 96, 0, True, False), (70, 40, 64, 1, False, False)])
+def test_emulated_linear_f16f6(lib, M, N, K, act, res, ref_kernel):
     """Seed of the next GEMM (fp16 pass + two MX-FP6 cross terms): device quantiser, plane records, fragment mapping of both
     instructions (emulated) against the numpy restatement of the decomposition and against the exact product."""
     rng = np.random.default_rng(M)
@@ -120,15 +121,19 @@ def test_emulated_linear_f16f6(lib, M, N, K, act, res):
     out = np.full((M, N), np.nan, np.float32)
     nb = lib.mdm_linear_f16f6_scratch_bytes(M, N, K)
     scratch = np.zeros(nb, np.uint8)
-    lib.check(lib.mdm_linear_f16f6(ptr(a), ptr(w), ptr(b), ptr(r) if res else None, ptr(out), M, N, K, act,
-                                   ptr(scratch), nb, None), "linear_f16f6")
+    lib.mdm_debug_set(4, 1 if ref_kernel else 0)       # reference kernel / the production skeleton with the f16f6 k-loop
+    try:
+        lib.check(lib.mdm_linear_f16f6(ptr(a), ptr(w), ptr(b), ptr(r) if res else None, ptr(out), M, N, K, act,
+                                       ptr(scratch), nb, None), "linear_f16f6")
+    finally:
+        lib.mdm_debug_set(4, 0)
 
     def finish(c):
         c = torch.from_numpy(c) + torch.from_numpy(b).double()
         c = torch.nn.functional.gelu(c) if act == 1 else c
         return (c + torch.from_numpy(r).double() if res else c).numpy()
     assert maxabs(out, finish(_f16f6_reference(a, w))) < 2e-5      # the scheme itself: fp32 accumulation order only
-    assert maxabs(out, finish(a.astype(np.float64) @ w.astype(np.float64).T)) < 3e-4   # vs the exact product
+    assert maxabs(out, finish(a.astype(np.float64) @ w.astype(np.float64).T)) < 6e-4   # vs the exact product (rows with 9x outliers: ~3e-5 of the output range)
 
 
 def test_emulated_attention_mask(lib):

@@ -265,8 +265,10 @@ def test_mdm_linear_bf16x3(M, N, K, act, res):
     assert err < 6e-5, err
 
 
-@pytest.mark.parametrize("M,N,K,act,res", [(197 * 4, 512, 512, 0, True), (333, 1024, 512, 1, False), (197 * 2, 512, 1024, 0, True)])
-def test_mdm_linear_f16f6(M, N, K, act, res):
+@pytest.mark.parametrize("M,N,K,act,res,ref_kernel", [(197 * 4, 512, 512, 0, True, True), (333, 1024, 512, 1, False, True),
+                                                      (197 * 256, 1536, 512, 0, False, False), (197 * 256, 512, 512, 0, True, False),
+                                                      (197 * 64, 1024, 512, 1, False, False), (197 * 64 + 5, 512, 1024, 0, True, False)])
+def test_mdm_linear_f16f6(M, N, K, act, res, ref_kernel):
     """Seed of the next GEMM (csrc/gemm_f16f6.h) on the real instructions: one v_mfma_f32_32x32x16_f16 pass + two
     v_mfma_scale_f32_32x32x64_f8f6f4 (MX-FP6) cross terms against fp64; the error budget is ~3x bf16x3's (1.2e-5 of rms)."""
     lib = _lib()
@@ -281,10 +283,14 @@ def test_mdm_linear_f16f6(M, N, K, act, res):
     out = torch.full((M, N), float("nan"), device="cuda")
     nb = lib.mdm_linear_f16f6_scratch_bytes(M, N, K)
     scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
-    lib.check(lib.mdm_linear_f16f6(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if res else None,
-                                   out.data_ptr(), M, N, K, act, scratch.data_ptr(), nb, _stream()), "mdm_linear_f16f6")
-    torch.cuda.synchronize()
-    ref = a.double() @ w.double().t() + b.double()
+    lib.mdm_debug_set(4, 1 if ref_kernel else 0)       # reference kernel / the production skeleton with the f16f6 k-loop
+    try:
+        lib.check(lib.mdm_linear_f16f6(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if res else None,
+                                       out.data_ptr(), M, N, K, act, scratch.data_ptr(), nb, _stream()), "mdm_linear_f16f6")
+        torch.cuda.synchronize()
+    finally:
+        lib.mdm_debug_set(4, 0)
+    ref = (ad.double() @ wd.double().t() + bd.double()).cpu()
     ref = torch.nn.functional.gelu(ref) if act == 1 else ref
     if res:
         ref = ref + r.double()
