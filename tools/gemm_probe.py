@@ -72,6 +72,34 @@ for name, m, n, k, act, res in shapes:
     lib.mdm_debug_set(0, 0)
     lib.mdm_debug_set(1, 0)
     lib.mdm_debug_set(2, 4)
+    # the same shape on the f16f6 k-loop (gemm_f16f6.h on this kernel's skeleton, 8 waves), production epilogue of the shape
+    # where it exists (act none +- res, gelu without res), kernel-only like the rows above
+    nb6 = lib.mdm_linear_f16f6_scratch_bytes(m, n, k)
+    scratch6 = torch.empty(nb6, dtype=torch.uint8, device=dev)
+    lib.mdm_debug_set(2, 8)
+
+    def run6(use_act, use_res):
+        lib.check(lib.mdm_linear_f16f6(a.data_ptr(), w.data_ptr(), b.data_ptr(), r.data_ptr() if use_res else None,
+                                       out.data_ptr(), m, n, k, use_act, scratch6.data_ptr(), nb6, stream), "f16f6")
+    run6(0, False)
+    lib.mdm_debug_set(1, 1)
+    f6v = [("f16f6", 0, False)] + ([("f16f6p", act, res)] if (act or res) else [])
+    t6 = {v: [] for v in f6v}
+    tb = []
+    for _ in range(ROUNDS):
+        for v in f6v:
+            t6[v].append(timeit(lambda: run6(v[1], v[2]), reps))
+        lib.mdm_debug_set(0, 0)
+        tb.append(timeit(lambda: lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), m, n, k, 0,
+                                                                   scratch.data_ptr(), nb, stream), "x3"), reps))
+    lib.mdm_debug_set(1, 0)
+    lib.mdm_debug_set(2, 4)
+    tb = sorted(tb)[len(tb) // 2]
+    for v in f6v:
+        ts = sorted(t6[v])
+        med = ts[len(ts) // 2]
+        print(f"{name:9s} N={n} K={k} {v[0]:6s} act={v[1]} res={int(v[2])}: median {med:7.1f} us  min {ts[0]:7.1f} us "
+              f"{2 * m * n * k / med / 1e6:6.1f} TF alg   (bf16x3 plain, interleaved: {tb:7.1f} us -> {tb / med:4.2f}x)", flush=True)
     for v in variants:
         ts = sorted(times[v])
         med, mn = ts[len(ts) // 2], ts[0]
