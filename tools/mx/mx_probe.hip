@@ -97,6 +97,70 @@ static int part_a() {
   return worst < 1e-5 * big ? 0 : 1;
 }
 
+// ---------------------------------------------------------------- part A2: the 16x16x128 form (the GEMM's 16-row last sub-tile)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void mx_one16(const i32x8* a, const i32x8* b, const int* sa, const int* sb, float* d) {
+  const int lane = threadIdx.x;
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[lane], b[lane], c, 2, 2, 0, sa[lane], 0, sb[lane]);
+  for (int i = 0; i < 4; ++i) d[lane * 4 + i] = c[i];
+}
+
+static int part_a2() {
+  std::vector<i32x8> a(64), b(64);
+  std::vector<int> sa(64), sb(64);
+  std::vector<float> av(64 * 32), bv(64 * 32);
+  uint32_t rng = 4242u;
+  auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+  for (int l = 0; l < 64; ++l) {
+    uint64_t bits_a[3] = {0, 0, 0}, bits_b[3] = {0, 0, 0};
+    for (int j = 0; j < 32; ++j) {
+      const int ca = next() & 63, cb = next() & 63;
+      av[l * 32 + j] = fp6_e2m3(ca);
+      bv[l * 32 + j] = fp6_e2m3(cb);
+      const int bit = 6 * j;
+      for (int t = 0; t < 6; ++t) {
+        if ((ca >> t) & 1) bits_a[(bit + t) >> 6] |= 1ull << ((bit + t) & 63);
+        if ((cb >> t) & 1) bits_b[(bit + t) >> 6] |= 1ull << ((bit + t) & 63);
+      }
+    }
+    for (int w = 0; w < 6; ++w) {
+      a[l][w] = (int)(uint32_t)(bits_a[w >> 1] >> (32 * (w & 1)));
+      b[l][w] = (int)(uint32_t)(bits_b[w >> 1] >> (32 * (w & 1)));
+    }
+    a[l][6] = a[l][7] = b[l][6] = b[l][7] = 0;
+    sa[l] = 121 + (int)(next() % 10);
+    sb[l] = 123 + (int)(next() % 8);
+  }
+  i32x8 *da, *db; int *dsa, *dsb; float* dd;
+  CK(hipMalloc(&da, 64 * sizeof(i32x8))); CK(hipMalloc(&db, 64 * sizeof(i32x8)));
+  CK(hipMalloc(&dsa, 256)); CK(hipMalloc(&dsb, 256)); CK(hipMalloc(&dd, 64 * 4 * 4));
+  CK(hipMemcpy(da, a.data(), 64 * sizeof(i32x8), hipMemcpyHostToDevice));
+  CK(hipMemcpy(db, b.data(), 64 * sizeof(i32x8), hipMemcpyHostToDevice));
+  CK(hipMemcpy(dsa, sa.data(), 256, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dsb, sb.data(), 256, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(mx_one16, dim3(1), dim3(64), 0, 0, da, db, dsa, dsb, dd);
+  CK(hipDeviceSynchronize());
+  std::vector<float> d(64 * 4);
+  CK(hipMemcpy(d.data(), dd, 64 * 4 * 4, hipMemcpyDeviceToHost));
+  // assumed: lane = (row|col = lane & 15, k block g = lane >> 4), 32 consecutive k per lane; D[reg]: row 4 (lane >> 4) + reg, col lane & 15
+  double worst = 0, big = 0;
+  for (int lane = 0; lane < 64; ++lane)
+    for (int reg = 0; reg < 4; ++reg) {
+      const int col = lane & 15, row = 4 * (lane >> 4) + reg;
+      double ref = 0;
+      for (int g = 0; g < 4; ++g)
+        for (int jj = 0; jj < 32; ++jj)
+          ref += std::ldexp((double)av[(row + 16 * g) * 32 + jj], sa[row + 16 * g] - 127) *
+                 std::ldexp((double)bv[(col + 16 * g) * 32 + jj], sb[col + 16 * g] - 127);
+      worst = std::fmax(worst, std::fabs(d[lane * 4 + reg] - ref));
+      big = std::fmax(big, std::fabs(ref));
+    }
+  printf("part A2: scaled FP6 16x16x128, lane = (row|col = lane & 15, k block = lane >> 4): max |D - ref| = %.3e, |ref| max %.3e -> %s\n",
+         worst, big, worst < 1e-5 * big ? "as assumed" : "MISMATCH");
+  return worst < 1e-5 * big ? 0 : 1;
+}
+
 // ---------------------------------------------------------------- part B
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void mix_kernel(float* out, int iters, const int* seeds) {
@@ -183,6 +247,7 @@ static double run_mix(const char* name, float* out, const int* seeds, int blocks
 
 int main() {
   int rc = part_a();
+  rc |= part_a2();
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   const int blocks = prop.multiProcessorCount * 2;   // two 4-wave blocks per CU = two waves per SIMD, like gemm_bf16x3
