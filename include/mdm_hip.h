@@ -200,7 +200,8 @@ int mdm_profile_reset(mdm_model_t* m);
 /* Switches for profiling experiments; value 0 = production behaviour.  what = 0: bf16x3 GEMM ablation code
  * (gemm_bf16x3.h ABL); what = 1: mdm_linear_bf16x3 reuses the operand planes already in scratch (kernel-only timing); what = 2: waves per
  * bf16x3 GEMM workgroup, 8 (default: 224x256 tiles, one workgroup per CU) or 4 (224x128 tiles, two per CU); what = 3: attention
- * ablation code; what = 4: mdm_linear_f16f6 on its reference kernel. */
+ * ablation code; what = 4: mdm_linear_f16f6 on its reference kernel; what = 5 (tests only): the `f32` mode's encoder GEMMs run
+ * unfused on the f16f6 kernel, operands packed per call into a library-owned scratch. */
 int mdm_debug_set(int what, int value);
 /* Timing experiments only: cycle counters of the split-precision GEMM's ablation build (idx 0..7; idx < 0 resets). */
 int mdm_debug_get(int idx, double* out);

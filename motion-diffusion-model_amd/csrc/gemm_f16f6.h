@@ -69,12 +69,12 @@ __host__ __device__ inline float fp6_e2m3_decode(uint32_t code) {
 
 // fp32 [R][K] -> planes; one thread per (row, 32-k block).  (The production path will never run this: its planes are written
 // by the producing GEMM's epilogue, where a wave's 32 output columns are exactly one block.)
-__global__ __launch_bounds__(256) void pack_f16f6_kernel(const float* __restrict__ x, F6Planes p, int R, int K) {
+__global__ __launch_bounds__(256) void pack_f16f6_kernel(const float* __restrict__ x, F6Planes p, int R, int K, int ld) {
   const int nb = K / 32;
   const int blk = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (blk >= R * nb) return;
   const int row = blk / nb, b = blk - row * nb;
-  const float* src = x + (size_t)row * K + b * 32;
+  const float* src = x + (size_t)row * ld + b * 32;      // ld: row stride of the fp32 source (>= K)
   f16_t* dst = p.h16 + (size_t)row * K + b * 32;
   float mh = 0.f, ml = 0.f;
   for (int j = 0; j < 32; ++j) {

@@ -274,8 +274,51 @@ int launch_attention_x3(Profiler* pf, const QkvPlanes& qp, const int* lengths, i
   }
 }
 
+// TEST-ONLY mode (mdm_debug_set(5, 1)): the `f32` mode's encoder GEMMs on the f16f6 kernel, UNFUSED -- operands packed per
+// call into a library-owned scratch (the one exception to "the caller owns every buffer": a debug path) -- so that the
+// f16f6 arithmetic can be held against the reference's golden trajectories through the product's own seams before the fused
+// path exists.  Not a performance path.
+int g_f6_linear = 0;
+void* g_f6_dbg_scratch = nullptr;
+size_t g_f6_dbg_bytes = 0;
+int launch_linear_f6_debug(Profiler* pf, const float* in, int ld_in, const float* w, const float* bias, const float* res,
+                           float* out, int M, int N, int K, int act, int scale_cols, float col_scale, hipStream_t s) {
+  const size_t wfrag = align_up(x3_packed_weight_elems(N, K) * 2, 256);
+  const size_t need = f6_plane_bytes(M, K) + 2 * wfrag;
+  if (need > g_f6_dbg_bytes) {
+#ifdef MDM_EMU
+    free(g_f6_dbg_scratch);
+    g_f6_dbg_scratch = malloc(need);
+#else
+    if (hipDeviceSynchronize() != hipSuccess) return fail(MDM_EHIP, "f16f6 debug mode: synchronize failed");
+    if (g_f6_dbg_scratch != nullptr) (void)hipFree(g_f6_dbg_scratch);
+    if (hipMalloc(&g_f6_dbg_scratch, need) != hipSuccess) { g_f6_dbg_scratch = nullptr; g_f6_dbg_bytes = 0; return fail(MDM_EHIP, "f16f6 debug mode: hipMalloc failed"); }
+#endif
+    g_f6_dbg_bytes = need;
+  }
+  ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
+  char* base = static_cast<char*>(g_f6_dbg_scratch);
+  const F6Planes pa = f6_carve(base, M, K);
+  bf16_t* wfh = reinterpret_cast<bf16_t*>(base + f6_plane_bytes(M, K));
+  bf16_t* wfl = reinterpret_cast<bf16_t*>(base + f6_plane_bytes(M, K) + wfrag);
+  MDM_LAUNCH(pack_f16f6_kernel, dim3((M * (K / 32) + 255) / 256), dim3(256), 0, s, in, pa, M, K, ld_in);
+  if (int rc = rt_launch_status()) return rc;
+  const int npad = (N + 31) / 32 * 32;
+  MDM_LAUNCH(pack_weight_f16f6_kernel, dim3((npad * (K / 32) + 255) / 256), dim3(256), 0, s, w, wfh, wfl, N, K);
+  if (int rc = rt_launch_status()) return rc;
+  X3Epilogue ep{out, bias, res, nullptr, nullptr, nullptr, nullptr, N, scale_cols, col_scale, QkvPlanes{}, 0, 0,
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1};
+  const X3Operand a{reinterpret_cast<const bf16_t*>(pa.h16), reinterpret_cast<const bf16_t*>(pa.rec)};
+  const int rc = launch_gemm_f16f6(a, X3Weights{wfh, wfl}, ep, M, N, K, act, s);
+  if (rc != 0) return fail(MDM_EUNSUPPORTED, "f16f6 debug mode: launch failed");
+  return rt_launch_status();
+}
+
 int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, const float* bias, const float* res,
                   float* out, int M, int N, int K, int act, int scale_cols, float col_scale, hipStream_t s) {
+  if (g_f6_linear && K % 32 == 0 && N % 4 == 0 && ld_in % 4 == 0 && (scale_cols % 256 == 0) &&
+      (act == ACT_NONE || (act == ACT_GELU && res == nullptr)))
+    return launch_linear_f6_debug(pf, in, ld_in, w, bias, res, out, M, N, K, act, scale_cols, col_scale, s);
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
   if (K % 4 != 0 || ld_in % 4 != 0) return fail(MDM_EINVAL, "linear: K and the row stride must be multiples of 4");
   RowMajorLoader al{in, ld_in, M, K};
@@ -1002,6 +1045,7 @@ int mdm_debug_set(int what, int value) {
   if (what == 2 && (value == 4 || value == 8)) x3_waves_setting() = value;
   if (what == 3) g_ax_ablate = value;
   if (what == 4) g_f6_reference = value;
+  if (what == 5) g_f6_linear = value;
   return MDM_OK;
 }
 
@@ -1102,13 +1146,13 @@ int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const f
   // the production skeleton (gemm_bf16x3_kernel<..., F6>) where its epilogues exist; else the one-wave-per-tile reference
   const bool fast = !g_f6_reference && N % 4 == 0 && ((act == ACT_NONE) || (act == ACT_GELU && res == nullptr));
   if (!g_x3_reuse_planes) {
-    MDM_LAUNCH(pack_f16f6_kernel, dim3((M * (K / 32) + 255) / 256), dim3(256), 0, s, in, pa, M, K);
+    MDM_LAUNCH(pack_f16f6_kernel, dim3((M * (K / 32) + 255) / 256), dim3(256), 0, s, in, pa, M, K, K);
     if (int rc = rt_launch_status()) return rc;
     if (fast) {
       const int npad = (N + 31) / 32 * 32;
       MDM_LAUNCH(pack_weight_f16f6_kernel, dim3((npad * (K / 32) + 255) / 256), dim3(256), 0, s, w, wfh, wfl, N, K);
     } else {
-      MDM_LAUNCH(pack_f16f6_kernel, dim3((N * (K / 32) + 255) / 256), dim3(256), 0, s, w, pw, N, K);
+      MDM_LAUNCH(pack_f16f6_kernel, dim3((N * (K / 32) + 255) / 256), dim3(256), 0, s, w, pw, N, K, K);
     }
     if (int rc = rt_launch_status()) return rc;
   }

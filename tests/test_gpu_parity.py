@@ -101,6 +101,28 @@ def test_loop_matches_reference_golden(golden_dir, sd, name, prec):
     assert err < TOL_LOOP[prec]
 
 
+def test_f16f6_arithmetic_on_the_reference_trajectory(golden_dir, sd):
+    """The NEXT GEMM arithmetic (fp16 pass + one scaled MX-FP6 MFMA per 32-k block, csrc/gemm_f16f6.h on the production GEMM
+    skeleton) held against the reference's 50-step guided trajectory through the product seams: `f32` mode with its encoder
+    GEMMs routed, unfused, to the f16f6 kernel (mdm_debug_set(5, 1), a test-only switch).  tools/precision_probe.py predicts
+    ~1e-4 from a CPU emulation of the same decomposition; the bar of the shipped bf16x3 mode is 5e-4, BASELINE's 1e-3."""
+    lib = _lib()
+    g = _g(golden_dir, "loop50_B2_T196")
+    case = golden_loop_inputs(g)
+    lib.mdm_debug_set(5, 1)
+    try:
+        out = run_product_loop(sd, case, DEV, precision="f32")
+        torch.cuda.synchronize()
+    finally:
+        lib.mdm_debug_set(5, 0)
+    exact = run_product_loop(sd, case, DEV, precision="f32")
+    err = maxabs(out.cpu(), g["final"])
+    print(f"[parity] loop50_B2_T196 f16f6 arithmetic (unfused, test-only): max-abs vs reference = {err:.3e}; "
+          f"vs this library's exact-fp32 mode = {maxabs(out.cpu(), exact.cpu()):.3e}")
+    assert maxabs(out.cpu(), exact.cpu()) > 1e-6          # the switch did route the GEMMs
+    assert err < 5e-4
+
+
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_loop_T196_with_dump_steps(golden_dir, sd, prec):
     """BASELINE config shape (T=196, 50 steps, CFG 2.5) at B=2, incl. p_sample_loop(dump_steps=...) (:630-657)."""
