@@ -965,6 +965,8 @@ inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Ep
 inline int launch_gemm_f16f6(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K, int act,
                              hipStream_t s) {
   const bool res = ep.res != nullptr;
+  if (act == ACT_NONE && !res && x3_waves_setting() == 4)   // A/B probes: two independent 4-wave workgroups per CU
+    return launch_gemm_bf16x3_w<4, ACT_NONE, 0, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
   if (act == ACT_NONE && !res)
     return launch_gemm_bf16x3_w<8, ACT_NONE, 0, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
   if (act == ACT_NONE && res)

@@ -83,12 +83,14 @@ for name, m, n, k, act, res in shapes:
                                        out.data_ptr(), m, n, k, use_act, scratch6.data_ptr(), nb6, stream), "f16f6")
     run6(0, False)
     lib.mdm_debug_set(1, 1)
-    f6v = [("f16f6", 0, False)] + ([("f16f6p", act, res)] if (act or res) else [])
+    f6v = [("f16f6", 0, False)] + ([("f16f6p", act, res)] if (act or res) else []) + [("f16f6w4", 0, False)]
     t6 = {v: [] for v in f6v}
     tb = []
     for _ in range(ROUNDS):
         for v in f6v:
+            lib.mdm_debug_set(2, 4 if v[0].endswith("w4") else 8)   # f16f6w4: two independent 4-wave workgroups per CU
             t6[v].append(timeit(lambda: run6(v[1], v[2]), reps))
+        lib.mdm_debug_set(2, 8)
         lib.mdm_debug_set(0, 0)
         tb.append(timeit(lambda: lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), m, n, k, 0,
                                                                    scratch.data_ptr(), nb, stream), "x3"), reps))
