@@ -54,6 +54,58 @@ def synth_y(B, T, seed, lengths=None, scale=2.5, clip_dim=512):
             "scale": torch.ones(B) * scale}
 
 
+def synth_state_dict_hostile(seed=0, latent_dim=512, ff_size=1024, num_layers=8, input_feats=263, clip_dim=512):
+    """"Trained-like" hostile statistics on top of `synth_state_dict` (same keys / shapes): what random-init weights never
+    show and checkpoints do.  Deterministic in `seed`.
+      * LayerNorm gamma log-normal over [0.05, 8] with a handful of channels pinned to both ends;
+      * a few OUTLIER CHANNELS: LayerNorm beta and the biases of the linears feeding the residual stream 50-300x the rest;
+      * every weight matrix has a few rows 10x the rest (outlier output features);
+      * the text embedding is scaled 20x by `synth_y_hostile`.
+    The residual stream then carries channels hundreds of times larger than the typical one, LayerNorm row means far from
+    zero relative to the bulk, and GEMM operands with a wide dynamic range inside every 32-wide block of k."""
+    sd = synth_state_dict(seed, latent_dim, ff_size, num_layers, input_feats, clip_dim)
+    g = torch.Generator().manual_seed(seed + 7919)
+    d = latent_dim
+    out_ch = torch.randperm(d, generator=g)[:4]            # the model-wide outlier channels of the residual stream
+
+    def rows10(w, n=3):
+        idx = torch.randperm(w.shape[0], generator=g)[:n]
+        w[idx] *= 10.0
+
+    def outlier_vec(v, idx, lo=50.0, hi=300.0):
+        typ = v.abs().mean().clamp_min(1e-3)
+        mag = lo + (hi - lo) * torch.rand(len(idx), generator=g)
+        sign = torch.where(torch.rand(len(idx), generator=g) < 0.5, -1.0, 1.0)
+        v[idx] = sign * mag * typ
+
+    for i in range(num_layers):
+        p = f"seqTransEncoder.layers.{i}."
+        for n in ("norm1", "norm2"):
+            gam = torch.exp(0.7 * torch.randn(d, generator=g)).clamp(0.05, 8.0)
+            ends = torch.randperm(d, generator=g)[:12]
+            gam[ends[:6]] = 8.0
+            gam[ends[6:]] = 0.05
+            sd[p + n + ".weight"] = gam
+            outlier_vec(sd[p + n + ".bias"], out_ch)
+        for n in ("self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight"):
+            rows10(sd[p + n])
+        outlier_vec(sd[p + "self_attn.out_proj.bias"], out_ch)
+        outlier_vec(sd[p + "linear2.bias"], out_ch)
+        outlier_vec(sd[p + "linear1.bias"], torch.randperm(ff_size, generator=g)[:4])
+    rows10(sd["input_process.poseEmbedding.weight"])
+    outlier_vec(sd["input_process.poseEmbedding.bias"], out_ch)
+    rows10(sd["embed_text.weight"])
+    rows10(sd["output_process.poseFinal.weight"])
+    return sd
+
+
+def synth_y_hostile(B, T, seed, lengths=None, scale=2.5, clip_dim=512):
+    """`synth_y` with the cached text embedding scaled 20x (CLIP features are not unit-variance)."""
+    y = synth_y(B, T, seed, lengths, scale, clip_dim)
+    y["text_embed"] = y["text_embed"] * 20.0
+    return y
+
+
 def synth_dip_state_dict(seed=0, latent_dim=512, ff_size=1024, num_layers=8, input_feats=263, bert_dim=768):
     """DiP (`--arch trans_dec --text_encoder_type bert`): reference key names / shapes of model/mdm.py:85-93, :127."""
     g = torch.Generator().manual_seed(seed)

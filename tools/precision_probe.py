@@ -80,6 +80,14 @@ def make_linear(scheme):
         elif scheme == "f16+f8a.f6w":   # activations-side operands fp8, weight-side operands fp6 (mixed formats are allowed)
             y = _real_linear(ah, wh) + _real_linear(f8_block(ah), mx_block(wl, "fp6")) + \
                 _real_linear(f8_block(al), mx_block(wh, "fp6"))
+        elif scheme == "f16+bf8c":      # E5M2 with CONSTANT scales: q(hi) = E5M2(hi) (fp16's exponent range), q(lo) = E5M2(lo * 2^11)
+            def b8(t, s=1.0):
+                return (t * s).to(torch.float8_e5m2).float() / s
+            y = _real_linear(ah, wh) + _real_linear(b8(ah), b8(wl, 2048.0)) + _real_linear(b8(al, 2048.0), b8(wh))
+        elif scheme == "f16+bf8c.e4w":  # activations E5M2 with constant scales, weights E4M3 with block scales
+            def b8(t, s=1.0):
+                return (t * s).to(torch.float8_e5m2).float() / s
+            y = _real_linear(ah, wh) + _real_linear(b8(ah), f8_block(wl)) + _real_linear(b8(al, 2048.0), f8_block(wh))
         elif scheme in ("f16x1", "bf16x1"):
             y = _real_linear(ah, wh)
         else:
@@ -97,20 +105,24 @@ def run(scheme, sd, tab, shape, y, x_T, noises):
 
 
 def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    B = int(pos[0]) if len(pos) > 0 else 2
+    steps = int(pos[1]) if len(pos) > 1 else 50
     T = 196
-    sd = synth_state_dict(seed=0)
+    hostile = "--hostile" in sys.argv
+    from oracle.synth import synth_state_dict_hostile, synth_y_hostile
+    sd = synth_state_dict_hostile(seed=0) if hostile else synth_state_dict(seed=0)
     tab = orc.Tables(orc.named_betas("cosine", steps))
     shape = (B, 263, 1, T)
-    y = synth_y(B, T, seed=7, lengths=[T, T - 50][:B] + [T] * max(0, B - 2))
+    y = (synth_y_hostile if hostile else synth_y)(B, T, seed=7, lengths=[T, T - 50][:B] + [T] * max(0, B - 2))
     x_T, noises = orc.make_noise(shape, steps, seed=3)
     with torch.no_grad():
         ref = run("f32", sd, tab, shape, y, x_T, noises)
-        print(f"|x0| max {ref.abs().max().item():.3f}", flush=True)
-        for scheme in ("bf16x3", "f16x3", "f16+f8x2", "f16+f6x2", "f16+f8a.f6w", "f16+f4x2", "bf16+f8x2", "f16x1"):
+        r64 = orc.sample_loop(sd, tab, shape, y, x_T, noises, cfg=True, dtype=torch.float64)
+        print(f"|x0| max {ref.abs().max().item():.3f}; fp32 oracle vs fp64 oracle {(ref.double() - r64).abs().max().item():.3e}", flush=True)
+        for scheme in ("bf16x3", "f16x3", "f16+f8x2", "f16+f6x2", "f16+bf8c", "f16+bf8c.e4w", "f16+f8a.f6w", "f16x1"):
             got = run(scheme, sd, tab, shape, y, x_T, noises)
-            print(f"{scheme:10s} max-abs vs fp32 oracle: {(got - ref).abs().max().item():.3e}", flush=True)
+            print(f"{scheme:12s} max-abs vs fp32 oracle: {(got - ref).abs().max().item():.3e}   vs fp64: {(got.double() - r64).abs().max().item():.3e}", flush=True)
 
 
 if __name__ == "__main__":
