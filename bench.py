@@ -3,21 +3,31 @@
 One "step" = one full `p_sample_loop` (x_T -> x_0: 50 diffusion steps, classifier-free guidance 2.5, i.e. 100
 denoiser forwards) over one batch of 128 synthetic HumanML3D-shaped motions [128, 263, 1, 196] per GPU, with the
 text embedding pre-cached and every input already resident in HBM (configs[1] of BASELINE.json).  N > 1: one
-process per GPU (torchrun), each rank samples its own 128-motion shard of a 128*N batch (weak scaling) and the
-final samples are all-gathered with RCCL inside the timed region.
+process per GPU, each rank samples its own 128-motion shard of a 128*N batch (weak scaling) and the final samples
+are all-gathered with RCCL inside the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+
+works from a bare shell for every N: with N > 1 and no torchrun environment the script re-launches itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`
+(one rank per GPU over RCCL); launched by torchrun directly (RANK / WORLD_SIZE set) it just joins the group.
 
 Prints ONE JSON line on rank 0.  Besides the contract fields it carries
   roofline      the dominant kernel class (encoder GEMMs) against the MFMA peak it runs on, from hipEvent pairs the
                 library records around every launch of one extra, untimed-for-throughput loop (mdm_profile_*),
   kernel_ms     per-kernel-class totals of that loop,
+  f32_mode      the same workload on the exact-fp32 MFMA kernels (one short extra pass; N = 1 only),
+  dip           the DiP configuration (BASELINE.json configs[4] per GPU: trans_dec, 5 windows x 10 steps) -- N = 1 only,
   cpu_baseline  the oracle (CPU restatement of the reference, pinned to it: tests/golden) timed on this box's host
-                cores on a bounded sample of the same workload (N=1, rank 0 only).
+                cores on a bounded sample of the same workload (N = 1, rank 0 only),
+  ranks         what the process group looked like (backend, world size) -- the evidence that RCCL carried the gather.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,16 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import mdm_amd  # noqa: E402,F401
-from mdm_amd import dist as mdist  # noqa: E402
-from mdm_amd import model_util  # noqa: E402
-from mdm_amd.cfg_sampler import ClassifierFreeSampleModel  # noqa: E402
-
 # algorithmic flops of one MDM forward of one sample (S=197, d=512, ff=1024, L=8, J=263)
-PEAKS_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0}      # MI355X_MICROARCH.md: fp32 MFMA / dense bf16 MFMA
+PEAKS_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}      # MI355X_MICROARCH.md: fp32 MFMA / dense fp16 MFMA
+PMC_PROFILE = os.path.join("profiles", "r02_pmc.json")
 
 
 def algorithmic_flops_per_forward(T, d=512, ff=1024, L=8, J=263):
@@ -43,18 +46,56 @@ def algorithmic_flops_per_forward(T, d=512, ff=1024, L=8, J=263):
     return 2 * T * J * d + L * per_layer + 2 * T * d * J + 3 * 2 * d * d
 
 
-def synthetic_y(B, T, device, seed):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed p_sample_loop passes")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=128, help="motions per GPU")
+    ap.add_argument("--frames", type=int, default=196)
+    ap.add_argument("--diffusion-steps", type=int, default=50)
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
+                    help="arithmetic of the encoder GEMMs (include/mdm_hip.h mdm_set_precision)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the f32_mode and dip sub-records")
+    # test infrastructure (tests/test_bench_launcher.py): the same launcher / sharding / gather / JSON code on CPU --
+    # gloo ranks, kernels in the CPU emulator, a tiny model.  Never a measurement.
+    ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--layers", type=int, default=8, help=argparse.SUPPRESS)
+    ap.add_argument("--latent-dim", type=int, default=512, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` from a bare shell: become the torchrun launcher of N ranks of this same command."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's only working path on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def synthetic_y(B, T, device, seed, clip_dim=512):
     """model_kwargs['y'] as sample/generate.py:107-132 builds it for a text prompt batch (all frames valid)."""
+    import torch
     g = torch.Generator().manual_seed(seed)
     return {"mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=device),
             "lengths": torch.full((B,), T, dtype=torch.long, device=device),
-            "text_embed": torch.randn(1, B, 512, generator=g).to(device),
+            "text_embed": torch.randn(1, B, clip_dim, generator=g).to(device),
             "scale": torch.full((B,), 2.5, device=device)}
 
 
 def cpu_baseline(state, T, dsteps, budget_s=15.0):
     """The oracle's p_sample_loop (CFG on) on the host cores: a bounded number of diffusion steps of a small batch,
     scaled to whole 50-step motions.  Checker code used as a reported baseline only."""
+    import torch
     from oracle import mdm_oracle as orc
     B = 4
     sd = {k: v.detach().cpu().float() for k, v in state.items()}
@@ -80,9 +121,11 @@ def cpu_baseline(state, T, dsteps, budget_s=15.0):
         for k in range(n):
             x = one_step(dsteps - 3 - k, x)
         per = (time.perf_counter() - t0) / n
-    return {"value": B / (per * dsteps), "unit": "motions/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle CFG p_sample: {n} of {dsteps} diffusion steps at B={B}, T={T}, scaled to {dsteps}-step "
-                      f"motions ({per * 1e3:.0f} ms per batch-step)"}
+    thr = torch.get_num_threads()
+    return {"value": B / (per * dsteps), "unit": "motions/s", "cores": thr, "kind": "port",
+            "sample": f"oracle (torch-CPU restatement of the reference, {thr} intra-op threads) CFG p_sample: {n} of {dsteps} "
+                      f"diffusion steps at B={B} (NOT the GPU run's B=128: a bounded sample), T={T}, scaled to {dsteps}-step "
+                      f"motions ({per * 1e3:.0f} ms per batch-step); a reported baseline, not a target"}
 
 
 # Mean ALGORITHMIC HBM bytes of one encoder-GEMM launch at the headline shape (256 sequences x 197 tokens, D=512, FF=1024;
@@ -91,49 +134,77 @@ def cpu_baseline(state, T, dsteps, budget_s=15.0):
 ALGORITHMIC_GEMM_BYTES_PER_LAUNCH = int((458.9e6 + 310.9e6 + 311.9e6 + 415.2e6) / 4)
 
 
+def csrc_sha256():
+    """Identity of the kernel sources the library was built from (what a committed PMC profile is tied to)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "motion-diffusion-model_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip")))
+    for p in files + [os.path.join(ROOT, "include", "mdm_hip.h")]:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def pmc_traffic_per_gemm_launch():
-    """HBM-side bytes per encoder-GEMM launch from the committed rocprofv3 PMC passes of THIS command
-    (profiles/r01_pmc.json, produced by tools/gpu_prof.sh + tools/pmc_to_json.py: FETCH_SIZE x2 per the gfx950 correction,
-    WRITE_SIZE as is; separate --pmc passes).  PMC collection needs rocprofv3 around the process, so the live run can
-    only quote the profile of the same build; None if the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    """HBM-side bytes per encoder-GEMM launch from the committed rocprofv3 PMC passes of THIS command (tools/gpu_prof.sh
+    + tools/pmc_to_json.py: FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE as is; separate --pmc passes).  PMC
+    collection needs rocprofv3 around the process, so the live run can only quote the profile of the same build: the
+    profile records the sha256 of the kernel sources it was taken on, and a profile of different sources yields null."""
+    path = os.path.join(ROOT, PMC_PROFILE)
     if not os.path.isfile(path):
-        return None, None
+        return None, f"{PMC_PROFILE} absent"
     try:
         with open(path) as f:
             d = json.load(f)
-        w = {"gemm_bf16x3<in_proj (LayerNorm folded) -> Q/K/V^T planes>": 1,
-             "gemm_bf16x3<out_proj | linear2, LayerNorm residual, planes + row stats>": 2,
-             "gemm_bf16x3<linear1 (LayerNorm folded) + GELU -> planes>": 1}
-        tot = sum(d[k]["hbm_bytes"] * n for k, n in w.items())
-        return int(tot / sum(w.values())), "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command)"
-    except (KeyError, ValueError, OSError):
-        return None, None
+        if d.get("csrc_sha256") != csrc_sha256():
+            return None, f"{PMC_PROFILE} was taken on other kernel sources (csrc_sha256 differs): stale, not quoted"
+        per_layer = {"in_proj": 1, "out_proj|linear2": 2, "linear1": 1}
+        tot = sum(d["gemm"][k]["hbm_bytes"] * n for k, n in per_layer.items())
+        return int(tot / sum(per_layer.values())), f"{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command)"
+    except (KeyError, ValueError, OSError) as e:
+        return None, f"{PMC_PROFILE} unreadable ({type(e).__name__})"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3, help="timed p_sample_loop passes")
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=128, help="motions per GPU")
-    ap.add_argument("--frames", type=int, default=196)
-    ap.add_argument("--diffusion-steps", type=int, default=50)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"],
-                    help="arithmetic of the encoder GEMMs (include/mdm_hip.h mdm_set_precision)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a, argv))
 
-    rank, world, local = mdist.init_from_env("nccl")
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    import torch
+    import torch.distributed as dist
+
+    import mdm_amd  # noqa: F401
+    from mdm_amd import dist as mdist
+    from mdm_amd import model_util
+    from mdm_amd.cfg_sampler import ClassifierFreeSampleModel
+
+    backend = "gloo" if a.emulate else "nccl"
+    rank, world, local = mdist.init_from_env(backend)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
+    native_lib = None
+    if a.emulate:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        from emu_lib import emu
+        native_lib = emu()
+        dev = torch.device("cpu")
+        torch.set_num_threads(1)
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
 
     B, T, DS = a.batch, a.frames, a.diffusion_steps
     torch.manual_seed(0)                                   # random-init weights of the named architecture
-    args = model_util.default_args(diffusion_steps=DS)
-    mdm, diffusion = model_util.create_model_and_diffusion(args, precision=a.precision)
+    args = model_util.default_args(diffusion_steps=DS, layers=a.layers, latent_dim=a.latent_dim)
+    mdm, diffusion = model_util.create_model_and_diffusion(args, precision=a.precision, _native_lib=native_lib,
+                                                           num_heads=a.latent_dim // 128)
     state = {k: v.clone() for k, v in mdm.state_dict().items()}
     model = ClassifierFreeSampleModel(mdm).to(dev).eval()
     y = synthetic_y(B, T, dev, seed=1000 + rank)
@@ -146,32 +217,53 @@ def main():
         return mdist.all_gather_samples(out, GB, world)
 
     def fence():
-        torch.cuda.synchronize(dev)
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
-    for w in range(a.warmup):
-        one_pass(w)
-    fence()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        out = one_pass(100 + k)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert out.shape[0] == GB and bool(torch.isfinite(out).all())
+    def timed(passes, warmup, seed0):
+        for w in range(warmup):
+            one_pass(w)
+        fence()
+        t0 = time.perf_counter()
+        out = None
+        for k in range(passes):
+            out = one_pass(seed0 + k)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        assert out.shape[0] == GB and bool(torch.isfinite(out).all())
+        return dt
+
+    dt = timed(a.steps, a.warmup, 100)
 
     # ---- per-kernel-class timing of one more pass (rank 0's GPU), hipEvents on the launch stream
     eng = mdm.engine()
     eng.profile(True)
     one_pass(999)
-    torch.cuda.synchronize(dev)
+    sync()
     prof = eng.profile_read()
     eng.profile(False)
+
+    extras = world == 1 and not a.no_extras and not a.emulate
+    f32_mode = dip = None
+    if extras and a.precision != "f32":
+        # the same workload on the exact-fp32 MFMA kernels (the on-device parity reference): one warm-up + one timed pass
+        mdm.precision = "f32"
+        f32_dt = timed(1, 1, 500)
+        mdm.precision = a.precision
+        fwd = algorithmic_flops_per_forward(T)
+        f32_tf = GB / f32_dt * DS * 2 * fwd / 1e12
+        f32_mode = {"value": round(GB / f32_dt, 3), "unit": "motions/s", "ms_per_step": round(f32_dt * 1e3, 3), "steps": 1,
+                    "model_tflops": round(f32_tf, 2), "frac_of_157.3TF": round(f32_tf / 157.3, 4),
+                    "dtype": "f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
+    if extras:
+        import bench_dip
+        dip = bench_dip.measure(dev, rank=0, world=1, B=32, steps=3, warmup=1, cpu=False)
 
     if rank == 0:
         traffic, traffic_src = pmc_traffic_per_gemm_launch()
@@ -179,22 +271,26 @@ def main():
         lin = prof["linear"]
         ach = lin["flops"] / (lin["ms"] * 1e-3) / 1e12 if lin["ms"] > 0 else 0.0
         peak = PEAKS_TFLOPS[a.precision]
-        x3 = a.precision == "bf16x3"
+        x3 = a.precision == "f16x3"
         fwd = algorithmic_flops_per_forward(T)
         line = {
             "metric": "motions/sec (B=128, T=196, 50-step DDPM)", "value": round(motions_s, 3), "unit": "motions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMA products, fp32 accumulate; everything "
+            "dtype": "f16x3 (fp32 operands split into fp16 hi+lo, 3 fp16 MFMA products, fp32 accumulate; everything "
                      "else fp32)" if x3 else "f32", "data": "synthetic",
             "config": {"workload": f"HumanML3D text2motion, {DS}-step p_sample_loop with CFG 2.5 (2 denoiser forwards "
-                                   f"per step), batch={B} per GPU, T={T}, 8-layer d=512 trans_enc MDM, random-init "
-                                   f"weights, cached text embedding", "global_batch": GB, "diffusion_steps": DS,
+                                   f"per step), batch={B} per GPU, T={T}, {a.layers}-layer d={a.latent_dim} trans_enc MDM, "
+                                   f"random-init weights, cached text embedding", "global_batch": GB, "diffusion_steps": DS,
                        "parallelism": f"dp{world}: batch shards, no data-path collective, all_gather of final samples"},
+            "ranks": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                      "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""))
+                      if dist.is_initialized() else "none (single process)",
+                      "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"},
             "sample_steps_per_s": round(motions_s * DS, 1),
             "model_tflops": round(motions_s * DS * 2 * fwd / 1e12, 2),
             "roofline": {"bound": "mfma",
-                         "kernel": ("gemm_bf16x3_kernel<Linear>" if x3 else "gemm_f32_kernel<RowMajor,RowMajor,Linear>")
+                         "kernel": ("gemm_x3_kernel" if x3 else "gemm_f32_kernel<RowMajor,RowMajor,Linear>")
                          + " (encoder GEMMs: in_proj, out_proj, linear1, linear2)",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
@@ -202,13 +298,17 @@ def main():
                          "launches": lin["launches"],
                          "avg_launch_us": round(lin["ms"] * 1e3 / max(lin["launches"], 1), 2),
                          "executed_mfma_tflops": round(ach * (3 if x3 else 1), 2),
-                         "peak_basis": ("dense bf16 MFMA (v_mfma_f32_32x32x16_bf16) 2.5 PFLOP/s; `achieved` counts the "
+                         "peak_basis": ("dense fp16 MFMA (v_mfma_f32_32x32x16_f16) 2.5 PFLOP/s; `achieved` counts the "
                                         "ALGORITHMIC fp32 flops 2MNK, the kernel executes 3x that on the matrix pipe, so "
                                         "frac <= 1/3 by construction" if x3 else
                                         "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md")},
             "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if f32_mode is not None:
+            line["f32_mode"] = f32_mode
+        if dip is not None:
+            line["dip"] = dip
+        if world == 1 and not a.no_cpu_baseline and not a.emulate:
             line["cpu_baseline"] = cpu_baseline(state, T, DS)
         print(json.dumps(line), flush=True)
     if world > 1:

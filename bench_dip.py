@@ -5,9 +5,9 @@ classifier-free guidance (2 denoiser forwards per step), B motions per GPU (256 
     python bench_dip.py [--gpus N] [--steps K] [--warmup W] [--batch B]
 
 Same contract as bench.py (one JSON line on rank 0; a "step" is one whole 196-frame generation of one batch); it is a
-separate file because bench.py is the driver's headline-metric entry point.  The decoder path is exact fp32 and, at
-these sizes (60-token windows), launch-bound: `roofline` prices the dominant kernel class (fp32 MFMA GEMMs) and
-`launches_per_motion_batch` / `kernel_ms` show where the wall time actually goes.
+separate file because bench.py is the driver's headline-metric entry point (bench.py embeds `measure()`'s record as its
+`dip` sub-line).  `roofline` prices the dominant kernel class (the decoder GEMMs); `launches_per_motion_batch` / `kernel_ms`
+show where the wall time goes.
 """
 import argparse
 import json
@@ -65,19 +65,9 @@ def cpu_baseline(state, budget_s=12.0):
                       f"{DSTEPS} steps per motion ({per_step * 1e3:.0f} ms per batch-step)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="motions per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
-    rank, world, local = mdist.init_from_env("nccl")
-    assert world == a.gpus and torch.cuda.is_available()
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    B = a.batch
+def measure(dev, rank, world, B, steps, warmup, cpu=True):
+    """Time `steps` whole 196-frame generations of B motions per rank on `dev`; returns the JSON record (rank 0) or None.
+    bench.py embeds this record as its `dip` sub-line so that the driver's BENCH file carries it."""
     torch.manual_seed(0)
     args = model_util.default_args(diffusion_steps=DSTEPS, arch="trans_dec", text_encoder_type="bert", context_len=CONTEXT,
                                    pred_len=PRED, mask_frames=False, guidance_param=7.5)
@@ -100,11 +90,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         one_pass()
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         out = one_pass()
     fence()
     dt = time.perf_counter() - t0
@@ -119,26 +109,45 @@ def main():
     torch.cuda.synchronize(dev)
     prof = eng.profile_read()
     eng.profile(False)
+    if rank != 0:
+        return None
+    lin = prof["linear"]
+    ach = lin["flops"] / (lin["ms"] * 1e-3) / 1e12 if lin["ms"] > 0 else 0.0
+    prec = mdm.precision
+    peak = 157.3 if prec == "f32" else 2500.0
+    line = {"metric": "motions/sec (DiP: 196 frames = 5 windows x 10 steps, CFG, B=32 per GPU)",
+            "value": round(GB * steps / dt, 3), "unit": "motions/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
+            "config": {"workload": f"DiP autoregressive text2motion: trans_dec 8 layers d=512, prefix 20 + window 40 "
+                                   f"frames, {NTOK}-token DistilBERT memory (cached), {DSTEPS} DDPM steps per window, "
+                                   f"CFG 7.5, batch={B} per GPU, random-init weights", "global_batch": GB,
+                       "parallelism": f"dp{world}: batch shards, all_gather of final samples"},
+            "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3_kernel") + ")",
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "traffic": None, "launches": lin["launches"],
+                         "avg_launch_us": round(lin["ms"] * 1e3 / max(lin["launches"], 1), 2)},
+            "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+            "launches_per_motion_batch": int(sum(v["launches"] for v in prof.values()))}
+    if world == 1 and cpu:
+        line["cpu_baseline"] = cpu_baseline(state)
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="motions per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    rank, world, local = mdist.init_from_env("nccl")
+    assert world == a.gpus and torch.cuda.is_available()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    line = measure(dev, rank, world, a.batch, a.steps, a.warmup, cpu=not a.no_cpu_baseline)
     if rank == 0:
-        lin = prof["linear"]
-        ach = lin["flops"] / (lin["ms"] * 1e-3) / 1e12 if lin["ms"] > 0 else 0.0
-        line = {"metric": "motions/sec (DiP: 196 frames = 5 windows x 10 steps, CFG, B=32 per GPU)",
-                "value": round(GB * a.steps / dt, 3), "unit": "motions/s", "n_gpus": world, "steps": a.steps,
-                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"DiP autoregressive text2motion: trans_dec 8 layers d=512, prefix 20 + window 40 "
-                                       f"frames, {NTOK}-token DistilBERT memory (cached), {DSTEPS} DDPM steps per window, "
-                                       f"CFG 7.5, batch={B} per GPU, random-init weights", "global_batch": GB,
-                           "parallelism": f"dp{world}: batch shards, all_gather of final samples"},
-                "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<RowMajor,RowMajor,Linear> (decoder GEMMs)",
-                             "achieved": round(ach, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
-                             "traffic": None, "launches": lin["launches"],
-                             "avg_launch_us": round(lin["ms"] * 1e3 / max(lin["launches"], 1), 2),
-                             "note": "60-token windows: launch-bound (kernel_ms total vs ms_per_step)"},
-                "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
-                "launches_per_motion_batch": int(sum(v["launches"] for v in prof.values()))}
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(state)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -33,7 +33,7 @@ extern "C" {
 #define MDM_EHIP (-4)     /* a HIP runtime call failed                         */
 #define MDM_EUNSUPPORTED (-5)
 
-#define MDM_ABI_VERSION 3
+#define MDM_ABI_VERSION 4
 
 typedef struct mdm_model mdm_model_t;
 
@@ -76,17 +76,19 @@ size_t mdm_const_bytes(const mdm_model_t* m);
 /* Validates that every weight is present and (re)builds the derived tables.  Call again after weights change. */
 int mdm_prepare(mdm_model_t* m, void* const_ws_dev, size_t const_ws_bytes, void* stream);
 
-/* Arithmetic of the encoder's dense contractions (in_proj / out_proj / linear1 / linear2):
- *   MDM_PREC_F32     exact fp32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an fp32 fma chain; the on-device parity
- *                    reference (157 TFLOP/s peak);
- *   MDM_PREC_BF16X3  default: operands split into bf16 hi + lo planes, three bf16 MFMA products per fp32 product
- *                    (hi*hi + hi*lo + lo*hi), fp32 accumulation: ~2^-16 relative per product, well inside the
- *                    1e-3 trajectory bar (2.5 PFLOP/s bf16 peak / 3 passes).
- * In MDM_PREC_BF16X3 the attention contractions (QK^T, PV) use the same three-product scheme on planes written by the
- * in_proj epilogue.  LayerNorm, GELU, softmax, the 263-wide input/output projections and the sampler update are fp32
- * in both modes.  May be called any time after mdm_create. */
+/* Arithmetic of the model's dense contractions:
+ *   MDM_PREC_F32     exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere: bit-for-bit an fp32 fma chain; the on-device
+ *                    parity reference (157 TFLOP/s peak);
+ *   MDM_PREC_F16X3   default: operands split into fp16 hi + lo planes (11 + 11 significant bits), three fp16 MFMA products
+ *                    per fp32 product (hi*hi + hi*lo + lo*hi), fp32 accumulation: ~2^-22 relative per product while the
+ *                    operands stay inside fp16's range (|x| <= 2 * 65504; 2^-25 absolute below 2^-14) -- on the reference's
+ *                    golden trajectories this is the fp32 re-association floor (2.5 PFLOP/s fp16 peak / 3 passes).
+ * In MDM_PREC_F16X3 every GEMM of MDM.forward runs on the split kernel -- in_proj / out_proj / linear1 / linear2, the
+ * 263-wide InputProcess / OutputProcess projections (K resp. N padded) -- and so do the attention contractions (QK^T, PV),
+ * on planes written by the in_proj epilogue.  LayerNorm statistics, GELU, softmax, the time / text embeddings and the
+ * sampler update are fp32 in both modes.  May be called any time after mdm_create. */
 #define MDM_PREC_F32 0
-#define MDM_PREC_BF16X3 1
+#define MDM_PREC_F16X3 1
 int mdm_set_precision(mdm_model_t* m, int32_t mode);
 
 /* Per-call activation workspace for `nseq` token sequences (B, or 2B under classifier-free guidance)
@@ -137,6 +139,7 @@ typedef struct mdm_step {
   uint64_t seed;         /* Philox key                                           */
   uint32_t sample_base;  /* global index of local sample 0 (shard-invariant RNG) */
   uint32_t draw;         /* draw index: 0 = x_T, 1+k = k-th loop iteration       */
+  int32_t const_noise;   /* 1: eps of sample 0 for every sample (gaussian_diffusion.py:527-528) */
 } mdm_step_t;
 
 int mdm_sampler_step(const float* x_t_dev, const float* out_cond_dev, const float* out_uncond_dev,
@@ -176,6 +179,8 @@ typedef struct mdm_sample_params {
   const int32_t* dump_steps;    /* host, ascending loop indices k to snapshot (p_sample_loop dump_steps) */
   int32_t num_dump;
   float* dump_dev;              /* [num_dump, B,J,F,T]                                               */
+  int32_t const_noise;          /* p_sample const_noise=True (gaussian_diffusion.py:527-528): every sample receives the
+                                 * step noise of (global) sample 0 -- noise[[0]].repeat(B, 1, 1, 1)     */
 } mdm_sample_params_t;
 
 /* x_dev [B,J,F,T]: in = x at index start_index (x_T, or q_sample(init) -- see mdm_randn), out = sample. */
@@ -197,15 +202,6 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x_dev, 
 int mdm_profile_enable(mdm_model_t* m, int on);
 int mdm_profile_read(mdm_model_t* m, int32_t category, double* total_ms, int64_t* launches, double* flops);
 int mdm_profile_reset(mdm_model_t* m);
-/* Switches for profiling experiments; value 0 = production behaviour.  what = 0: bf16x3 GEMM ablation code
- * (gemm_bf16x3.h ABL); what = 1: mdm_linear_bf16x3 reuses the operand planes already in scratch (kernel-only timing); what = 2: waves per
- * bf16x3 GEMM workgroup, 8 (default: 224x256 tiles, one workgroup per CU) or 4 (224x128 tiles, two per CU); what = 3: attention
- * ablation code; what = 4: mdm_linear_f16f6 on its reference kernel; what = 5 (tests only): the `f32` mode's encoder GEMMs run
- * unfused on the f16f6 kernel, operands packed per call into a library-owned scratch. */
-int mdm_debug_set(int what, int value);
-/* Timing experiments only: cycle counters of the split-precision GEMM's ablation build (idx 0..7; idx < 0 resets). */
-int mdm_debug_get(int idx, double* out);
-
 /* Building blocks, exported for the parity tests and for callers that compose their own layers.
  *   mdm_linear:    out[M,N] = act(in[M,K] . w[N,K]^T + bias) (+ res)     act: 0 none, 1 gelu(erf), 2 silu
  *   mdm_layernorm: in-place LayerNorm over rows of D (eps 1e-5)
@@ -213,29 +209,19 @@ int mdm_debug_get(int idx, double* out);
  *                  Q columns are pre-scaled by 1/sqrt(head_dim); lengths as in mdm_forward (indexed seq % B). */
 int mdm_linear(const float* in_dev, const float* w_dev, const float* bias_dev, const float* res_dev, float* out_dev,
                int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
-/*   mdm_linear_bf16x3: the same contract as mdm_linear computed by the split-precision kernel (K % 32 == 0);
- *                      `scratch_dev` (mdm_linear_bf16x3_scratch_bytes) receives the bf16 planes of both operands. */
-size_t mdm_linear_bf16x3_scratch_bytes(int32_t M, int32_t N, int32_t K);
-int mdm_linear_bf16x3(const float* in_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
+/*   mdm_linear_x3: the same contract as mdm_linear computed by the split-precision kernel (K % 32 == 0);
+ *                      `scratch_dev` (mdm_linear_x3_scratch_bytes) receives the 16-bit hi / lo planes of both operands. */
+size_t mdm_linear_x3_scratch_bytes(int32_t M, int32_t N, int32_t K);
+int mdm_linear_x3(const float* in_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
                       float* out_dev, int32_t M, int32_t N, int32_t K, int32_t act, void* scratch_dev,
                       size_t scratch_bytes, void* stream);
-/*   mdm_linear_f16f6: the same contract (res may be null) on the SEED of the next split-precision GEMM (csrc/gemm_f16f6.h:
- *                      one fp16 MFMA pass + two cross terms on block-scaled MX-FP6 operands, K % 32 == 0), through a
- *                      production GEMM skeleton with the f16f6 k-loop (N % 4 == 0; act none with or without res, gelu without)
- *                      or a one-wave-per-tile reference kernel (otherwise, or after mdm_debug_set(4, 1)) -- exported so that
- *                      the quantiser, the plane layout and the k-loop are under parity tests before the model's GEMMs move
- *                      to it; `scratch_dev` receives both operands' planes. */
-size_t mdm_linear_f16f6_scratch_bytes(int32_t M, int32_t N, int32_t K);
-int mdm_linear_f16f6(const float* in_dev, const float* w_dev, const float* bias_dev, const float* res_dev,
-                     float* out_dev, int32_t M, int32_t N, int32_t K, int32_t act, void* scratch_dev,
-                     size_t scratch_bytes, void* stream);
 int mdm_layernorm(float* x_dev, const float* gamma_dev, const float* beta_dev, int32_t rows, int32_t D, void* stream);
 int mdm_attention(const float* qkv_dev, float* out_dev, const int32_t* lengths_dev, int32_t nseq, int32_t B,
                   int32_t S, int32_t D, int32_t H, void* stream);
-/*   mdm_attention_bf16x3: the same contract computed by the split-precision kernel the bf16x3 mode uses (QK^T and PV
- *                  as three bf16 MFMA products each, fp32 softmax); `scratch_dev` receives the Q/K/V^T bf16 planes. */
-size_t mdm_attention_bf16x3_scratch_bytes(int32_t nseq, int32_t S, int32_t D);
-int mdm_attention_bf16x3(const float* qkv_dev, float* out_dev, const int32_t* lengths_dev, int32_t nseq, int32_t B,
+/*   mdm_attention_x3: the same contract computed by the split-precision kernel the f16x3 mode uses (QK^T and PV
+ *                  as three 16-bit MFMA products each, fp32 softmax); `scratch_dev` receives the Q/K/V^T hi / lo planes. */
+size_t mdm_attention_x3_scratch_bytes(int32_t nseq, int32_t S, int32_t D);
+int mdm_attention_x3(const float* qkv_dev, float* out_dev, const int32_t* lengths_dev, int32_t nseq, int32_t B,
                          int32_t S, int32_t D, int32_t H, void* scratch_dev, size_t scratch_bytes, void* stream);
 
 /* Post-sampling transform of sample/generate.py:160-166, on the device:

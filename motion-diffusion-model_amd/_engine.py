@@ -1,6 +1,7 @@
 """Native engine handle: owns one `mdm_model_t` (include/mdm_hip.h) per (module, device) and the torch
 tensors that back its pointers.  PyTorch is used for device memory and streams only.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -13,10 +14,21 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _on_own_device(method):
+    """Run an Engine method with the engine's device current (see Engine._on_device)."""
+    import functools
+
+    @functools.wraps(method)
+    def guarded(self, *a, **k):
+        with self._on_device():
+            return method(self, *a, **k)
+    return guarded
+
+
 class Engine:
     """Binds a state-dict (reference key names) to a native model and runs forward / sample loops."""
 
-    def __init__(self, cfg, lib=None, precision="bf16x3"):
+    def __init__(self, cfg, lib=None, precision="f16x3"):
         self.lib = lib if lib is not None else nat.load_native()
         self.is_emulation = not self.lib.path.endswith(nat.LIB_NAME)
         self.cfg = nat.MdmConfig(**cfg)
@@ -39,7 +51,7 @@ class Engine:
             pass
 
     def set_precision(self, precision):
-        """'bf16x3' (default: split-precision bf16 MFMA for the encoder GEMMs) or 'f32' (exact-fp32 MFMA)."""
+        """'f16x3' (default: split-precision bf16 MFMA for the encoder GEMMs) or 'f32' (exact-fp32 MFMA)."""
         if precision not in nat.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(nat.PRECISIONS)}, got {precision!r}")
         self.lib.check(self.lib.mdm_set_precision(self.handle, nat.PRECISIONS[precision]), "mdm_set_precision")
@@ -55,9 +67,20 @@ class Engine:
             return torch.cuda.current_stream(self.device).cuda_stream
         return None
 
+    def _on_device(self):
+        """Every native call runs with the engine's device current: the library launches on the calling thread's HIP
+        device, so a model on cuda:1 must not be driven while cuda:0 is current (foreign stream, foreign pointers)."""
+        if self.device is not None and self.device.type == "cuda":
+            return torch.cuda.device(self.device)
+        return contextlib.nullcontext()
+
     def bind(self, state, device):
         """Register every tensor of `state` (reference state-dict keys incl. 'sequence_pos_encoder.pe')."""
         self.device = torch.device(device)
+        with self._on_device():
+            self._bind(state)
+
+    def _bind(self, state):
         self._weights = {}
         for name, t in state.items():
             t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -70,6 +93,7 @@ class Engine:
         self.lib.check(self.lib.mdm_prepare(self.handle, self._const_ws.data_ptr(), nbytes, self.stream()), "mdm_prepare")
         self.ready = True
 
+    @_on_own_device
     def workspace(self, nseq, T):
         need = self.lib.mdm_workspace_bytes(self.handle, nseq, T)
         if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
@@ -78,10 +102,12 @@ class Engine:
         return self._ws
 
     # ---- per-kernel-class timing (bench.py roofline) ------------------------------------------------
+    @_on_own_device
     def profile(self, on):
         self.lib.check(self.lib.mdm_profile_reset(self.handle), "mdm_profile_reset")
         self.lib.check(self.lib.mdm_profile_enable(self.handle, int(bool(on))), "mdm_profile_enable")
 
+    @_on_own_device
     def profile_read(self):
         """{class: {"ms": total, "launches": n, "flops": algorithmic flops}} of everything recorded since profile(True)."""
         out = {}
@@ -93,6 +119,7 @@ class Engine:
         return out
 
     # ---- MDM.forward ------------------------------------------------------------------------
+    @_on_own_device
     def forward(self, x, timesteps, text_embed, lengths, branches):
         B, J, Fe, T = x.shape
         self._check_device(x)
@@ -105,6 +132,7 @@ class Engine:
         return out
 
     # ---- MDM.forward, trans_dec (DiP) ----------------------------------------------------------
+    @_on_own_device
     def forward_dec(self, x, prefix, timesteps, text_tokens, text_lengths, lengths, branches):
         """x [B,J,F,pred_len], prefix [B,J,F,context_len] | None, text_tokens [ntok,B,dim],
         text_lengths [B] int32, lengths [B] int32 | None  ->  [B or 2B, J, F, pred_len]."""
@@ -124,19 +152,21 @@ class Engine:
         return out
 
     # ---- fused sampler pieces -----------------------------------------------------------------
+    @_on_own_device
     def sampler_step(self, x_t, out_cond, out_uncond, scale, inpaint_mask, inpaint_motion, noise, a_x0, a_xt, sigma,
-                     clip_denoised=False, seed=0, sample_base=0, draw=0, want_x0=False):
+                     clip_denoised=False, seed=0, sample_base=0, draw=0, want_x0=False, const_noise=False):
         B = x_t.shape[0]
         per = x_t[0].numel()
         x_prev = torch.empty_like(x_t)
         x0 = torch.empty_like(x_t) if want_x0 else None
-        st = nat.MdmStep(a_x0, a_xt, sigma, int(bool(clip_denoised)), seed, sample_base, draw)
+        st = nat.MdmStep(a_x0, a_xt, sigma, int(bool(clip_denoised)), seed, sample_base, draw, int(bool(const_noise)))
         self.lib.check(self.lib.mdm_sampler_step(x_t.data_ptr(), out_cond.data_ptr(), _ptr(out_uncond), _ptr(scale),
                                                  _ptr(inpaint_mask), _ptr(inpaint_motion), _ptr(noise),
                                                  x_prev.data_ptr(), _ptr(x0), B, per, C.byref(st), self.stream()),
                        "mdm_sampler_step")
         return x_prev, x0
 
+    @_on_own_device
     def randn(self, shape, device, seed, sample_base, draw, init=None, eps=None, a=0.0, s=1.0):
         out = torch.empty(shape, dtype=torch.float32, device=device)
         self._check_device(out)
@@ -145,9 +175,10 @@ class Engine:
                                           sample_base, draw, self.stream()), "mdm_randn")
         return out
 
+    @_on_own_device
     def sample_loop(self, x, *, a_x0, a_xt, sigma, timestep_map, start_index, text_embed, scale, lengths,
                     inpaint_mask=None, inpaint_motion=None, noise=None, seed=0, sample_base=0, clip_denoised=False,
-                    force_uncond=False, want_x0=False, dump_steps=None):
+                    force_uncond=False, want_x0=False, dump_steps=None, const_noise=False):
         """In-place loop on x [B,J,F,T] (x at index start_index).  Returns (x, x0 or None, dumps or None)."""
         B, J, Fe, T = x.shape
         self._check_device(x)
@@ -172,7 +203,8 @@ class Engine:
             seed=int(seed), sample_base=int(sample_base), clip_denoised=int(bool(clip_denoised)),
             force_uncond=int(bool(force_uncond)), x0_dev=_ptr(x0),
             dump_steps=(dsteps.ctypes.data if dsteps is not None else None),
-            num_dump=(len(dsteps) if dsteps is not None else 0), dump_dev=_ptr(dumps))
+            num_dump=(len(dsteps) if dsteps is not None else 0), dump_dev=_ptr(dumps),
+            const_noise=int(bool(const_noise)))
         self.lib.check(self.lib.mdm_sample_loop(self.handle, C.byref(p), x.data_ptr(), ws.data_ptr(), ws.numel(),
                                                 self.stream()), "mdm_sample_loop")
         return x, x0, dumps

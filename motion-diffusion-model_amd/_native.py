@@ -10,21 +10,24 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libmdm_hip.so"
 LIB_PATH = os.path.join(_HERE, "csrc", LIB_NAME)
+PROBE_LIB_PATH = os.path.join(_HERE, "csrc", "libmdm_hip_probe.so")   # -DMDM_PROBES build: tools/ and probe-only tests
 
 MDM_OK = 0
 BRANCH_COND, BRANCH_UNCOND, BRANCH_BOTH = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
-PRECISIONS = {"f32": 0, "bf16x3": 1}
+PRECISIONS = {"f32": 0, "f16x3": 1}
 PROF_CLASSES = ("linear", "attention", "layernorm", "embed", "outproj", "elementwise")
 
 EXPORTED_SYMBOLS = [
     "mdm_abi_version", "mdm_last_error", "mdm_create", "mdm_destroy", "mdm_set_weight", "mdm_const_bytes",
     "mdm_prepare", "mdm_workspace_bytes", "mdm_forward", "mdm_sampler_step", "mdm_randn", "mdm_sample_loop",
-    "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset", "mdm_set_precision", "mdm_linear_bf16x3", "mdm_linear_f16f6", "mdm_linear_f16f6_scratch_bytes",
-    "mdm_linear_bf16x3_scratch_bytes", "mdm_debug_set", "mdm_attention_bf16x3", "mdm_attention_bf16x3_scratch_bytes", "mdm_recover_from_ric",
-    "mdm_workspace_bytes_dec", "mdm_forward_dec", "mdm_debug_get",
+    "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset",
+    "mdm_set_precision", "mdm_linear_x3", "mdm_linear_x3_scratch_bytes", "mdm_attention_x3", "mdm_attention_x3_scratch_bytes",
+    "mdm_recover_from_ric", "mdm_workspace_bytes_dec", "mdm_forward_dec",
 ]
-ABI_VERSION = 3
+# include/mdm_hip_probe.h: exported by the probe build only
+PROBE_SYMBOLS = ["mdm_debug_set", "mdm_debug_get", "mdm_linear_f16f6", "mdm_linear_f16f6_scratch_bytes"]
+ABI_VERSION = 4
 ARCH = {"trans_enc": 0, "trans_dec": 1}
 
 
@@ -35,7 +38,7 @@ class MdmConfig(C.Structure):
 
 class MdmStep(C.Structure):
     _fields_ = [("a_x0", C.c_float), ("a_xt", C.c_float), ("sigma", C.c_float), ("clip_denoised", C.c_int32),
-                ("seed", C.c_uint64), ("sample_base", C.c_uint32), ("draw", C.c_uint32)]
+                ("seed", C.c_uint64), ("sample_base", C.c_uint32), ("draw", C.c_uint32), ("const_noise", C.c_int32)]
 
 
 class MdmSampleParams(C.Structure):
@@ -46,7 +49,7 @@ class MdmSampleParams(C.Structure):
         ("inpaint_mask_dev", C.c_void_p), ("inpaint_motion_dev", C.c_void_p), ("noise_dev", C.c_void_p),
         ("seed", C.c_uint64), ("sample_base", C.c_uint32), ("clip_denoised", C.c_int32),
         ("force_uncond", C.c_int32), ("x0_dev", C.c_void_p), ("dump_steps", C.c_void_p), ("num_dump", C.c_int32),
-        ("dump_dev", C.c_void_p),
+        ("dump_dev", C.c_void_p), ("const_noise", C.c_int32),
     ]
 
 
@@ -83,14 +86,10 @@ class MdmLib:
             "mdm_layernorm": (C.c_int, [vp, vp, vp, i32, i32, vp]),
             "mdm_attention": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
             "mdm_set_precision": (C.c_int, [vp, i32]),
-            "mdm_debug_set": (C.c_int, [C.c_int, C.c_int]),
-            "mdm_debug_get": (C.c_int, [C.c_int, P(C.c_double)]),
-            "mdm_linear_bf16x3_scratch_bytes": (sz, [i32, i32, i32]),
-            "mdm_linear_bf16x3": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
-            "mdm_linear_f16f6_scratch_bytes": (sz, [i32, i32, i32]),
-            "mdm_linear_f16f6": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
-            "mdm_attention_bf16x3_scratch_bytes": (sz, [i32, i32, i32]),
-            "mdm_attention_bf16x3": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+            "mdm_linear_x3_scratch_bytes": (sz, [i32, i32, i32]),
+            "mdm_linear_x3": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+            "mdm_attention_x3_scratch_bytes": (sz, [i32, i32, i32]),
+            "mdm_attention_x3": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
             "mdm_recover_from_ric": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
             "mdm_workspace_bytes_dec": (sz, [vp, i32, i32, i32]),
             "mdm_forward_dec": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
@@ -98,6 +97,15 @@ class MdmLib:
             "mdm_profile_read": (C.c_int, [vp, i32, P(C.c_double), P(i64), P(C.c_double)]),
             "mdm_profile_reset": (C.c_int, [vp]),
         }
+        probe_sig = {
+            "mdm_debug_set": (C.c_int, [C.c_int, C.c_int]),
+            "mdm_debug_get": (C.c_int, [C.c_int, P(C.c_double)]),
+            "mdm_linear_f16f6_scratch_bytes": (sz, [i32, i32, i32]),
+            "mdm_linear_f16f6": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+        }
+        self.has_probes = hasattr(lib, "mdm_debug_set")   # libmdm_hip_probe.so / the emulator build
+        if self.has_probes:
+            sig.update(probe_sig)
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.restype = res
@@ -123,3 +131,16 @@ def load_native():
     if _LIB is None:
         _LIB = MdmLib(os.environ.get("MDM_HIP_LIB", LIB_PATH))
     return _LIB
+
+
+_PROBE_LIB = None
+
+
+def load_probe():
+    """libmdm_hip_probe.so (include/mdm_hip_probe.h): experiments and probe-only tests; never used by the seams."""
+    global _PROBE_LIB
+    if _PROBE_LIB is None:
+        _PROBE_LIB = MdmLib(os.environ.get("MDM_HIP_PROBE_LIB", PROBE_LIB_PATH))
+        if not _PROBE_LIB.has_probes:
+            raise MdmError(f"{_PROBE_LIB.path} was not built with -DMDM_PROBES")
+    return _PROBE_LIB

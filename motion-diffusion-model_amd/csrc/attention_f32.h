@@ -49,7 +49,7 @@ struct AttnF32Args {
 // blockDim.x = 64 * ceil(Sq / 32): wave w owns query rows [32w, 32w + 32); NKT = ceil(Sk / 32) key tiles.
 template <int NKT>
 __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float* __restrict__ out, int D, int H,
-                                                             bf16_t* __restrict__ oh, bf16_t* __restrict__ ol) {
+                                                             p16_t* __restrict__ oh, p16_t* __restrict__ ol) {
   MDM_DYN_SMEM(float, smem);  // max(NKT, query tiles) * 32 rows x ATT_KLD floats
   const int NT = (int)blockDim.x;
   constexpr int ROWS = 32 * NKT;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
       const float4 v = ld4(&smem[qq * ATT_KLD + 4 * c4]);
       const size_t o = obase + (size_t)qq * D + 4 * c4;
       if (out != nullptr) st4(out + o, v);
-      if (oh != nullptr) split4_store(oh + o, ol + o, v);  // planes for the out_proj bf16x3 GEMM
+      if (oh != nullptr) split4_store(oh + o, ol + o, v);  // planes for the out_proj f16x3 GEMM
     }
   }
 }

@@ -1,5 +1,5 @@
 // Fused multi-head self-attention for the MDM encoder in split precision (three bf16 MFMA products per fp32
-// product, fp32 accumulate -- the same arithmetic class as gemm_bf16x3.h), fed by the bf16 hi/lo planes that the
+// product, fp32 accumulate -- the same arithmetic class as gemm_x3.h), fed by the bf16 hi/lo planes that the
 // in_proj GEMM's epilogue writes in exactly the layouts this kernel wants.
 //
 // Replaces, per layer, torch's head split / scaled_dot_product_attention / head merge
@@ -20,7 +20,7 @@
 //   phase 1  St[key][query] = K . Q^T    A = K fragments (LDS, XOR-swizzled 256-byte rows, conflict-free b128 reads)
 //                                        B = this wave's Q fragments (registers, loaded once)
 //   softmax  per lane over its 16 keys per tile x NKT tiles + ONE cross-half shuffle; normalisation deferred to O
-//   phase 2  Ot[d][query]  = V^T . P^T   A = V^T fragments (LDS, 64-byte rows swizzled like gemm_bf16x3.h)
+//   phase 2  Ot[d][query]  = V^T . P^T   A = V^T fragments (LDS, 64-byte rows swizzled like gemm_x3.h)
 //                                        B = split(P) straight from the phase-1 registers
 // K and V^T arrive by global_load_lds_dwordx4 (no staging registers) through a ring of LDS slots (see the kernel).
 #pragma once
@@ -32,18 +32,18 @@ constexpr int AX_HD = 128;
 constexpr int AX_OLD = AX_HD + 4;  // fp32 output staging row stride (floats)
 
 struct QkvPlanes {
-  bf16_t *qh, *ql, *kh, *kl, *vh, *vl;
+  p16_t *qh, *ql, *kh, *kl, *vh, *vl;
   int SP, NKT, H;
 };
 
 // position p (0..15) inside a 16-key group  <->  key offset, the MFMA accumulator row order (see header)
 __host__ __device__ __forceinline__ int ax_key_of_pos(int p) { return (p & 3) + 8 * ((p >> 2) & 1) + 4 * (p >> 3); }
 
-__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+__device__ __forceinline__ void split8(const float* v, p16x8& hi, p16x8& lo) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    bf16_t a, b;
-    split_bf16(v[j], a, b);
+    p16_t a, b;
+    split_p16(v[j], a, b);
     hi[j] = (short)a;
     lo[j] = (short)b;
   }
@@ -68,9 +68,9 @@ static_assert(AX_SLOT + 4 * 32 * AX_OST * 4 <= AX_RING * AX_SLOT, "output stagin
 // ABL (timing experiments only, 0 in production; results are garbage): 1 = no MFMAs, 2 = no LDS fragment reads,
 // 4 = no softmax, 8 = no output staging / stores, 16 = no K / V^T streaming after the prologue, 32 = no per-tile barrier.
 template <int NKT, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, const int* __restrict__ lengths,
+__global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const int* __restrict__ lengths,
                                                                     int S, int D, int B, float* __restrict__ out,
-                                                                    bf16_t* __restrict__ oh, bf16_t* __restrict__ ol,
+                                                                    p16_t* __restrict__ oh, p16_t* __restrict__ ol,
                                                                     int items) {
   MDM_DYN_SMEM(unsigned char, lds);
   constexpr int SP = 32 * NKT;
@@ -119,13 +119,13 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
     }
   };
   // ---- this wave's Q fragments: query q = 32 qt + r, k-step st covers d = 16 st + 8h .. +7
-  bf16x8 qh[8], ql[8];
+  p16x8 qh[8], ql[8];
   auto load_q = [&](size_t sh) {
     const size_t qo = (sh * SP + min(32 * (active ? qt : 0) + r, S - 1)) * AX_HD + 8 * h;   // pad queries: last real row
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
-      qh[st] = *reinterpret_cast<const bf16x8*>(P.qh + qo + 16 * st);
-      ql[st] = *reinterpret_cast<const bf16x8*>(P.ql + qo + 16 * st);
+      qh[st] = *reinterpret_cast<const p16x8*>(P.qh + qo + 16 * st);
+      ql[st] = *reinterpret_cast<const p16x8*>(P.ql + qo + 16 * st);
     }
   };
   issue_tile((size_t)item_of(vb), 0, lane);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
     if constexpr (t < NKT) {
       // ---- phase 1, key tile t: St[key][query] += K . Q^T, three products per 16-deep k step
       if (active) {
-        bf16x8 kh[3], kl[3];
+        p16x8 kh[3], kl[3];
 #ifdef MDM_EMU
 #define AX_RD_K(dst, plane, st) lds_read16(dst, lds, slot * AX_SLOT + (plane) * 8192 + (klane ^ ((st) << 5)))
 #else
@@ -212,9 +212,9 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
               asm volatile("" ::"v"(kl[st % 3]), "v"(kh[st % 3]), "v"(qh[st]), "v"(ql[st]));
 #endif
             } else {
-              p[t] = mfma_bf16(kl[st % 3], qh[st], p[t]);
-              p[t] = mfma_bf16(kh[st % 3], ql[st], p[t]);
-              p[t] = mfma_bf16(kh[st % 3], qh[st], p[t]);
+              p[t] = mfma_p16(kl[st % 3], qh[st], p[t]);
+              p[t] = mfma_p16(kh[st % 3], ql[st], p[t]);
+              p[t] = mfma_p16(kh[st % 3], qh[st], p[t]);
             }
 #ifndef MDM_EMU
             __builtin_amdgcn_sched_barrier(0);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
           for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
       }
       if (active) {
-        bf16x8 vh[3], vl[3], ph, pl;
+        p16x8 vh[3], vl[3], ph, pl;
 #ifdef MDM_EMU
 #define AX_RD_V(dst, plane, s2, dt) lds_read16(dst, lds, slot * AX_SLOT + (plane) * 8192 + (dt) * 2048 + (vlane ^ ((s2) << 5)))
 #else
@@ -295,9 +295,9 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
               asm volatile("" ::"v"(vl[uv % 3]), "v"(vh[uv % 3]), "v"(ph), "v"(pl));
 #endif
             } else if (kt < NKT - 1 || s2 == 0 || last_group) {
-              o[dt] = mfma_bf16(vl[uv % 3], ph, o[dt]);
-              o[dt] = mfma_bf16(vh[uv % 3], pl, o[dt]);
-              o[dt] = mfma_bf16(vh[uv % 3], ph, o[dt]);
+              o[dt] = mfma_p16(vl[uv % 3], ph, o[dt]);
+              o[dt] = mfma_p16(vh[uv % 3], pl, o[dt]);
+              o[dt] = mfma_p16(vh[uv % 3], ph, o[dt]);
             }
 #ifndef MDM_EMU
             __builtin_amdgcn_sched_barrier(0);
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x3_kernel(QkvPlanes P, c
           const float4 v = ld4(&so[row * AX_OST + 4 * c4]);
           const size_t oo = obase + (size_t)qq * D + 64 * pass + 4 * c4;
           if (out != nullptr) st4(out + oo, v);
-          if (oh != nullptr) split4_store(oh + oo, ol + oo, v);  // planes for the out_proj bf16x3 GEMM
+          if (oh != nullptr) split4_store(oh + oo, ol + oo, v);  // planes for the out_proj f16x3 GEMM
         }
       }
       wave_lds_fence();
@@ -371,16 +371,16 @@ __global__ __launch_bounds__(256) void qkv_pack_kernel(const float* __restrict__
       const float* row = qkv + ((size_t)seq * S + tok) * 3 * D + head * AX_HD + d;
       q = row[0]; k = row[D]; v = row[2 * D];
     }
-    bf16_t a, b;
+    p16_t a, b;
     const size_t rk = (shd * SP + tok) * AX_HD + d;
-    split_bf16(q, a, b); P.qh[rk] = a; P.ql[rk] = b;
-    split_bf16(k, a, b); P.kh[rk] = a; P.kl[rk] = b;
+    split_p16(q, a, b); P.qh[rk] = a; P.ql[rk] = b;
+    split_p16(k, a, b); P.kh[rk] = a; P.kl[rk] = b;
     const int kt = tok >> 5, k32 = tok & 31, g16 = k32 >> 4, k16 = k32 & 15;
     int pos = 0;  // inverse of ax_key_of_pos
     for (int pp = 0; pp < 16; ++pp)
       if (ax_key_of_pos(pp) == k16) pos = pp;
     const size_t vk = ((shd * P.NKT + kt) * AX_HD + d) * 32 + 16 * g16 + pos;
-    split_bf16(v, a, b); P.vh[vk] = a; P.vl[vk] = b;
+    split_p16(v, a, b); P.vh[vk] = a; P.vl[vk] = b;
   }
 }
 

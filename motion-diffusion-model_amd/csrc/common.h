@@ -20,9 +20,22 @@
 namespace mdm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short p16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kWave = 64;
+
+// Ordinal of the calling thread's current HIP device: host-side caches of per-device facts (CU count, function attributes)
+// are indexed by it, so that one process may drive several GPUs (one model handle per device).
+constexpr int kMaxDevices = 64;
+inline int rt_device_ordinal() {
+#ifdef MDM_EMU
+  return 0;
+#else
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+#endif
+}
 
 // v_mfma_f32_32x32x2_f32: exact-fp32 matrix FMA (64 cyc/SIMD, 157 TF chip peak).
 //   lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
@@ -35,20 +48,37 @@ __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
 #endif
 }
 
-// v_mfma_f32_32x32x16_bf16: lane l supplies 8 consecutive-k bf16 of row/col (l&31), k-block (l>>5).
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-#ifdef MDM_EMU
-  return emu::mfma_f32_32x32x16_bf16(a, b, c);
+// ---------------------------------------------------------------------------------------------
+// The 16-bit element of the split-precision ("x3") operand planes.  DEFAULT: IEEE fp16 ("f16x3": 11 + 11 significant bits per
+// fp32 value).  -DMDM_SPLIT_BF16 builds the round-1 bfloat16 form ("f16x3": 8 + 8 bits, fp32's exponent range) for A/B
+// runs.  Same bytes, same MFMA rate (v_mfma_f32_32x32x16_f16 / _bf16), same kernels: only these helpers differ.
+// Why fp16: on "trained-like" weights (oracle/synth.py synth_state_dict_hostile) the bf16 split is 10x the fp32 reference's own
+// rounding noise, the fp16 split sits AT that noise (tools/precision_probe.py, tools/fold_probe.py).
+// Range: |x| <= 65504 * (1 + 2^-11) is representable (hi saturates, lo takes the rest); below 2^-14 the planes keep an absolute
+// precision of 2^-25 (fp16 subnormals -- gfx950's MFMA does not flush them).
+// ---------------------------------------------------------------------------------------------
+#ifdef MDM_SPLIT_BF16
+constexpr bool kSplitF16 = false;
 #else
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+constexpr bool kSplitF16 = true;
+#endif
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// v_mfma_f32_32x32x16_{f16,bf16}: lane l supplies 8 consecutive-k elements of row/col (l&31), k-block (l>>5).
+__device__ __forceinline__ f32x16 mfma_p16(p16x8 a, p16x8 b, f32x16 c) {
+#ifdef MDM_EMU
+  if constexpr (kSplitF16) return emu::mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c);
+  else return emu::mfma_f32_32x32x16_bf16(a, b, c);
+#else
+  if constexpr (kSplitF16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 #endif
 }
 
 // ---- the instructions of the "f16f6" seed GEMM (gemm_f16f6.h)
-typedef _Float16 f16_t;
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-// v_mfma_f32_32x32x16_f16: operand / result layout of mfma_bf16 above, fp16 elements.
+// v_mfma_f32_32x32x16_f16: operand / result layout of mfma_p16 above, fp16 elements.
 __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
 #ifdef MDM_EMU
   return emu::mfma_f32_32x32x16_f16(a, b, c);
@@ -71,13 +101,15 @@ __device__ __forceinline__ f32x16 mfma_mx_fp6(i32x8 a, i32x8 b, f32x16 c, int sc
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// v_mfma_f32_16x16x32_bf16: lane l supplies 8 consecutive-k bf16 of row/col (l&15), k-block (l>>4) (k = 8*(l>>4)+e);
+// v_mfma_f32_16x16x32_{f16,bf16}: lane l supplies 8 consecutive-k elements of row/col (l&15), k-block (l>>4) (k = 8*(l>>4)+e);
 // D[reg] is row 4*(l>>4) + reg, column l&15.
-__device__ __forceinline__ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+__device__ __forceinline__ f32x4 mfma16_p16(p16x8 a, p16x8 b, f32x4 c) {
 #ifdef MDM_EMU
-  return emu::mfma_f32_16x16x32_bf16(a, b, c);
+  if constexpr (kSplitF16) return emu::mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c);
+  else return emu::mfma_f32_16x16x32_bf16(a, b, c);
 #else
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  if constexpr (kSplitF16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 #endif
 }
 
@@ -86,7 +118,7 @@ __device__ __forceinline__ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
 //   in   w0 = [r0-15 k0-7 | r16-31 k0-7 | r0-15 k8-15 | r16-31 k8-15]    w1 = the same with k + 16
 //   v_permlane32_swap (lanes 32-63 of w0 <-> lanes 0-31 of w1), then v_permlane16_swap (odd rows of w0 <-> even rows of w1)
 //   out  w0 = [r0-15 k0-7 | r0-15 k8-15 | r0-15 k16-23 | r0-15 k24-31]   w1 = the same for r16-31
-__device__ __forceinline__ void frag32_to_frag16(bf16x8& w0, bf16x8& w1) {
+__device__ __forceinline__ void frag32_to_frag16(p16x8& w0, p16x8& w1) {
   u32x4 a = __builtin_bit_cast(u32x4, w0), b = __builtin_bit_cast(u32x4, w1);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -103,8 +135,8 @@ __device__ __forceinline__ void frag32_to_frag16(bf16x8& w0, bf16x8& w1) {
     a[i] = x;
     b[i] = y;
   }
-  w0 = __builtin_bit_cast(bf16x8, a);
-  w1 = __builtin_bit_cast(bf16x8, b);
+  w0 = __builtin_bit_cast(p16x8, a);
+  w1 = __builtin_bit_cast(p16x8, b);
 }
 
 // value of `v` in lane `src_lane` (wave-uniform control flow required)
@@ -148,39 +180,49 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // ---------------------------------------------------------------------------------------------
-// Split-precision helpers: x = hi + lo (+ O(2^-17 |x|)), hi = bf16_rne(x), lo = bf16_rne(x - hi).
-// A fp32 product a*w is then carried by three bf16 MFMA products  ah*wh + ah*wl + al*wh  (the al*wl term,
-// ~2^-16 relative, is dropped), accumulated in fp32: SURVEY.md section 7 "Precision vs. peak".
+// Split-precision helpers: x = hi + lo, hi = rne16(x), lo = rne16(x - hi)  (fp16: +O(2^-22 |x|); bf16 build: +O(2^-17 |x|)).
+// A fp32 product a*w is then carried by three 16-bit MFMA products  ah*wh + ah*wl + al*wh  (the al*wl term is dropped),
+// accumulated in fp32: SURVEY.md section 7 "Precision vs. peak".
 // ---------------------------------------------------------------------------------------------
-typedef unsigned short bf16_t;
+typedef unsigned short p16_t;
 
-__host__ __device__ __forceinline__ float bf16_bits_to_f32(bf16_t b) {
-  const uint32_t u = (uint32_t)b << 16;
-  float f;
-  __builtin_memcpy(&f, &u, 4);
-  return f;
+__host__ __device__ __forceinline__ float p16_to_f32(p16_t b) {
+  if constexpr (kSplitF16) {
+    return (float)__builtin_bit_cast(f16_t, b);
+  } else {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+  }
 }
 
-__host__ __device__ __forceinline__ bf16_t f32_to_bf16_rne(float x) {
+__host__ __device__ __forceinline__ p16_t f32_to_p16(float x) {
+  if constexpr (kSplitF16) {
+    // round-to-nearest-even; saturating (65504) instead of inf, so that hi + lo still carries values up to 2 * 65504
+    const float c = __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f);
+    return __builtin_bit_cast(p16_t, (f16_t)c);
+  } else {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_bit_cast(unsigned short, (__bf16)x);   // v_cvt_pk_bf16_f32 (round-to-nearest-even)
+    return __builtin_bit_cast(unsigned short, (__bf16)x);   // v_cvt_pk_bf16_f32 (round-to-nearest-even)
 #else
-  uint32_t u;
-  __builtin_memcpy(&u, &x, 4);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+    uint32_t u;
+    __builtin_memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (p16_t)(u >> 16);
 #endif
+  }
 }
 
-__host__ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
-  hi = f32_to_bf16_rne(x);
-  lo = f32_to_bf16_rne(x - bf16_bits_to_f32(hi));
+__host__ __device__ __forceinline__ void split_p16(float x, p16_t& hi, p16_t& lo) {
+  hi = f32_to_p16(x);
+  lo = f32_to_p16(x - p16_to_f32(hi));
 }
 
 // 4 consecutive values -> 8-byte packed hi and lo groups
-__device__ __forceinline__ void split4_store(bf16_t* hi_p, bf16_t* lo_p, float4 v) {
-  bf16_t h[4], l[4];
-  split_bf16(v.x, h[0], l[0]); split_bf16(v.y, h[1], l[1]); split_bf16(v.z, h[2], l[2]); split_bf16(v.w, h[3], l[3]);
+__device__ __forceinline__ void split4_store(p16_t* hi_p, p16_t* lo_p, float4 v) {
+  p16_t h[4], l[4];
+  split_p16(v.x, h[0], l[0]); split_p16(v.y, h[1], l[1]); split_p16(v.z, h[2], l[2]); split_p16(v.w, h[3], l[3]);
   *reinterpret_cast<uint2*>(hi_p) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
   *reinterpret_cast<uint2*>(lo_p) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
 }
@@ -209,38 +251,38 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // LDS fragment read that hipcc does NOT track (cdna_hip_programming.md 5.7 form (ii)): hipcc's waitcnt pass retires
 // tracked ds_reads with lgkmcnt(0) only (measured: a full drain every third MFMA unit halves the matrix-pipe duty of
-// the bf16x3 main loop), so the hot loops issue their reads through lds_read16 and retire them IN ORDER with a counted
+// the f16x3 main loop), so the hot loops issue their reads through lds_read16 and retire them IN ORDER with a counted
 // lds_wait<N>(regs...) that names the registers becoming valid -- no consumer of those registers can be scheduled
 // above the wait, and any copy the compiler made earlier is dead.
 #ifdef MDM_EMU
-__device__ __forceinline__ void lds_read16(bf16x8& dst, const unsigned char* base, uint32_t byte_off) {
-  dst = *reinterpret_cast<const bf16x8*>(base + byte_off);
+__device__ __forceinline__ void lds_read16(p16x8& dst, const unsigned char* base, uint32_t byte_off) {
+  dst = *reinterpret_cast<const p16x8*>(base + byte_off);
 }
-template <int N> __device__ __forceinline__ void lds_wait(bf16x8&, bf16x8&) {}
-template <int N> __device__ __forceinline__ void lds_wait(bf16x8&, bf16x8&, bf16x8&, bf16x8&) {}
-template <int N> __device__ __forceinline__ void lds_wait(bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&) {}
+template <int N> __device__ __forceinline__ void lds_wait(p16x8&, p16x8&) {}
+template <int N> __device__ __forceinline__ void lds_wait(p16x8&, p16x8&, p16x8&, p16x8&) {}
+template <int N> __device__ __forceinline__ void lds_wait(p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&) {}
 template <int N>
-__device__ __forceinline__ void lds_wait(bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&) {}
+__device__ __forceinline__ void lds_wait(p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&) {}
 #else
 // `lds_addr` = 32-bit LDS byte address (lds_addr_of), IMM = compile-time byte offset < 65536
-template <int IMM> __device__ __forceinline__ void lds_read16(bf16x8& dst, uint32_t lds_addr) {
+template <int IMM> __device__ __forceinline__ void lds_read16(p16x8& dst, uint32_t lds_addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(IMM));
 }
-template <int N> __device__ __forceinline__ void lds_wait(bf16x8& a, bf16x8& b) {
+template <int N> __device__ __forceinline__ void lds_wait(p16x8& a, p16x8& b) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N));
 }
-template <int N> __device__ __forceinline__ void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+template <int N> __device__ __forceinline__ void lds_wait(p16x8& a, p16x8& b, p16x8& c, p16x8& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));
 }
 template <int N>
-__device__ __forceinline__ void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e, bf16x8& f, bf16x8& g,
-                                         bf16x8& h) {
+__device__ __forceinline__ void lds_wait(p16x8& a, p16x8& b, p16x8& c, p16x8& d, p16x8& e, p16x8& f, p16x8& g,
+                                         p16x8& h) {
   asm volatile("s_waitcnt lgkmcnt(%8)"
                : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)
                : "i"(N));
 }
 template <int N>
-__device__ __forceinline__ void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e, bf16x8& f) {
+__device__ __forceinline__ void lds_wait(p16x8& a, p16x8& b, p16x8& c, p16x8& d, p16x8& e, p16x8& f) {
   asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "i"(N));
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
@@ -266,7 +308,7 @@ template <int N> __device__ __forceinline__ void vmem_wait(f32x4& a, f32x4& b, f
 }
 #endif
 
-// 8-byte flavour (four bf16 of one plane): the residual stream of the bf16x3 mode lives only as hi/lo planes
+// 8-byte flavour (four bf16 of one plane): the residual stream of the f16x3 mode lives only as hi/lo planes
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifdef MDM_EMU
 __device__ __forceinline__ void gload8_async(u32x2& dst, const void* p) { memcpy(&dst, p, 8); }

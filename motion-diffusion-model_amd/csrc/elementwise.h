@@ -12,7 +12,7 @@ namespace mdm {
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int rows, float eps,
-                                                        bf16_t* __restrict__ xh, bf16_t* __restrict__ xl,
+                                                        p16_t* __restrict__ xh, p16_t* __restrict__ xl,
                                                         int write_f32) {
   constexpr int D = 256 * NV;
   const int lane = threadIdx.x & 63;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
     const float4 o = make_float4(v[i].x * rstd * g.x + b.x, v[i].y * rstd * g.y + b.y, v[i].z * rstd * g.z + b.z,
                                  v[i].w * rstd * g.w + b.w);
     if (write_f32) st4(xr + 256 * i + 4 * lane, o);
-    if (xh != nullptr) {  // split planes for the next bf16x3 GEMM (and, in that mode, the residual stream itself)
+    if (xh != nullptr) {  // split planes for the next f16x3 GEMM (and, in that mode, the residual stream itself)
       const size_t off = (size_t)row * D + 256 * i + 4 * lane;
       split4_store(xh + off, xl + off, o);
     }
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void cond_token_kernel(float* __restrict__ tok
                                                          int t_uniform,  // used when timesteps == null
                                                          const float* __restrict__ pe, int B, int S, int D,
                                                          int uncond_from_branch, int table_rows,
-                                                         bf16_t* __restrict__ th, bf16_t* __restrict__ tl) {
+                                                         p16_t* __restrict__ th, p16_t* __restrict__ tl) {
   const int seq = blockIdx.x, b = seq % B, br = seq / B;
   long long t = (timesteps != nullptr) ? timesteps[b] : (long long)t_uniform;
   if (t < 0) t = 0;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, con
   }
 }
 
-// Tail of the split-precision OutputProcess: the bf16x3 GEMM leaves every token's 263 output features as a fp32 ROW
+// Tail of the split-precision OutputProcess: the f16x3 GEMM leaves every token's 263 output features as a fp32 ROW
 // (out_tok [nseq*S][ldo]); this kernel drops token 0 (mdm.py:253), transposes 32x32 tiles through LDS into the
 // reference's [.., JF, T] pose layout (mdm.py:385) and fuses, per element, what OutProjEpilogue fuses in the fp32 path:
 // mode 0 plain model output for every sequence; mode 1 classifier-free-guidance combine of the two branches
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256) void outproj_finish_kernel(const float* __rest
 // InputProcess operand for the split-precision GEMM: poses x [B][JF][T] (frames contiguous) -> bf16 hi/lo planes
 // [B*T][KP] (row = (b, t), features contiguous, zero-padded from JF to KP) -- the permute of mdm.py:345 as a 32x32 LDS
 // tile transpose.  grid (ceil(T/32), KP/32, B), 256 threads.
-__global__ __launch_bounds__(256) void pose_to_planes_kernel(const float* __restrict__ x, bf16_t* __restrict__ ph,
-                                                             bf16_t* __restrict__ pl, int T, int JF, int KP) {
+__global__ __launch_bounds__(256) void pose_to_planes_kernel(const float* __restrict__ x, p16_t* __restrict__ ph,
+                                                             p16_t* __restrict__ pl, int T, int JF, int KP) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int t0 = blockIdx.x * 32, j0 = blockIdx.y * 32, b = blockIdx.z;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void pose_to_planes_kernel(const float* __rest
   }
 }
 
-// LayerNorm folded into the linear layer that consumes it (mdm_prepare; gemm_bf16x3.h X3Epilogue):
+// LayerNorm folded into the linear layer that consumes it (mdm_prepare; gemm_x3.h X3Epilogue):
 //   wf[n][k] = w[n][k] * gamma[k];  colsum[n] = sum_k wf[n][k];  biasf[n] = bias[n] + sum_k w[n][k] * beta[k]
 // so that  W.LN(x) + b = rstd * (Wf.x - mean * colsum) + biasf.  One wave per output row; rows N..Npad-1 of the
 // vectors are zeroed.  fp64 accumulation of the two sums (they are constants of the model).
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __rest
 }
 
 // hi/lo bf16 planes of a fp32 array (weights at mdm_prepare; test inputs).  n must be a multiple of 4.
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi,
-                                                           bf16_t* __restrict__ lo, size_t n4) {
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, p16_t* __restrict__ hi,
+                                                           p16_t* __restrict__ lo, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
     split4_store(hi + 4 * i, lo + 4 * i, ld4(src + 4 * i));
 }

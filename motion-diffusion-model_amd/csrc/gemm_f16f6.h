@@ -3,8 +3,8 @@
 // ah = fp16(a), al = a - ah (same for w); q6 = MX-FP6 (OCP Microscaling E2M3) with one power-of-two scale (E8M0) per 32
 // consecutive k.  The main term is ONE v_mfma_f32_32x32x16_f16 pass; the two cross terms -- 2^-11 of it, so ~5 bits do -- run on
 // v_mfma_scale_f32_32x32x64_f8f6f4, which gfx950 executes at four times the fp16 rate: 1.5 pass-equivalents instead of the
-// three bf16 passes of gemm_bf16x3.h (measured at the matrix pipe: 1.75x; 50-step trajectory error 9.8e-5 vs 4.4e-5, bar 1e-3:
-// tools/precision_probe.py, tools/mx/, profiles/r01h_*).  Replaces nothing in the reference that gemm_bf16x3.h does not
+// three bf16 passes of gemm_x3.h (measured at the matrix pipe: 1.75x; 50-step trajectory error 9.8e-5 vs 4.4e-5, bar 1e-3:
+// tools/precision_probe.py, tools/mx/, profiles/r01h_*).  Replaces nothing in the reference that gemm_x3.h does not
 // already replace (the `addmm`s of model/mdm.py:77-84).
 //
 // This file pins down what the production kernel will be built on and is exercised by the emulator and GPU parity tests
@@ -17,7 +17,7 @@
 //                            string at bit 6j of its dwords c0..c5):  [hi c0-c3 | lo c0-c3 | hi c4 c5, hi scale (127 + e), 0 |
 //                            lo c4 c5, lo scale, 0] -- lane half h of the production k-loop reads chunk h in k sub-step 0 and
 //                            chunk 2 + h in sub-step 1, exactly the two 16-byte reads it issues on today's lo plane
-// i.e. 2 + 2 bytes per element, the byte geometry of gemm_bf16x3.h's hi / lo planes (its LDS-DMA staging carries over).
+// i.e. 2 + 2 bytes per element, the byte geometry of gemm_x3.h's hi / lo planes (its LDS-DMA staging carries over).
 // Fragments, per 32-k block: fp16 MFMA, k sub-step s in {0, 1}: lane (r = lane & 31, h = lane >> 5) holds k = 16 s + 8 h .. + 7 of
 // row (column) r; scaled MFMA (K = 64 = both cross terms of the block): A lane (r, h) holds the block's 32 codes of hi (h = 0) /
 // lo (h = 1) and that part's scale in byte 0; B lane (c, h) holds the codes of lo (h = 0) / hi (h = 1) of column c.
@@ -105,12 +105,12 @@ __global__ __launch_bounds__(256) void pack_f16f6_kernel(const float* __restrict
   rec[12] = wl[4]; rec[13] = wl[5]; rec[14] = (uint32_t)(127 + el); rec[15] = 0;
 }
 
-// Weights fp32 [N][K] -> the fragment-ordered planes the production k-loop streams straight into registers (gemm_bf16x3.h
-// header: [n/32][k/16][lane][16 B], rows >= N zero): plane `hi` holds fp16 values where bf16x3 holds bf16; plane `lo` holds,
+// Weights fp32 [N][K] -> the fragment-ordered planes the production k-loop streams straight into registers (gemm_x3.h
+// header: [n/32][k/16][lane][16 B], rows >= N zero): plane `hi` holds fp16 values where f16x3 holds bf16; plane `lo` holds,
 // per 32-k block, for B-operand lane half 0 the codes of LO and for half 1 the codes of HI (the scaled MFMA pairs them with
 // the A operand's hi / lo codes): k16 slot 2 kb: code dwords c0-c3, slot 2 kb + 1: [c4, c5, scale, 0].  One thread per (n, block).
-__global__ __launch_bounds__(256) void pack_weight_f16f6_kernel(const float* __restrict__ w, bf16_t* __restrict__ hi,
-                                                                bf16_t* __restrict__ lo, int N, int K) {
+__global__ __launch_bounds__(256) void pack_weight_f16f6_kernel(const float* __restrict__ w, p16_t* __restrict__ hi,
+                                                                p16_t* __restrict__ lo, int N, int K) {
   const int npad = (N + 31) / 32 * 32, nb = K / 32;
   const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (idx >= npad * nb) return;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void gemm_f16f6_ref_kernel(F6Planes A, F6Planes
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  // One 32-k block per iteration -- the production kernel's k step (gemm_bf16x3.h stages are 32 deep): two fp16 MFMAs for the
+  // One 32-k block per iteration -- the production kernel's k step (gemm_x3.h stages are 32 deep): two fp16 MFMAs for the
   // main term and ONE scaled MFMA whose K = 64 holds BOTH cross terms of the block: lane half 0 supplies q6(ah) (A) against
   // q6(wl) (B), lane half 1 supplies q6(al) against q6(wh); the K reduction adds the two.
   for (int kb = 0; kb < nb; ++kb) {

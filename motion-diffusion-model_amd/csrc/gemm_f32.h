@@ -105,7 +105,7 @@ struct CfgTokenLoader {
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
 
 // v = act(acc + bias[n]) * (n < scale_cols ? col_scale : 1) + (res ? res[m][n] : 0);
-// out[m][n] = v (if out) and/or the bf16 split planes oh/ol[m][n] = hi/lo(v) (if oh) for a following bf16x3 GEMM.
+// out[m][n] = v (if out) and/or the bf16 split planes oh/ol[m][n] = hi/lo(v) (if oh) for a following f16x3 GEMM.
 struct LinearEpilogue {
   float* out;        // may be null when only the planes are wanted
   const float* bias;
@@ -114,8 +114,8 @@ struct LinearEpilogue {
   int act;
   int scale_cols;   // columns [0, scale_cols) are multiplied by col_scale (q * 1/sqrt(hd) for in_proj)
   float col_scale;
-  bf16_t* oh;       // optional split planes, same [M][ld] shape
-  bf16_t* ol;
+  p16_t* oh;       // optional split planes, same [M][ld] shape
+  p16_t* ol;
   struct Row { size_t base; };
   struct Col { int n; float bias, mult; };
   __device__ __forceinline__ Row row(int m) const { return Row{(size_t)m * ld}; }
@@ -128,7 +128,7 @@ struct LinearEpilogue {
     const size_t o = r.base + c.n;
     if (res != nullptr) v += res[o];
     if (out != nullptr) out[o] = v;
-    if (oh != nullptr) split_bf16(v, oh[o], ol[o]);
+    if (oh != nullptr) split_p16(v, oh[o], ol[o]);
   }
 };
 
@@ -139,8 +139,8 @@ struct EmbedEpilogue {
   const float* bias;   // [D]
   const float* pe;     // [max_len, D]
   int B, T, S, D, nbranch;
-  bf16_t* th;          // optional split planes of tok (bf16x3 mode)
-  bf16_t* tl;
+  p16_t* th;          // optional split planes of tok (f16x3 mode)
+  p16_t* tl;
   int lead = 1;        // token rows in front of the frames: 1 (condition token, trans_enc) or 0 (trans_dec: S == T)
   struct Row { size_t tok_off, pe_off; };
   struct Col { int n; float bias; };
@@ -154,8 +154,8 @@ struct EmbedEpilogue {
     tok[r.tok_off + c.n] = v;
     if (nbranch == 2) tok[r.tok_off + (size_t)B * S * D + c.n] = v;
     if (th != nullptr) {
-      bf16_t hi, lo;
-      split_bf16(v, hi, lo);
+      p16_t hi, lo;
+      split_p16(v, hi, lo);
       th[r.tok_off + c.n] = hi; tl[r.tok_off + c.n] = lo;
       if (nbranch == 2) { th[r.tok_off + (size_t)B * S * D + c.n] = hi; tl[r.tok_off + (size_t)B * S * D + c.n] = lo; }
     }
@@ -174,9 +174,11 @@ struct NoiseSource {
   uint64_t seed;
   uint32_t sample_base;  // global index of local sample 0 (sharding-invariant streams)
   uint32_t draw;         // draw index: 0 = x_T, 1 + k = k-th step
+  uint32_t const_noise;  // p_sample(const_noise=True), gaussian_diffusion.py:527-528: every sample gets the eps of GLOBAL sample 0
+                         // (the reference repeats row 0 of its batch; keyed by the global index so that shards agree)
   __device__ __forceinline__ float get(int b, uint32_t elem, size_t off) const {
-    if (noise != nullptr) return noise[off];
-    return philox_normal(seed, elem, sample_base + (uint32_t)b, draw);
+    if (noise != nullptr) return noise[off];   // injected noise: the caller hands over the already-repeated tensor
+    return philox_normal(seed, elem, const_noise ? 0u : sample_base + (uint32_t)b, draw);
   }
 };
 

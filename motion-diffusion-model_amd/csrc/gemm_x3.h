@@ -1,5 +1,5 @@
-// Split-precision ("bf16x3") MFMA GEMM for the encoder's dense contractions:
-//     C[m][n] = sum_k A[m][k] * W[n][k],   A = Ah + Al,  W = Wh + Wl  (bf16 planes, see common.h split_bf16)
+// Split-precision ("f16x3") MFMA GEMM for the encoder's dense contractions:
+//     C[m][n] = sum_k A[m][k] * W[n][k],   A = Ah + Al,  W = Wh + Wl  (bf16 planes, see common.h split_p16)
 //             ~ sum_k  Ah*Wh + Ah*Wl + Al*Wh            three v_mfma_f32_32x32x16_bf16 passes, fp32 accumulate.
 //
 // Why: the reference computes these `addmm`s in fp32 (model/mdm.py:77-84 -> torch TransformerEncoderLayer) and
@@ -38,7 +38,7 @@
 //   * W fragments for step g+1 are fetched into registers during step g (plain loads, waited with the step's vmcnt);
 //   * XCD-aware tile order keeps the workgroups that share an activation row panel on one XCD's L2.
 #pragma once
-#include "attention_bf16x3.h"  // QkvPlanes: the in_proj epilogue writes the attention kernel's operand planes
+#include "attention_x3.h"  // QkvPlanes: the in_proj epilogue writes the attention kernel's operand planes
 #include "common.h"
 #include "gemm_f32.h"  // ACT_* enums
 #include <cstdlib>
@@ -75,25 +75,25 @@ constexpr int X3_A_GROUPS = X3_A_STAGE / 1024;                   // 28 LDS-DMA w
 constexpr int x3_a_pieces(int waves) { return (X3_A_GROUPS + waves - 1) / waves; }  // 7 (4 waves) / 4 (8 waves)
 
 struct X3Operand {   // activations: [rows][K] planes
-  const bf16_t* hi;
-  const bf16_t* lo;
+  const p16_t* hi;
+  const p16_t* lo;
 };
 struct X3Weights {   // fragment-ordered planes (see header); rows padded to a multiple of 32
-  const bf16_t* hi;
-  const bf16_t* lo;
+  const p16_t* hi;
+  const p16_t* lo;
 };
 inline size_t x3_packed_weight_elems(int N, int K) { return (size_t)((N + 31) / 32 * 32) * K; }
 
 // v = act(acc + bias[n]) * (n < scale_cols ? col_scale : 1) + (res ? res[m][n] : 0) -> fp32 out and/or split planes,
-// or (OUT_QKV) the attention operand planes of attention_bf16x3.h.
+// or (OUT_QKV) the attention operand planes of attention_x3.h.
 struct X3Epilogue {
   float* out;        // [M][ld] or null
   const float* bias;
   const float* res;  // RES == 1: fp32 residual [M][ld]; may alias out
-  const bf16_t* resh;  // RES == 2: the residual as hi/lo planes [M][ld] (value = hi + lo)
-  const bf16_t* resl;
-  bf16_t* oh;        // [M][ld] split planes or null
-  bf16_t* ol;
+  const p16_t* resh;  // RES == 2: the residual as hi/lo planes [M][ld] (value = hi + lo)
+  const p16_t* resl;
+  p16_t* oh;        // [M][ld] split planes or null
+  p16_t* ol;
   int ld;
   int scale_cols;
   float col_scale;
@@ -101,7 +101,8 @@ struct X3Epilogue {
   int S, D;          // OUT_QKV only: tokens per sequence (= rows per tile), model width (N = 3 D)
   // ---- LayerNorm folded into the GEMMs around it (no LayerNorm kernel, no normalised copy of the residual stream):
   // the producer of a pre-norm sum x (out_proj / linear2, OSTAT) writes x as planes plus, per row and column tile, the
-  // partial sums (sum x, sum x^2) over its columns; every consumer rebuilds mean / rstd from those partials.
+  // partial statistics (sum x, sum (x - tile mean)^2) over its columns; every consumer merges them into mean / rstd
+  // (Chan's pairwise update: no E[x^2] - mean^2 cancellation).  OSTAT needs N % 256 == 0.
   //   FOLD  the A operand is x itself and the weights were pre-multiplied by gamma (mdm_prepare), so
   //         W.LN(x) + b = rstd * (W'.x - mean * colsum) + b'       with colsum[n] = sum_k W'[n][k], b' = b + W.beta
   //   RES 3 the residual is LN(x) = (x - mean) * rstd * gamma + beta, rebuilt on the fly from x's planes
@@ -142,8 +143,8 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 }
 
 // fp32 [N][K] -> fragment-ordered hi/lo planes (rows >= N zero).  One thread per 8 consecutive k of one row.
-__global__ __launch_bounds__(256) void pack_weight_planes_kernel(const float* __restrict__ w, bf16_t* __restrict__ hi,
-                                                                 bf16_t* __restrict__ lo, int N, int K) {
+__global__ __launch_bounds__(256) void pack_weight_planes_kernel(const float* __restrict__ w, p16_t* __restrict__ hi,
+                                                                 p16_t* __restrict__ lo, int N, int K) {
   const int npad = (N + 31) / 32 * 32, k8n = K / 8;
   const size_t total = (size_t)npad * k8n;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -151,12 +152,12 @@ __global__ __launch_bounds__(256) void pack_weight_planes_kernel(const float* __
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (n < N) ? w[(size_t)n * K + 8 * k8 + j] : 0.f;
-    bf16x8 h8, l8;
+    p16x8 h8, l8;
     split8(v, h8, l8);
     const int kstep = k8 >> 1, half = k8 & 1, lane = (n & 31) + 32 * half;
     const size_t o = (((size_t)(n >> 5) * (K / 16) + kstep) * 64 + lane) * 8;
-    *reinterpret_cast<bf16x8*>(hi + o) = h8;
-    *reinterpret_cast<bf16x8*>(lo + o) = l8;
+    *reinterpret_cast<p16x8*>(hi + o) = h8;
+    *reinterpret_cast<p16x8*>(lo + o) = l8;
   }
 }
 
@@ -172,7 +173,8 @@ constexpr int x3_res_younger_rounds(int t, int rr, bool t16) {
 // ABL & 128 (timing experiment): cycles (s_memtime) wave 0 of every workgroup spends [0] in the end-of-step vmcnt(0) of a
 // tile's FIRST k step -- which also drains the previous tile's epilogue stores --, [1] in the same wait of all other steps,
 // [2] in whole k-loops, [3] in whole epilogues; [4] tiles, [5] k steps.  Read with mdm_debug_get.
-#ifndef MDM_EMU
+#if !defined(MDM_EMU) && defined(MDM_PROBES)
+#define MDM_X3_DBG 1
 __device__ unsigned long long g_x3_dbg[8];
 __device__ __forceinline__ unsigned long long x3_now() { return __builtin_readcyclecounter(); }
 #endif
@@ -199,7 +201,7 @@ struct X3Cursor {
 // 16-byte record reads (k sub-steps 0 and 1) meet in ONE scaled MFMA; 2 + 1 MFMAs per sub-tile and step instead of 6.
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
           bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false>
-__global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N,
+__global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N,
                                                                      int K, int rows_per_tile, int tiles_n, int total) {
   MDM_DYN_SMEM(unsigned char, lds);
   constexpr int X3_WAVES = WAVES, X3_TN = x3_tn(WAVES), X3_A_PIECES = x3_a_pieces(WAVES);
@@ -262,15 +264,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
 
   // ---- W fragments of this wave for k step `k` of tile `v`: four 16-byte loads per lane, each a contiguous 1 KB per wave
   const size_t wk16 = (size_t)(K / 16);
-  auto load_w = [&](int v, int k, bf16x8 (&fh)[2], bf16x8 (&fl)[2]) {
+  auto load_w = [&](int v, int k, p16x8 (&fh)[2], p16x8 (&fl)[2]) {
     int m0, n0;
     tile_origin(v, m0, n0);
     const size_t nb = (size_t)((n0 >> 5) + wid);
     const size_t o = ((nb * wk16 + 2 * (size_t)k) * 64 + lane) * 8;
-    fh[0] = *reinterpret_cast<const bf16x8*>(W.hi + o);
-    fl[0] = *reinterpret_cast<const bf16x8*>(W.lo + o);
-    fh[1] = *reinterpret_cast<const bf16x8*>(W.hi + o + 512);
-    fl[1] = *reinterpret_cast<const bf16x8*>(W.lo + o + 512);
+    fh[0] = *reinterpret_cast<const p16x8*>(W.hi + o);
+    fl[0] = *reinterpret_cast<const p16x8*>(W.lo + o);
+    fh[1] = *reinterpret_cast<const p16x8*>(W.hi + o + 512);
+    fl[1] = *reinterpret_cast<const p16x8*>(W.lo + o + 512);
   };
 
   // ---- fragment read offsets (bytes inside a plane tile): row*64 + ((ksub*2 + h) ^ sw)*16, sw = (row>>2)&3
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     if constexpr (FOLD || RES == 3) stats_dma(m0f, 0);
     cvec_dma(n0f, 0);
   }
-  bf16x8 wh[2], wl[2], wnh[2], wnl[2];
+  p16x8 wh[2], wl[2], wnh[2], wnl[2];
 #pragma unroll
   for (int i = 0; i < X3_A_PIECES; ++i) piece_a(ca, i, 0);
   advance_a(ca);
@@ -364,13 +366,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       }
       if (tid < X3_TM) {
         const float* sraw = reinterpret_cast<const float*>(lds + x3_raw_base(WAVES) + tile_parity * X3_RAW_BYTES);
-        float s1 = 0.f, s2 = 0.f;
-        for (int p = 0; p < ep.stat_parts; ++p) {
-          s1 += sraw[(tid * ep.stat_parts + p) * 2];
-          s2 += sraw[(tid * ep.stat_parts + p) * 2 + 1];
-        }
+        // partials are (sum, CENTRED sum of squares about the partial's own mean) of X3_TN columns each; merged by Chan's
+        // formula -- no E[x^2] - mean^2 cancellation when a row's mean is large against its spread
+        float s1 = 0.f;
+        for (int p = 0; p < ep.stat_parts; ++p) s1 += sraw[(tid * ep.stat_parts + p) * 2];
         const float mean = s1 * ep.inv_dim;
-        const float var = fmaxf(s2 * ep.inv_dim - mean * mean, 0.f);
+        float m2 = 0.f;
+        for (int p = 0; p < ep.stat_parts; ++p) {
+          const float dm = sraw[(tid * ep.stat_parts + p) * 2] * (1.0f / X3_TN) - mean;
+          m2 += sraw[(tid * ep.stat_parts + p) * 2 + 1] + (float)X3_TN * dm * dm;
+        }
+        const float var = m2 * ep.inv_dim;
 #ifdef MDM_EMU
         stab[tid] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
 #else
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     }
     float2* const atab = stab;   // FOLD: statistics of the A rows;  RES == 3: of the residual rows (a kernel has one)
     float2* const rtab = stab;
-#ifndef MDM_EMU
+#ifdef MDM_X3_DBG
     unsigned long long dbg_t0 = 0, dbg_w0 = 0, dbg_w1 = 0, dbg_bar = 0;
     if constexpr ((ABL & 128) != 0) dbg_t0 = x3_now();
 #endif
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       // DEPTH units deep: the reads of unit u+DEPTH are issued, then a COUNTED wait (2*DEPTH younger reads may stay in
       // flight) retires unit u's, then its 3 MFMAs go.  One LDS-DMA piece of A(g+1) rides behind each of the first seven.
       constexpr int DEPTH = 2, RING = DEPTH + 1;  // fragment-read lookahead in units
-      bf16x8 ah[RING], al[RING];
+      p16x8 ah[RING], al[RING];
 #ifdef MDM_EMU
       const unsigned char* sa = lds + abuf * X3_A_STAGE;
 #define X3_RD_A(dst, plane, t, ks) lds_read16(dst, sa, (plane) * X3_A_BYTES + fa + (t) * 2048 + ((((ks) * 2 + h) ^ sw) * 16))
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
 #endif
       // T16: the 16-row sub-tile's A fragments (one per plane covers the whole 32-deep step) are read FIRST, so they are
       // older than every unit's reads and retired by unit 0's wait; its W fragments come from wh / wl by lane swaps
-      bf16x8 a16h, a16l, w16h[2], w16l[2];
+      p16x8 a16h, a16l, w16h[2], w16l[2];
       if constexpr (T16) {
 #ifdef MDM_EMU
         lds_read16(a16h, sa, fa16);
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
         frag32_to_frag16(w16l[0], w16l[1]);
       }
       constexpr int NU = 2 * NT32;  // units per stage
-      bf16x8 f6_hold = {0, 0, 0, 0, 0, 0, 0, 0};   // F6 only
+      p16x8 f6_hold = {0, 0, 0, 0, 0, 0, 0, 0};   // F6 only
       static_for<NU + DEPTH>([&](auto u_tag) __attribute__((always_inline)) {
         constexpr int u = decltype(u_tag)::value;
         if constexpr (u < NU && (!(ABL & 64) || u % 2 == 0)) {   // 64: timing experiment -- half the fragment reads
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
             // (both cross terms of 32 k fill its K = 64); loads, LDS traffic and barriers as in production (the planned plane
             // records have the bytes of today's lo plane).  Operands of the scaled MFMA are whatever bits the lo fragments
             // hold: results are garbage, only the time is representative.
-            acc[t] = mfma_bf16(ah[uv % RING], wh[ks], acc[t]);
+            acc[t] = mfma_p16(ah[uv % RING], wh[ks], acc[t]);
 #ifndef MDM_EMU
             if constexpr (ks == 0) {
               const u32x4 qa0 = __builtin_bit_cast(u32x4, al[uv % RING]), qa1 = __builtin_bit_cast(u32x4, ah[uv % RING]);
@@ -482,15 +488,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
             }
 #endif
           } else {
-            acc[t] = mfma_bf16(al[uv % RING], wh[ks], acc[t]);
-            acc[t] = mfma_bf16(ah[uv % RING], wl[ks], acc[t]);
-            acc[t] = mfma_bf16(ah[uv % RING], wh[ks], acc[t]);
+            acc[t] = mfma_p16(al[uv % RING], wh[ks], acc[t]);
+            acc[t] = mfma_p16(ah[uv % RING], wl[ks], acc[t]);
+            acc[t] = mfma_p16(ah[uv % RING], wh[ks], acc[t]);
             if constexpr (T16 && uv == 0) {
 #pragma unroll
               for (int cb = 0; cb < 2; ++cb) {
-                acc16[cb] = mfma16_bf16(a16l, w16h[cb], acc16[cb]);
-                acc16[cb] = mfma16_bf16(a16h, w16l[cb], acc16[cb]);
-                acc16[cb] = mfma16_bf16(a16h, w16h[cb], acc16[cb]);
+                acc16[cb] = mfma16_p16(a16l, w16h[cb], acc16[cb]);
+                acc16[cb] = mfma16_p16(a16h, w16l[cb], acc16[cb]);
+                acc16[cb] = mfma16_p16(a16h, w16h[cb], acc16[cb]);
               }
             }
           }
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       });
 #undef X3_RD_A
       advance_a(ca);
-#ifndef MDM_EMU
+#ifdef MDM_X3_DBG
       if constexpr ((ABL & 128) != 0) {
         const unsigned long long a0 = x3_now();
         wait_vmem_all();
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       }
 #endif
       if (!(ABL & 8)) wait_vmem_all();   // 8: experiment -- loads issued but never waited for (results are garbage)
-#ifndef MDM_EMU
+#ifdef MDM_X3_DBG
       if constexpr ((ABL & 128) != 0) {
         const unsigned long long b0 = x3_now();
         wg_barrier();
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     // each wave transposes 8 rows x 32 columns at a time (accumulator registers 4g..4g+3 of both lane halves) through
     // its private 1 KB LDS patch -- disjoint from the A stages, which already hold the next tile's first stage
     // -- and writes 16 bytes per lane: lane -> (row = lane>>3, 4 consecutive columns).
-#ifndef MDM_EMU
+#ifdef MDM_X3_DBG
     unsigned long long dbg_t1 = 0;
     if constexpr ((ABL & 128) != 0) dbg_t1 = x3_now();
 #endif
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
     };
 
     if (OUT_QKV) {
-      // in_proj -> attention operand planes (attention_bf16x3.h).  rows_per_tile == S: tile row == token, tile_m == sequence.
+      // in_proj -> attention operand planes (attention_x3.h).  rows_per_tile == S: tile row == token, tile_m == sequence.
       // Pad tokens (S <= token < SP): V^T pads are written with whatever finite values the neighbouring activation rows
       // produce (the attention kernel multiplies them by p == 0 exactly); Q / K pad rows are never read by it and are not
       // stored in the last sub-tile (masking every round cost 112 hoisted lane masks, 280 spilled SGPRs).
@@ -612,8 +618,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
       if (ncol0 < N && !(ABL & 1)) {
         if (which == 2) {
           // V^T: accumulator registers 8 s2 .. 8 s2 + 7 of a lane ARE positions 8h .. 8h+7 of 16-key group s2
-          bf16_t* vhp = ep.qkv.vh + ((shq * ep.qkv.NKT) * AX_HD + d0 + r) * 32 + 8 * h;
-          bf16_t* vlp = ep.qkv.vl + ((shq * ep.qkv.NKT) * AX_HD + d0 + r) * 32 + 8 * h;
+          p16_t* vhp = ep.qkv.vh + ((shq * ep.qkv.NKT) * AX_HD + d0 + r) * 32 + 8 * h;
+          p16_t* vlp = ep.qkv.vl + ((shq * ep.qkv.NKT) * AX_HD + d0 + r) * 32 + 8 * h;
           const int nkt = ep.qkv.NKT;
 #pragma unroll
           for (int t = 0; t < NT32; ++t) {
@@ -630,10 +636,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
                     vv[j] = acc[t][8 * s2 + j] + bias;
                   }
                 }
-                bf16x8 vh8, vl8;
+                p16x8 vh8, vl8;
                 split8(vv, vh8, vl8);
-                *reinterpret_cast<bf16x8*>(vhp + t * (AX_HD * 32) + 16 * s2) = vh8;
-                *reinterpret_cast<bf16x8*>(vlp + t * (AX_HD * 32) + 16 * s2) = vl8;
+                *reinterpret_cast<p16x8*>(vhp + t * (AX_HD * 32) + 16 * s2) = vh8;
+                *reinterpret_cast<p16x8*>(vlp + t * (AX_HD * 32) + 16 * s2) = vl8;
               }
             }
           }
@@ -663,8 +669,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
           }
         } else {
           // Q / K rows: one base pointer per plane, 32-bit offsets
-          bf16_t* dh = (which == 0 ? ep.qkv.qh : ep.qkv.kh) + shq * SPq * AX_HD + d0 + pc4;
-          bf16_t* dl = (which == 0 ? ep.qkv.ql : ep.qkv.kl) + shq * SPq * AX_HD + d0 + pc4;
+          p16_t* dh = (which == 0 ? ep.qkv.qh : ep.qkv.kh) + shq * SPq * AX_HD + d0 + pc4;
+          p16_t* dl = (which == 0 ? ep.qkv.ql : ep.qkv.kl) + shq * SPq * AX_HD + d0 + pc4;
           const int nkt = ep.qkv.NKT;
           patch_write(std::integral_constant<int, 0>{});
           float2 st_cur = row_stats(std::integral_constant<int, 0>{});
@@ -753,10 +759,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
           } else if constexpr (RES_PLANES) {
             const u32x2 a = rh[t % RR][g], b = rl[t % RR][g];
             float4 x4 = make_float4(
-                bf16_bits_to_f32((bf16_t)(a[0] & 0xffffu)) + bf16_bits_to_f32((bf16_t)(b[0] & 0xffffu)),
-                bf16_bits_to_f32((bf16_t)(a[0] >> 16)) + bf16_bits_to_f32((bf16_t)(b[0] >> 16)),
-                bf16_bits_to_f32((bf16_t)(a[1] & 0xffffu)) + bf16_bits_to_f32((bf16_t)(b[1] & 0xffffu)),
-                bf16_bits_to_f32((bf16_t)(a[1] >> 16)) + bf16_bits_to_f32((bf16_t)(b[1] >> 16)));
+                p16_to_f32((p16_t)(a[0] & 0xffffu)) + p16_to_f32((p16_t)(b[0] & 0xffffu)),
+                p16_to_f32((p16_t)(a[0] >> 16)) + p16_to_f32((p16_t)(b[0] >> 16)),
+                p16_to_f32((p16_t)(a[1] & 0xffffu)) + p16_to_f32((p16_t)(b[1] & 0xffffu)),
+                p16_to_f32((p16_t)(a[1] >> 16)) + p16_to_f32((p16_t)(b[1] >> 16)));
             if constexpr (RES == 3) {   // the residual is LayerNorm(x), rebuilt from x's planes and its row statistics
               x4.x = (x4.x - st.x) * st.y * g4.x + be4.x; x4.y = (x4.y - st.x) * st.y * g4.y + be4.y;
               x4.z = (x4.z - st.x) * st.y * g4.z + be4.z; x4.w = (x4.w - st.x) * st.y * g4.w + be4.w;
@@ -764,12 +770,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
             v4.x += x4.x; v4.y += x4.y; v4.z += x4.z; v4.w += x4.w;
           }
         }
-        if constexpr (OSTAT) {   // partial (sum, sum of squares) of this row over the wave's 32 columns
-          float s1 = (v4.x + v4.y) + (v4.z + v4.w);
-          float s2 = (v4.x * v4.x + v4.y * v4.y) + (v4.z * v4.z + v4.w * v4.w);
-          s1 = sum_lanes8(s1);
-          s2 = sum_lanes8(s2);
-          if ((lane & 7) == 0) part[row_in_tile] = make_float2(s1, s2);
+        if constexpr (OSTAT) {   // partial (sum, centred sum of squares) of this row over the wave's 32 columns
+          const float s1 = sum_lanes8((v4.x + v4.y) + (v4.z + v4.w));
+          const float mw = s1 * (1.0f / 32.0f);
+          const float dx = v4.x - mw, dy = v4.y - mw, dz = v4.z - mw, dw = v4.w - mw;
+          const float m2 = sum_lanes8((dx * dx + dy * dy) + (dz * dz + dw * dw));
+          if ((lane & 7) == 0) part[row_in_tile] = make_float2(s1, m2);
         }
         if (!(ABL & 1)) {
           const int m = m0 + row_in_tile;
@@ -792,18 +798,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16x3_kernel(X3Operand A,
         wg_barrier();
         if (tid < X3_TM && m0 + tid < m_end) {
           const float2* pp = reinterpret_cast<const float2*>(lds + x3_part_base(WAVES));
-          float s1 = 0.f, s2 = 0.f;
+          float s1 = 0.f;
+#pragma unroll
+          for (int w8 = 0; w8 < X3_WAVES; ++w8) s1 += pp[w8 * X3_TM + tid].x;
+          const float mt = s1 * (1.0f / X3_TN);     // OSTAT launches have N % X3_TN == 0: every wave contributes 32 columns
+          float m2 = 0.f;
 #pragma unroll
           for (int w8 = 0; w8 < X3_WAVES; ++w8) {
             const float2 v = pp[w8 * X3_TM + tid];
-            s1 += v.x;
-            s2 += v.y;
+            const float dm = v.x * (1.0f / 32.0f) - mt;
+            m2 += v.y + 32.0f * dm * dm;
           }
-          *reinterpret_cast<float2*>(ep.ostat + ((size_t)(m0 + tid) * tiles_n + n0 / X3_TN) * 2) = make_float2(s1, s2);
+          *reinterpret_cast<float2*>(ep.ostat + ((size_t)(m0 + tid) * tiles_n + n0 / X3_TN) * 2) = make_float2(s1, m2);
         }
       }
     }
-#ifndef MDM_EMU
+#ifdef MDM_X3_DBG
     if constexpr ((ABL & 128) != 0) {
       const unsigned long long t2 = x3_now();
       if (tid == 0) {
@@ -829,11 +839,12 @@ inline int x3_grid_limit(int per_cu) {
   (void)per_cu;
   return 3;  // small, so that the emulator exercises the tile roll-over paths
 #else
-  static int cus = 0;
+  static int cus_of[kMaxDevices] = {};   // per device ordinal: a process may drive several GPUs
+  const int dev = rt_device_ordinal();
+  int& cus = cus_of[dev];
   if (cus == 0) {
-    int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
   const int wgs = per_cu * cus / 8 * 8;  // xcd_remap keeps a workgroup on one XCD only if the stride is a multiple of 8
@@ -843,6 +854,7 @@ inline int x3_grid_limit(int per_cu) {
 
 // workgroup shape used by the launchers below: 8 waves (default: whole-bench A/B on one box 307 vs 302 motions/s) or 4
 // (mdm_debug_set(2, waves) / MDM_X3_WAVES for A/B probes)
+#ifdef MDM_PROBES
 inline int& x3_waves_setting() {
   static int waves = [] {
     const char* e = getenv("MDM_X3_WAVES");   // A/B runs of whole benchmarks
@@ -850,26 +862,30 @@ inline int& x3_waves_setting() {
   }();
   return waves;
 }
+#else
+inline int x3_waves_setting() { return 8; }   // the 4-wave form is compiled into the probe library only
+#endif
 
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
           bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false>
-inline int launch_gemm_bf16x3_w(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
+inline int launch_gemm_x3_w(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                                 int rpt, hipStream_t stream) {
   constexpr int TN = x3_tn(WAVES);
   constexpr bool LN = FOLD || OSTAT || RES == 3;
   const int tiles_m = (M + rpt - 1) / rpt, tiles_n = (N + TN - 1) / TN;
   const int total = tiles_m * tiles_n;
   static_assert(!(F6 && T16), "the f16f6 k-loop has no 16-row sub-tile yet");
-  auto kfn = &gemm_bf16x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16, F6>;
+  auto kfn = &gemm_x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16, F6>;
   if (T16 && rpt > X3_TM - 16) return -2;
 #ifndef MDM_EMU
   if (x3_lds_bytes(WAVES, LN) > 65536) {
-    static bool configured = false;  // per instantiation
-    if (!configured) {
+    static bool configured[kMaxDevices] = {};  // per instantiation and device (the attribute belongs to the device's code object)
+    bool& done = configured[rt_device_ordinal()];
+    if (!done) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               x3_lds_bytes(WAVES, LN)) != hipSuccess)
         return -1;
-      configured = true;
+      done = true;
     }
   }
 #endif
@@ -886,15 +902,15 @@ inline int launch_gemm_bf16x3_w(const X3Operand& A, const X3Weights& W, const X3
 //   kind 4  OutputProcess                       FOLD -> fp32
 //   kind 5  InputProcess                        + positional rows, planes to the token rows of every branch (EMBED)
 template <bool T16>
-inline int launch_gemm_bf16x3_ln_t(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
+inline int launch_gemm_x3_ln_t(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
                                    int K, int rpt, hipStream_t s) {
   switch (kind) {
-    case 0: return launch_gemm_bf16x3_w<8, ACT_NONE, 0, false, false, true, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
-    case 1: return launch_gemm_bf16x3_w<8, ACT_NONE, 2, false, true, false, 0, false, true, false, T16>(A, W, ep, M, N, K, rpt, s);
-    case 2: return launch_gemm_bf16x3_w<8, ACT_NONE, 3, false, true, false, 0, false, true, false, T16>(A, W, ep, M, N, K, rpt, s);
-    case 3: return launch_gemm_bf16x3_w<8, ACT_GELU, 0, false, true, false, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
-    case 4: return launch_gemm_bf16x3_w<8, ACT_NONE, 0, true, false, false, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
-    case 5: return launch_gemm_bf16x3_w<8, ACT_NONE, 1, false, true, false, 0, false, false, true, T16>(A, W, ep, M, N, K, rpt, s);
+    case 0: return launch_gemm_x3_w<8, ACT_NONE, 0, false, false, true, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
+    case 1: return launch_gemm_x3_w<8, ACT_NONE, 2, false, true, false, 0, false, true, false, T16>(A, W, ep, M, N, K, rpt, s);
+    case 2: return launch_gemm_x3_w<8, ACT_NONE, 3, false, true, false, 0, false, true, false, T16>(A, W, ep, M, N, K, rpt, s);
+    case 3: return launch_gemm_x3_w<8, ACT_GELU, 0, false, true, false, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
+    case 4: return launch_gemm_x3_w<8, ACT_NONE, 0, true, false, false, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
+    case 5: return launch_gemm_x3_w<8, ACT_NONE, 1, false, true, false, 0, false, false, true, T16>(A, W, ep, M, N, K, rpt, s);
     default: return -2;
   }
 }
@@ -906,84 +922,92 @@ inline bool x3_t16_setting() {
   }();
   return on;
 }
-inline int launch_gemm_bf16x3_ln(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
+inline int launch_gemm_x3_ln(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
                                  int K, int rpt, hipStream_t s) {
-  if (rpt <= X3_TM - 16 && x3_t16_setting()) return launch_gemm_bf16x3_ln_t<true>(kind, A, W, ep, M, N, K, rpt, s);
-  return launch_gemm_bf16x3_ln_t<false>(kind, A, W, ep, M, N, K, rpt, s);
+  if (rpt <= X3_TM - 16 && x3_t16_setting()) return launch_gemm_x3_ln_t<true>(kind, A, W, ep, M, N, K, rpt, s);
+  return launch_gemm_x3_ln_t<false>(kind, A, W, ep, M, N, K, rpt, s);
 }
 
 template <int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL = 0>
-inline int launch_gemm_bf16x3_t(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
+inline int launch_gemm_x3_t(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                                 int rpt, hipStream_t stream) {
-  if (x3_waves_setting() == 8)
-    return launch_gemm_bf16x3_w<8, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>(A, W, ep, M, N, K, rpt, stream);
-  return launch_gemm_bf16x3_w<4, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>(A, W, ep, M, N, K, rpt, stream);
+#ifdef MDM_PROBES
+  if (x3_waves_setting() == 4)
+    return launch_gemm_x3_w<4, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>(A, W, ep, M, N, K, rpt, stream);
+#endif
+  return launch_gemm_x3_w<8, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL>(A, W, ep, M, N, K, rpt, stream);
 }
 
 // runtime (act, res, outputs) -> one of the instantiations the encoder needs
-inline int launch_gemm_bf16x3(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K, int act,
+inline int launch_gemm_x3(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K, int act,
                               int seq_len, hipStream_t s, int ablate = 0) {
   const bool res = ep.res != nullptr, f32 = ep.out != nullptr, pl = ep.oh != nullptr;
   const int rpt = x3_rows_per_tile(M, seq_len);
-  if (ep.resh != nullptr) {  // residual stream held as planes (the model's bf16x3 mode)
+  if (ep.resh != nullptr) {  // residual stream held as planes (the model's f16x3 mode)
     if (ablate == 0 && act == ACT_NONE && !res && f32 && !pl)
-      return launch_gemm_bf16x3_t<ACT_NONE, 2, true, false, false>(A, W, ep, M, N, K, rpt, s);
+      return launch_gemm_x3_t<ACT_NONE, 2, true, false, false>(A, W, ep, M, N, K, rpt, s);
     return -2;
   }
+#ifdef MDM_PROBES
   if (ablate != 0) {  // profiling experiments (mdm_debug_set): only the plain fp32-out variant is instantiated
     if (!(act == ACT_NONE && !res && f32 && !pl)) return -2;
     switch (ablate) {
-      case 1: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 1>(A, W, ep, M, N, K, rpt, s);
-      case 2: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 2>(A, W, ep, M, N, K, rpt, s);
-      case 3: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 3>(A, W, ep, M, N, K, rpt, s);
-      case 4: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 4>(A, W, ep, M, N, K, rpt, s);
-      case 8: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 8>(A, W, ep, M, N, K, rpt, s);
-      case 16: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 16>(A, W, ep, M, N, K, rpt, s);
-      case 32: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 32>(A, W, ep, M, N, K, rpt, s);
-      case 64: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 64>(A, W, ep, M, N, K, rpt, s);
-      case 128: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 128>(A, W, ep, M, N, K, rpt, s);
-      case 256: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 256>(A, W, ep, M, N, K, rpt, s);
+      case 1: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 1>(A, W, ep, M, N, K, rpt, s);
+      case 2: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 2>(A, W, ep, M, N, K, rpt, s);
+      case 3: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 3>(A, W, ep, M, N, K, rpt, s);
+      case 4: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 4>(A, W, ep, M, N, K, rpt, s);
+      case 8: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 8>(A, W, ep, M, N, K, rpt, s);
+      case 16: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 16>(A, W, ep, M, N, K, rpt, s);
+      case 32: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 32>(A, W, ep, M, N, K, rpt, s);
+      case 64: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 64>(A, W, ep, M, N, K, rpt, s);
+      case 128: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 128>(A, W, ep, M, N, K, rpt, s);
+      case 256: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 256>(A, W, ep, M, N, K, rpt, s);
       // decomposition of the no-MFMA floor: 5 = 4|1 (also no stores), 6 = 4|2 (also no loads), 7 = 4|2|1, 68 = 4|64 (half the reads)
-      case 5: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 5>(A, W, ep, M, N, K, rpt, s);
-      case 6: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 6>(A, W, ep, M, N, K, rpt, s);
-      case 7: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 7>(A, W, ep, M, N, K, rpt, s);
-      case 68: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 68>(A, W, ep, M, N, K, rpt, s);
-      case 9: return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false, 9>(A, W, ep, M, N, K, rpt, s);
+      case 5: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 5>(A, W, ep, M, N, K, rpt, s);
+      case 6: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 6>(A, W, ep, M, N, K, rpt, s);
+      case 7: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 7>(A, W, ep, M, N, K, rpt, s);
+      case 68: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 68>(A, W, ep, M, N, K, rpt, s);
+      case 9: return launch_gemm_x3_t<ACT_NONE, 0, true, false, false, 9>(A, W, ep, M, N, K, rpt, s);
       default: return -2;
     }
   }
-  if (act == ACT_NONE && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_NONE, 0, true, false, false>(A, W, ep, M, N, K, rpt, s);
-  if (act == ACT_NONE && res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_NONE, 1, true, false, false>(A, W, ep, M, N, K, rpt, s);
-  if (act == ACT_GELU && !res && !f32 && pl) return launch_gemm_bf16x3_t<ACT_GELU, 0, false, true, false>(A, W, ep, M, N, K, rpt, s);
-  if (act == ACT_GELU && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_GELU, 0, true, false, false>(A, W, ep, M, N, K, rpt, s);
-  if (act == ACT_GELU && res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_GELU, 1, true, false, false>(A, W, ep, M, N, K, rpt, s);
-  if (act == ACT_SILU && !res && f32 && !pl) return launch_gemm_bf16x3_t<ACT_SILU, 0, true, false, false>(A, W, ep, M, N, K, rpt, s);
+#else
+  if (ablate != 0) return -2;
+#endif
+  if (act == ACT_NONE && !res && f32 && !pl) return launch_gemm_x3_t<ACT_NONE, 0, true, false, false>(A, W, ep, M, N, K, rpt, s);
+  if (act == ACT_NONE && res && f32 && !pl) return launch_gemm_x3_t<ACT_NONE, 1, true, false, false>(A, W, ep, M, N, K, rpt, s);
+  if (act == ACT_GELU && !res && !f32 && pl) return launch_gemm_x3_t<ACT_GELU, 0, false, true, false>(A, W, ep, M, N, K, rpt, s);
+  if (act == ACT_GELU && !res && f32 && !pl) return launch_gemm_x3_t<ACT_GELU, 0, true, false, false>(A, W, ep, M, N, K, rpt, s);
+  if (act == ACT_GELU && res && f32 && !pl) return launch_gemm_x3_t<ACT_GELU, 1, true, false, false>(A, W, ep, M, N, K, rpt, s);
+  if (act == ACT_SILU && !res && f32 && !pl) return launch_gemm_x3_t<ACT_SILU, 0, true, false, false>(A, W, ep, M, N, K, rpt, s);
   return -2;
 }
 
+#ifdef MDM_PROBES
 // The f16f6 building block (mdm_linear_f16f6): plain fp32-out epilogues on the F6 k-loop, 224-row tiles
 inline int launch_gemm_f16f6(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K, int act,
                              hipStream_t s) {
   const bool res = ep.res != nullptr;
   if (act == ACT_NONE && !res && x3_waves_setting() == 4)   // A/B probes: two independent 4-wave workgroups per CU
-    return launch_gemm_bf16x3_w<4, ACT_NONE, 0, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
+    return launch_gemm_x3_w<4, ACT_NONE, 0, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
   if (act == ACT_NONE && !res)
-    return launch_gemm_bf16x3_w<8, ACT_NONE, 0, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
+    return launch_gemm_x3_w<8, ACT_NONE, 0, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
   if (act == ACT_NONE && res)
-    return launch_gemm_bf16x3_w<8, ACT_NONE, 1, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
+    return launch_gemm_x3_w<8, ACT_NONE, 1, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
   if (act == ACT_GELU && !res)
-    return launch_gemm_bf16x3_w<8, ACT_GELU, 0, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
+    return launch_gemm_x3_w<8, ACT_GELU, 0, true, false, false, 0, false, false, false, false, true>(A, W, ep, M, N, K, X3_TM, s);
   return -2;
 }
+#endif
 
 // in_proj: tokens [nseq*S][D] x W [3D][D] -> the attention operand planes; one sequence per tile (tile row == token)
-inline int launch_gemm_bf16x3_qkv(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int nseq, int S, int D,
+inline int launch_gemm_x3_qkv(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int nseq, int S, int D,
                                   hipStream_t s) {
   if (S > X3_TM) return -2;
   if (x3_waves_setting() == 8 && S <= X3_TM - 16 && x3_t16_setting())
-    return launch_gemm_bf16x3_w<8, ACT_NONE, 0, false, false, true, 0, false, false, false, true>(A, W, ep, nseq * S, 3 * D, D,
+    return launch_gemm_x3_w<8, ACT_NONE, 0, false, false, true, 0, false, false, false, true>(A, W, ep, nseq * S, 3 * D, D,
                                                                                                  S, s);
-  return launch_gemm_bf16x3_t<ACT_NONE, 0, false, false, true>(A, W, ep, nseq * S, 3 * D, D, S, s);
+  return launch_gemm_x3_t<ACT_NONE, 0, false, false, true>(A, W, ep, nseq * S, 3 * D, D, S, s);
 }
 
 }  // namespace mdm

@@ -3,6 +3,9 @@
 // (utils/sampler_util.py:27-34), GaussianDiffusion.p_sample_loop / ddim_sample_loop
 // (diffusion/gaussian_diffusion.py:591-727, :876-990).  No torch, no allocation: caller-owned pointers.
 #include "../../include/mdm_hip.h"
+#ifdef MDM_PROBES
+#include "../../include/mdm_hip_probe.h"
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -13,13 +16,15 @@
 #include <string>
 #include <vector>
 
-#include "attention_bf16x3.h"
+#include "attention_x3.h"
 #include "attention_f32.h"
 #include "common.h"
 #include "elementwise.h"
 #include "gemm_f32.h"
-#include "gemm_bf16x3.h"
+#include "gemm_x3.h"
+#ifdef MDM_PROBES
 #include "gemm_f16f6.h"
+#endif
 #include "motion_recover.h"
 
 using namespace mdm;
@@ -27,9 +32,13 @@ using namespace mdm;
 namespace {
 
 thread_local std::string g_err;
-int g_x3_ablate = 0;  // profiling experiments only (mdm_debug_set)
-int g_x3_reuse_planes = 0;  // probes only: mdm_linear_bf16x3 skips the operand split and reuses the planes in scratch
-int g_f6_reference = 0;     // tests / probes: mdm_linear_f16f6 on the one-wave-per-tile reference kernel
+#ifdef MDM_PROBES   // libmdm_hip_probe.so only (include/mdm_hip_probe.h): process-global experiment switches
+int g_x3_ablate = 0;        // gemm_x3.h ABL code
+int g_x3_reuse_planes = 0;  // mdm_linear_x3 skips the operand split and reuses the planes in scratch
+int g_f6_reference = 0;     // mdm_linear_f16f6 on the one-wave-per-tile reference kernel
+#else
+constexpr int g_x3_ablate = 0, g_x3_reuse_planes = 0;
+#endif
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -108,18 +117,18 @@ struct mdm_model {
   float* w_in_pad = nullptr;    // [D][JFpad]
   float* time_table = nullptr;  // [max_len][D]
   int jf = 0, jf_pad = 0;
-  int precision = MDM_PREC_BF16X3;
+  int precision = MDM_PREC_F16X3;
   struct LayerPlanes { X3Weights in_proj, out_proj, linear1, linear2; };
   std::vector<LayerPlanes> planes;  // fragment-ordered bf16 hi/lo planes of the encoder weights (mdm_prepare)
-  // LayerNorm folded into its consumers (gemm_bf16x3.h X3Epilogue): gamma-scaled weight planes, column sums, folded biases
+  // LayerNorm folded into its consumers (gemm_x3.h X3Epilogue): gamma-scaled weight planes, column sums, folded biases
   struct LayerFold { X3Weights in_proj, linear1; float *c_qkv, *b_qkv, *c_1, *b_1; };
   std::vector<LayerFold> fold;
-  X3Weights in_planes{nullptr, nullptr};   // poseEmbedding.weight, K zero-padded to jf_k (bf16x3 InputProcess)
+  X3Weights in_planes{nullptr, nullptr};   // poseEmbedding.weight, K zero-padded to jf_k (f16x3 InputProcess)
   int jf_k = 0;                             // njoints*nfeats rounded up to a multiple of 32
   X3Weights out_planes_f{nullptr, nullptr};
   float *c_out = nullptr, *b_out = nullptr;
-  bool lnfold = false;                      // bf16x3 mode without LayerNorm kernels (set by mdm_prepare)
-  X3Weights out_planes{nullptr, nullptr};  // poseFinal.weight, rows padded to jf_out (bf16x3 OutputProcess)
+  bool lnfold = false;                      // f16x3 mode without LayerNorm kernels (set by mdm_prepare)
+  X3Weights out_planes{nullptr, nullptr};  // poseFinal.weight, rows padded to jf_out (f16x3 OutputProcess)
   float* out_bias_pad = nullptr;            // poseFinal.bias padded to jf_out
   int jf_out = 0;                           // njoints*nfeats rounded up to a multiple of 4
 
@@ -134,12 +143,12 @@ namespace {
 
 struct Workspace {
   float *tok, *qkv, *att, *ffn, *cond;
-  QkvPlanes qp;         // bf16x3 mode: the in_proj epilogue writes Q/K/V^T planes over the qkv region
-  bf16_t *xah, *xal;    // folded-LayerNorm mode: planes of the post-attention pre-norm sum (alias tok)
+  QkvPlanes qp;         // f16x3 mode: the in_proj epilogue writes Q/K/V^T planes over the qkv region
+  p16_t *xah, *xal;    // folded-LayerNorm mode: planes of the post-attention pre-norm sum (alias tok)
   float *stat1, *stat2; // folded-LayerNorm mode: per-row partial (sum, sum^2) of xa / of tokh|tokl
-  bf16_t *tokh, *tokl;  // split planes of tok (bf16x3 mode)
-  bf16_t *atth, *attl;  // alias att: the attention output is only consumed by the out_proj GEMM
-  bf16_t *ffnh, *ffnl;  // alias ffn: the GELU output is only consumed by the linear2 GEMM
+  p16_t *tokh, *tokl;  // split planes of tok (f16x3 mode)
+  p16_t *atth, *attl;  // alias att: the attention output is only consumed by the out_proj GEMM
+  p16_t *ffnh, *ffnl;  // alias ffn: the GELU output is only consumed by the linear2 GEMM
   size_t bytes;
 };
 
@@ -154,25 +163,25 @@ Workspace carve(const mdm_model* m, int nseq, int T, void* base) {
   Workspace w;
   w.tok = take(M * D);
   const size_t NKT = (S + 31) / 32, SP = 32 * NKT;
-  w.qkv = take((size_t)nseq * SP * 3 * D);  // fp32 [M][3D] (f32 mode) or six bf16 planes of nseq*SP*D (bf16x3 mode)
+  w.qkv = take((size_t)nseq * SP * 3 * D);  // fp32 [M][3D] (f32 mode) or six bf16 planes of nseq*SP*D (f16x3 mode)
   w.att = take(M * D);
   w.ffn = take(M * FF);
   w.cond = take((size_t)nseq * D);
   float* tp = take(M * D);  // two bf16 planes = one fp32 array's worth of bytes
-  w.tokh = reinterpret_cast<bf16_t*>(tp);
+  w.tokh = reinterpret_cast<p16_t*>(tp);
   w.tokl = tp ? w.tokh + M * D : nullptr;
-  w.atth = reinterpret_cast<bf16_t*>(w.att);
+  w.atth = reinterpret_cast<p16_t*>(w.att);
   w.attl = w.att ? w.atth + M * D : nullptr;
-  w.ffnh = reinterpret_cast<bf16_t*>(w.ffn);
+  w.ffnh = reinterpret_cast<p16_t*>(w.ffn);
   w.ffnl = w.ffn ? w.ffnh + M * FF : nullptr;
-  w.xah = reinterpret_cast<bf16_t*>(w.tok);
+  w.xah = reinterpret_cast<p16_t*>(w.tok);
   w.xal = w.tok ? w.xah + M * D : nullptr;
   const size_t parts = (D + 255) / 256;
   w.stat1 = take(M * parts * 2);
   w.stat2 = take(M * parts * 2);
   {
     const size_t plane = (size_t)nseq * SP * D;
-    bf16_t* q = reinterpret_cast<bf16_t*>(w.qkv);
+    p16_t* q = reinterpret_cast<p16_t*>(w.qkv);
     w.qp = QkvPlanes{q, q ? q + plane : nullptr, q ? q + 2 * plane : nullptr, q ? q + 3 * plane : nullptr,
                      q ? q + 4 * plane : nullptr, q ? q + 5 * plane : nullptr, (int)SP, (int)NKT, m->cfg.num_heads};
   }
@@ -180,7 +189,7 @@ Workspace carve(const mdm_model* m, int nseq, int T, void* base) {
   return w;
 }
 
-int launch_layernorm(Profiler* pf, float* x, const float* g, const float* b, int rows, int D, bf16_t* xh, bf16_t* xl,
+int launch_layernorm(Profiler* pf, float* x, const float* g, const float* b, int rows, int D, p16_t* xh, p16_t* xl,
                      hipStream_t s, bool write_f32 = true) {
   ProfScope ps(pf, MDM_PROF_LAYERNORM, 0.0, s);
   const dim3 grid((rows + 3) / 4), block(256);
@@ -195,7 +204,7 @@ int launch_layernorm(Profiler* pf, float* x, const float* g, const float* b, int
 }
 
 template <int NKT>
-int launch_attention_t(const AttnF32Args& a, float* out, int nseq, int D, int H, bf16_t* oh, bf16_t* ol, hipStream_t s) {
+int launch_attention_t(const AttnF32Args& a, float* out, int nseq, int D, int H, p16_t* oh, p16_t* ol, hipStream_t s) {
   auto k = &attention_f32_kernel<NKT>;
   const int nqt = (a.Sq + 31) / 32;
   const size_t lds = attention_lds_bytes(NKT, nqt);
@@ -205,7 +214,7 @@ int launch_attention_t(const AttnF32Args& a, float* out, int nseq, int D, int H,
 }
 
 // exact-fp32 attention with separate query / key-value sources (attention_f32.h AttnF32Args)
-int launch_attention_args(Profiler* pf, const AttnF32Args& a, float* out, int nseq, int D, int H, bf16_t* oh, bf16_t* ol,
+int launch_attention_args(Profiler* pf, const AttnF32Args& a, float* out, int nseq, int D, int H, p16_t* oh, p16_t* ol,
                           hipStream_t s) {
   ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * H * (double)a.Sq * a.Sk * ATT_HD, s);
   if (D != H * ATT_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
@@ -224,16 +233,18 @@ int launch_attention_args(Profiler* pf, const AttnF32Args& a, float* out, int ns
 
 // self-attention over packed qkv rows [nseq*S][3D]; `lead` tokens in front of the frames are never masked
 int launch_attention(Profiler* pf, const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D,
-                     int H, bf16_t* oh, bf16_t* ol, hipStream_t s, int lead = 1) {
+                     int H, p16_t* oh, p16_t* ol, hipStream_t s, int lead = 1) {
   const AttnF32Args a{qkv, 3 * D, qkv + D, qkv + 2 * D, 3 * D, S, S, lengths, lead, B};
   return launch_attention_args(pf, a, out, nseq, D, H, oh, ol, s);
 }
 
-int g_ax_ablate = 0;   // mdm_debug_set(3, code): timing experiments on the NKT = 7 attention kernel (attention_bf16x3.h ABL)
+#ifdef MDM_PROBES
+int g_ax_ablate = 0;   // mdm_debug_set(3, code): timing experiments on the NKT = 7 attention kernel (attention_x3.h ABL)
+#endif
 template <int NKT, int ABL = 0>
-int launch_attention_x3_t(const QkvPlanes& qp, const int* lengths, int nseq, int B, int S, int D, float* out, bf16_t* oh,
-                          bf16_t* ol, hipStream_t s) {
-  auto k = &attention_bf16x3_kernel<NKT, ABL>;
+int launch_attention_x3_t(const QkvPlanes& qp, const int* lengths, int nseq, int B, int S, int D, float* out, p16_t* oh,
+                          p16_t* ol, hipStream_t s) {
+  auto k = &attention_x3_kernel<NKT, ABL>;
   const size_t lds = attention_x3_lds_bytes(NKT);
   if (int rc = rt_allow_lds(k, lds)) return rc;
   // two workgroups (query halves) per (sequence, head); the item <-> block mapping pairs blocks b and b + 8 (same XCD),
@@ -247,7 +258,7 @@ int launch_attention_x3_t(const QkvPlanes& qp, const int* lengths, int nseq, int
 
 // split-precision attention on the operand planes written by the in_proj epilogue (or qkv_pack_kernel)
 int launch_attention_x3(Profiler* pf, const QkvPlanes& qp, const int* lengths, int nseq, int B, int S, int D, float* out,
-                        bf16_t* oh, bf16_t* ol, hipStream_t s) {
+                        p16_t* oh, p16_t* ol, hipStream_t s) {
   ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * qp.H * (double)S * S * AX_HD, s);
   if (D != qp.H * AX_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
   if (S < 1 || S > 224) return fail(MDM_EUNSUPPORTED, "attention: 1 <= S <= 224 tokens (T <= 223 frames)");
@@ -259,6 +270,7 @@ int launch_attention_x3(Profiler* pf, const QkvPlanes& qp, const int* lengths, i
     case 5: return launch_attention_x3_t<5>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
     case 6: return launch_attention_x3_t<6>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
     default:
+#ifdef MDM_PROBES
       switch (g_ax_ablate) {
         case 1: return launch_attention_x3_t<7, 1>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
         case 2: return launch_attention_x3_t<7, 2>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
@@ -269,11 +281,14 @@ int launch_attention_x3(Profiler* pf, const QkvPlanes& qp, const int* lengths, i
         case 32: return launch_attention_x3_t<7, 32>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
         case 48: return launch_attention_x3_t<7, 48>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
         case 63: return launch_attention_x3_t<7, 63>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        default: return launch_attention_x3_t<7>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        default: break;
       }
+#endif
+      return launch_attention_x3_t<7>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
   }
 }
 
+#ifdef MDM_PROBES
 // TEST-ONLY mode (mdm_debug_set(5, 1)): the `f32` mode's encoder GEMMs on the f16f6 kernel, UNFUSED -- operands packed per
 // call into a library-owned scratch (the one exception to "the caller owns every buffer": a debug path) -- so that the
 // f16f6 arithmetic can be held against the reference's golden trajectories through the product's own seams before the fused
@@ -299,8 +314,8 @@ int launch_linear_f6_debug(Profiler* pf, const float* in, int ld_in, const float
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
   char* base = static_cast<char*>(g_f6_dbg_scratch);
   const F6Planes pa = f6_carve(base, M, K);
-  bf16_t* wfh = reinterpret_cast<bf16_t*>(base + f6_plane_bytes(M, K));
-  bf16_t* wfl = reinterpret_cast<bf16_t*>(base + f6_plane_bytes(M, K) + wfrag);
+  p16_t* wfh = reinterpret_cast<p16_t*>(base + f6_plane_bytes(M, K));
+  p16_t* wfl = reinterpret_cast<p16_t*>(base + f6_plane_bytes(M, K) + wfrag);
   MDM_LAUNCH(pack_f16f6_kernel, dim3((M * (K / 32) + 255) / 256), dim3(256), 0, s, in, pa, M, K, ld_in);
   if (int rc = rt_launch_status()) return rc;
   const int npad = (N + 31) / 32 * 32;
@@ -308,17 +323,20 @@ int launch_linear_f6_debug(Profiler* pf, const float* in, int ld_in, const float
   if (int rc = rt_launch_status()) return rc;
   X3Epilogue ep{out, bias, res, nullptr, nullptr, nullptr, nullptr, N, scale_cols, col_scale, QkvPlanes{}, 0, 0,
                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1};
-  const X3Operand a{reinterpret_cast<const bf16_t*>(pa.h16), reinterpret_cast<const bf16_t*>(pa.rec)};
+  const X3Operand a{reinterpret_cast<const p16_t*>(pa.h16), reinterpret_cast<const p16_t*>(pa.rec)};
   const int rc = launch_gemm_f16f6(a, X3Weights{wfh, wfl}, ep, M, N, K, act, s);
   if (rc != 0) return fail(MDM_EUNSUPPORTED, "f16f6 debug mode: launch failed");
   return rt_launch_status();
 }
+#endif
 
 int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, const float* bias, const float* res,
                   float* out, int M, int N, int K, int act, int scale_cols, float col_scale, hipStream_t s) {
+#ifdef MDM_PROBES
   if (g_f6_linear && K % 32 == 0 && N % 4 == 0 && ld_in % 4 == 0 && (scale_cols % 256 == 0) &&
       (act == ACT_NONE || (act == ACT_GELU && res == nullptr)))
     return launch_linear_f6_debug(pf, in, ld_in, w, bias, res, out, M, N, K, act, scale_cols, col_scale, s);
+#endif
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
   if (K % 4 != 0 || ld_in % 4 != 0) return fail(MDM_EINVAL, "linear: K and the row stride must be multiples of 4");
   RowMajorLoader al{in, ld_in, M, K};
@@ -328,34 +346,34 @@ int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, cons
   return rt_launch_status();
 }
 
-// bf16x3 GEMM on pre-split operands; writes fp32 `out` and/or split planes oh/ol.  seq_len > 0 tells the tiler that
+// f16x3 GEMM on pre-split operands; writes fp32 `out` and/or split planes oh/ol.  seq_len > 0 tells the tiler that
 // the M rows are token sequences of that length (tile = whole sequences).
 int launch_linear_x3(Profiler* pf, X3Operand a, X3Weights w, const float* bias, const float* res, float* out,
-                     bf16_t* oh, bf16_t* ol, int M, int N, int K, int act, int scale_cols, float col_scale, int seq_len,
+                     p16_t* oh, p16_t* ol, int M, int N, int K, int act, int scale_cols, float col_scale, int seq_len,
                      hipStream_t s, X3Operand res_planes = X3Operand{nullptr, nullptr}) {
-  if (K % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 linear: K must be a multiple of 32");
-  if (N % 4 != 0) return fail(MDM_EINVAL, "bf16x3 linear: N must be a multiple of 4");
+  if (K % X3_BK != 0) return fail(MDM_EINVAL, "f16x3 linear: K must be a multiple of 32");
+  if (N % 4 != 0) return fail(MDM_EINVAL, "f16x3 linear: N must be a multiple of 4");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
   X3Epilogue ep{out, bias, res, res_planes.hi, res_planes.lo, oh, ol, N, scale_cols, col_scale, QkvPlanes{}, 0, 0,
                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1};
-  const int rc = launch_gemm_bf16x3(a, w, ep, M, N, K, act, seq_len, s, g_x3_ablate);
-  if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 linear: unsupported (activation, residual, output) combination");
+  const int rc = launch_gemm_x3(a, w, ep, M, N, K, act, seq_len, s, g_x3_ablate);
+  if (rc == -2) return fail(MDM_EUNSUPPORTED, "f16x3 linear: unsupported (activation, residual, output) combination");
   return rt_launch_status();
 }
 
-// in_proj in split precision: tokens -> Q (pre-scaled) / K / V^T operand planes of attention_bf16x3.h
+// in_proj in split precision: tokens -> Q (pre-scaled) / K / V^T operand planes of attention_x3.h
 int launch_in_proj_x3(Profiler* pf, X3Operand a, X3Weights w, const float* bias, const QkvPlanes& qp, int nseq, int S,
                       int D, float qscale, hipStream_t s) {
-  if (D % X3_BK != 0) return fail(MDM_EINVAL, "bf16x3 in_proj: latent_dim must be a multiple of 32");
+  if (D % X3_BK != 0) return fail(MDM_EINVAL, "f16x3 in_proj: latent_dim must be a multiple of 32");
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * nseq * S * 3.0 * D * (double)D, s);
   X3Epilogue ep{nullptr, bias, nullptr, nullptr, nullptr, nullptr, nullptr, 3 * D, D, qscale, qp, S, D,
                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1};
-  const int rc = launch_gemm_bf16x3_qkv(a, w, ep, nseq, S, D, s);
-  if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 in_proj: sequences longer than 224 tokens");
+  const int rc = launch_gemm_x3_qkv(a, w, ep, nseq, S, D, s);
+  if (rc == -2) return fail(MDM_EUNSUPPORTED, "f16x3 in_proj: sequences longer than 224 tokens");
   return rt_launch_status();
 }
 
-// One GEMM of the folded-LayerNorm encoder (gemm_bf16x3.h launch_gemm_bf16x3_ln kinds)
+// One GEMM of the folded-LayerNorm encoder (gemm_x3.h launch_gemm_x3_ln kinds)
 struct LnArgs {
   const float* astat = nullptr; const float* colsum = nullptr;                                   // FOLD
   X3Operand res{nullptr, nullptr}; const float* rstat = nullptr; const float* rgamma = nullptr; const float* rbeta = nullptr;  // residual
@@ -364,23 +382,23 @@ struct LnArgs {
   const float* res_f32 = nullptr; int emb_T = 1, emb_B = 1, emb_nbranch = 1;                     // EMBED (kind 5)
 };
 int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w, const float* bias, const LnArgs& ln,
-                 float* out, bf16_t* oh, bf16_t* ol, const QkvPlanes* qp, int M, int N, int K, int S, int D,
+                 float* out, p16_t* oh, p16_t* ol, const QkvPlanes* qp, int M, int N, int K, int S, int D,
                  int scale_cols, float col_scale, hipStream_t s) {
-  if (K % X3_BK != 0 || N % 4 != 0) return fail(MDM_EINVAL, "bf16x3 linear: K % 32 and N % 4 must be 0");
+  if (K % X3_BK != 0 || N % 4 != 0) return fail(MDM_EINVAL, "f16x3 linear: K % 32 and N % 4 must be 0");
   if (ln.parts < 1 || ln.parts > 4) return fail(MDM_EUNSUPPORTED, "folded LayerNorm: at most 4 partial sums per row (D <= 1024)");
   ProfScope ps(pf, prof_cat, 2.0 * M * (double)N * K, s);
   X3Epilogue ep{out, bias, ln.res_f32, ln.res.hi, ln.res.lo, oh, ol, N, scale_cols, col_scale, qp ? *qp : QkvPlanes{}, S, D,
                 ln.astat, ln.colsum, ln.rstat, ln.rgamma, ln.rbeta, ln.ostat, ln.parts, ln.inv_dim, ln.emb_T, ln.emb_B,
                 ln.emb_nbranch};
   const int rpt = (kind == 0) ? S : x3_rows_per_tile(M, kind == 5 ? ln.emb_T : S);
-  const int rc = launch_gemm_bf16x3_ln(kind, a, w, ep, M, N, K, rpt, s);
-  if (rc == -1) return fail(MDM_EHIP, "bf16x3 linear: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-  if (rc == -2) return fail(MDM_EUNSUPPORTED, "bf16x3 linear: unsupported folded-LayerNorm GEMM kind");
+  const int rc = launch_gemm_x3_ln(kind, a, w, ep, M, N, K, rpt, s);
+  if (rc == -1) return fail(MDM_EHIP, "f16x3 linear: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  if (rc == -2) return fail(MDM_EUNSUPPORTED, "f16x3 linear: unsupported folded-LayerNorm GEMM kind");
   return rt_launch_status();
 }
 
-// fp32 [N][K] weights -> fragment-ordered hi/lo planes (gemm_bf16x3.h header); K % 16 == 0
-int launch_pack_weights(const float* src, bf16_t* hi, bf16_t* lo, int N, int K, hipStream_t s) {
+// fp32 [N][K] weights -> fragment-ordered hi/lo planes (gemm_x3.h header); K % 16 == 0
+int launch_pack_weights(const float* src, p16_t* hi, p16_t* lo, int N, int K, hipStream_t s) {
   if (K % 16 != 0) return fail(MDM_EINVAL, "pack_weights: K must be a multiple of 16");
   const size_t n = x3_packed_weight_elems(N, K) / 8;
   const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
@@ -388,7 +406,7 @@ int launch_pack_weights(const float* src, bf16_t* hi, bf16_t* lo, int N, int K, 
   return rt_launch_status();
 }
 
-int launch_split(const float* src, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t s) {
+int launch_split(const float* src, p16_t* hi, p16_t* lo, size_t n, hipStream_t s) {
   if (n % 4 != 0) return fail(MDM_EINVAL, "split: element count must be a multiple of 4");
   const size_t n4 = n / 4;
   const int grid = (int)std::min<size_t>((n4 + 255) / 256, 4096);
@@ -401,8 +419,8 @@ int launch_split(const float* src, bf16_t* hi, bf16_t* lo, size_t n, hipStream_t
 int embed_frames_x3(mdm_model* m, const Workspace& ws, const float* x, int B, int T, int nbranch, hipStream_t s) {
   const int D = m->cfg.latent_dim, KP = m->jf_k;
   ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
-  bf16_t* ph = reinterpret_cast<bf16_t*>(ws.ffn);
-  bf16_t* pl = ph + (size_t)B * T * KP;
+  p16_t* ph = reinterpret_cast<p16_t*>(ws.ffn);
+  p16_t* pl = ph + (size_t)B * T * KP;
   MDM_LAUNCH(pose_to_planes_kernel, dim3((T + 31) / 32, KP / 32, B), dim3(256), 0, s, x, ph, pl, T, m->jf, KP);
   if (int rc = rt_launch_status()) return rc;
   LnArgs a;
@@ -412,7 +430,7 @@ int embed_frames_x3(mdm_model* m, const Workspace& ws, const float* x, int B, in
                       nullptr, ws.tokh, ws.tokl, nullptr, B * T, D, KP, T + 1, D, 0, 1.f, s);
 }
 inline bool use_embed_x3(const mdm_model* m, int T) {
-  return m->precision == MDM_PREC_BF16X3 && x3_waves_setting() == 8 && T + 1 <= X3_TM;
+  return m->precision == MDM_PREC_F16X3 && x3_waves_setting() == 8 && T + 1 <= X3_TM;
 }
 
 // Tokens for every sequence: frame tokens via the InputProcess GEMM, token 0 via cond_token_kernel.
@@ -423,7 +441,7 @@ int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long l
   const int D = m->cfg.latent_dim, S = T + 1;
   PoseGatherLoader al{x, T, m->jf, B * T};
   RowMajorLoader bl{m->w_in_pad, m->jf_pad, D, m->jf_pad};
-  const bool x3 = m->precision == MDM_PREC_BF16X3;
+  const bool x3 = m->precision == MDM_PREC_F16X3;
   EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D,
                    nbranch, x3 ? ws.tokh : nullptr, x3 ? ws.tokl : nullptr};
   if (use_embed_x3(m, T)) {
@@ -436,7 +454,7 @@ int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long l
   ProfScope ps(&m->prof, MDM_PROF_ELEMENTWISE, 0.0, s);
   MDM_LAUNCH(cond_token_kernel, dim3(nbranch * B), dim3(128), 0, s, ws.tok, cond_emb, m->W("embed_text.bias"),
              (const float*)m->time_table, timesteps, 0, m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from_branch,
-             (int)m->cfg.max_len, x3 ? ws.tokh : (bf16_t*)nullptr, x3 ? ws.tokl : (bf16_t*)nullptr);
+             (int)m->cfg.max_len, x3 ? ws.tokh : (p16_t*)nullptr, x3 ? ws.tokl : (p16_t*)nullptr);
   return rt_launch_status();
 }
 
@@ -445,10 +463,10 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
   Profiler* pf = &m->prof;
   const int D = m->cfg.latent_dim, FF = m->cfg.ff_size, H = m->cfg.num_heads, M = nseq * S;
   const float qscale = 1.0f / sqrtf((float)(D / H));
-  if (m->precision == MDM_PREC_BF16X3 && m->lnfold && x3_waves_setting() == 8 && S <= X3_TM) {
+  if (m->precision == MDM_PREC_F16X3 && m->lnfold && x3_waves_setting() == 8 && S <= X3_TM) {
     // No LayerNorm kernels: xb = tokh|tokl holds the layer input / the post-FFN PRE-norm sum, xa the post-attention
     // pre-norm sum, each with per-row partial (sum, sum^2) written by its producer; consumers fold the normalisation
-    // (gemm_bf16x3.h X3Epilogue).  Layer 0's input (the embedding) is not normalised: plain in_proj, plain residual.
+    // (gemm_x3.h X3Epilogue).  Layer 0's input (the embedding) is not normalised: plain in_proj, plain residual.
     const X3Operand xb{ws.tokh, ws.tokl}, xa{ws.xah, ws.xal}, attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
     const int parts = (D + 255) / 256;
     const float inv_dim = 1.0f / (float)D;
@@ -483,7 +501,7 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
     }
     return 0;   // the encoder's output is LN2(L-1)(xb): folded into OutputProcess (outproj_x3)
   }
-  if (m->precision == MDM_PREC_BF16X3) {
+  if (m->precision == MDM_PREC_F16X3) {
     // tok (fp32, residual stream) travels with its split planes tokh/tokl; attention and GELU outputs exist only as planes
     const X3Operand tokp{ws.tokh, ws.tokl}, attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
     for (int l = 0; l < m->cfg.num_layers; ++l) {
@@ -678,8 +696,8 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
   m->planes.assign(m->cfg.num_layers, mdm_model::LayerPlanes{});
   auto make_planes = [&](const float* src, int N, int K, X3Weights& op) -> int {
     const size_t n = x3_packed_weight_elems(N, K);
-    bf16_t* hi = reinterpret_cast<bf16_t*>(base);
-    bf16_t* lo = hi + n;
+    p16_t* hi = reinterpret_cast<p16_t*>(base);
+    p16_t* lo = hi + n;
     base += align_up(n * 4, 256);
     op = X3Weights{hi, lo};
     return launch_pack_weights(src, hi, lo, N, K, s);
@@ -732,7 +750,7 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
     if (int rc = rt_launch_status()) return rc;
     {
       const size_t n = x3_packed_weight_elems(D, m->jf_k);
-      bf16_t* hi = reinterpret_cast<bf16_t*>(base);
+      p16_t* hi = reinterpret_cast<p16_t*>(base);
       base += align_up(n * 4, 256);
       m->in_planes = X3Weights{hi, hi + n};
       if (int rc = launch_pack_weights(scratch_w, hi, hi + n, D, m->jf_k, s)) return rc;
@@ -746,10 +764,10 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
 
 int mdm_set_precision(mdm_model_t* m, int32_t mode) {
   if (m == nullptr) return fail(MDM_EINVAL, "mdm_set_precision: null model");
-  if (mode != MDM_PREC_F32 && mode != MDM_PREC_BF16X3) return fail(MDM_EINVAL, "mdm_set_precision: unknown mode");
-  if (mode == MDM_PREC_BF16X3 && (m->cfg.latent_dim % X3_BK != 0 || m->cfg.ff_size % X3_BK != 0))
-    return fail(MDM_EUNSUPPORTED, "bf16x3 needs latent_dim and ff_size to be multiples of 32");
-  if (mode == MDM_PREC_BF16X3 && m->cfg.arch == MDM_ARCH_TRANS_DEC)
+  if (mode != MDM_PREC_F32 && mode != MDM_PREC_F16X3) return fail(MDM_EINVAL, "mdm_set_precision: unknown mode");
+  if (mode == MDM_PREC_F16X3 && (m->cfg.latent_dim % X3_BK != 0 || m->cfg.ff_size % X3_BK != 0))
+    return fail(MDM_EUNSUPPORTED, "f16x3 needs latent_dim and ff_size to be multiples of 32");
+  if (mode == MDM_PREC_F16X3 && m->cfg.arch == MDM_ARCH_TRANS_DEC)
     return fail(MDM_EUNSUPPORTED, "the trans_dec (DiP) denoiser runs in exact fp32 only");
   m->precision = mode;
   return MDM_OK;
@@ -783,7 +801,7 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
                             uncond_from, s)) return rc;
   if (int rc = encoder(m, ws, nseq, B, S, len, s)) return rc;
   // OutputProcess, plain: every branch's tokens -> [nseq, JF, T]
-  if (m->precision == MDM_PREC_BF16X3)
+  if (m->precision == MDM_PREC_F16X3)
     return outproj_x3(m, ws, nseq, B, T, nullptr, 0, out, nullptr, nullptr, NoiseSource{}, nullptr, nullptr, StepCoefs{}, s);
   RowMajorLoader al{m->W("output_process.poseFinal.weight"), D, m->jf, D};
   CfgTokenLoader bl{ws.tok, nullptr, nseq, T, S, D, nseq * T};
@@ -920,7 +938,7 @@ int mdm_sampler_step(const float* x_t, const float* out_cond, const float* out_u
   if ((inpaint_mask == nullptr) != (inpaint_motion == nullptr)) return fail(MDM_EINVAL, "mdm_sampler_step: inpainting needs mask and motion");
   if (B <= 0 || per_sample <= 0) return fail(MDM_EINVAL, "mdm_sampler_step: bad shape");
   StepCoefs co{st->a_x0, st->a_xt, st->sigma, st->clip_denoised};
-  NoiseSource ns{noise, st->seed, st->sample_base, st->draw};
+  NoiseSource ns{noise, st->seed, st->sample_base, st->draw, (uint32_t)(st->const_noise != 0)};
   const size_t total = (size_t)B * per_sample;
   const int grid = (int)std::min<size_t>((total + 255) / 256, 2048);
   MDM_LAUNCH(sampler_step_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x_t, out_cond,
@@ -928,15 +946,20 @@ int mdm_sampler_step(const float* x_t, const float* out_cond, const float* out_u
   return rt_launch_status();
 }
 
-int mdm_randn(float* out, const float* init, const float* eps, float a, float s, int32_t B, int32_t per_sample,
-              uint64_t seed, uint32_t sample_base, uint32_t draw, void* stream) {
+static int launch_randn(float* out, const float* init, const float* eps, float a, float s, int32_t B, int32_t per_sample,
+                        uint64_t seed, uint32_t sample_base, uint32_t draw, uint32_t const_noise, void* stream) {
   if (out == nullptr || B <= 0 || per_sample <= 0) return fail(MDM_EINVAL, "mdm_randn: bad argument");
-  NoiseSource ns{nullptr, seed, sample_base, draw};
+  NoiseSource ns{nullptr, seed, sample_base, draw, const_noise};
   const size_t total = (size_t)B * per_sample;
   const int grid = (int)std::min<size_t>((total + 255) / 256, 2048);
   MDM_LAUNCH(randn_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), out, init, eps, a, s,
              per_sample, B, ns);
   return rt_launch_status();
+}
+
+int mdm_randn(float* out, const float* init, const float* eps, float a, float s, int32_t B, int32_t per_sample,
+              uint64_t seed, uint32_t sample_base, uint32_t draw, void* stream) {
+  return launch_randn(out, init, eps, a, s, B, per_sample, seed, sample_base, draw, 0u, stream);
 }
 
 int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void* ws_dev, size_t ws_bytes,
@@ -977,7 +1000,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
     {
       PoseGatherLoader al{x, T, m->jf, B * T};
       RowMajorLoader bl{m->w_in_pad, m->jf_pad, D, m->jf_pad};
-      const bool x3 = m->precision == MDM_PREC_BF16X3;
+      const bool x3 = m->precision == MDM_PREC_F16X3;
       EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D, nbranch,
                        x3 ? ws.tokh : nullptr, x3 ? ws.tokl : nullptr};
       if (use_embed_x3(m, T)) {
@@ -991,27 +1014,28 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
       MDM_LAUNCH(cond_token_kernel, dim3(nseq), dim3(128), 0, s, ws.tok, (const float*)ws.cond,
                  m->W("embed_text.bias"), (const float*)m->time_table, (const long long*)nullptr,
                  (int)p->timestep_map[i], m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from,
-                 (int)m->cfg.max_len, x3 ? ws.tokh : (bf16_t*)nullptr, x3 ? ws.tokl : (bf16_t*)nullptr);
+                 (int)m->cfg.max_len, x3 ? ws.tokh : (p16_t*)nullptr, x3 ? ws.tokl : (p16_t*)nullptr);
       if (int rc = rt_launch_status()) return rc;
     }
     if (int rc = encoder(m, ws, nseq, B, S, len, s)) return rc;
     // this step's eps: injected, or the counter-based stream -- drawn inline by the split-precision tail kernel, into the
     // (now dead) attention buffer for the exact-fp32 OutputProcess epilogue
-    const bool x3mode = m->precision == MDM_PREC_BF16X3;
+    const bool x3mode = m->precision == MDM_PREC_F16X3;
     const float* step_noise = nullptr;
     if (p->sigma[i] != 0.f) {
       if (p->noise_dev != nullptr) step_noise = p->noise_dev + (size_t)k * B * per_sample;
       else if (!x3mode) {
         ProfScope ps(&m->prof, MDM_PROF_ELEMENTWISE, 0.0, s);
-        if (int rc = mdm_randn(ws.att, nullptr, nullptr, 0.f, 1.f, B, (int)per_sample, p->seed, p->sample_base,
-                               (uint32_t)(1 + k), stream)) return rc;
+        if (int rc = launch_randn(ws.att, nullptr, nullptr, 0.f, 1.f, B, (int)per_sample, p->seed, p->sample_base,
+                                  (uint32_t)(1 + k), (uint32_t)(p->const_noise != 0), stream)) return rc;
         step_noise = ws.att;
       }
     }
     // OutputProcess + CFG combine + sampler update, in place on x
     if (x3mode) {
       if (int rc = outproj_x3(m, ws, nseq, B, T, cfg ? p->scale_dev : nullptr, 1, x, (i == 0) ? p->x0_dev : nullptr, x,
-                              NoiseSource{step_noise, p->seed, p->sample_base, (uint32_t)(1 + k)}, p->inpaint_mask_dev,
+                              NoiseSource{step_noise, p->seed, p->sample_base, (uint32_t)(1 + k), (uint32_t)(p->const_noise != 0)},
+                              p->inpaint_mask_dev,
                               p->inpaint_motion_dev,
                               StepCoefs{p->a_x0[i], p->a_xt[i], p->sigma[i], p->clip_denoised}, s)) return rc;
     } else {
@@ -1039,6 +1063,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
   return MDM_OK;
 }
 
+#ifdef MDM_PROBES
 int mdm_debug_set(int what, int value) {
   if (what == 0) g_x3_ablate = value;
   if (what == 1) g_x3_reuse_planes = value;
@@ -1049,7 +1074,7 @@ int mdm_debug_set(int what, int value) {
   return MDM_OK;
 }
 
-int mdm_debug_get(int idx, double* out) {   // ABL & 128 cycle counters of gemm_bf16x3.h; idx < 0 resets them
+int mdm_debug_get(int idx, double* out) {   // ABL & 128 cycle counters of gemm_x3.h; idx < 0 resets them
 #ifndef MDM_EMU
   unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (idx < 0) return hipMemcpyToSymbol(HIP_SYMBOL(g_x3_dbg), v, sizeof(v)) == hipSuccess ? MDM_OK : fail(MDM_EHIP, "mdm_debug_get: reset failed");
@@ -1062,6 +1087,7 @@ int mdm_debug_get(int idx, double* out) {   // ABL & 128 cycle counters of gemm_
 #endif
   return MDM_OK;
 }
+#endif
 
 int mdm_profile_enable(mdm_model_t* m, int on) {
   if (m == nullptr) return fail(MDM_EINVAL, "mdm_profile_enable: null model");
@@ -1103,20 +1129,20 @@ int mdm_linear(const float* in, const float* w, const float* bias, const float* 
   return launch_linear(nullptr, in, K, w, bias, res, out, M, N, K, act, 0, 1.f, static_cast<hipStream_t>(stream));
 }
 
-size_t mdm_linear_bf16x3_scratch_bytes(int32_t M, int32_t N, int32_t K) {
+size_t mdm_linear_x3_scratch_bytes(int32_t M, int32_t N, int32_t K) {
   return align_up((size_t)M * K * 4, 256) + align_up(x3_packed_weight_elems(N, K) * 4, 256);
 }
 
-int mdm_linear_bf16x3(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M,
+int mdm_linear_x3(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M,
                       int32_t N, int32_t K, int32_t act, void* scratch, size_t scratch_bytes, void* stream) {
-  if (!in || !w || !bias || !out || !scratch || M <= 0 || N <= 0 || K <= 0) return fail(MDM_EINVAL, "mdm_linear_bf16x3: bad argument");
-  if (K % X3_BK != 0) return fail(MDM_EINVAL, "mdm_linear_bf16x3: K must be a multiple of 32");
-  if (scratch_bytes < mdm_linear_bf16x3_scratch_bytes(M, N, K)) return fail(MDM_ENOSPC, "mdm_linear_bf16x3: scratch too small");
+  if (!in || !w || !bias || !out || !scratch || M <= 0 || N <= 0 || K <= 0) return fail(MDM_EINVAL, "mdm_linear_x3: bad argument");
+  if (K % X3_BK != 0) return fail(MDM_EINVAL, "mdm_linear_x3: K must be a multiple of 32");
+  if (scratch_bytes < mdm_linear_x3_scratch_bytes(M, N, K)) return fail(MDM_ENOSPC, "mdm_linear_x3: scratch too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  bf16_t* ah = static_cast<bf16_t*>(scratch);
-  bf16_t* al = ah + (size_t)M * K;
-  bf16_t* wh = reinterpret_cast<bf16_t*>(static_cast<char*>(scratch) + align_up((size_t)M * K * 4, 256));
-  bf16_t* wl = wh + x3_packed_weight_elems(N, K);
+  p16_t* ah = static_cast<p16_t*>(scratch);
+  p16_t* al = ah + (size_t)M * K;
+  p16_t* wh = reinterpret_cast<p16_t*>(static_cast<char*>(scratch) + align_up((size_t)M * K * 4, 256));
+  p16_t* wl = wh + x3_packed_weight_elems(N, K);
   if (!g_x3_reuse_planes) {
     if (int rc = launch_split(in, ah, al, (size_t)M * K, s)) return rc;
     if (int rc = launch_pack_weights(w, wh, wl, N, K, s)) return rc;
@@ -1125,6 +1151,7 @@ int mdm_linear_bf16x3(const float* in, const float* w, const float* bias, const 
                           1.f, 0, s);
 }
 
+#ifdef MDM_PROBES
 size_t mdm_linear_f16f6_scratch_bytes(int32_t M, int32_t N, int32_t K) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0) return 0;
   // A planes | W as fragment-ordered planes (fast kernel) | W as row-major planes (reference kernel)
@@ -1140,10 +1167,10 @@ int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const f
   hipStream_t s = static_cast<hipStream_t>(stream);
   char* base = static_cast<char*>(scratch);
   const F6Planes pa = f6_carve(base, M, K);
-  bf16_t* wfh = reinterpret_cast<bf16_t*>(base + f6_plane_bytes(M, K));
-  bf16_t* wfl = reinterpret_cast<bf16_t*>(base + f6_plane_bytes(M, K) + align_up(x3_packed_weight_elems(N, K) * 2, 256));
+  p16_t* wfh = reinterpret_cast<p16_t*>(base + f6_plane_bytes(M, K));
+  p16_t* wfl = reinterpret_cast<p16_t*>(base + f6_plane_bytes(M, K) + align_up(x3_packed_weight_elems(N, K) * 2, 256));
   const F6Planes pw = f6_carve(base + f6_plane_bytes(M, K) + 2 * align_up(x3_packed_weight_elems(N, K) * 2, 256), N, K);
-  // the production skeleton (gemm_bf16x3_kernel<..., F6>) where its epilogues exist; else the one-wave-per-tile reference
+  // the production skeleton (gemm_x3_kernel<..., F6>) where its epilogues exist; else the one-wave-per-tile reference
   const bool fast = !g_f6_reference && N % 4 == 0 && ((act == ACT_NONE) || (act == ACT_GELU && res == nullptr));
   if (!g_x3_reuse_planes) {
     MDM_LAUNCH(pack_f16f6_kernel, dim3((M * (K / 32) + 255) / 256), dim3(256), 0, s, in, pa, M, K, K);
@@ -1159,7 +1186,7 @@ int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const f
   if (fast) {
     X3Epilogue ep{out, bias, res, nullptr, nullptr, nullptr, nullptr, N, 0, 1.f, QkvPlanes{}, 0, 0,
                   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1};
-    const X3Operand a{reinterpret_cast<const bf16_t*>(pa.h16), reinterpret_cast<const bf16_t*>(pa.rec)};
+    const X3Operand a{reinterpret_cast<const p16_t*>(pa.h16), reinterpret_cast<const p16_t*>(pa.rec)};
     const int rc = launch_gemm_f16f6(a, X3Weights{wfh, wfl}, ep, M, N, K, act, s);
     if (rc == -1) return fail(MDM_EHIP, "mdm_linear_f16f6: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     if (rc == -2) return fail(MDM_EUNSUPPORTED, "mdm_linear_f16f6: unsupported (activation, residual) combination");
@@ -1171,6 +1198,7 @@ int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const f
   else MDM_LAUNCH(gemm_f16f6_ref_kernel<ACT_NONE>, grid, dim3(64), 0, s, pa, pw, bias, res, out, M, N, K);
   return rt_launch_status();
 }
+#endif
 
 int mdm_layernorm(float* x, const float* gamma, const float* beta, int32_t rows, int32_t D, void* stream) {
   if (!x || !gamma || !beta || rows <= 0 || D % 256 != 0) return fail(MDM_EINVAL, "mdm_layernorm: bad argument");
@@ -1183,21 +1211,21 @@ int mdm_attention(const float* qkv, float* out, const int32_t* lengths, int32_t 
   return launch_attention(nullptr, qkv, out, lengths, nseq, B, S, D, H, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
-size_t mdm_attention_bf16x3_scratch_bytes(int32_t nseq, int32_t S, int32_t D) {
+size_t mdm_attention_x3_scratch_bytes(int32_t nseq, int32_t S, int32_t D) {
   if (nseq <= 0 || S <= 0 || D <= 0) return 0;
   const size_t SP = (size_t)(S + 31) / 32 * 32;
   return (size_t)nseq * SP * D * 12;
 }
 
-int mdm_attention_bf16x3(const float* qkv, float* out, const int32_t* lengths, int32_t nseq, int32_t B, int32_t S,
+int mdm_attention_x3(const float* qkv, float* out, const int32_t* lengths, int32_t nseq, int32_t B, int32_t S,
                          int32_t D, int32_t H, void* scratch, size_t scratch_bytes, void* stream) {
-  if (!qkv || !out || !scratch || nseq <= 0 || B <= 0 || S <= 0 || H <= 0) return fail(MDM_EINVAL, "mdm_attention_bf16x3: bad argument");
+  if (!qkv || !out || !scratch || nseq <= 0 || B <= 0 || S <= 0 || H <= 0) return fail(MDM_EINVAL, "mdm_attention_x3: bad argument");
   if (D != H * AX_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
-  if (scratch_bytes < mdm_attention_bf16x3_scratch_bytes(nseq, S, D)) return fail(MDM_ENOSPC, "mdm_attention_bf16x3: scratch too small");
+  if (scratch_bytes < mdm_attention_x3_scratch_bytes(nseq, S, D)) return fail(MDM_ENOSPC, "mdm_attention_x3: scratch too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int NKT = (S + 31) / 32, SP = 32 * NKT;
   const size_t plane = (size_t)nseq * SP * D;
-  bf16_t* q = static_cast<bf16_t*>(scratch);
+  p16_t* q = static_cast<p16_t*>(scratch);
   QkvPlanes qp{q, q + plane, q + 2 * plane, q + 3 * plane, q + 4 * plane, q + 5 * plane, SP, NKT, H};
   const int grid = (int)std::min<size_t>((plane + 255) / 256, 4096);
   if (!g_x3_reuse_planes) {   // mdm_debug_set(1, 1): kernel-only timing, the planes of the previous call are reused

@@ -12,9 +12,13 @@ What is different from the reference, by design:
     torch's global CPU generator, so `utils/fixseed.py` still makes runs reproducible.  Parity tests inject
     the reference's CPU noise stream instead (`noise_sequence=`).
 Scope: ModelMeanType.START_X with FIXED_SMALL / FIXED_LARGE variance (the only configuration
-utils/model_util.py:75-116 creates).  Training losses, PLMS, cond_fn guidance are out of scope and raise.
+utils/model_util.py:75-116 creates).  What has no native path -- cond_fn / denoised_fn guidance, randomize_class, PLMS,
+training losses, foreign (non-MI355X) models -- is handed to the REFERENCE's own `diffusion` package when that is
+importable (the drop-in situation: sample/generate.py runs from the reference tree), driving whatever
+model it is given step by step; without the reference on the path those calls raise NotImplementedError.
 """
 import enum
+import importlib
 import math
 
 import numpy as np
@@ -76,6 +80,35 @@ def _unwrap(model):
     return None, False
 
 
+class _MappedModel:
+    """respace.py:113-134 `_WrappedModel`: the model sees the ORIGINAL timestep of a respaced process."""
+
+    def __init__(self, model, timestep_map):
+        self.model, self.timestep_map = model, timestep_map
+
+    def __call__(self, x, ts, **kwargs):
+        tmap = torch.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
+        return self.model(x, tmap[ts], **kwargs)
+
+    def __getattr__(self, name):          # .parameters(), .encode_text, .model ...: whatever the loops poke at
+        return getattr(self.__dict__["model"], name)
+
+
+class _ReferenceTwin:
+    """Method proxy onto the reference's GaussianDiffusion: every sampler / loss entry point takes the model first."""
+
+    def __init__(self, base, timestep_map):
+        self.base, self.timestep_map = base, timestep_map
+        self.identity = timestep_map == list(range(len(timestep_map)))
+
+    def __getattr__(self, name):
+        fn = getattr(self.__dict__["base"], name)
+
+        def call(model, *a, **k):
+            return fn(model if self.identity else _MappedModel(model, self.timestep_map), *a, **k)
+        return call
+
+
 class GaussianDiffusion:
     def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False, **kargs):
         self.model_mean_type = model_mean_type
@@ -84,6 +117,9 @@ class GaussianDiffusion:
         self.rescale_timesteps = rescale_timesteps
         for k, v in kargs.items():            # lambda_* / data_rep: training-loss knobs, kept as attributes
             setattr(self, k, v)
+        self._ctor_kwargs = dict(betas=np.array(betas, dtype=np.float64), rescale_timesteps=rescale_timesteps, **kargs)
+        self._ctor_enums = (model_mean_type.name, model_var_type.name, loss_type.name)
+        self._ref_twin = None
         # compared by name so that the reference's own enum objects are accepted (drop-in via utils/model_util.py)
         if model_mean_type.name != "START_X":
             raise NotImplementedError("only ModelMeanType.START_X (utils/model_util.py:77: predict_xstart=True)")
@@ -112,6 +148,29 @@ class GaussianDiffusion:
         self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
         self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
         self.timestep_map = list(range(self.num_timesteps))   # identity unless SpacedDiffusion overrides it
+
+    # ---- what has no native path goes to the reference's own sampler (when importable) -----------------
+    def _reference(self, why):
+        """The reference's own `GaussianDiffusion` over this object's (respaced) betas, for what has no native path (SURVEY.md
+        8a: "fall back to the reference implementation" for cond_fn, denoised_fn, randomize_class, PLMS, training losses
+        and foreign models).  It drives any callable `model(x, t, **model_kwargs)` -- the MI355X MDM included -- one step at a
+        time in torch; a non-identity timestep map is applied by wrapping the model, as respace.py:113-134 does.
+        Raises NotImplementedError when the reference's `diffusion` package is not importable."""
+        if self._ref_twin is None:
+            try:
+                rgd = importlib.import_module("diffusion.gaussian_diffusion")
+            except ImportError as e:
+                raise NotImplementedError(
+                    f"{why}: outside the MI355X hot path (SURVEY.md 8a), and the reference's `diffusion` package is not "
+                    f"importable to take over ({e}); put the reference tree on PYTHONPATH") from None
+            if issubclass(rgd.GaussianDiffusion, GaussianDiffusion):
+                raise NotImplementedError(f"{why}: diffusion.gaussian_diffusion.GaussianDiffusion has been rebound to the "
+                                          f"MI355X class, so there is no reference implementation to hand over to")
+            mean, var, loss = self._ctor_enums
+            kw = dict(self._ctor_kwargs)          # betas: the respaced ones (SpacedDiffusion passes them up, respace.py:74-88)
+            kw.update(model_mean_type=rgd.ModelMeanType[mean], model_var_type=rgd.ModelVarType[var], loss_type=rgd.LossType[loss])
+            self._ref_twin = _ReferenceTwin(rgd.GaussianDiffusion(**kw), list(self.timestep_map))
+        return self._ref_twin
 
     # ---- host-folded per-step scalars ----------------------------------------------------------------
     def ddpm_coefficients(self):
@@ -178,39 +237,51 @@ class GaussianDiffusion:
             raise NotImplementedError("per-sample timesteps inside one sampler step are not supported")
         return i
 
-    def _step(self, model, x, t, coefs, clip_denoised, denoised_fn, cond_fn, model_kwargs, noise, draw, index=None):
-        if denoised_fn is not None or cond_fn is not None:
-            raise NotImplementedError("denoised_fn / cond_fn guidance is outside the MI355X hot path (no live caller)")
+    def _step(self, model, x, t, coefs, clip_denoised, denoised_fn, cond_fn, model_kwargs, noise, draw, index=None,
+              const_noise=False):
+        assert denoised_fn is None and cond_fn is None      # callers route those to the reference's sampler
         y = (model_kwargs or {}).get('y', {})
         i = self._uniform_index(t) if index is None else index   # (a loop knows its index: no device round trip)
         oc, ou, scale, eng = self._model_x0_parts(model, x, t, model_kwargs)
         im = y.get('inpainting_mask', None)
         imo = y.get('inpainted_motion', None)
         if im is not None and imo is not None:
-            im = im.to(device=x.device).to(torch.uint8).contiguous()
-            imo = imo.to(device=x.device, dtype=torch.float32).contiguous()
+            # the reference asserts both have the model output's shape (:301-303); broadcastable inputs are expanded, the
+            # kernel indexes a full [B, J, F, T] array
+            im = im.to(device=x.device).expand(x.shape).to(torch.uint8).contiguous()
+            imo = imo.to(device=x.device, dtype=torch.float32).expand(x.shape).contiguous()
         else:
             im = imo = None
+        if noise is not None:
+            noise = noise.to(x.device, torch.float32)
+            if const_noise:
+                noise = noise[[0]].repeat(x.shape[0], 1, 1, 1)                    # :527-528
+            noise = noise.contiguous()
         a_x0, a_xt, sigma = coefs
         seed, base = self._rng_state()
-        x_prev, x0 = eng.sampler_step(x.contiguous(), oc, ou, scale, im, imo,
-                                      None if noise is None else noise.to(x.device, torch.float32).contiguous(),
+        x_prev, x0 = eng.sampler_step(x.contiguous(), oc, ou, scale, im, imo, noise,
                                       float(a_x0[i]), float(a_xt[i]), float(sigma[i]), clip_denoised,
-                                      seed=seed, sample_base=base, draw=draw, want_x0=True)
+                                      seed=seed, sample_base=base, draw=draw, want_x0=True, const_noise=const_noise)
         return {"sample": x_prev, "pred_xstart": x0}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                  const_noise=False, noise=None):
         """gaussian_diffusion.py:489-541.  `noise` (extra kwarg) injects eps; otherwise the Philox stream is used."""
-        if const_noise:
-            raise NotImplementedError("const_noise=True")
-        return self._step(model, x, t, self.ddpm_coefficients(), clip_denoised, denoised_fn, cond_fn, model_kwargs,
-                          noise, draw=self._next_draw())
+        if denoised_fn is not None or cond_fn is not None or _unwrap(model)[0] is None:
+            return self._reference("p_sample with cond_fn / denoised_fn / a foreign model").p_sample(
+                model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                model_kwargs=model_kwargs, const_noise=const_noise)
+        return self._step(model, x, t, self.ddpm_coefficients(), clip_denoised, None, None, model_kwargs,
+                          noise, draw=self._next_draw(), const_noise=const_noise)
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0,
                     noise=None):
         """gaussian_diffusion.py:729-779."""
-        return self._step(model, x, t, self.ddim_coefficients(eta), clip_denoised, denoised_fn, cond_fn, model_kwargs,
+        if denoised_fn is not None or cond_fn is not None or _unwrap(model)[0] is None:
+            return self._reference("ddim_sample with cond_fn / denoised_fn / a foreign model").ddim_sample(
+                model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                model_kwargs=model_kwargs, eta=eta)
+        return self._step(model, x, t, self.ddim_coefficients(eta), clip_denoised, None, None, model_kwargs,
                           noise, draw=self._next_draw())
 
     # RNG bookkeeping for the step-at-a-time API
@@ -239,9 +310,19 @@ class GaussianDiffusion:
                       randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False,
                       noise_sequence=None, seed=None):
         """gaussian_diffusion.py:591-658.  Returns the final sample (or the list of dumped steps)."""
-        return self._loop(model, shape, self.ddpm_coefficients(), noise, clip_denoised, denoised_fn, cond_fn,
-                          model_kwargs, device, skip_timesteps, init_image, randomize_class, cond_fn_with_grad,
-                          dump_steps, const_noise, noise_sequence, seed)
+        if self._needs_reference(model, denoised_fn, cond_fn, cond_fn_with_grad, randomize_class):
+            return self._reference("p_sample_loop with cond_fn / denoised_fn / randomize_class / a foreign model").p_sample_loop(
+                model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                model_kwargs=model_kwargs, device=device, progress=progress, skip_timesteps=skip_timesteps,
+                init_image=init_image, randomize_class=randomize_class, cond_fn_with_grad=cond_fn_with_grad,
+                dump_steps=dump_steps, const_noise=const_noise)
+        return self._loop(model, shape, self.ddpm_coefficients(), noise, clip_denoised, model_kwargs, device,
+                          skip_timesteps, init_image, dump_steps, const_noise, noise_sequence, seed)
+
+    @staticmethod
+    def _needs_reference(model, denoised_fn, cond_fn, cond_fn_with_grad, randomize_class):
+        return (denoised_fn is not None or cond_fn is not None or bool(cond_fn_with_grad) or bool(randomize_class)
+                or _unwrap(model)[0] is None)
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                          model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
@@ -252,20 +333,17 @@ class GaussianDiffusion:
             raise NotImplementedError()          # as the reference (:900-901)
         if const_noise == True:                  # noqa: E712  (:902-903)
             raise NotImplementedError()
-        return self._loop(model, shape, self.ddim_coefficients(eta), noise, clip_denoised, denoised_fn, cond_fn,
-                          model_kwargs, device, skip_timesteps, init_image, randomize_class, cond_fn_with_grad,
-                          None, False, noise_sequence, seed)
+        if self._needs_reference(model, denoised_fn, cond_fn, cond_fn_with_grad, randomize_class):
+            return self._reference("ddim_sample_loop with cond_fn / denoised_fn / randomize_class / a foreign model").ddim_sample_loop(
+                model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                model_kwargs=model_kwargs, device=device, progress=progress, eta=eta, skip_timesteps=skip_timesteps,
+                init_image=init_image, randomize_class=randomize_class, cond_fn_with_grad=cond_fn_with_grad)
+        return self._loop(model, shape, self.ddim_coefficients(eta), noise, clip_denoised, model_kwargs, device,
+                          skip_timesteps, init_image, None, False, noise_sequence, seed)
 
-    def _loop(self, model, shape, coefs, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
-              skip_timesteps, init_image, randomize_class, cond_fn_with_grad, dump_steps, const_noise,
-              noise_sequence, seed):
-        if denoised_fn is not None or cond_fn is not None or cond_fn_with_grad or randomize_class or const_noise:
-            raise NotImplementedError("cond_fn / denoised_fn / randomize_class / const_noise have no live caller in the "
-                                      "reference sampling path and are outside the MI355X hot path (SURVEY.md 8a)")
+    def _loop(self, model, shape, coefs, noise, clip_denoised, model_kwargs, device, skip_timesteps, init_image,
+              dump_steps, const_noise, noise_sequence, seed):
         mdm, guided = _unwrap(model)
-        if mdm is None:
-            raise NotImplementedError("p_sample_loop drives the MI355X MDM (optionally wrapped in "
-                                      "ClassifierFreeSampleModel); foreign models are out of scope")
         model_kwargs = {} if model_kwargs is None else model_kwargs
         y = model_kwargs.get('y', {})
         if device is None:
@@ -278,7 +356,7 @@ class GaussianDiffusion:
             y['text_embed'] = model.encode_text(y['text'])
         if mdm.arch == 'trans_dec':
             return self._loop_stepwise(model, mdm, shape, coefs, noise, clip_denoised, model_kwargs, device,
-                                       skip_timesteps, init_image, dump_steps, noise_sequence, seed)
+                                       skip_timesteps, init_image, dump_steps, noise_sequence, seed, const_noise)
 
         eng = mdm.engine()
         with torch.no_grad():
@@ -319,7 +397,10 @@ class GaussianDiffusion:
                 nsteps = start + 1
                 assert len(noise_sequence) >= 1 + nsteps, "noise_sequence = [x_T, eps_0, ..., eps_{nsteps-1}]"
                 nz = torch.stack([n.to(device=device, dtype=torch.float32).contiguous()
-                                  for n in noise_sequence[1:1 + nsteps]]).contiguous()
+                                  for n in noise_sequence[1:1 + nsteps]])
+                if const_noise:                                                     # :527-528 on the injected stream
+                    nz = nz[:, :1].expand(nz.shape)
+                nz = nz.contiguous()
             a_x0, a_xt, sigma = coefs
             kept = sorted(set(int(k) for k in dump_steps if 0 <= int(k) <= start)) if dump_steps is not None else None
             out, _, dumps = eng.sample_loop(
@@ -327,13 +408,13 @@ class GaussianDiffusion:
                 text_embed=te, scale=scale, lengths=lengths, inpaint_mask=im, inpaint_motion=imo, noise=nz,
                 seed=seed, sample_base=base, clip_denoised=clip_denoised,
                 force_uncond=bool(y.get('uncond', False)) or mdm.cond_mode == 'no_cond',
-                dump_steps=kept)
+                dump_steps=kept, const_noise=const_noise)
         if dump_steps is not None:      # the reference appends in loop order (:654-657)
             return [dumps[j] for j in range(len(kept))] if kept else []
         return out
 
     def _loop_stepwise(self, model, mdm, shape, coefs, noise, clip_denoised, model_kwargs, device, skip_timesteps,
-                       init_image, dump_steps, noise_sequence, seed):
+                       init_image, dump_steps, noise_sequence, seed, const_noise=False):
         """The same loop, one native forward + one fused step kernel per iteration: the DiP decoder (10 steps x 60 tokens
         per window) is not in the fused trans_enc loop of mdm_sample_loop."""
         eng = mdm.engine()
@@ -360,23 +441,34 @@ class GaussianDiffusion:
             for k, i in enumerate(range(start, -1, -1)):
                 t = torch.full((shape[0],), i, device=device, dtype=torch.long)
                 nz = None if noise_sequence is None else noise_sequence[1 + k]
-                out = self._step(model, img, t, coefs, clip_denoised, None, None, model_kwargs, nz, draw=1 + k, index=i)
+                out = self._step(model, img, t, coefs, clip_denoised, None, None, model_kwargs, nz, draw=1 + k, index=i,
+                                 const_noise=const_noise)
                 img = out["sample"]
-                if dump_steps is not None and i in dump_steps:
+                if dump_steps is not None and k in dump_steps:       # the loop's enumerate index (:637-655), not t
                     dumps.append(img.clone())
         return dumps if dump_steps is not None else img
 
     # ---- progressive generators (the reference yields per step; kept for callers that iterate) ---------
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
-                                  randomize_class=False, cond_fn_with_grad=False, const_noise=False, _ddim_eta=None):
+                                  randomize_class=False, cond_fn_with_grad=False, const_noise=False, _ddim_eta=None,
+                                  noise_sequence=None):
         """gaussian_diffusion.py:660-727: yields {'sample', 'pred_xstart'} per step (one native forward + one fused
-        step kernel per iteration; use p_sample_loop for the fully-fused loop)."""
-        if randomize_class or cond_fn_with_grad or const_noise:
-            raise NotImplementedError("randomize_class / cond_fn_with_grad / const_noise")
+        step kernel per iteration; use p_sample_loop for the fully-fused loop).  `noise_sequence` = [x_T, eps_0, ...]
+        (extra kwarg) injects the noise stream, as in p_sample_loop."""
+        if self._needs_reference(model, denoised_fn, cond_fn, cond_fn_with_grad, randomize_class):
+            ref = self._reference("progressive sampling with cond_fn / denoised_fn / randomize_class / a foreign model")
+            kw = dict(noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                      model_kwargs=model_kwargs, device=device, progress=progress, skip_timesteps=skip_timesteps,
+                      init_image=init_image, randomize_class=randomize_class, cond_fn_with_grad=cond_fn_with_grad)
+            if _ddim_eta is None:
+                yield from ref.p_sample_loop_progressive(model, shape, const_noise=const_noise, **kw)
+            else:
+                yield from ref.ddim_sample_loop_progressive(model, shape, eta=_ddim_eta, **kw)
+            return
         mdm, _ = _unwrap(model)
-        if mdm is None:
-            raise NotImplementedError("foreign models are out of scope")
+        if noise is None and noise_sequence is not None:
+            noise = noise_sequence[0]
         if device is None:
             device = next(mdm.parameters()).device
         shape = tuple(int(s) for s in shape)
@@ -395,25 +487,32 @@ class GaussianDiffusion:
             elif img is None:
                 img = eng.randn(shape, device, seed, self.sample_base, 0)
             coefs = self.ddpm_coefficients() if _ddim_eta is None else self.ddim_coefficients(_ddim_eta)
-            for i in range(start, -1, -1):
+            for k, i in enumerate(range(start, -1, -1)):
                 t = torch.full((shape[0],), i, device=device, dtype=torch.long)
-                out = self._step(model, img, t, coefs, clip_denoised, denoised_fn, cond_fn, model_kwargs, None,
-                                 draw=self._next_draw())
+                nz = None if noise_sequence is None else noise_sequence[1 + k]
+                out = self._step(model, img, t, coefs, clip_denoised, None, None, model_kwargs, nz,
+                                 draw=self._next_draw(), index=i, const_noise=const_noise)
                 yield out
                 img = out["sample"]
 
     def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
                                      cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,
                                      skip_timesteps=0, init_image=None, randomize_class=False,
-                                     cond_fn_with_grad=False):
+                                     cond_fn_with_grad=False, noise_sequence=None):
         """gaussian_diffusion.py:925-990."""
         return self.p_sample_loop_progressive(model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
                                               device, progress, skip_timesteps, init_image, randomize_class,
-                                              cond_fn_with_grad, False, _ddim_eta=eta)
+                                              cond_fn_with_grad, False, _ddim_eta=eta, noise_sequence=noise_sequence)
 
-    # ---- explicitly out of scope -----------------------------------------------------------------------
+    # ---- no native path: the reference's own implementation takes over when it is importable -----------------
     def training_losses(self, *a, **k):
-        raise NotImplementedError("training is outside the MI355X sampling hot path (SURVEY.md 2)")
+        return self._reference("training_losses (training is outside the MI355X sampling hot path, SURVEY.md 2)").training_losses(*a, **k)
 
     def plms_sample_loop(self, *a, **k):
-        raise NotImplementedError("PLMS sampling has no live caller in the reference and is out of scope")
+        return self._reference("plms_sample_loop (no live caller in the reference, gaussian_diffusion.py:1099-1187)").plms_sample_loop(*a, **k)
+
+    def plms_sample_loop_progressive(self, *a, **k):
+        return self._reference("plms_sample_loop_progressive").plms_sample_loop_progressive(*a, **k)
+
+    def p_sample_with_grad(self, *a, **k):
+        return self._reference("p_sample_with_grad (gaussian_diffusion.py:543-589)").p_sample_with_grad(*a, **k)

@@ -107,8 +107,8 @@ class MDM(nn.Module):
         self.text_encoder_type = kargs.get('text_encoder_type', 'clip')
         self.clip_version = clip_version
         self._native_lib = kargs.get('_native_lib', None)      # tests inject the CPU emulation here
-        # arithmetic of the encoder GEMMs (include/mdm_hip.h mdm_set_precision): 'bf16x3' | 'f32'
-        self.precision = kargs.get('precision', os.environ.get('MDM_PRECISION', 'bf16x3'))
+        # arithmetic of the encoder GEMMs (include/mdm_hip.h mdm_set_precision): 'f16x3' | 'f32'
+        self.precision = kargs.get('precision', os.environ.get('MDM_PRECISION', 'f16x3'))
 
         if arch not in ('trans_enc', 'trans_dec'):
             raise NotImplementedError(f"arch={arch!r}: trans_enc and trans_dec (DiP) only (SURVEY.md 8f)")
@@ -219,12 +219,25 @@ class MDM(nn.Module):
 
     def lengths_from_mask(self, y, T):
         """y['mask'] [B,1,1,T] bool -> int32 valid-frame counts, or None when the reference would not mask
-        (model/mdm.py:241-247).  collate builds prefix masks (data_loaders/tensors.py:3-8, :22-40)."""
+        (model/mdm.py:241-247).  collate builds prefix masks (data_loaders/tensors.py:3-8, :22-40) and the attention
+        kernels take the mask as a valid-frame count, so a mask that is NOT a prefix mask raises instead of being
+        silently reduced to its popcount.  The (host-synchronising) check runs once per mask tensor: a sampling loop
+        hands over the same `y` every step; the cache entry keeps the mask alive so that its address cannot be recycled."""
         mask = y.get('mask', None) if y is not None else None
         if not self.mask_frames or mask is None or mask.shape[-1] <= 1:
             return None
-        m = mask[..., :T].reshape(mask.shape[0], -1)
-        return m.sum(dim=1).to(torch.int32).contiguous()
+        key = (mask.data_ptr(), mask._version, tuple(mask.shape), str(mask.device), int(T))
+        cached = getattr(self, '_len_cache', None)
+        if cached is not None and cached[0] == key and cached[1] is mask:
+            return cached[2]
+        m = mask[..., :T].reshape(mask.shape[0], -1).to(torch.bool)
+        lengths = m.sum(dim=1)
+        if not bool((m == (torch.arange(m.shape[1], device=m.device)[None, :] < lengths[:, None])).all()):
+            raise NotImplementedError("y['mask'] must be a prefix mask (valid frames first, data_loaders/tensors.py:3-8): "
+                                      "the MI355X attention kernels mask by valid-frame count")
+        lengths = lengths.to(torch.int32).contiguous()
+        self._len_cache = (key, mask, lengths)
+        return lengths
 
     def text_embedding(self, y, device):
         """The [B, clip_dim] block the library projects with embed_text (model/mdm.py:209-218)."""
@@ -256,7 +269,7 @@ class MDM(nn.Module):
         key = (e0.data_ptr(), e0._version, tuple(e0.shape), str(dev), bs, x.shape[-1],
                (enc[1].data_ptr(), enc[1]._version) if isinstance(enc, tuple) else None,
                (mask.data_ptr(), mask._version) if use_mask else None)
-        if getattr(self, '_dec_cache', (None,))[0] != key:
+        if (getattr(self, '_dec_cache', None) or (None,))[0] != key:
             if isinstance(enc, tuple):
                 tok, pad = enc                               # [Ntok, B, 768], [B or 1, Ntok] True = no token
                 pad = pad.to(dev)
@@ -276,7 +289,9 @@ class MDM(nn.Module):
                 if not bool((m2 == (torch.arange(m2.shape[1], device=dev)[None, :] < m2.sum(dim=1)[:, None])).all()):
                     raise NotImplementedError("frame masks must be prefix masks (data_loaders/tensors.py:3-8)")
                 lengths = (self.context_len + m2.sum(dim=1)).to(torch.int32).contiguous()
-            self._dec_cache = (key, (tok, tl.to(torch.int32).contiguous(), lengths))
+            # the entry keeps the SOURCE tensors alive: a later batch of the same shape must not be able to land on a
+            # recycled address with _version 0 and hit this entry
+            self._dec_cache = (key, (tok, tl.to(torch.int32).contiguous(), lengths), (enc, mask))
         tok, tl, lengths = self._dec_cache[1]
         return prefix, tok, tl, lengths
 
@@ -335,4 +350,5 @@ class MDM(nn.Module):
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._engine = None   # parameters moved: rebind lazily
+        self._len_cache = self._dec_cache = None
         return r

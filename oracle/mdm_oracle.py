@@ -213,7 +213,7 @@ def ddim_step(tab, x, x0, t, noise, eta=0.0):
 
 def sample_loop(sd, tab, shape, y, x_T, step_noise, *, cfg=True, ddim=False, eta=0.0, clip_denoised=False,
                 skip_timesteps=0, init_image=None, timestep_map=None, num_heads=4, mask_frames=True,
-                dtype=torch.float32, return_all=False):
+                dtype=torch.float32, return_all=False, const_noise=False):
     """p_sample_loop / ddim_sample_loop with an injected noise sequence.
 
     x_T: the torch.randn(*shape) of gaussian_diffusion.py:691; step_noise[k]: the k-th randn_like of
@@ -240,6 +240,8 @@ def sample_loop(sd, tab, shape, y, x_T, step_noise, *, cfg=True, ddim=False, eta
         t = torch.full((B,), i, dtype=torch.long)
         x0 = predict_x0(model_fn, img, t, y, clip_denoised)
         nz = step_noise[k].to(dtype)
+        if const_noise:                                                           # gaussian_diffusion.py:527-528
+            nz = nz[[0]].repeat(B, 1, 1, 1)
         img = ddim_step(tab, img, x0, t, nz, eta) if ddim else ddpm_step(tab, img, x0, t, nz)
         if return_all:
             traj.append(img.clone())

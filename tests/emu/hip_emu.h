@@ -47,7 +47,7 @@ using std::max;
 namespace emu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short p16x8 __attribute__((ext_vector_type(8)));
 
 struct Fiber {
   ucontext_t ctx;
@@ -61,7 +61,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct WaveBuf {
   float fa[64], fb[64];
-  bf16x8 ha[64], hb[64];
+  p16x8 ha[64], hb[64];
   uint32_t ua[64], ub[64];
   i32x8 qa[64], qb[64];      // scaled-MFMA operands
   int sa[64], sb[64];        // and their scale registers
@@ -139,7 +139,7 @@ inline float bf16_to_f32(short s) {
   return f;
 }
 
-inline f32x16 mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+inline f32x16 mfma_f32_32x32x16_bf16(p16x8 a, p16x8 b, f32x16 c) {
   WaveBuf& w = blk().waves[wave_id()];
   int l = lane_id();
   w.ha[l] = a;
@@ -162,8 +162,8 @@ inline f32x16 mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 inline f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
   WaveBuf& w = blk().waves[wave_id()];
   int l = lane_id();
-  w.ha[l] = __builtin_bit_cast(bf16x8, a);
-  w.hb[l] = __builtin_bit_cast(bf16x8, b);
+  w.ha[l] = __builtin_bit_cast(p16x8, a);
+  w.hb[l] = __builtin_bit_cast(p16x8, b);
   wave_barrier();
   int j = l & 31, h = l >> 5;
   for (int r = 0; r < 16; ++r) {
@@ -217,7 +217,7 @@ inline f32x16 mfma_scale_f32_32x32x64_fp6(i32x8 a, i32x8 b, f32x16 c, int scale_
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x32_bf16: A row / B column = l&15, k = 8*(l>>4)+e; D[reg]: row 4*(l>>4)+reg, column l&15
-inline f32x4 mfma_f32_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+inline f32x4 mfma_f32_16x16x32_bf16(p16x8 a, p16x8 b, f32x4 c) {
   WaveBuf& w = blk().waves[wave_id()];
   int l = lane_id();
   w.ha[l] = a;
@@ -230,6 +230,27 @@ inline f32x4 mfma_f32_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     for (int kg = 0; kg < 4; ++kg)
       for (int e = 0; e < 8; ++e)
         acc = fmaf(bf16_to_f32(w.ha[i + 16 * kg][e]), bf16_to_f32(w.hb[j + 16 * kg][e]), acc);
+    c[r] = acc;
+  }
+  wave_barrier();
+  return c;
+}
+
+// v_mfma_f32_16x16x32_f16: the bf16 form's layout with fp16 elements
+inline f32x4 mfma_f32_16x16x32_f16(f16x8 a, f16x8 b, f32x4 c) {
+  WaveBuf& w = blk().waves[wave_id()];
+  int l = lane_id();
+  w.ha[l] = __builtin_bit_cast(p16x8, a);
+  w.hb[l] = __builtin_bit_cast(p16x8, b);
+  wave_barrier();
+  int j = l & 15, g = l >> 4;
+  for (int r = 0; r < 4; ++r) {
+    int i = 4 * g + r;
+    float acc = c[r];
+    for (int kg = 0; kg < 4; ++kg) {
+      const f16x8 fa = __builtin_bit_cast(f16x8, w.ha[i + 16 * kg]), fb = __builtin_bit_cast(f16x8, w.hb[j + 16 * kg]);
+      for (int e = 0; e < 8; ++e) acc = fmaf((float)fa[e], (float)fb[e], acc);
+    }
     c[r] = acc;
   }
   wave_barrier();

@@ -18,7 +18,7 @@ from oracle import dip_oracle as dip  # noqa: E402
 from oracle.synth import synth_dip_state_dict, synth_dip_y, synth_state_dict, synth_y  # noqa: E402
 
 
-def make_pair(sd, steps, device, guided=True, native_lib=None, precision="bf16x3", **arg_over):
+def make_pair(sd, steps, device, guided=True, native_lib=None, precision="f16x3", **arg_over):
     """(model, diffusion) exactly as sample/generate.py:85-96 assembles them."""
     dec = any(k.startswith("seqTransDecoder.layers.") for k in sd)
     layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith(("seqTransEncoder.layers.", "seqTransDecoder.layers.")))
@@ -54,7 +54,7 @@ def golden_loop_inputs(g):
                 cfg=bool(g["cfg"]), ddim=bool(g["ddim"]), eta=float(g["eta"]))
 
 
-def run_product_loop(sd, case, device, native_lib=None, dump_steps=None, precision="bf16x3"):
+def run_product_loop(sd, case, device, native_lib=None, dump_steps=None, precision="f16x3"):
     """The golden case through SpacedDiffusion.p_sample_loop / ddim_sample_loop of the product."""
     model, diffusion = make_pair(sd, case["steps"], device, guided=case["cfg"], native_lib=native_lib,
                                  precision=precision)

@@ -30,7 +30,21 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib.lib, n), f"{n} declared in include/mdm_hip.h but not exported"
     assert sorted(_native.EXPORTED_SYMBOLS) == names       # the ctypes view covers the whole header
-    assert lib.mdm_abi_version() == 3
+    assert lib.mdm_abi_version() == 4
+
+
+def test_probe_surface_is_not_in_the_production_library(lib):
+    """include/mdm_hip_probe.h (experiment switches, the f16f6 kernel) is exported by libmdm_hip_probe.so only."""
+    from mdm_amd import _native
+    src = open(os.path.join(ROOT, "include", "mdm_hip_probe.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mdm_[a-z_0-9]+)\s*\(", src)))
+    assert names == sorted(_native.PROBE_SYMBOLS)
+    probe = _native.MdmLib(_native.PROBE_LIB_PATH)
+    for n in names:
+        assert not hasattr(lib.lib, n), f"{n} leaked into the production library"
+        assert hasattr(probe.lib, n)
+    assert not lib.has_probes and probe.has_probes
 
 
 def test_no_cuda_or_torch_in_the_abi():

@@ -21,7 +21,7 @@ def lib():
     return emu()
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-4), ("f32", 2e-5)])
+@pytest.mark.parametrize("prec,tol", [("f16x3", 1e-4), ("f32", 2e-5)])
 def test_emulated_cfg_loop_matches_oracle(lib, prec, tol):
     steps, B, T = 2, 2, 9
     sd = small_state_dict(num_layers=1)
@@ -38,10 +38,10 @@ def test_emulated_cfg_loop_matches_oracle(lib, prec, tol):
 
 @pytest.mark.parametrize("prec,tol,layers,B,T,lengths", [
     ("f32", 1e-5, 1, 2, 33, [33, 5]),
-    ("bf16x3", 1e-4, 2, 2, 33, [33, 5]),        # S = 34: two key tiles, ragged tail; six sequences per 208-row GEMM tile
-    ("bf16x3", 1e-4, 2, 1, 196, [150]),         # S = 197 (headline): one sequence per 208-row tile, 16-row last sub-tile
-    ("bf16x3", 1e-4, 1, 1, 207, [207]),         # S = 208: the 16-row sub-tile completely used
-    ("bf16x3", 1e-4, 1, 1, 208, [208]),         # S = 209: does not fit 208 rows -> the 224-row (7 x 32) form
+    ("f16x3", 1e-4, 2, 2, 33, [33, 5]),        # S = 34: two key tiles, ragged tail; six sequences per 208-row GEMM tile
+    ("f16x3", 1e-4, 2, 1, 196, [150]),         # S = 197 (headline): one sequence per 208-row tile, 16-row last sub-tile
+    ("f16x3", 1e-4, 1, 1, 207, [207]),         # S = 208: the 16-row sub-tile completely used
+    ("f16x3", 1e-4, 1, 1, 208, [208]),         # S = 209: does not fit 208 rows -> the 224-row (7 x 32) form
 ])
 def test_emulated_forward_branches(lib, prec, tol, layers, B, T, lengths):
     """layers = 2 reaches the GEMM kinds only a second layer uses: in_proj with the previous LayerNorm folded in, and
@@ -71,17 +71,17 @@ def test_emulated_linear(lib, M, N, K, act, res):
 
 
 @pytest.mark.parametrize("M,N,K,act,res", [(130, 72, 64, 0, True), (5, 132, 32, 1, False), (260, 256, 96, 0, False)])
-def test_emulated_linear_bf16x3(lib, M, N, K, act, res):
-    """LDS-DMA source swizzle, fragment reads and the 3-product accumulation of gemm_bf16x3.h, incl. ragged M/N tiles."""
+def test_emulated_linear_f16x3(lib, M, N, K, act, res):
+    """LDS-DMA source swizzle, fragment reads and the 3-product accumulation of gemm_x3.h, incl. ragged M/N tiles."""
     rng = np.random.default_rng(M)
     a, w = f32(rng.standard_normal((M, K))), f32(rng.standard_normal((N, K)) / np.sqrt(K))
     b = f32(rng.standard_normal(N))
     r = f32(rng.standard_normal((M, N))) if res else None
     out = np.full((M, N), np.nan, np.float32)
-    nb = lib.mdm_linear_bf16x3_scratch_bytes(M, N, K)
+    nb = lib.mdm_linear_x3_scratch_bytes(M, N, K)
     scratch = np.zeros(nb, np.uint8)
-    lib.check(lib.mdm_linear_bf16x3(ptr(a), ptr(w), ptr(b), ptr(r) if res else None, ptr(out), M, N, K, act,
-                                    ptr(scratch), nb, None), "linear_bf16x3")
+    lib.check(lib.mdm_linear_x3(ptr(a), ptr(w), ptr(b), ptr(r) if res else None, ptr(out), M, N, K, act,
+                                    ptr(scratch), nb, None), "linear_f16x3")
     ref = torch.from_numpy(a).double() @ torch.from_numpy(w).double().t() + torch.from_numpy(b).double()
     ref = torch.nn.functional.gelu(ref) if act == 1 else ref
     if res:
@@ -154,7 +154,7 @@ def test_emulated_attention_mask(lib):
 
 
 @pytest.mark.parametrize("S,lengths", [(37, [36, 3]), (70, [69, 40]), (197, [196, 100])])
-def test_emulated_attention_bf16x3(lib, S, lengths):
+def test_emulated_attention_f16x3(lib, S, lengths):
     """Split-precision attention: plane layouts (swizzled K rows, MFMA-ordered V^T), masking, deferred normalisation."""
     nseq, B, D, H, hd = 2, 2, 256, 2, 128
     rng = np.random.default_rng(S)
@@ -162,10 +162,10 @@ def test_emulated_attention_bf16x3(lib, S, lengths):
     qkv[:, :D] /= np.sqrt(hd)
     lengths = np.array(lengths, np.int32)
     out = np.full((nseq * S, D), np.nan, np.float32)
-    nb = lib.mdm_attention_bf16x3_scratch_bytes(nseq, S, D)
+    nb = lib.mdm_attention_x3_scratch_bytes(nseq, S, D)
     scratch = np.zeros(nb, np.uint8)
-    lib.check(lib.mdm_attention_bf16x3(ptr(qkv), ptr(out), ptr(lengths), nseq, B, S, D, H, ptr(scratch), nb, None),
-              "attention_bf16x3")
+    lib.check(lib.mdm_attention_x3(ptr(qkv), ptr(out), ptr(lengths), nseq, B, S, D, H, ptr(scratch), nb, None),
+              "attention_f16x3")
     t = torch.from_numpy(qkv).double()
     q, k, v = (u.view(nseq, S, H, hd).transpose(1, 2) for u in t.split(D, -1))
     sc = q @ k.transpose(-1, -2)

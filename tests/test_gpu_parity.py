@@ -7,7 +7,7 @@ Tolerances: BASELINE.json's bar is 1e-3 max-abs on the final samples of a fixed-
 of the encoder GEMMs are tested (include/mdm_hip.h mdm_set_precision):
   * 'f32'    exact-fp32 MFMA: held to 1e-4 on full loops and 2e-5 on single forwards / building blocks (two fp32
              implementations that only differ in summation order agree to ~5e-6: tests/golden/PIN_REPORT.json);
-  * 'bf16x3' the default split-precision mode (3 bf16 MFMA products per fp32 product, ~2^-16 relative each): held to
+  * 'f16x3' the default split-precision mode (3 bf16 MFMA products per fp32 product, ~2^-16 relative each): held to
              5e-4 on full loops (half the stated bar) and 1e-4 on single forwards.
 """
 import os
@@ -22,9 +22,9 @@ from helpers import (ClassifierFreeSampleModel, dip, golden_loop_inputs, make_pa
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-PRECISIONS = ["bf16x3", "f32"]
-TOL_LOOP = {"f32": 1e-4, "bf16x3": 5e-4}      # stated bar: 1e-3
-TOL_FWD = {"f32": 2e-5, "bf16x3": 1e-4}
+PRECISIONS = ["f16x3", "f32"]
+TOL_LOOP = {"f32": 1e-4, "f16x3": 5e-4}      # stated bar: 1e-3
+TOL_FWD = {"f32": 2e-5, "f16x3": 1e-4}
 
 
 @pytest.fixture(scope="module")
@@ -105,17 +105,17 @@ def test_f16f6_arithmetic_on_the_reference_trajectory(golden_dir, sd):
     """The NEXT GEMM arithmetic (fp16 pass + one scaled MX-FP6 MFMA per 32-k block, csrc/gemm_f16f6.h on the production GEMM
     skeleton) held against the reference's 50-step guided trajectory through the product seams: `f32` mode with its encoder
     GEMMs routed, unfused, to the f16f6 kernel (mdm_debug_set(5, 1), a test-only switch).  tools/precision_probe.py predicts
-    ~1e-4 from a CPU emulation of the same decomposition; the bar of the shipped bf16x3 mode is 5e-4, BASELINE's 1e-3."""
-    lib = _lib()
+    ~1e-4 from a CPU emulation of the same decomposition; the bar of the shipped f16x3 mode is 5e-4, BASELINE's 1e-3."""
+    lib = _probe()                     # the experiment build (include/mdm_hip_probe.h); the model is bound to it explicitly
     g = _g(golden_dir, "loop50_B2_T196")
     case = golden_loop_inputs(g)
     lib.mdm_debug_set(5, 1)
     try:
-        out = run_product_loop(sd, case, DEV, precision="f32")
+        out = run_product_loop(sd, case, DEV, precision="f32", native_lib=lib)
         torch.cuda.synchronize()
     finally:
         lib.mdm_debug_set(5, 0)
-    exact = run_product_loop(sd, case, DEV, precision="f32")
+    exact = run_product_loop(sd, case, DEV, precision="f32", native_lib=lib)
     err = maxabs(out.cpu(), g["final"])
     print(f"[parity] loop50_B2_T196 f16f6 arithmetic (unfused, test-only): max-abs vs reference = {err:.3e}; "
           f"vs this library's exact-fp32 mode = {maxabs(out.cpu(), exact.cpu()):.3e}")
@@ -161,7 +161,7 @@ def test_progressive_generator_equals_fused_loop(sd):
                                                    model_kwargs={"y": dict(y)}):
         last = out
     # the fused loop applies the guidance combine to the tokens BEFORE the output projection, the progressive path
-    # after it: a re-association on top of the split-precision GEMMs (default bf16x3), hence 1e-4 and not 1e-5
+    # after it: a re-association on top of the split-precision GEMMs (default f16x3), hence 1e-4 and not 1e-5
     assert maxabs(fused.cpu(), last["sample"].cpu()) < 1e-4
     assert torch.equal(last["sample"], last["pred_xstart"])        # coef1[0]=1, coef2[0]=0, no noise
 
@@ -201,7 +201,7 @@ def test_full_size_shard_invariance_and_determinism(sd):
           "scale": y["scale"][i:i + 1]}
     want = orc.sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), (1, 263, 1, T), y1, seq[0], seq[1:],
                            cfg=True)
-    assert maxabs(a[i:i + 1].cpu(), want) < TOL_LOOP["bf16x3"]
+    assert maxabs(a[i:i + 1].cpu(), want) < TOL_LOOP["f16x3"]
 
 
 def test_philox_normal_statistics():
@@ -226,6 +226,11 @@ def test_philox_normal_statistics():
 def _lib():
     from mdm_amd import _native
     return _native.load_native()
+
+
+def _probe():
+    from mdm_amd import _native
+    return _native.load_probe()
 
 
 def _stream():
@@ -260,7 +265,7 @@ def test_mdm_linear(M, N, K, act, res):
 @pytest.mark.parametrize("M,N,K,act,res", [(197, 512, 512, 0, False), (2 * 197 * 3, 1536, 512, 0, False),
                                            (1000, 1024, 512, 1, True), (777, 512, 1024, 0, True),
                                            (5, 72, 32, 2, False), (129, 132, 96, 0, True), (50432, 512, 1024, 0, True)])
-def test_mdm_linear_bf16x3(M, N, K, act, res):
+def test_mdm_linear_x3(M, N, K, act, res):
     """The split-precision kernel against an fp64 reference: error ~2^-16 * sum|a*w| (three bf16 products per fp32
     product), i.e. fp32-class, NOT bf16-class (a plain bf16 GEMM would be ~4e-3 relative)."""
     g = torch.Generator().manual_seed(M + N + K)
@@ -279,10 +284,10 @@ def test_mdm_linear_bf16x3(M, N, K, act, res):
         ref = ref + rd.double()
     out = torch.full((M, N), float("nan"), device=DEV)
     lib = _lib()
-    nb = lib.mdm_linear_bf16x3_scratch_bytes(M, N, K)
+    nb = lib.mdm_linear_x3_scratch_bytes(M, N, K)
     scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
-    lib.check(lib.mdm_linear_bf16x3(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if res else None,
-                                    out.data_ptr(), M, N, K, act, scratch.data_ptr(), nb, _stream()), "mdm_linear_bf16x3")
+    lib.check(lib.mdm_linear_x3(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), rd.data_ptr() if res else None,
+                                    out.data_ptr(), M, N, K, act, scratch.data_ptr(), nb, _stream()), "mdm_linear_x3")
     err = float((out.double() - ref).abs().max())
     assert err < 6e-5, err
 
@@ -292,8 +297,8 @@ def test_mdm_linear_bf16x3(M, N, K, act, res):
                                                       (197 * 64, 1024, 512, 1, False, False), (197 * 64 + 5, 512, 1024, 0, True, False)])
 def test_mdm_linear_f16f6(M, N, K, act, res, ref_kernel):
     """Seed of the next GEMM (csrc/gemm_f16f6.h) on the real instructions: one v_mfma_f32_32x32x16_f16 pass + two
-    v_mfma_scale_f32_32x32x64_f8f6f4 (MX-FP6) cross terms against fp64; the error budget is ~3x bf16x3's (1.2e-5 of rms)."""
-    lib = _lib()
+    v_mfma_scale_f32_32x32x64_f8f6f4 (MX-FP6) cross terms against fp64; the error budget is ~3x the bf16 split's (1.2e-5 of rms)."""
+    lib = _probe()
     g = torch.Generator().manual_seed(M + N)
     a = torch.randn(M, K, generator=g)
     a[::5, ::9] *= 10.0
@@ -354,12 +359,12 @@ def test_mdm_attention(nseq, B, S, lengths):
     lib.check(lib.mdm_attention(qd.data_ptr(), out.data_ptr(), ld.data_ptr() if ld is not None else None, nseq, B, S,
                                 D, H, _stream()), "mdm_attention")
     assert maxabs(out.cpu(), ref) < 1e-5
-    # the split-precision kernel of the bf16x3 mode, same contract (planes packed into scratch)
-    nb = lib.mdm_attention_bf16x3_scratch_bytes(nseq, S, D)
+    # the split-precision kernel of the f16x3 mode, same contract (planes packed into scratch)
+    nb = lib.mdm_attention_x3_scratch_bytes(nseq, S, D)
     scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
     out3 = torch.full((nseq * S, D), float("nan"), device=DEV)
-    lib.check(lib.mdm_attention_bf16x3(qd.data_ptr(), out3.data_ptr(), ld.data_ptr() if ld is not None else None,
-                                       nseq, B, S, D, H, scratch.data_ptr(), nb, _stream()), "mdm_attention_bf16x3")
+    lib.check(lib.mdm_attention_x3(qd.data_ptr(), out3.data_ptr(), ld.data_ptr() if ld is not None else None,
+                                       nseq, B, S, D, H, scratch.data_ptr(), nb, _stream()), "mdm_attention_x3")
     assert maxabs(out3.cpu(), ref) < 5e-5
 
 
@@ -541,4 +546,4 @@ def test_eval_caller_call_sequence(sd):
               "scale": torch.ones(1) * scale}
         want = orc.sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), (1, 263, 1, T), yb, x_T[b:b + 1],
                                [n[b:b + 1] for n in noises], cfg=True)
-        assert maxabs(outs[0][b:b + 1].cpu(), want) < TOL_LOOP["bf16x3"]
+        assert maxabs(outs[0][b:b + 1].cpu(), want) < TOL_LOOP["f16x3"]

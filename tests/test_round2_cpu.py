@@ -1,0 +1,131 @@
+"""Round-2 CPU tests: the oracle against the round-2 fixtures the REFERENCE produced (oracle/make_golden_r2.py), the
+self-launching bench, and -- in the build container only, where /root/reference exists -- INTEGRATION.md's drop-in
+launcher executed against the reference's own factory / loader / collate, incl. the hand-over to the reference's sampler."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, maxabs, orc
+from oracle.synth import synth_state_dict, synth_state_dict_hostile, synth_y, synth_y_hostile
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _g(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def test_oracle_on_hostile_weights_is_within_the_reference_arithmetics_own_noise():
+    """'Trained-like' weights (outlier channels, gamma in [0.05, 8], 10x rows, 20x text embedding) amplify rounding noise:
+    the fixture records `floor` = |reference fp32 - fp64 oracle|.  Two fp32 implementations can only agree to a few floors."""
+    sd = synth_state_dict_hostile(0)
+    g = _g("hostile_fwd_B2_T196")
+    B, T = 2, 196
+    y = synth_y_hostile(B, T, seed=int(g["y_seed"]), lengths=list(g["lengths"]))
+    x = torch.randn(B, 263, 1, T, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    t = torch.from_numpy(g["t"])
+    assert float(np.abs(g["out_cfg"]).max()) > 10.0                  # the outlier rows reach the output
+    assert maxabs(orc.cfg_forward(sd, x, t, y), g["out_cfg"]) < max(1e-4, 4 * float(g["floor_cfg"]))
+    assert maxabs(orc.cfg_forward(sd, x, t, y, dtype=torch.float64), g["out_cfg"]) < 1.5 * float(g["floor_cfg"]) + 1e-6
+    g = _g("hostile_loop50_B2_T196")
+    steps, seed = int(g["steps"]), int(g["seed"])
+    shape = (B, 263, 1, T)
+    y = synth_y_hostile(B, T, seed=seed + 1000, lengths=list(g["lengths"]))
+    x_T, noises = orc.make_noise(shape, steps, seed)
+    got = orc.sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), shape, y, x_T, noises, cfg=True)
+    assert maxabs(got, g["final"]) < max(5e-4, 4 * float(g["floor"]))
+
+
+@pytest.mark.parametrize("name", ["respaced_ddim50of1000_B2_T64", "respaced_p50of1000_B2_T64"])
+def test_oracle_respaced_process_matches_reference(name):
+    """Non-identity timestep map (respace.py:74-88, :125-130): 50 of 1000 steps."""
+    g = _g(name)
+    sd = synth_state_dict(0)
+    B, T, seed = int(g["B"]), int(g["T"]), int(g["seed"])
+    tmap = [int(v) for v in g["timestep_map"]]
+    assert tmap != list(range(len(tmap))) and len(tmap) == 50
+    nb, tm2 = orc.respace_betas(orc.named_betas("cosine", int(g["base_steps"])), tmap)
+    assert tm2 == tmap
+    shape = (B, 263, 1, T)
+    y = synth_y(B, T, seed=seed + 1000, lengths=list(g["lengths"]))
+    x_T, noises = orc.make_noise(shape, len(tmap), seed)
+    got = orc.sample_loop(sd, orc.Tables(nb), shape, y, x_T, noises, cfg=True, ddim=bool(g["ddim"]), timestep_map=tmap)
+    assert maxabs(got, g["final"]) < 2e-5
+
+
+def test_oracle_progressive_and_const_noise_match_reference():
+    sd = synth_state_dict(0)
+    g = _g("progressive8_B2_T24")
+    steps, B, T, seed = int(g["steps"]), int(g["B"]), int(g["T"]), int(g["seed"])
+    shape = (B, 263, 1, T)
+    y = synth_y(B, T, seed=seed + 1000, lengths=list(g["lengths"]))
+    x_T, noises = orc.make_noise(shape, steps, seed)
+    _, traj = orc.sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), shape, y, x_T, noises, cfg=True, return_all=True)
+    for k in range(steps):
+        assert maxabs(traj[k], g["samples"][k]) < 2e-5
+    assert np.array_equal(g["samples"][-1], g["pred_xstart"][-1])      # coef1[0] = 1, coef2[0] = 0, no noise
+    g = _g("const_noise50_B3_T32")
+    steps, B, T, seed = int(g["steps"]), int(g["B"]), int(g["T"]), int(g["seed"])
+    shape = (B, 263, 1, T)
+    y = synth_y(B, T, seed=seed + 1000, lengths=list(g["lengths"]))
+    x_T, noises = orc.make_noise(shape, steps, seed)
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    assert maxabs(orc.sample_loop(sd, tab, shape, y, x_T, noises, cfg=True, const_noise=True), g["final"]) < 2e-5
+    assert maxabs(orc.sample_loop(sd, tab, shape, y, x_T, noises, cfg=True), g["final"]) > 1e-2      # the flag matters
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    return env
+
+
+def test_bench_self_launches_two_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no torchrun environment must re-launch itself as two ranks, shard the global batch,
+    gather it and print ONE JSON line from rank 0 (the driver's SCALE runs).  CPU stand-ins: gloo instead
+    of RCCL, the kernels in the emulator, a tiny model -- the launcher / sharding / gather / JSON code is the product's."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    from emu_lib import emu
+    emu()                                              # build the emulator once, before the ranks race for it
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--emulate", "--layers", "1", "--latent-dim", "256",
+           "--batch", "2", "--frames", "6", "--diffusion-steps", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=_clean_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
+    assert d["ranks"]["world_size"] == 2 and d["ranks"]["backend"].startswith("gloo")
+    assert d["ranks"]["launcher"] == "torch.distributed.run"
+    assert d["value"] > 0 and d["steps"] == 1 and d["warmup"] == 0 and "roofline" in d
+    # an inconsistent launch is an error, not a silent single-rank run
+    env = _clean_env()
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--emulate"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/utils/model_util.py"), reason="needs the reference tree (build container)")
+def test_integration_md_drop_in_launcher_and_reference_handover():
+    """tests/dropin_replay.py: the rebinding of INTEGRATION.md section 1 through the REFERENCE's create_model_and_diffusion /
+    load_model_wo_clip / collate, generate.py:93-158's call sequence, and the hand-over of cond_fn / PLMS / foreign models
+    to the reference's own sampler."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    from emu_lib import SO, emu
+    emu()
+    env = _clean_env()
+    env["MDM_HIP_LIB"] = SO                              # CPU emulation of the library (the container has no GPU)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_replay.py")], env=env, capture_output=True,
+                       text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("DROPIN ")][0][len("DROPIN "):])
+    assert res["generate_call_sequence_vs_oracle"] < 1e-4
+    assert res["cond_fn_handover_vs_oracle"] < 1e-4
+    assert res["foreign_model_handover_vs_oracle"] < 2e-5 and res["plms_runs"]

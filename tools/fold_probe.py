@@ -1,6 +1,6 @@
 """CPU probe (no GPU): the PRODUCTION arithmetic of the split-precision encoder, restated in torch, on the oracle's guided loop.
 
-tools/precision_probe.py only swaps the GEMM operand decomposition.  This probe restates what csrc/gemm_bf16x3.h + attention_bf16x3.h
+tools/precision_probe.py only swaps the GEMM operand decomposition.  This probe restates what csrc/gemm_x3.h + attention_x3.h
 actually compute in the default mode:
   * the residual stream lives as hi + lo 16-bit planes of the PRE-norm sums (so every stored activation is rounded to hi + lo);
   * LayerNorm is folded into its consumers: W.LN(x) + b = rstd * (W'.x - mean * colsum(W')) + (b + W.beta), W' = W * gamma, with
@@ -30,6 +30,8 @@ def split(x, dt):
 
 
 def planes(x, dt):
+    if dt is None:
+        return x
     hi, lo = split(x, dt)
     return hi + lo
 
@@ -59,10 +61,24 @@ def row_stats(x, mode, tile=256):
 
 
 class X3Model:
-    def __init__(self, sd, dt, stats, heads=4):
+    def __init__(self, sd, dt, stats, heads=4, ablate=""):
         self.sd, self.dt, self.stats, self.H = sd, dt, stats, heads
+        # what-if switches (component attribution): "p" stored activations keep fp32 (no plane rounding), "a" exact fp32
+        # attention, "f" LayerNorm applied to the operand instead of folded into the weights
+        self.ab = ablate
         self.L = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("seqTransEncoder.layers."))
         self.pe = orc.positional_table(5000, sd["input_process.poseEmbedding.weight"].shape[0])
+
+    def pl(self, x):
+        return x if "p" in self.ab else planes(x, self.dt)
+
+    def lin_ln(self, x, w, b, g, be):
+        """W.LN(x) + b"""
+        mean, rstd = row_stats(x, self.stats)
+        if "f" in self.ab:
+            return mm3((x - mean) * rstd * g + be, w, self.dt) + b, mean, rstd
+        wf, cs, bf = self.fold(w, b, g, be)
+        return rstd * (mm3(x, wf, self.dt) - mean * cs) + bf, mean, rstd
 
     def fold(self, w, b, g, be):
         wf = w * g[None, :]
@@ -73,6 +89,12 @@ class X3Model:
         d = d3 // 3
         hd = d // self.H
         q, k, v = qkv.split(d, dim=-1)
+        if "a" in self.ab:
+            q, k, v = (t.view(N, S, self.H, hd).transpose(1, 2) for t in (q, k, v))
+            sc = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(hd))
+            if key_pad is not None:
+                sc = sc.masked_fill(key_pad[:, None, None, :], float("-inf"))
+            return self.pl((torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(N, S, d))
         q = planes(q * (1.0 / math.sqrt(hd)), self.dt).view(N, S, self.H, hd).transpose(1, 2)
         k = planes(k, self.dt).view(N, S, self.H, hd).transpose(1, 2)
         v = planes(v, self.dt).view(N, S, self.H, hd).transpose(1, 2)
@@ -86,11 +108,11 @@ class X3Model:
         ph, pl = split(p, self.dt)
         vh, vl = split(v, self.dt)
         o = (ph @ vh + (ph @ vl + pl @ vh)) * inv
-        return planes(o.transpose(1, 2).reshape(N, S, d), self.dt)
+        return self.pl(o.transpose(1, 2).reshape(N, S, d))
 
     def encoder(self, seq, key_pad):
         sd, dt = self.sd, self.dt
-        xb = planes(seq, dt)                       # layer 0 input: the embedding, as planes
+        xb = self.pl(seq)                          # layer 0 input: the embedding, as planes
         for l in range(self.L):
             p = f"seqTransEncoder.layers.{l}."
             wq, bq = sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"]
@@ -99,19 +121,15 @@ class X3Model:
                 res = xb
             else:
                 g, be = sd[f"seqTransEncoder.layers.{l - 1}.norm2.weight"], sd[f"seqTransEncoder.layers.{l - 1}.norm2.bias"]
-                wf, cs, bf = self.fold(wq, bq, g, be)
-                mean, rstd = row_stats(xb, self.stats)
-                qkv = rstd * (mm3(xb, wf, dt) - mean * cs) + bf
+                qkv, mean, rstd = self.lin_ln(xb, wq, bq, g, be)
                 res = (xb - mean) * rstd * g + be
             att = self.attention(qkv, key_pad)
-            xa = planes(mm3(att, sd[p + "self_attn.out_proj.weight"], dt) + sd[p + "self_attn.out_proj.bias"] + res, dt)
+            xa = self.pl(mm3(att, sd[p + "self_attn.out_proj.weight"], dt) + sd[p + "self_attn.out_proj.bias"] + res)
             g1, be1 = sd[p + "norm1.weight"], sd[p + "norm1.bias"]
-            wf, cs, bf = self.fold(sd[p + "linear1.weight"], sd[p + "linear1.bias"], g1, be1)
-            mean, rstd = row_stats(xa, self.stats)
-            h = rstd * (mm3(xa, wf, dt) - mean * cs) + bf
-            h = planes(0.5 * h * (1.0 + torch.erf(h * (1.0 / math.sqrt(2.0)))), dt)
+            h, mean, rstd = self.lin_ln(xa, sd[p + "linear1.weight"], sd[p + "linear1.bias"], g1, be1)
+            h = self.pl(0.5 * h * (1.0 + torch.erf(h * (1.0 / math.sqrt(2.0)))))
             res = (xa - mean) * rstd * g1 + be1
-            xb = planes(mm3(h, sd[p + "linear2.weight"], dt) + sd[p + "linear2.bias"] + res, dt)
+            xb = self.pl(mm3(h, sd[p + "linear2.weight"], dt) + sd[p + "linear2.bias"] + res)
         return xb
 
     def forward_both(self, x, t, y):
@@ -123,15 +141,13 @@ class X3Model:
         c = F.linear(enc, sd["embed_text.weight"], sd["embed_text.bias"]) + temb
         u = sd["embed_text.bias"][None] + temb
         h = x.permute(0, 3, 1, 2).reshape(B, T, J * Fe)
-        h = mm3(planes(h, dt), sd["input_process.poseEmbedding.weight"], dt) + sd["input_process.poseEmbedding.bias"]
+        h = mm3(self.pl(h), sd["input_process.poseEmbedding.weight"], dt) + sd["input_process.poseEmbedding.bias"]
         fm = ~y["mask"][..., :T].reshape(B, T)
         key_pad = torch.cat([torch.zeros(B, 1, dtype=torch.bool), fm], dim=1)
         seq = torch.cat([torch.cat([c[:, None], h], 1), torch.cat([u[:, None], h], 1)], 0) + self.pe[: T + 1][None]
         xb = self.encoder(seq, torch.cat([key_pad, key_pad], 0))
         g, be = sd[f"seqTransEncoder.layers.{self.L - 1}.norm2.weight"], sd[f"seqTransEncoder.layers.{self.L - 1}.norm2.bias"]
-        wf, cs, bf = self.fold(sd["output_process.poseFinal.weight"], sd["output_process.poseFinal.bias"], g, be)
-        mean, rstd = row_stats(xb, self.stats)
-        out = rstd * (mm3(xb, wf, dt) - mean * cs) + bf
+        out, _, _ = self.lin_ln(xb, sd["output_process.poseFinal.weight"], sd["output_process.poseFinal.bias"], g, be)
         out = out[:, 1:].reshape(2 * B, T, J, Fe).permute(0, 2, 3, 1)
         oc, ou = out[:B], out[B:]
         return ou + y["scale"].view(-1, 1, 1, 1) * (oc - ou)
@@ -163,6 +179,13 @@ def main():
         r64 = orc.sample_loop(sd, tab, shape, y, x_T, noises, cfg=True, dtype=torch.float64)
         print(f"{'hostile' if hostile else 'standard'} weights: |x0| max {ref.abs().max().item():.3f}; fp32 oracle vs fp64 oracle "
               f"{(ref.double() - r64).abs().max().item():.3e}", flush=True)
+        abl = [a[len("--ablate="):] for a in sys.argv if a.startswith("--ablate=")]
+        if abl:     # component attribution on the fp16 split with merged (chan) statistics
+            for ab in abl[0].split(","):
+                got = loop(X3Model(sd, torch.float16, "chan", ablate=ab), tab, shape, y, x_T, noises)
+                print(f"f16x3 chan ablate={ab!r:6s} vs fp32 oracle {(got - ref).abs().max().item():.3e}   vs fp64 "
+                      f"{(got.double() - r64).abs().max().item():.3e}", flush=True)
+            return
         for dt, name in ((torch.bfloat16, "bf16x3"), (torch.float16, "f16x3")):
             for stats in ("naive", "chan"):
                 got = loop(X3Model(sd, dt, stats), tab, shape, y, x_T, noises)

@@ -9,7 +9,7 @@ import torch
 import mdm_amd  # noqa: F401
 from mdm_amd import _native
 
-lib = _native.load_native()
+lib = _native.load_probe()     # the -DMDM_PROBES build (include/mdm_hip_probe.h)
 dev = "cuda:0"
 NSEQ, S = 256, 197
 M = NSEQ * S
@@ -19,11 +19,11 @@ for name, n, k in (("in_proj", 1536, 512), ("out_proj", 512, 512), ("linear1", 1
     w = torch.randn(n, k, device=dev) / k ** 0.5
     b = torch.randn(n, device=dev)
     out = torch.empty(M, n, device=dev)
-    nb = lib.mdm_linear_bf16x3_scratch_bytes(M, n, k)
+    nb = lib.mdm_linear_x3_scratch_bytes(M, n, k)
     scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
 
     def run():
-        lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), M, n, k, 0,
+        lib.check(lib.mdm_linear_x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), M, n, k, 0,
                                         scratch.data_ptr(), nb, stream), "x3")
     lib.mdm_debug_set(2, 8)
     run()

@@ -1,12 +1,12 @@
 """Kernel probes at the headline shapes (256 sequences x 197 tokens), through the C ABI, timed with events on the launch
 stream.  Usage: python tools/gemm_probe.py [reps] [ablate,ablate,...]
-  * the four encoder GEMM shapes on the bf16x3 kernel, per ablation code (mdm_debug_set(0, code): 0 production,
+  * the four encoder GEMM shapes on the f16x3 kernel, per ablation code (mdm_debug_set(0, code): 0 production,
     1 no epilogue stores, 2 no loads after the prologue, 4 no MFMAs, 8 LDS-DMA issued as a burst; codes other than 0
     only exist for the plain fp32-out variant, so every shape is run as (act none, no residual) under ablation);
   * attention: exact-fp32 kernel vs the split-precision kernel (the latter timed without its test-only pack kernel
     by timing pack alone and subtracting is NOT done -- the x3 number includes qkv_pack; see the model-level
     kernel_ms in bench.py for the in-situ figure).
-The GEMM timings are kernel-only: after one normal call, mdm_debug_set(1, 1) makes mdm_linear_bf16x3 reuse the operand
+The GEMM timings are kernel-only: after one normal call, mdm_debug_set(1, 1) makes mdm_linear_x3 reuse the operand
 planes already in its scratch."""
 import os
 import sys
@@ -16,7 +16,7 @@ import torch
 import mdm_amd  # noqa: F401
 from mdm_amd import _native
 
-lib = _native.load_native()
+lib = _native.load_probe()     # the -DMDM_PROBES build (include/mdm_hip_probe.h)
 dev = "cuda:0"
 NSEQ, S, D, H = 256, 197, 512, 4
 M = NSEQ * S
@@ -48,9 +48,9 @@ for name, m, n, k, act, res in shapes:
     b = torch.randn(n, device=dev)
     r = torch.randn(m, n, device=dev) if res else None
     out = torch.empty(m, n, device=dev)
-    nb = lib.mdm_linear_bf16x3_scratch_bytes(m, n, k)
+    nb = lib.mdm_linear_x3_scratch_bytes(m, n, k)
     scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-    lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), m, n, k, 0,
+    lib.check(lib.mdm_linear_x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), m, n, k, 0,
                                     scratch.data_ptr(), nb, stream), "x3")   # fills the planes
     lib.mdm_debug_set(1, 1)
     # variants: every ablation code on the plain epilogue (act none, no residual) + the production epilogue of this shape
@@ -65,7 +65,7 @@ for name, m, n, k, act, res in shapes:
             lib.mdm_debug_set(2, int(tag[1]))
 
             def run():
-                lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(),
+                lib.check(lib.mdm_linear_x3(a.data_ptr(), w.data_ptr(), b.data_ptr(),
                                                 r.data_ptr() if use_res else None, out.data_ptr(), m, n, k, use_act,
                                                 scratch.data_ptr(), nb, stream), "x3")
             times[v].append(timeit(run, reps))
@@ -92,7 +92,7 @@ for name, m, n, k, act, res in shapes:
             t6[v].append(timeit(lambda: run6(v[1], v[2]), reps))
         lib.mdm_debug_set(2, 8)
         lib.mdm_debug_set(0, 0)
-        tb.append(timeit(lambda: lib.check(lib.mdm_linear_bf16x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), m, n, k, 0,
+        tb.append(timeit(lambda: lib.check(lib.mdm_linear_x3(a.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), m, n, k, 0,
                                                                    scratch.data_ptr(), nb, stream), "x3"), reps))
     lib.mdm_debug_set(1, 0)
     lib.mdm_debug_set(2, 4)
@@ -101,7 +101,7 @@ for name, m, n, k, act, res in shapes:
         ts = sorted(t6[v])
         med = ts[len(ts) // 2]
         print(f"{name:9s} N={n} K={k} {v[0]:6s} act={v[1]} res={int(v[2])}: median {med:7.1f} us  min {ts[0]:7.1f} us "
-              f"{2 * m * n * k / med / 1e6:6.1f} TF alg   (bf16x3 plain, interleaved: {tb:7.1f} us -> {tb / med:4.2f}x)", flush=True)
+              f"{2 * m * n * k / med / 1e6:6.1f} TF alg   (f16x3 plain, interleaved: {tb:7.1f} us -> {tb / med:4.2f}x)", flush=True)
     for v in variants:
         ts = sorted(times[v])
         med, mn = ts[len(ts) // 2], ts[0]
@@ -114,10 +114,10 @@ qkv[:, :D] *= 128 ** -0.5
 out = torch.empty(M, D, device=dev)
 us32 = timeit(lambda: lib.check(lib.mdm_attention(qkv.data_ptr(), out.data_ptr(), None, NSEQ, NSEQ, S, D, H, stream),
                                 "att"), reps)
-nb = lib.mdm_attention_bf16x3_scratch_bytes(NSEQ, S, D)
+nb = lib.mdm_attention_x3_scratch_bytes(NSEQ, S, D)
 scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-us3 = timeit(lambda: lib.check(lib.mdm_attention_bf16x3(qkv.data_ptr(), out.data_ptr(), None, NSEQ, NSEQ, S, D, H,
+us3 = timeit(lambda: lib.check(lib.mdm_attention_x3(qkv.data_ptr(), out.data_ptr(), None, NSEQ, NSEQ, S, D, H,
                                                          scratch.data_ptr(), nb, stream), "att3"), reps)
 fl = 4.0 * NSEQ * H * S * S * 128
 print(f"attention f32   : {us32:8.1f} us  {fl / us32 / 1e6:6.1f} TF alg")
-print(f"attention bf16x3: {us3:8.1f} us  (includes the test-only qkv_pack kernel)")
+print(f"attention f16x3: {us3:8.1f} us  (includes the test-only qkv_pack kernel)")

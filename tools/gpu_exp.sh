@@ -3,7 +3,7 @@
 # Usage: bash tools/gpu_exp.sh <tag> [pytest -k expression]
 set -u
 TAG=${1:-exp}
-KEXPR=${2:-"attention or linear_bf16x3 or forward_matches or loop_matches"}
+KEXPR=${2:-"attention or linear_f16x3 or forward_matches or loop_matches"}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel trace + one PMC pass (MFMA busy) of tools/gemm_probe.py: the f16f6 k-loop next to the bf16x3 kernel at the
+# rocprofv3 kernel trace + one PMC pass (MFMA busy) of tools/gemm_probe.py: the f16f6 k-loop next to the f16x3 kernel at the
 # encoder's GEMM shapes.  Usage: bash tools/gpu_prof_f6.sh <tag>
 set -u
 TAG=${1:-f6prof}
@@ -15,4 +15,4 @@ find $OUT/prof -name '*.csv' -size +2M -delete
 DB=$(find $OUT/pmc1 -name '*.db' | head -1)
 if [ -n "$DB" ]; then python tools/rocpd_pmc.py $DB > $OUT/pmc1.txt 2>&1; rm -f $DB; fi
 find $OUT/pmc1 -name '*.csv' -size +1M -delete
-grep -A4 "gemm_bf16x3_kernel" $OUT/pmc1.txt | cut -c1-200 | head -80
+grep -A4 "gemm_x3_kernel" $OUT/pmc1.txt | cut -c1-200 | head -80

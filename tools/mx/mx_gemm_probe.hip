@@ -1,7 +1,7 @@
 // GEMM-level check of the split "fp16 + 2 x MX-FP6" product on the hardware (see tools/mx/mx_probe.hip and DESIGN.md section 8):
 // device pack kernel (fp32 -> fp16 hi plane, FP6/E2M3 codes + E8M0 block scales of hi and lo) and a deliberately simple GEMM
 // (one wave per 32x32 output tile, fragments loaded straight from global memory) using the real instructions, compared with
-// fp64 and with host emulations of this scheme and of the production bf16x3 scheme.  Test infrastructure, not product code;
+// fp64 and with host emulations of this scheme and of the production f16x3 scheme.  Test infrastructure, not product code;
 // what it pins down for the production kernel: the quantiser, the plane layouts that feed the fragments, the error per GEMM.
 //   hipcc --offload-arch=gfx950 -O3 tools/mx/mx_gemm_probe.hip -o build/mx_gemm_probe
 #include <hip/hip_runtime.h>
@@ -178,7 +178,7 @@ static void run_case(const char* name, int M, int N, int K, float outlier, unsig
   CK(hipDeviceSynchronize());
   std::vector<float> c((size_t)M * N);
   CK(hipMemcpy(c.data(), dc, c.size() * 4, hipMemcpyDeviceToHost));
-  // host: exact fp64, emulated f16+f6x2, emulated bf16x3 -- on a sample of rows (all columns)
+  // host: exact fp64, emulated f16+f6x2, emulated f16x3 -- on a sample of rows (all columns)
   std::vector<HostQ> wq(N);
   for (int n = 0; n < N; ++n) host_quant(&w[(size_t)n * K], K, wq[n]);
   double se_dev = 0, se_emu = 0, se_b3 = 0, s2 = 0, mx_dev = 0, mx_emu = 0, mx_b3 = 0, mx_de = 0;
@@ -207,7 +207,7 @@ static void run_case(const char* name, int M, int N, int K, float outlier, unsig
   printf("    f16+f6x2 on the GPU   : rms err %.3e (%.2e of rms)  max-abs %.3e   | device vs host emulation max %.3e\n",
          std::sqrt(se_dev / cnt), std::sqrt(se_dev / cnt) / rms, mx_dev, mx_de);
   printf("    f16+f6x2 host emulation: rms err %.3e (%.2e of rms)  max-abs %.3e\n", std::sqrt(se_emu / cnt), std::sqrt(se_emu / cnt) / rms, mx_emu);
-  printf("    bf16x3   host emulation: rms err %.3e (%.2e of rms)  max-abs %.3e\n", std::sqrt(se_b3 / cnt), std::sqrt(se_b3 / cnt) / rms, mx_b3);
+  printf("    f16x3   host emulation: rms err %.3e (%.2e of rms)  max-abs %.3e\n", std::sqrt(se_b3 / cnt), std::sqrt(se_b3 / cnt) / rms, mx_b3);
   CK(hipFree(da)); CK(hipFree(dw)); CK(hipFree(dc));
 }
 

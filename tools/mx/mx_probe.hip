@@ -1,11 +1,11 @@
 // Probe for the NEXT GEMM scheme: an fp32 product carried by ONE fp16 MFMA pass plus two cross terms on
 // block-scaled MX-FP6 (E2M3) operands, v_mfma_scale_f32_32x32x64_f8f6f4, which gfx950 runs at four times the fp16 rate:
 //     a*w ~ ah*wh + q6(ah)*q6(wl) + q6(al)*q6(wh)       ah = fp16(a), al = a - ah (same for w); q6 = MX-FP6 with one 2^e per 32 k
-// i.e. 1.5 pass-equivalents instead of the three bf16 passes of gemm_bf16x3.h (tools/precision_probe.py: 9.8e-5 max-abs on
-// the 50-step guided trajectory; bf16x3 4.4e-5; bar 1e-3).  Stand-alone (hipcc tools/mx/mx_probe.hip -o build/mx_probe):
+// i.e. 1.5 pass-equivalents instead of the three bf16 passes of gemm_x3.h (tools/precision_probe.py: 9.8e-5 max-abs on
+// the 50-step guided trajectory; f16x3 4.4e-5; bar 1e-3).  Stand-alone (hipcc tools/mx/mx_probe.hip -o build/mx_probe):
 //   part A  operand / scale semantics of the scaled MFMA against a host reference (per-lane random FP6 codes + E8M0 scales)
 //   part B  matrix-pipe throughput of the instruction mixes, K = 64 per group and accumulator:
-//             bf16x3      12 x v_mfma_f32_32x32x16_bf16            (today)
+//             f16x3      12 x v_mfma_f32_32x32x16_bf16            (today)
 //             f16+f6x2     4 x v_mfma_f32_32x32x16_f16 + 2 x scaled 32x32x64 FP6
 //             f16+f8x2     4 x f16 + 2 x scaled 32x32x64 FP8
 //             f6 only      2 x scaled FP6 (raw rate of the new instruction)
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void mix_kernel(float* out, int iters, cons
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int t = 0; t < NACC; ++t) {
-      if constexpr (MODE == 0) {          // bf16x3: K = 64 -> 4 k sub-steps x 3 products
+      if constexpr (MODE == 0) {          // f16x3: K = 64 -> 4 k sub-steps x 3 products
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[k], wbh, acc[t], 0, 0, 0);
@@ -250,7 +250,7 @@ int main() {
   rc |= part_a2();
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
-  const int blocks = prop.multiProcessorCount * 2;   // two 4-wave blocks per CU = two waves per SIMD, like gemm_bf16x3
+  const int blocks = prop.multiProcessorCount * 2;   // two 4-wave blocks per CU = two waves per SIMD, like gemm_f16x3
   float* out; int* seeds;
   CK(hipMalloc(&out, (size_t)blocks * 256 * 4));
   std::vector<int> hs(1024);
@@ -261,11 +261,11 @@ int main() {
   const int iters = 20000;
   printf("%s, %d CUs, %d blocks x 4 waves, %d iterations x 4 accumulators\n", prop.name, prop.multiProcessorCount, blocks, iters);
   for (int round = 0; round < 2; ++round) {
-    const double t0 = run_mix<0>("bf16x3", out, seeds, blocks, iters);
+    const double t0 = run_mix<0>("f16x3", out, seeds, blocks, iters);
     const double t1 = run_mix<1>("f16+f6x2", out, seeds, blocks, iters);
     const double t2 = run_mix<2>("f16+f8x2", out, seeds, blocks, iters);
     run_mix<3>("f6 only", out, seeds, blocks, iters);
-    printf("        speed-up over bf16x3 at the matrix pipe: f16+f6x2 %.2fx, f16+f8x2 %.2fx\n", t0 / t1, t0 / t2);
+    printf("        speed-up over f16x3 at the matrix pipe: f16+f6x2 %.2fx, f16+f8x2 %.2fx\n", t0 / t1, t0 / t2);
   }
   return rc;
 }

@@ -12,15 +12,15 @@ def key(name):
     name = name.strip()
     # template tails: <WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16> (names arrive truncated on
     # the left); the patterns below match with or without the trailing EMBED / T16 arguments
-    for pat, k in [(r"0, 0, false, false, true, 0, true, false(, false)?(, true|, false)?>", "gemm_bf16x3<in_proj (LayerNorm folded) -> Q/K/V^T planes>"),
-                   (r"0, 0, false, false, true, 0, false, false(, false)?(, true|, false)?>", "gemm_bf16x3<in_proj layer 0 -> Q/K/V^T planes>"),
-                   (r"0, 3, false, true, false, 0, false, true(, false)?(, true|, false)?>", "gemm_bf16x3<out_proj | linear2, LayerNorm residual, planes + row stats>"),
-                   (r"0, 2, false, true, false, 0, false, true(, false)?(, true|, false)?>", "gemm_bf16x3<out_proj layer 0, planes + row stats>"),
-                   (r"1, 0, false, true, false, 0, true, false(, false)?(, true|, false)?>", "gemm_bf16x3<linear1 (LayerNorm folded) + GELU -> planes>"),
-                   (r"0, 0, true, false, false, 0, true, false(, false)?(, true|, false)?>", "gemm_bf16x3<OutputProcess (LayerNorm folded)>"),
-                   (r"0, 1, false, true, false, 0, false, false, true(, true|, false)?>", "gemm_bf16x3<InputProcess (EMBED)>"),
+    for pat, k in [(r"0, 0, false, false, true, 0, true, false(, false)?(, true|, false)?>", "gemm_f16x3<in_proj (LayerNorm folded) -> Q/K/V^T planes>"),
+                   (r"0, 0, false, false, true, 0, false, false(, false)?(, true|, false)?>", "gemm_f16x3<in_proj layer 0 -> Q/K/V^T planes>"),
+                   (r"0, 3, false, true, false, 0, false, true(, false)?(, true|, false)?>", "gemm_f16x3<out_proj | linear2, LayerNorm residual, planes + row stats>"),
+                   (r"0, 2, false, true, false, 0, false, true(, false)?(, true|, false)?>", "gemm_f16x3<out_proj layer 0, planes + row stats>"),
+                   (r"1, 0, false, true, false, 0, true, false(, false)?(, true|, false)?>", "gemm_f16x3<linear1 (LayerNorm folded) + GELU -> planes>"),
+                   (r"0, 0, true, false, false, 0, true, false(, false)?(, true|, false)?>", "gemm_f16x3<OutputProcess (LayerNorm folded)>"),
+                   (r"0, 1, false, true, false, 0, false, false, true(, true|, false)?>", "gemm_f16x3<InputProcess (EMBED)>"),
                    (r"pose_to_planes_kernel", "pose_to_planes"),
-                   (r"attention_bf16x3_kernel", "attention_bf16x3"), (r"layernorm_kernel", "layernorm"),
+                   (r"attention_x3_kernel", "attention_f16x3"), (r"layernorm_kernel", "layernorm"),
                    (r"outproj_finish_kernel", "outproj_finish"), (r"EmbedEpilogue", "gemm_f32<InputProcess>")]:
         if re.search(pat, name):
             return k

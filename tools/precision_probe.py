@@ -1,11 +1,11 @@
 """CPU probe (no GPU): trajectory error of candidate GEMM operand decompositions on the oracle's 50-step guided loop.
 
-The production `bf16x3` GEMM carries an fp32 product by three bf16 MFMA passes (ah*wh + ah*wl + al*wh).  This probe
+The production `f16x3` GEMM carries an fp32 product by three fp16 MFMA passes (ah*wh + ah*wl + al*wh; round 1: bf16).  This probe
 patches torch.nn.functional.linear inside the oracle (test infrastructure) with emulations of cheaper schemes and reports
 the max-abs trajectory error against the fp32 oracle on the same weights / noise -- the figure BASELINE's 1e-3 bar is on:
 
-  bf16x3     the production scheme (reference point)
-  f16x3      fp16 hi/lo split, three passes
+  bf16x3     the round-1 production scheme: bf16 hi/lo split, three passes
+  f16x3      the production scheme: fp16 hi/lo split, three passes
   f16+f8x2   fp16 main term + the two cross terms on FP8 (e4m3) operands with power-of-two block scales over 32 k
              (the MX block format of gfx950's v_mfma_scale_f32_32x32x64_f8f6f4, twice the fp16 MFMA rate: 2 passes' worth)
   bf16+f8x2  same with a bf16 main term
