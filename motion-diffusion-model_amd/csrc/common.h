@@ -54,7 +54,7 @@ __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
 // runs.  Same bytes, same MFMA rate (v_mfma_f32_32x32x16_f16 / _bf16), same kernels: only these helpers differ.
 // Why fp16: on "trained-like" weights (oracle/synth.py synth_state_dict_hostile) the bf16 split is 10x the fp32 reference's own
 // rounding noise, the fp16 split sits AT that noise (tools/precision_probe.py, tools/fold_probe.py).
-// Range: |x| <= 65504 * (1 + 2^-11) is representable (hi saturates, lo takes the rest); below 2^-14 the planes keep an absolute
+// Range: values are clamped to +-65504 when they are split (a model whose activations leave fp16's range needs the f32 mode); below 2^-14 the planes keep an absolute
 // precision of 2^-25 (fp16 subnormals -- gfx950's MFMA does not flush them).
 // ---------------------------------------------------------------------------------------------
 #ifdef MDM_SPLIT_BF16
@@ -199,9 +199,14 @@ __host__ __device__ __forceinline__ float p16_to_f32(p16_t b) {
 
 __host__ __device__ __forceinline__ p16_t f32_to_p16(float x) {
   if constexpr (kSplitF16) {
-    // round-to-nearest-even; saturating (65504) instead of inf, so that hi + lo still carries values up to 2 * 65504
-    const float c = __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f);
-    return __builtin_bit_cast(p16_t, (f16_t)c);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDM_F16_NOCLAMP)
+    // round-to-nearest-even; saturating (65504) instead of inf.
+    // One v_med3_f32 (fminf / fmaxf would add a NaN-quieting v_max per value)
+    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+#elif !defined(__HIP_DEVICE_COMPILE__)
+    x = x > 65504.f ? 65504.f : (x < -65504.f ? -65504.f : x);
+#endif
+    return __builtin_bit_cast(p16_t, (f16_t)x);
   } else {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_bit_cast(unsigned short, (__bf16)x);   // v_cvt_pk_bf16_f32 (round-to-nearest-even)
@@ -213,18 +218,51 @@ __host__ __device__ __forceinline__ p16_t f32_to_p16(float x) {
 #endif
   }
 }
+// the lo part: |x - hi| <= 2^-11 |hi| cannot overflow (unless hi saturated, where inf is the honest answer): no clamp
+__host__ __device__ __forceinline__ p16_t f32_to_p16_lo(float x) {
+  if constexpr (kSplitF16) return __builtin_bit_cast(p16_t, (f16_t)x);
+  else return f32_to_p16(x);
+}
 
 __host__ __device__ __forceinline__ void split_p16(float x, p16_t& hi, p16_t& lo) {
   hi = f32_to_p16(x);
-  lo = f32_to_p16(x - p16_to_f32(hi));
+  lo = f32_to_p16_lo(x - p16_to_f32(hi));
+}
+
+// Two values -> packed (hi, hi) and (lo, lo) dwords.  On the device the fp16 form is written on 2-vectors so that hipcc selects
+// the packed conversions: per PAIR 2 v_med3 + v_cvt_pk_f16_f32 + 2 v_cvt_f32_f16 (SDWA halves) + 2 v_sub + v_cvt_pk_f16_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_p16(float a, float b, uint32_t& hi2, uint32_t& lo2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (kSplitF16) {
+#ifndef MDM_F16_NOCLAMP
+    a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+    b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+#endif
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    hi2 = __builtin_bit_cast(uint32_t, h);
+    lo2 = __builtin_bit_cast(uint32_t, l);
+    return;
+  }
+#endif
+  p16_t h0, l0, h1, l1;
+  split_p16(a, h0, l0);
+  split_p16(b, h1, l1);
+  hi2 = (uint32_t)h0 | ((uint32_t)h1 << 16);
+  lo2 = (uint32_t)l0 | ((uint32_t)l1 << 16);
 }
 
 // 4 consecutive values -> 8-byte packed hi and lo groups
 __device__ __forceinline__ void split4_store(p16_t* hi_p, p16_t* lo_p, float4 v) {
-  p16_t h[4], l[4];
-  split_p16(v.x, h[0], l[0]); split_p16(v.y, h[1], l[1]); split_p16(v.z, h[2], l[2]); split_p16(v.w, h[3], l[3]);
-  *reinterpret_cast<uint2*>(hi_p) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-  *reinterpret_cast<uint2*>(lo_p) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+  uint32_t h01, l01, h23, l23;
+  split2_p16(v.x, v.y, h01, l01);
+  split2_p16(v.z, v.w, h23, l23);
+  *reinterpret_cast<uint2*>(hi_p) = make_uint2(h01, h23);
+  *reinterpret_cast<uint2*>(lo_p) = make_uint2(l01, l23);
 }
 
 // Direct global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the LDS destination is

@@ -219,14 +219,28 @@ struct OutProjEpilogue {
 // ------------------------------------------------------------------------------------------------
 // BT = block tile edge: 128 (wave tile 64x64 = 2x2 accumulators) or 64 (wave tile 32x32, one accumulator) -- the small
 // tile exists for problems whose 128x128 tiling leaves most of the 256 CUs idle (the DiP decoder's 3840-row GEMMs).
-template <class AL, class BL, class EP, int BT>
+// X3 = the split-precision arithmetic of gemm_x3.h on THIS skeleton (same loaders, same epilogues, fp32 operands in memory):
+// each staged fp32 value is split into fp16 hi + lo on its way into LDS and a 32-deep k tile costs 6 v_mfma_f32_32x32x16_f16
+// per accumulator (hi*hi + hi*lo + lo*hi, two k sub-steps) instead of 16 v_mfma_f32_32x32x2_f32 -- 5.3x less matrix-pipe time.
+// It is what the DiP decoder runs in the default `f16x3` mode: its GEMMs are too small for gemm_x3.h's 208-row tiles and
+// their operands are not worth a planes round trip.  LDS image of a plane: [rows][40] halfs (80-byte rows: the 16-byte
+// fragment reads of 16 consecutive rows fall on 16 distinct bank quads).
+constexpr int GEMM_X3_LD = 40;   // halfs per LDS row of a split plane
+template <class AL, class BL, class EP, int BT, bool X3 = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl, EP ep, int M, int N, int K,
                                                                     int tiles_n) {
   constexpr int WT = BT / 2;          // wave tile edge
   constexpr int NA = WT / 32;         // 32x32 accumulators per wave tile edge
   constexpr int NST = BT / 32;        // float4 per operand per thread while staging
-  __shared__ __attribute__((aligned(16))) float As[BT * GEMM_LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[BT * GEMM_LDS_LD];
+  // fp32 tiles (exact mode) or hi | lo fp16 planes of the same tiles (X3): the split image is smaller
+  constexpr int OP_BYTES = X3 ? 2 * BT * GEMM_X3_LD * 2 : BT * GEMM_LDS_LD * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * OP_BYTES];
+  float* const As = reinterpret_cast<float*>(lds_raw);
+  float* const Bs = reinterpret_cast<float*>(lds_raw + OP_BYTES);
+  p16_t* const Ah = reinterpret_cast<p16_t*>(lds_raw);
+  p16_t* const Al = Ah + BT * GEMM_X3_LD;
+  p16_t* const Bh = reinterpret_cast<p16_t*>(lds_raw + OP_BYTES);
+  p16_t* const Bl = Bh + BT * GEMM_X3_LD;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -266,8 +280,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
   for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-      st4(&As[a_row[i] * GEMM_LDS_LD + a_k[i]], ra[i]);
-      st4(&Bs[b_row[i] * GEMM_LDS_LD + b_k[i]], rb[i]);
+      if constexpr (X3) {
+        split4_store(&Ah[a_row[i] * GEMM_X3_LD + a_k[i]], &Al[a_row[i] * GEMM_X3_LD + a_k[i]], ra[i]);
+        split4_store(&Bh[b_row[i] * GEMM_X3_LD + b_k[i]], &Bl[b_row[i] * GEMM_X3_LD + b_k[i]], rb[i]);
+      } else {
+        st4(&As[a_row[i] * GEMM_LDS_LD + a_k[i]], ra[i]);
+        st4(&Bs[b_row[i] * GEMM_LDS_LD + b_k[i]], rb[i]);
+      }
     }
     __syncthreads();
     if (kt + 1 < nk) {
@@ -278,6 +297,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
         rb[i] = bl.load4(n0 + b_row[i], kb + b_k[i]);
       }
     }
+    if constexpr (X3) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {   // two 16-deep k sub-steps: lane (r, h) holds k = 16 ks + 8 h .. + 7 of row r
+        p16x8 ah[NA], al_[NA], bh[NA], bl_[NA];
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+          const int ao = (wm * WT + t * 32 + r) * GEMM_X3_LD + 16 * ks + 8 * h;
+          const int bo = (wn * WT + t * 32 + r) * GEMM_X3_LD + 16 * ks + 8 * h;
+          ah[t] = *reinterpret_cast<const p16x8*>(&Ah[ao]);
+          al_[t] = *reinterpret_cast<const p16x8*>(&Al[ao]);
+          bh[t] = *reinterpret_cast<const p16x8*>(&Bh[bo]);
+          bl_[t] = *reinterpret_cast<const p16x8*>(&Bl[bo]);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int j = 0; j < NA; ++j) {
+            acc[i][j] = mfma_p16(al_[i], bh[j], acc[i][j]);
+            acc[i][j] = mfma_p16(ah[i], bl_[j], acc[i][j]);
+            acc[i][j] = mfma_p16(ah[i], bh[j], acc[i][j]);
+          }
+      }
+    } else
 #pragma unroll
     for (int c = 0; c < 4; ++c) {  // 4 chunks of 4 k-pairs each
       float4 fa[NA], fb[NA];
@@ -322,17 +364,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
 }
 
 // 128x128 tiles unless they would leave more than half of the chip's workgroup slots (2 per CU) empty
-template <class AL, class BL, class EP>
-inline void launch_gemm_f32(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream) {
+template <bool X3, class AL, class BL, class EP>
+inline void launch_gemm_f32_t(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream) {
   const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   if (tiles_m * tiles_n < 512 && (size_t)M * N >= 64 * 64 * 4) {
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
-    auto kfn = &gemm_f32_kernel<AL, BL, EP, 64>;
+    auto kfn = &gemm_f32_kernel<AL, BL, EP, 64, X3>;
     MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K, tn);
     return;
   }
-  auto kfn = &gemm_f32_kernel<AL, BL, EP, 128>;
+  auto kfn = &gemm_f32_kernel<AL, BL, EP, 128, X3>;
   MDM_LAUNCH(kfn, dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K, tiles_n);
+}
+template <class AL, class BL, class EP>
+inline void launch_gemm_f32(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream,
+                            bool x3 = false) {
+  if (x3) launch_gemm_f32_t<true>(al, bl, ep, M, N, K, stream);
+  else launch_gemm_f32_t<false>(al, bl, ep, M, N, K, stream);
 }
 
 }  // namespace mdm

@@ -330,8 +330,9 @@ int launch_linear_f6_debug(Profiler* pf, const float* in, int ld_in, const float
 }
 #endif
 
+// x3: the split-precision arithmetic on this (fp32-in-memory) skeleton -- the DiP decoder's GEMMs in the f16x3 mode
 int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, const float* bias, const float* res,
-                  float* out, int M, int N, int K, int act, int scale_cols, float col_scale, hipStream_t s) {
+                  float* out, int M, int N, int K, int act, int scale_cols, float col_scale, hipStream_t s, bool x3 = false) {
 #ifdef MDM_PROBES
   if (g_f6_linear && K % 32 == 0 && N % 4 == 0 && ld_in % 4 == 0 && (scale_cols % 256 == 0) &&
       (act == ACT_NONE || (act == ACT_GELU && res == nullptr)))
@@ -342,7 +343,7 @@ int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, cons
   RowMajorLoader al{in, ld_in, M, K};
   RowMajorLoader bl{w, K, N, K};
   LinearEpilogue ep{out, bias, res, N, act, scale_cols, col_scale, nullptr, nullptr};
-  launch_gemm_f32(al, bl, ep, M, N, K, s);
+  launch_gemm_f32(al, bl, ep, M, N, K, s, x3);
   return rt_launch_status();
 }
 
@@ -458,6 +459,15 @@ int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long l
   return rt_launch_status();
 }
 
+// sequence groups of the encoder stack: 0 = automatic (see encoder()), n >= 1 = forced (MDM_ENC_GROUPS, A/B runs)
+inline int enc_groups_setting() {
+  static const int v = [] {
+    const char* e = getenv("MDM_ENC_GROUPS");
+    return (e != nullptr && e[0] >= '0' && e[0] <= '9') ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 // seqTransEncoder: num_layers post-norm layers over ws.tok [nseq*S, D] (in place).
 int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int* lengths, hipStream_t s) {
   Profiler* pf = &m->prof;
@@ -467,37 +477,61 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
     // No LayerNorm kernels: xb = tokh|tokl holds the layer input / the post-FFN PRE-norm sum, xa the post-attention
     // pre-norm sum, each with per-row partial (sum, sum^2) written by its producer; consumers fold the normalisation
     // (gemm_x3.h X3Epilogue).  Layer 0's input (the embedding) is not normalised: plain in_proj, plain residual.
-    const X3Operand xb{ws.tokh, ws.tokl}, xa{ws.xah, ws.xal}, attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
+    // Sequences are independent, so the stack can run over GROUPS of sequences one after the other: with the whole batch
+    // the planes in flight between two launches (Q/K/V^T 352 MB, ffn 207 MB at 256 sequences) exceed the 256 MB Infinity
+    // Cache and every hand-over goes through HBM; half the batch at a time keeps each producer -> consumer hand-over
+    // cache-resident.  Groups must keep every launch a whole number of tiles per CU (gemm_x3.h: 256 sequences x N/256
+    // tiles on 256 CUs), so only an even split of a batch of >= 256 sequences is taken (MDM_ENC_GROUPS overrides: A/B runs).
     const int parts = (D + 255) / 256;
     const float inv_dim = 1.0f / (float)D;
+    int groups = enc_groups_setting();
+    if (groups <= 0) groups = 1;   // (until the A/B on the hardware says otherwise)
+    if (groups > 1 && (nseq % groups != 0 || (nseq / groups) % 8 != 0)) groups = 1;
+    const int ns = nseq / groups, Mg = ns * S;
+    for (int gi = 0; gi < groups; ++gi) {
+    const size_t r0 = (size_t)gi * Mg;                       // first token row of the group
+    const size_t q0 = (size_t)gi * ns * H * ws.qp.SP * AX_HD;  // first element of the group in every Q/K/V^T plane
+    const X3Operand xb{ws.tokh + r0 * D, ws.tokl + r0 * D}, xa{ws.xah + r0 * D, ws.xal + r0 * D},
+        attp{ws.atth + r0 * D, ws.attl + r0 * D}, ffnp{ws.ffnh + r0 * FF, ws.ffnl + r0 * FF};
+    p16_t* const xah = ws.xah + r0 * D; p16_t* const xal = ws.xal + r0 * D;
+    p16_t* const tokh = ws.tokh + r0 * D; p16_t* const tokl = ws.tokl + r0 * D;
+    p16_t* const atth = ws.atth + r0 * D; p16_t* const attl = ws.attl + r0 * D;
+    p16_t* const ffnh = ws.ffnh + r0 * FF; p16_t* const ffnl = ws.ffnl + r0 * FF;
+    float* const stat1 = ws.stat1 + r0 * parts * 2; float* const stat2 = ws.stat2 + r0 * parts * 2;
+    const QkvPlanes qp{ws.qp.qh + q0, ws.qp.ql + q0, ws.qp.kh + q0, ws.qp.kl + q0, ws.qp.vh + q0, ws.qp.vl + q0,
+                       ws.qp.SP, ws.qp.NKT, ws.qp.H};
+    // key-padding lengths are indexed seq % B: a group of whole branches keeps the pointer, a group inside a branch moves it
+    const int* glen = lengths == nullptr ? nullptr : lengths + ((size_t)gi * ns) % B;
+    const int gB = (ns % B == 0) ? B : ns;                  // (ns divides B or is a multiple of it: nseq = B or 2B)
     for (int l = 0; l < m->cfg.num_layers; ++l) {
       const mdm_model::LayerPlanes& P = m->planes[l];
       const mdm_model::LayerFold& F = m->fold[l];
       if (l == 0) {
-        if (int rc = launch_in_proj_x3(pf, xb, P.in_proj, m->L(l, "self_attn.in_proj_bias"), ws.qp, nseq, S, D, qscale, s)) return rc;
+        if (int rc = launch_in_proj_x3(pf, xb, P.in_proj, m->L(l, "self_attn.in_proj_bias"), qp, ns, S, D, qscale, s)) return rc;
       } else {
-        LnArgs a; a.astat = ws.stat2; a.colsum = F.c_qkv; a.parts = parts; a.inv_dim = inv_dim;
-        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, xb, F.in_proj, F.b_qkv, a, nullptr, nullptr, nullptr, &ws.qp, M,
+        LnArgs a; a.astat = stat2; a.colsum = F.c_qkv; a.parts = parts; a.inv_dim = inv_dim;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, xb, F.in_proj, F.b_qkv, a, nullptr, nullptr, nullptr, &qp, Mg,
                                   3 * D, D, S, D, D, qscale, s)) return rc;
       }
-      if (int rc = launch_attention_x3(pf, ws.qp, lengths, nseq, B, S, D, nullptr, ws.atth, ws.attl, s)) return rc;
+      if (int rc = launch_attention_x3(pf, qp, glen, ns, gB, S, D, nullptr, atth, attl, s)) return rc;
       {  // xa = att.Wo + bo + layer input (normalised on the fly for l >= 1), + row statistics
-        LnArgs a; a.res = xb; a.ostat = ws.stat1; a.parts = parts; a.inv_dim = inv_dim;
-        if (l >= 1) { a.rstat = ws.stat2; a.rgamma = m->L(l - 1, "norm2.weight"); a.rbeta = m->L(l - 1, "norm2.bias"); }
+        LnArgs a; a.res = xb; a.ostat = stat1; a.parts = parts; a.inv_dim = inv_dim;
+        if (l >= 1) { a.rstat = stat2; a.rgamma = m->L(l - 1, "norm2.weight"); a.rbeta = m->L(l - 1, "norm2.bias"); }
         if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, l == 0 ? 1 : 2, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"),
-                                  a, nullptr, ws.xah, ws.xal, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
+                                  a, nullptr, xah, xal, nullptr, Mg, D, D, S, D, 0, 1.f, s)) return rc;
       }
       {  // ffn = gelu(LN1(xa).W1 + b1), LN1 folded
-        LnArgs a; a.astat = ws.stat1; a.colsum = F.c_1; a.parts = parts; a.inv_dim = inv_dim;
-        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 3, xa, F.linear1, F.b_1, a, nullptr, ws.ffnh, ws.ffnl, nullptr, M, FF,
+        LnArgs a; a.astat = stat1; a.colsum = F.c_1; a.parts = parts; a.inv_dim = inv_dim;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 3, xa, F.linear1, F.b_1, a, nullptr, ffnh, ffnl, nullptr, Mg, FF,
                                   D, S, D, 0, 1.f, s)) return rc;
       }
       {  // xb = ffn.W2 + b2 + LN1(xa), + row statistics
-        LnArgs a; a.res = xa; a.rstat = ws.stat1; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias");
-        a.ostat = ws.stat2; a.parts = parts; a.inv_dim = inv_dim;
-        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, ffnp, P.linear2, m->L(l, "linear2.bias"), a, nullptr, ws.tokh,
-                                  ws.tokl, nullptr, M, D, FF, S, D, 0, 1.f, s)) return rc;
+        LnArgs a; a.res = xa; a.rstat = stat1; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias");
+        a.ostat = stat2; a.parts = parts; a.inv_dim = inv_dim;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, ffnp, P.linear2, m->L(l, "linear2.bias"), a, nullptr, tokh,
+                                  tokl, nullptr, Mg, D, FF, S, D, 0, 1.f, s)) return rc;
       }
+    }
     }
     return 0;   // the encoder's output is LN2(L-1)(xb): folded into OutputProcess (outproj_x3)
   }
@@ -685,8 +719,7 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
                              m->W("embed_timestep.time_embed.2.bias"), nullptr, m->time_table, R, D, D, ACT_NONE, 0,
                              1.f, s))
     return rc;
-  if (m->cfg.arch == MDM_ARCH_TRANS_DEC) {   // the DiP decoder runs in exact fp32: no operand planes
-    m->precision = MDM_PREC_F32;
+  if (m->cfg.arch == MDM_ARCH_TRANS_DEC) {   // the DiP decoder splits its fp32 operands inside the GEMM (gemm_f32.h X3): no planes
     m->prepared = true;
     return MDM_OK;
   }
@@ -767,8 +800,6 @@ int mdm_set_precision(mdm_model_t* m, int32_t mode) {
   if (mode != MDM_PREC_F32 && mode != MDM_PREC_F16X3) return fail(MDM_EINVAL, "mdm_set_precision: unknown mode");
   if (mode == MDM_PREC_F16X3 && (m->cfg.latent_dim % X3_BK != 0 || m->cfg.ff_size % X3_BK != 0))
     return fail(MDM_EUNSUPPORTED, "f16x3 needs latent_dim and ff_size to be multiples of 32");
-  if (mode == MDM_PREC_F16X3 && m->cfg.arch == MDM_ARCH_TRANS_DEC)
-    return fail(MDM_EUNSUPPORTED, "the trans_dec (DiP) denoiser runs in exact fp32 only");
   m->precision = mode;
   return MDM_OK;
 }
@@ -868,6 +899,7 @@ int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const i
   Profiler* pf = &m->prof;
   const int* len = m->cfg.mask_frames ? lengths : nullptr;
   const float qscale = 1.0f / sqrtf((float)ATT_HD);
+  const bool x3 = m->precision == MDM_PREC_F16X3;   // GEMM arithmetic (gemm_f32.h X3); attention, LayerNorm stay fp32
 
   // ---- text memory: embed_text over every token (cond branch), + time embedding (mdm.py:217-219)
   if (branches != MDM_BRANCH_UNCOND)
@@ -887,35 +919,35 @@ int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const i
     EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, S, S, D, nbranch,
                      nullptr, nullptr, 0};
     ProfScope ps(pf, MDM_PROF_EMBED, 2.0 * B * S * (double)D * m->jf, s);
-    launch_gemm_f32(al, bl, ep, B * S, D, m->jf_pad, s);
+    launch_gemm_f32(al, bl, ep, B * S, D, m->jf_pad, s, x3);
     if (int rc = rt_launch_status()) return rc;
   }
   // ---- nn.TransformerDecoder (mdm.py:265; post-norm layers, no final norm)
   for (int l = 0; l < m->cfg.num_layers; ++l) {
     // x = norm1(x + self_attn(x))
     if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "self_attn.in_proj_weight"), m->L(l, "self_attn.in_proj_bias"), nullptr,
-                               ws.qkv, M, 3 * D, D, ACT_NONE, D, qscale, s)) return rc;
+                               ws.qkv, M, 3 * D, D, ACT_NONE, D, qscale, s, x3)) return rc;
     if (int rc = launch_attention(pf, ws.qkv, ws.att, len, nseq, B, S, D, H, nullptr, nullptr, s, /*lead=*/0)) return rc;
     if (int rc = launch_linear(pf, ws.att, D, m->L(l, "self_attn.out_proj.weight"), m->L(l, "self_attn.out_proj.bias"),
-                               ws.tok, ws.tok, M, D, D, ACT_NONE, 0, 1.f, s)) return rc;
+                               ws.tok, ws.tok, M, D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
     if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, nullptr, nullptr, s)) return rc;
     // x = norm2(x + multihead_attn(x, memory, memory)): q from the tokens, k | v from the memory (packed in_proj rows)
     const float* wc = m->L(l, "multihead_attn.in_proj_weight");
     const float* bc = m->L(l, "multihead_attn.in_proj_bias");
-    if (int rc = launch_linear(pf, ws.tok, D, wc, bc, nullptr, ws.qkv, M, D, D, ACT_NONE, D, qscale, s)) return rc;
-    if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s)) return rc;
+    if (int rc = launch_linear(pf, ws.tok, D, wc, bc, nullptr, ws.qkv, M, D, D, ACT_NONE, D, qscale, s, x3)) return rc;
+    if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
     {
       const AttnF32Args a{ws.qkv, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
       if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s)) return rc;
     }
     if (int rc = launch_linear(pf, ws.att, D, m->L(l, "multihead_attn.out_proj.weight"), m->L(l, "multihead_attn.out_proj.bias"),
-                               ws.tok, ws.tok, M, D, D, ACT_NONE, 0, 1.f, s)) return rc;
+                               ws.tok, ws.tok, M, D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
     if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, nullptr, nullptr, s)) return rc;
     // x = norm3(x + linear2(gelu(linear1(x))))
     if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "linear1.weight"), m->L(l, "linear1.bias"), nullptr, ws.ffn, M, FF, D,
-                               ACT_GELU, 0, 1.f, s)) return rc;
+                               ACT_GELU, 0, 1.f, s, x3)) return rc;
     if (int rc = launch_linear(pf, ws.ffn, FF, m->L(l, "linear2.weight"), m->L(l, "linear2.bias"), ws.tok, ws.tok, M, D, FF,
-                               ACT_NONE, 0, 1.f, s)) return rc;
+                               ACT_NONE, 0, 1.f, s, x3)) return rc;
     if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm3.weight"), m->L(l, "norm3.bias"), M, D, nullptr, nullptr, s)) return rc;
   }
   // ---- OutputProcess over the completed suffix (mdm.py:278-282): token rows context_len .. S-1 of every sequence
@@ -926,7 +958,7 @@ int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const i
   ep.out = out;
   ep.T = pred_len; ep.JF = m->jf; ep.mode = 0;
   ProfScope ps(pf, MDM_PROF_OUTPROJ, 2.0 * nseq * pred_len * (double)D * m->jf, s);
-  launch_gemm_f32(al, bl, ep, m->jf, nseq * pred_len, D, s);
+  launch_gemm_f32(al, bl, ep, m->jf, nseq * pred_len, D, s, x3);
   return rt_launch_status();
 }
 

@@ -7,8 +7,8 @@ sub-modules below exist only to hold parameters under the reference's names.
 
 Scope: arch='trans_enc', text conditioning with a cached `y['text_embed']`
 (or no conditioning), inference only; and (DiP) arch='trans_dec' with prefix completion
-and a cached token-level text embedding (DistilBERT) or a single CLIP token as the decoder memory, in exact
-fp32.  Everything else raises NotImplementedError loudly.
+and a cached token-level text embedding (DistilBERT) or a single CLIP token as the decoder memory (its GEMMs split their
+fp32 operands on the fly in the default f16x3 mode; attention / LayerNorm fp32).  Everything else raises NotImplementedError loudly.
 """
 import math
 import os
@@ -130,7 +130,6 @@ class MDM(nn.Module):
                 raise ValueError('We only support [CLIP, BERT] text encoders')
             if self.text_encoder_type == 'bert':
                 self.clip_dim = clip_dim = 768          # model/mdm.py:127
-            self.precision = 'f32'                       # the decoder path is exact fp32 (include/mdm_hip.h)
 
         self.input_process = InputProcess(data_rep, self.input_feats, latent_dim)
         self.sequence_pos_encoder = PositionalEncoding(latent_dim, dropout, max_len=kargs.get('pos_embed_max_len', 5000))

@@ -100,7 +100,7 @@ def main():
                                 init_image=init)
     torch.manual_seed(78)      # the MI355X model driven by the reference's generator: ONE (emulated) step, zero gradient
     got = diffusion.p_sample_loop(model, motion_shape, clip_denoised=False, model_kwargs=model_kwargs, skip_timesteps=1,
-                                  init_image=init, cond_fn=lambda x, t, p_mean_var, **kw: torch.zeros_like(x))
+                                  init_image=init, cond_fn=lambda x, t, **kw: torch.zeros_like(x))
     res["cond_fn_handover_vs_oracle"] = maxabs(got, want_skip)
     assert type(diffusion._reference("test").base).__module__ == "diffusion.gaussian_diffusion"
     # a foreign model: the reference's own torch MDM through OUR diffusion object

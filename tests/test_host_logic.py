@@ -108,10 +108,10 @@ def test_wrapper_and_scope_errors():
                dict(text_encoder_type="bert")):
         with pytest.raises(NotImplementedError):
             model_util.create_model_and_diffusion(model_util.default_args(**kw))
-    # DiP configuration (DiP.md): constructs, keeps the reference's state-dict keys, runs in exact fp32
+    # DiP configuration (DiP.md): constructs, keeps the reference's state-dict keys
     md, _ = model_util.create_model_and_diffusion(model_util.default_args(
         arch="trans_dec", text_encoder_type="bert", context_len=20, pred_len=40, layers=1))
-    assert md.clip_dim == 768 and md.precision == "f32" and md.is_prefix_comp
+    assert md.clip_dim == 768 and md.precision == "f16x3" and md.is_prefix_comp
     keys = set(md.state_dict().keys())
     assert "seqTransDecoder.layers.0.multihead_attn.in_proj_weight" in keys and "seqTransDecoder.layers.0.norm3.bias" in keys
     assert md.embed_text.weight.shape == (512, 768)

@@ -36,11 +36,14 @@ def planes(x, dt):
     return hi + lo
 
 
+WSCALE = 1.0    # --wscale=S: weights are split as hi/lo of w * S (a power of two) and the product is scaled back
+
+
 def mm3(a, w, dt):
     """a [.., K] x w [N, K] -> three-product split GEMM, fp32 accumulate"""
     ah, al = split(a, dt)
-    wh, wl = split(w, dt)
-    return ah @ wh.t() + (ah @ wl.t() + al @ wh.t())
+    wh, wl = split(w * WSCALE, dt)
+    return (ah @ wh.t() + (ah @ wl.t() + al @ wh.t())) * (1.0 / WSCALE)
 
 
 def row_stats(x, mode, tile=256):
@@ -168,12 +171,20 @@ def main():
     B = int(pos[0]) if len(pos) > 0 else 2
     steps = int(pos[1]) if len(pos) > 1 else 50
     hostile = "--hostile" in sys.argv
+    global WSCALE
+    for a in sys.argv:
+        if a.startswith("--wscale="):
+            WSCALE = float(a[len("--wscale="):])
     T = 196
     sd = synth_state_dict_hostile(0) if hostile else synth_state_dict(0)
     tab = orc.Tables(orc.named_betas("cosine", steps))
     shape = (B, 263, 1, T)
-    y = (synth_y_hostile if hostile else synth_y)(B, T, seed=7, lengths=[T, T - 50][:B] + [T] * max(0, B - 2))
-    x_T, noises = orc.make_noise(shape, steps, seed=3)
+    if "--fixture" in sys.argv:      # the inputs of tests/golden/hostile_loop50_B2_T196.npz (oracle/make_golden_r2.py)
+        y = synth_y_hostile(B, T, seed=1031, lengths=[196, 150])
+        x_T, noises = orc.make_noise(shape, steps, seed=31)
+    else:
+        y = (synth_y_hostile if hostile else synth_y)(B, T, seed=7, lengths=[T, T - 50][:B] + [T] * max(0, B - 2))
+        x_T, noises = orc.make_noise(shape, steps, seed=3)
     with torch.no_grad():
         ref = orc.sample_loop(sd, tab, shape, y, x_T, noises, cfg=True)
         r64 = orc.sample_loop(sd, tab, shape, y, x_T, noises, cfg=True, dtype=torch.float64)

@@ -14,7 +14,7 @@ fi
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 3000 $OUT/bench.json
 R=$PWD
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o trace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/$OUT/prof_bench.json 2> $R/$OUT/prof.err)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o trace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $R/$OUT/prof_bench.json 2> $R/$OUT/prof.err)
 DB=$(find $OUT/prof -name '*.db' | head -1)
 if [ -n "$DB" ]; then python tools/rocpd_summary.py $DB > $OUT/kernel_stats.md; cat $OUT/kernel_stats.md; rm -f $DB; fi
 find $OUT/prof -name '*.csv' -size +2M -delete

@@ -1,31 +1,51 @@
 """Condense gpurun_out/<tag>/pmc*.txt (tools/gpu_prof.sh ... pmc) + kernel_stats.md into profiles/<name>.json:
 per kernel the mean duration, FETCH_SIZE / WRITE_SIZE (KB as reported) and the derived HBM-side bytes per launch with the
 gfx950 correction MI355X_MICROARCH.md prescribes (FETCH_SIZE counts 64 B per 128-B request on wide streaming reads:
-x2; WRITE_SIZE as is -- both calibrated here on layernorm_kernel, whose traffic is known exactly), MFMA busy fraction
-and the shader clock.  Usage: python tools/pmc_to_json.py gpurun_out/p3 profiles/r01_pmc.json"""
-import json, re, sys, os
+x2; WRITE_SIZE as is -- both calibrated in round 1 on layernorm_kernel, whose traffic is known exactly), MFMA busy fraction
+and the shader clock.  The file records the sha256 of the kernel sources it was taken on (bench.csrc_sha256): bench.py
+quotes `roofline.traffic` from it only while the sources are the same.
+Usage: python tools/pmc_to_json.py gpurun_out/p3 profiles/r02_pmc.json"""
+import json
+import os
+import re
+import subprocess
+import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 src, dst = sys.argv[1], sys.argv[2]
+
+
+def classify(name):
+    """-> (section, key) for the kernels of the sampling loop; the GEMM is told apart by its template arguments
+    <WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16, F6> read from the END (names arrive
+    truncated on the left)."""
+    name = name.strip().strip("`")
+    if "gemm_x3_kernel" in name or re.search(r"(true|false)(, (true|false)){4}>", name):
+        args = [a.strip() for a in name[name.rfind("<") + 1:name.rfind(">")].split(",")] if "<" in name else \
+            [a.strip() for a in name[:name.rfind(">")].split(",")]
+        if len(args) >= 11:
+            f6, t16, embed, ostat, fold, abl, qkv, planes, f32, res, act = args[::-1][:11]
+            b = lambda v: v == "true"   # noqa: E731
+            if b(embed):
+                return "gemm", "InputProcess"
+            if b(qkv):
+                return "gemm", "in_proj" if b(fold) else "in_proj_layer0"
+            if b(ostat):
+                return "gemm", "out_proj|linear2" if res == "3" else "out_proj_layer0"
+            if act == "1":
+                return "gemm", "linear1"
+            if b(f32) and b(fold):
+                return "gemm", "OutputProcess"
+            return "gemm", "other<" + ",".join(args[-11:]) + ">"
+    for pat, k in (("attention_x3_kernel", "attention"), ("pose_to_planes_kernel", "pose_to_planes"), ("layernorm_kernel", "layernorm"),
+                   ("outproj_finish_kernel", "outproj_finish"), ("cond_token_kernel", "cond_token")):
+        if pat in name:
+            return "other", k
+    return None, None
+
+
 ker = {}
-
-def key(name):
-    name = name.strip()
-    # template tails: <WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16> (names arrive truncated on
-    # the left); the patterns below match with or without the trailing EMBED / T16 arguments
-    for pat, k in [(r"0, 0, false, false, true, 0, true, false(, false)?(, true|, false)?>", "gemm_f16x3<in_proj (LayerNorm folded) -> Q/K/V^T planes>"),
-                   (r"0, 0, false, false, true, 0, false, false(, false)?(, true|, false)?>", "gemm_f16x3<in_proj layer 0 -> Q/K/V^T planes>"),
-                   (r"0, 3, false, true, false, 0, false, true(, false)?(, true|, false)?>", "gemm_f16x3<out_proj | linear2, LayerNorm residual, planes + row stats>"),
-                   (r"0, 2, false, true, false, 0, false, true(, false)?(, true|, false)?>", "gemm_f16x3<out_proj layer 0, planes + row stats>"),
-                   (r"1, 0, false, true, false, 0, true, false(, false)?(, true|, false)?>", "gemm_f16x3<linear1 (LayerNorm folded) + GELU -> planes>"),
-                   (r"0, 0, true, false, false, 0, true, false(, false)?(, true|, false)?>", "gemm_f16x3<OutputProcess (LayerNorm folded)>"),
-                   (r"0, 1, false, true, false, 0, false, false, true(, true|, false)?>", "gemm_f16x3<InputProcess (EMBED)>"),
-                   (r"pose_to_planes_kernel", "pose_to_planes"),
-                   (r"attention_x3_kernel", "attention_f16x3"), (r"layernorm_kernel", "layernorm"),
-                   (r"outproj_finish_kernel", "outproj_finish"), (r"EmbedEpilogue", "gemm_f32<InputProcess>")]:
-        if re.search(pat, name):
-            return k
-    return None
-
 for i in range(1, 9):
     f = os.path.join(src, f"pmc{i}.txt")
     if not os.path.isfile(f):
@@ -33,22 +53,21 @@ for i in range(1, 9):
     cur = None
     for line in open(f):
         if line.startswith("=="):
-            cur = key(line[2:])
-        elif cur and "mean" in line:
-            name, _, val = line.split()[0], None, float(line.split()[-1])
-            ker.setdefault(cur, {})[name] = val
+            cur = classify(line[2:].split(" grid=")[0])
+        elif cur and cur[0] and "mean" in line:
+            ker.setdefault(cur, {})[line.split()[0]] = float(line.split()[-1])
 ks = os.path.join(src, "kernel_stats.md")
 if os.path.isfile(ks):
     for line in open(ks):
         if not line.startswith("| `"):
             continue
         cells = [c.strip() for c in line.strip().strip("|").split("|")]
-        k = key(cells[0])
-        if k:
+        k = classify(cells[0])
+        if k[0]:
             ker.setdefault(k, {})["avg_us"] = float(cells[3])
             ker[k]["calls"] = int(cells[1])
-out = {}
-for k, c in ker.items():
+out = {"gemm": {}, "other": {}}
+for (sec, k), c in ker.items():
     e = dict(c)
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         e["hbm_read_bytes"] = c["FETCH_SIZE"] * 1024 * 2
@@ -59,6 +78,13 @@ for k, c in ker.items():
         e["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc)   # 256 CUs x 4 SIMDs
         if "avg_us" in c:
             e["shader_clock_ghz_under_pmc"] = cyc / c["avg_us"] / 1e3
-    out[k] = e
+    out[sec][k] = e
+import bench  # noqa: E402
+out["csrc_sha256"] = bench.csrc_sha256()
+try:
+    out["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    out["commit"] = None
+out["source"] = f"tools/gpu_prof.sh {os.path.basename(src.rstrip('/'))} pmc (rocprofv3 --kernel-trace --pmc, separate passes)"
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -12,7 +12,7 @@ def main(path, filt=""):
     for name, grid, cn, val, did in rows:
         if filt and filt not in name:
             continue
-        per[(name.split("(")[0][-60:], grid)][cn][did] += val      # sum over instances of one dispatch
+        per[(name.split("(")[0][-100:], grid)][cn][did] += val      # sum over instances of one dispatch
     for key, counters in sorted(per.items(), key=lambda kv: -len(kv[1])):
         nd = max(len(v) for v in counters.values())
         print(f"== {key[0]} grid={key[1]} dispatches={nd}")
