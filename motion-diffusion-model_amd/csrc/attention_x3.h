@@ -234,6 +234,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
             mx = fmaxf(mx, sc);
           }
         mx = fmaxf(mx, shfl_xor_f32(mx, 32));
+        // fp16 planes: the probabilities are split as hi / lo of p * 2^10 -- free, by lowering the subtracted maximum by
+        // 10 ln 2; the factor cancels in 1 / sum.  Unscaled, a typical p ~ 1/S = 0.005 has an fp16-SUBNORMAL lo part
+        // (2^-25 absolute = 2^-17 relative): P.V would be the one bf16-class product left in the path.
+        if constexpr (kSplitF16) mx -= 6.931471805599453f;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)

@@ -54,7 +54,8 @@ __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
 // runs.  Same bytes, same MFMA rate (v_mfma_f32_32x32x16_f16 / _bf16), same kernels: only these helpers differ.
 // Why fp16: on "trained-like" weights (oracle/synth.py synth_state_dict_hostile) the bf16 split is 10x the fp32 reference's own
 // rounding noise, the fp16 split sits AT that noise (tools/precision_probe.py, tools/fold_probe.py).
-// Range: values are clamped to +-65504 when they are split (a model whose activations leave fp16's range needs the f32 mode); below 2^-14 the planes keep an absolute
+// Range: |x| <= 65504; beyond it the split yields inf and the sample NaN (a model whose activations leave fp16's range
+// needs the f32 mode -- the sampler seam checks the result and says so); below 2^-14 the planes keep an absolute
 // precision of 2^-25 (fp16 subnormals -- gfx950's MFMA does not flush them).
 // ---------------------------------------------------------------------------------------------
 #ifdef MDM_SPLIT_BF16
@@ -64,6 +65,12 @@ constexpr bool kSplitF16 = true;
 #endif
 typedef _Float16 f16_t;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// WEIGHTS are split as hi / lo of (w * 2^8) and the accumulators scaled back by 2^-8 (exact): nn.Linear weights are O(1/sqrt(K))
+// ~ 0.03, whose lo part (~2^-16) would be an fp16 SUBNORMAL with only ~8 significant bits -- the weight would carry 2^-20
+// instead of 2^-23.  Scaled, lo is a normal number for every |w| >= 2^-11; |w| < 255 keeps hi finite.  (bf16 build: 1.)
+constexpr float kX3WeightScale = kSplitF16 ? 256.f : 1.f;
+constexpr float kX3AccScale = kSplitF16 ? 1.f / 256.f : 1.f;
 
 // v_mfma_f32_32x32x16_{f16,bf16}: lane l supplies 8 consecutive-k elements of row/col (l&31), k-block (l>>5).
 __device__ __forceinline__ f32x16 mfma_p16(p16x8 a, p16x8 b, f32x16 c) {
@@ -199,13 +206,9 @@ __host__ __device__ __forceinline__ float p16_to_f32(p16_t b) {
 
 __host__ __device__ __forceinline__ p16_t f32_to_p16(float x) {
   if constexpr (kSplitF16) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDM_F16_NOCLAMP)
-    // round-to-nearest-even; saturating (65504) instead of inf.
-    // One v_med3_f32 (fminf / fmaxf would add a NaN-quieting v_max per value)
-    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
-#elif !defined(__HIP_DEVICE_COMPILE__)
-    x = x > 65504.f ? 65504.f : (x < -65504.f ? -65504.f : x);
-#endif
+    // round-to-nearest-even, NOT saturating: a value beyond +-65504 becomes inf and surfaces as NaN in the sample -- loud,
+    // and caught by the sampler seam (gaussian_diffusion.py _check_finite) -- instead of being clamped into a plausible
+    // wrong number.  (A v_med3 clamp per value also cost 1.3 % of the whole loop: profiles/r02_ab.md.)
     return __builtin_bit_cast(p16_t, (f16_t)x);
   } else {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -218,15 +221,10 @@ __host__ __device__ __forceinline__ p16_t f32_to_p16(float x) {
 #endif
   }
 }
-// the lo part: |x - hi| <= 2^-11 |hi| cannot overflow (unless hi saturated, where inf is the honest answer): no clamp
-__host__ __device__ __forceinline__ p16_t f32_to_p16_lo(float x) {
-  if constexpr (kSplitF16) return __builtin_bit_cast(p16_t, (f16_t)x);
-  else return f32_to_p16(x);
-}
 
 __host__ __device__ __forceinline__ void split_p16(float x, p16_t& hi, p16_t& lo) {
   hi = f32_to_p16(x);
-  lo = f32_to_p16_lo(x - p16_to_f32(hi));
+  lo = f32_to_p16(x - p16_to_f32(hi));
 }
 
 // Two values -> packed (hi, hi) and (lo, lo) dwords.  On the device the fp16 form is written on 2-vectors so that hipcc selects
@@ -236,10 +234,6 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2_p16(float a, float b, uint32_t& hi2, uint32_t& lo2) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (kSplitF16) {
-#ifndef MDM_F16_NOCLAMP
-    a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
-    b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
-#endif
     const f32x2 v = {a, b};
     const f16x2 h = __builtin_convertvector(v, f16x2);
     const f32x2 r = v - __builtin_convertvector(h, f32x2);

@@ -223,18 +223,27 @@ struct OutProjEpilogue {
 // each staged fp32 value is split into fp16 hi + lo on its way into LDS and a 32-deep k tile costs 6 v_mfma_f32_32x32x16_f16
 // per accumulator (hi*hi + hi*lo + lo*hi, two k sub-steps) instead of 16 v_mfma_f32_32x32x2_f32 -- 5.3x less matrix-pipe time.
 // It is what the DiP decoder runs in the default `f16x3` mode: its GEMMs are too small for gemm_x3.h's 208-row tiles and
-// their operands are not worth a planes round trip.  LDS image of a plane: [rows][40] halfs (80-byte rows: the 16-byte
-// fragment reads of 16 consecutive rows fall on 16 distinct bank quads).
-constexpr int GEMM_X3_LD = 40;   // halfs per LDS row of a split plane
+// their operands are not worth a planes round trip.
+// These GEMMs are small (M = 3840 rows at 32 motions): a 64x64 tile's matrix work per 32-deep k tile is 6 MFMAs (0.1 us), so
+// the kernel's time is the chain of global-load -> LDS -> barrier round trips, one per k tile.  The X3 form therefore
+// stages BK = 128 k per step (4 steps for K = 512 instead of 16): 8 float4 per operand and thread in flight.
+// LDS image of a plane: [rows][BK + 8] halfs (row stride = 4 dwords mod 64: the 16-byte fragment reads of 16 consecutive
+// rows fall on 16 distinct bank quads).
+constexpr int GEMM_X3_BK = 128;
+constexpr int GEMM_X3_LD = GEMM_X3_BK + 8;   // halfs per LDS row of a split plane
+constexpr int gemm_f32_lds_bytes(int bt, bool x3) { return 2 * (x3 ? 2 * bt * GEMM_X3_LD * 2 : bt * (GEMM_BK + 4) * 4); }
 template <class AL, class BL, class EP, int BT, bool X3 = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl, EP ep, int M, int N, int K,
-                                                                    int tiles_n) {
+                                                                    int tiles_n, int weight_is_a) {
+  constexpr int BK = X3 ? GEMM_X3_BK : GEMM_BK;
   constexpr int WT = BT / 2;          // wave tile edge
   constexpr int NA = WT / 32;         // 32x32 accumulators per wave tile edge
-  constexpr int NST = BT / 32;        // float4 per operand per thread while staging
-  // fp32 tiles (exact mode) or hi | lo fp16 planes of the same tiles (X3): the split image is smaller
-  constexpr int OP_BYTES = X3 ? 2 * BT * GEMM_X3_LD * 2 : BT * GEMM_LDS_LD * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * OP_BYTES];
+  constexpr int NST = BT * BK / 4 / GEMM_THREADS;   // float4 per operand per thread while staging
+  constexpr int TPR = BK / 4;         // threads sweeping the k's of one row (row-major staging)
+  constexpr int RPP = GEMM_THREADS / TPR;           // rows per staging pass
+  // fp32 tiles (exact mode) or hi | lo fp16 planes of the same tiles (X3)
+  constexpr int OP_BYTES = gemm_f32_lds_bytes(BT, X3) / 2;
+  MDM_DYN_SMEM(unsigned char, lds_raw);   // 2 * OP_BYTES (the X3 image of a 64-row tile pair is 68 KB: beyond static LDS)
   float* const As = reinterpret_cast<float*>(lds_raw);
   float* const Bs = reinterpret_cast<float*>(lds_raw + OP_BYTES);
   p16_t* const Ah = reinterpret_cast<p16_t*>(lds_raw);
@@ -255,10 +264,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
   int a_row[NST], a_k[NST], b_row[NST], b_k[NST];
 #pragma unroll
   for (int i = 0; i < NST; ++i) {
-    if (AL::kColumnStaging) { a_row[i] = tid & (BT - 1); a_k[i] = (tid / BT + (256 / BT) * i) * 4; }
-    else { a_row[i] = (tid >> 3) + 32 * i; a_k[i] = (tid & 7) * 4; }
-    if (BL::kColumnStaging) { b_row[i] = tid & (BT - 1); b_k[i] = (tid / BT + (256 / BT) * i) * 4; }
-    else { b_row[i] = (tid >> 3) + 32 * i; b_k[i] = (tid & 7) * 4; }
+    if (AL::kColumnStaging) { a_row[i] = tid & (BT - 1); a_k[i] = (tid / BT + (GEMM_THREADS / BT) * i) * 4; }
+    else { a_row[i] = tid / TPR + RPP * i; a_k[i] = (tid % TPR) * 4; }
+    if (BL::kColumnStaging) { b_row[i] = tid & (BT - 1); b_k[i] = (tid / BT + (GEMM_THREADS / BT) * i) * 4; }
+    else { b_row[i] = tid / TPR + RPP * i; b_k[i] = (tid % TPR) * 4; }
   }
 
   f32x16 acc[NA][NA];
@@ -276,13 +285,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
     rb[i] = bl.load4(n0 + b_row[i], b_k[i]);
   }
 
-  const int nk = (K + GEMM_BK - 1) / GEMM_BK;
+  const int nk = (K + BK - 1) / BK;
   for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       if constexpr (X3) {
-        split4_store(&Ah[a_row[i] * GEMM_X3_LD + a_k[i]], &Al[a_row[i] * GEMM_X3_LD + a_k[i]], ra[i]);
-        split4_store(&Bh[b_row[i] * GEMM_X3_LD + b_k[i]], &Bl[b_row[i] * GEMM_X3_LD + b_k[i]], rb[i]);
+        // the WEIGHT operand (B; A for the transposed OutputProcess) is split as hi / lo of w * 2^8 (common.h kX3WeightScale)
+        const float sa = weight_is_a ? kX3WeightScale : 1.f, sb = weight_is_a ? 1.f : kX3WeightScale;
+        split4_store(&Ah[a_row[i] * GEMM_X3_LD + a_k[i]], &Al[a_row[i] * GEMM_X3_LD + a_k[i]],
+                     make_float4(ra[i].x * sa, ra[i].y * sa, ra[i].z * sa, ra[i].w * sa));
+        split4_store(&Bh[b_row[i] * GEMM_X3_LD + b_k[i]], &Bl[b_row[i] * GEMM_X3_LD + b_k[i]],
+                     make_float4(rb[i].x * sb, rb[i].y * sb, rb[i].z * sb, rb[i].w * sb));
       } else {
         st4(&As[a_row[i] * GEMM_LDS_LD + a_k[i]], ra[i]);
         st4(&Bs[b_row[i] * GEMM_LDS_LD + b_k[i]], rb[i]);
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
     }
     __syncthreads();
     if (kt + 1 < nk) {
-      const int kb = (kt + 1) * GEMM_BK;
+      const int kb = (kt + 1) * BK;
 #pragma unroll
       for (int i = 0; i < NST; ++i) {
         ra[i] = al.load4(m0 + a_row[i], kb + a_k[i]);
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
     }
     if constexpr (X3) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {   // two 16-deep k sub-steps: lane (r, h) holds k = 16 ks + 8 h .. + 7 of row r
+      for (int ks = 0; ks < BK / 16; ++ks) {   // 16-deep k sub-steps: lane (r, h) holds k = 16 ks + 8 h .. + 7 of row r
         p16x8 ah[NA], al_[NA], bh[NA], bl_[NA];
 #pragma unroll
         for (int t = 0; t < NA; ++t) {
@@ -358,29 +371,44 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
         const typename EP::Row rc = ep.row(m);
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-          if (nv[j]) ep.store(rc, cc[j], acc[i][j][e]);
+          if (nv[j]) ep.store(rc, cc[j], X3 ? acc[i][j][e] * kX3AccScale : acc[i][j][e]);
       }
     }
 }
 
 // 128x128 tiles unless they would leave more than half of the chip's workgroup slots (2 per CU) empty
+template <class KF>
+inline void gemm_f32_allow_lds(KF kfn, int bytes) {
+#ifndef MDM_EMU
+  if (bytes > 65536) {
+    static bool configured[kMaxDevices] = {};   // per instantiation (KF) and device
+    bool& done = configured[rt_device_ordinal()];
+    if (!done) done = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  }
+#else
+  (void)kfn; (void)bytes;
+#endif
+}
 template <bool X3, class AL, class BL, class EP>
-inline void launch_gemm_f32_t(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream) {
+inline void launch_gemm_f32_t(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream,
+                              int weight_is_a) {
   const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   if (tiles_m * tiles_n < 512 && (size_t)M * N >= 64 * 64 * 4) {
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
     auto kfn = &gemm_f32_kernel<AL, BL, EP, 64, X3>;
-    MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K, tn);
+    gemm_f32_allow_lds(kfn, gemm_f32_lds_bytes(64, X3));
+    MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS), gemm_f32_lds_bytes(64, X3), stream, al, bl, ep, M, N, K, tn, weight_is_a);
     return;
   }
   auto kfn = &gemm_f32_kernel<AL, BL, EP, 128, X3>;
-  MDM_LAUNCH(kfn, dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), 0, stream, al, bl, ep, M, N, K, tiles_n);
+  gemm_f32_allow_lds(kfn, gemm_f32_lds_bytes(128, X3));
+  MDM_LAUNCH(kfn, dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), gemm_f32_lds_bytes(128, X3), stream, al, bl, ep, M, N, K, tiles_n, weight_is_a);
 }
 template <class AL, class BL, class EP>
 inline void launch_gemm_f32(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream,
-                            bool x3 = false) {
-  if (x3) launch_gemm_f32_t<true>(al, bl, ep, M, N, K, stream);
-  else launch_gemm_f32_t<false>(al, bl, ep, M, N, K, stream);
+                            bool x3 = false, bool weight_is_a = false) {
+  if (x3) launch_gemm_f32_t<true>(al, bl, ep, M, N, K, stream, (int)weight_is_a);
+  else launch_gemm_f32_t<false>(al, bl, ep, M, N, K, stream, 0);
 }
 
 }  // namespace mdm

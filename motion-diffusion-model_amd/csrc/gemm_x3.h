@@ -117,6 +117,7 @@ struct X3Epilogue {
   // ---- EMBED (InputProcess, mdm.py:343-349 + :251-252): GEMM row m = (b, t) of [B*T]; the value gets the positional row
   // res[(1 + t) * ld + n] added and is written, as planes, to token row b*S + 1 + t of every branch (S = emb_T + 1)
   int emb_T, emb_B, emb_nbranch;
+  float acc_scale = kX3AccScale;   // accumulators -> value: undoes the 2^8 the weight planes carry (common.h kX3WeightScale)
 };
 
 // exact-GELU with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, i.e. fp32-rounding class): one v_exp, one v_rcp
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void pack_weight_planes_kernel(const float* __
     const int n = (int)(i / k8n), k8 = (int)(i - (size_t)n * k8n);
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (n < N) ? w[(size_t)n * K + 8 * k8 + j] : 0.f;
+    for (int j = 0; j < 8; ++j) v[j] = (n < N) ? w[(size_t)n * K + 8 * k8 + j] * kX3WeightScale : 0.f;
     p16x8 h8, l8;
     split8(v, h8, l8);
     const int kstep = k8 >> 1, half = k8 & 1, lane = (n & 31) + 32 * half;
@@ -562,7 +563,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     float csum = 0.f;
     if constexpr (FOLD) csum = cvec[256 + wid * 32 + r];
     // accumulator values of one round, row-major, -> the GEMM's value:  fold / bias, activation, Q scale
+    const float accs = ep.acc_scale;
     auto finish4 = [&](float4 v4, float2 st) __attribute__((always_inline)) {
+      v4.x *= accs; v4.y *= accs; v4.z *= accs; v4.w *= accs;
       if constexpr (FOLD) {
         v4.x = st.y * (v4.x - st.x * c4.x) + b4.x; v4.y = st.y * (v4.y - st.x * c4.y) + b4.y;
         v4.z = st.y * (v4.z - st.x * c4.z) + b4.z; v4.w = st.y * (v4.w - st.x * c4.w) + b4.w;
@@ -631,9 +634,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
                 for (int j = 0; j < 8; ++j) {
                   if constexpr (FOLD) {
                     const float2 st = atab[32 * t + mfma_row(8 * s2 + j, h)];
-                    vv[j] = st.y * (acc[t][8 * s2 + j] - st.x * csum) + bias;
+                    vv[j] = st.y * (acc[t][8 * s2 + j] * accs - st.x * csum) + bias;
                   } else {
-                    vv[j] = acc[t][8 * s2 + j] + bias;
+                    vv[j] = acc[t][8 * s2 + j] * accs + bias;
                   }
                 }
                 p16x8 vh8, vl8;
@@ -657,9 +660,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
                 for (int e = 0; e < 4; ++e) {
                   if constexpr (FOLD) {
                     const float2 st = atab[192 + 4 * g16 + e];
-                    vv[e] = st.y * (acc16[cb][e] - st.x * c16) + b16;
+                    vv[e] = st.y * (acc16[cb][e] * accs - st.x * c16) + b16;
                   } else {
-                    vv[e] = acc16[cb][e] + b16;
+                    vv[e] = acc16[cb][e] * accs + b16;
                   }
                 }
                 const size_t o = ((shq * ep.qkv.NKT + NT32) * AX_HD + d0 + cl) * 32 + 4 * ((g16 >> 1) + 2 * (g16 & 1));

@@ -322,7 +322,7 @@ int launch_linear_f6_debug(Profiler* pf, const float* in, int ld_in, const float
   MDM_LAUNCH(pack_weight_f16f6_kernel, dim3((npad * (K / 32) + 255) / 256), dim3(256), 0, s, w, wfh, wfl, N, K);
   if (int rc = rt_launch_status()) return rc;
   X3Epilogue ep{out, bias, res, nullptr, nullptr, nullptr, nullptr, N, scale_cols, col_scale, QkvPlanes{}, 0, 0,
-                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1};
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1, 1.f};
   const X3Operand a{reinterpret_cast<const p16_t*>(pa.h16), reinterpret_cast<const p16_t*>(pa.rec)};
   const int rc = launch_gemm_f16f6(a, X3Weights{wfh, wfl}, ep, M, N, K, act, s);
   if (rc != 0) return fail(MDM_EUNSUPPORTED, "f16f6 debug mode: launch failed");
@@ -459,15 +459,6 @@ int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long l
   return rt_launch_status();
 }
 
-// sequence groups of the encoder stack: 0 = automatic (see encoder()), n >= 1 = forced (MDM_ENC_GROUPS, A/B runs)
-inline int enc_groups_setting() {
-  static const int v = [] {
-    const char* e = getenv("MDM_ENC_GROUPS");
-    return (e != nullptr && e[0] >= '0' && e[0] <= '9') ? atoi(e) : 0;
-  }();
-  return v;
-}
-
 // seqTransEncoder: num_layers post-norm layers over ws.tok [nseq*S, D] (in place).
 int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int* lengths, hipStream_t s) {
   Profiler* pf = &m->prof;
@@ -477,61 +468,39 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
     // No LayerNorm kernels: xb = tokh|tokl holds the layer input / the post-FFN PRE-norm sum, xa the post-attention
     // pre-norm sum, each with per-row partial (sum, sum^2) written by its producer; consumers fold the normalisation
     // (gemm_x3.h X3Epilogue).  Layer 0's input (the embedding) is not normalised: plain in_proj, plain residual.
-    // Sequences are independent, so the stack can run over GROUPS of sequences one after the other: with the whole batch
-    // the planes in flight between two launches (Q/K/V^T 352 MB, ffn 207 MB at 256 sequences) exceed the 256 MB Infinity
-    // Cache and every hand-over goes through HBM; half the batch at a time keeps each producer -> consumer hand-over
-    // cache-resident.  Groups must keep every launch a whole number of tiles per CU (gemm_x3.h: 256 sequences x N/256
-    // tiles on 256 CUs), so only an even split of a batch of >= 256 sequences is taken (MDM_ENC_GROUPS overrides: A/B runs).
+    const X3Operand xb{ws.tokh, ws.tokl}, xa{ws.xah, ws.xal}, attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
     const int parts = (D + 255) / 256;
     const float inv_dim = 1.0f / (float)D;
-    int groups = enc_groups_setting();
-    if (groups <= 0) groups = 1;   // (until the A/B on the hardware says otherwise)
-    if (groups > 1 && (nseq % groups != 0 || (nseq / groups) % 8 != 0)) groups = 1;
-    const int ns = nseq / groups, Mg = ns * S;
-    for (int gi = 0; gi < groups; ++gi) {
-    const size_t r0 = (size_t)gi * Mg;                       // first token row of the group
-    const size_t q0 = (size_t)gi * ns * H * ws.qp.SP * AX_HD;  // first element of the group in every Q/K/V^T plane
-    const X3Operand xb{ws.tokh + r0 * D, ws.tokl + r0 * D}, xa{ws.xah + r0 * D, ws.xal + r0 * D},
-        attp{ws.atth + r0 * D, ws.attl + r0 * D}, ffnp{ws.ffnh + r0 * FF, ws.ffnl + r0 * FF};
-    p16_t* const xah = ws.xah + r0 * D; p16_t* const xal = ws.xal + r0 * D;
-    p16_t* const tokh = ws.tokh + r0 * D; p16_t* const tokl = ws.tokl + r0 * D;
-    p16_t* const atth = ws.atth + r0 * D; p16_t* const attl = ws.attl + r0 * D;
-    p16_t* const ffnh = ws.ffnh + r0 * FF; p16_t* const ffnl = ws.ffnl + r0 * FF;
-    float* const stat1 = ws.stat1 + r0 * parts * 2; float* const stat2 = ws.stat2 + r0 * parts * 2;
-    const QkvPlanes qp{ws.qp.qh + q0, ws.qp.ql + q0, ws.qp.kh + q0, ws.qp.kl + q0, ws.qp.vh + q0, ws.qp.vl + q0,
-                       ws.qp.SP, ws.qp.NKT, ws.qp.H};
-    // key-padding lengths are indexed seq % B: a group of whole branches keeps the pointer, a group inside a branch moves it
-    const int* glen = lengths == nullptr ? nullptr : lengths + ((size_t)gi * ns) % B;
-    const int gB = (ns % B == 0) ? B : ns;                  // (ns divides B or is a multiple of it: nseq = B or 2B)
+    // (Running the stack over two half-batches, so that every producer -> consumer hand-over stays inside the 256 MB Infinity
+    // Cache, was built and measured: 1.5 % SLOWER on the same box -- profiles/r02_ab.md -- and removed.)
     for (int l = 0; l < m->cfg.num_layers; ++l) {
       const mdm_model::LayerPlanes& P = m->planes[l];
       const mdm_model::LayerFold& F = m->fold[l];
       if (l == 0) {
-        if (int rc = launch_in_proj_x3(pf, xb, P.in_proj, m->L(l, "self_attn.in_proj_bias"), qp, ns, S, D, qscale, s)) return rc;
+        if (int rc = launch_in_proj_x3(pf, xb, P.in_proj, m->L(l, "self_attn.in_proj_bias"), ws.qp, nseq, S, D, qscale, s)) return rc;
       } else {
-        LnArgs a; a.astat = stat2; a.colsum = F.c_qkv; a.parts = parts; a.inv_dim = inv_dim;
-        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, xb, F.in_proj, F.b_qkv, a, nullptr, nullptr, nullptr, &qp, Mg,
+        LnArgs a; a.astat = ws.stat2; a.colsum = F.c_qkv; a.parts = parts; a.inv_dim = inv_dim;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, xb, F.in_proj, F.b_qkv, a, nullptr, nullptr, nullptr, &ws.qp, M,
                                   3 * D, D, S, D, D, qscale, s)) return rc;
       }
-      if (int rc = launch_attention_x3(pf, qp, glen, ns, gB, S, D, nullptr, atth, attl, s)) return rc;
+      if (int rc = launch_attention_x3(pf, ws.qp, lengths, nseq, B, S, D, nullptr, ws.atth, ws.attl, s)) return rc;
       {  // xa = att.Wo + bo + layer input (normalised on the fly for l >= 1), + row statistics
-        LnArgs a; a.res = xb; a.ostat = stat1; a.parts = parts; a.inv_dim = inv_dim;
-        if (l >= 1) { a.rstat = stat2; a.rgamma = m->L(l - 1, "norm2.weight"); a.rbeta = m->L(l - 1, "norm2.bias"); }
+        LnArgs a; a.res = xb; a.ostat = ws.stat1; a.parts = parts; a.inv_dim = inv_dim;
+        if (l >= 1) { a.rstat = ws.stat2; a.rgamma = m->L(l - 1, "norm2.weight"); a.rbeta = m->L(l - 1, "norm2.bias"); }
         if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, l == 0 ? 1 : 2, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"),
-                                  a, nullptr, xah, xal, nullptr, Mg, D, D, S, D, 0, 1.f, s)) return rc;
+                                  a, nullptr, ws.xah, ws.xal, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
       }
       {  // ffn = gelu(LN1(xa).W1 + b1), LN1 folded
-        LnArgs a; a.astat = stat1; a.colsum = F.c_1; a.parts = parts; a.inv_dim = inv_dim;
-        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 3, xa, F.linear1, F.b_1, a, nullptr, ffnh, ffnl, nullptr, Mg, FF,
+        LnArgs a; a.astat = ws.stat1; a.colsum = F.c_1; a.parts = parts; a.inv_dim = inv_dim;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 3, xa, F.linear1, F.b_1, a, nullptr, ws.ffnh, ws.ffnl, nullptr, M, FF,
                                   D, S, D, 0, 1.f, s)) return rc;
       }
       {  // xb = ffn.W2 + b2 + LN1(xa), + row statistics
-        LnArgs a; a.res = xa; a.rstat = stat1; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias");
-        a.ostat = stat2; a.parts = parts; a.inv_dim = inv_dim;
-        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, ffnp, P.linear2, m->L(l, "linear2.bias"), a, nullptr, tokh,
-                                  tokl, nullptr, Mg, D, FF, S, D, 0, 1.f, s)) return rc;
+        LnArgs a; a.res = xa; a.rstat = ws.stat1; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias");
+        a.ostat = ws.stat2; a.parts = parts; a.inv_dim = inv_dim;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, ffnp, P.linear2, m->L(l, "linear2.bias"), a, nullptr, ws.tokh,
+                                  ws.tokl, nullptr, M, D, FF, S, D, 0, 1.f, s)) return rc;
       }
-    }
     }
     return 0;   // the encoder's output is LN2(L-1)(xb): folded into OutputProcess (outproj_x3)
   }
@@ -958,7 +927,7 @@ int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const i
   ep.out = out;
   ep.T = pred_len; ep.JF = m->jf; ep.mode = 0;
   ProfScope ps(pf, MDM_PROF_OUTPROJ, 2.0 * nseq * pred_len * (double)D * m->jf, s);
-  launch_gemm_f32(al, bl, ep, m->jf, nseq * pred_len, D, s, x3);
+  launch_gemm_f32(al, bl, ep, m->jf, nseq * pred_len, D, s, x3, /*weight_is_a=*/true);
   return rt_launch_status();
 }
 
@@ -1217,7 +1186,7 @@ int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const f
   }
   if (fast) {
     X3Epilogue ep{out, bias, res, nullptr, nullptr, nullptr, nullptr, N, 0, 1.f, QkvPlanes{}, 0, 0,
-                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1};
+                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1, 1.f};
     const X3Operand a{reinterpret_cast<const p16_t*>(pa.h16), reinterpret_cast<const p16_t*>(pa.rec)};
     const int rc = launch_gemm_f16f6(a, X3Weights{wfh, wfl}, ep, M, N, K, act, s);
     if (rc == -1) return fail(MDM_EHIP, "mdm_linear_f16f6: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");

@@ -409,9 +409,24 @@ class GaussianDiffusion:
                 seed=seed, sample_base=base, clip_denoised=clip_denoised,
                 force_uncond=bool(y.get('uncond', False)) or mdm.cond_mode == 'no_cond',
                 dump_steps=kept, const_noise=const_noise)
+        self._check_finite(out, mdm)
         if dump_steps is not None:      # the reference appends in loop order (:654-657)
             return [dumps[j] for j in range(len(kept))] if kept else []
         return out
+
+    @staticmethod
+    def _check_finite(sample, mdm):
+        """The fp16 operand planes of the default mode do not saturate: an activation beyond +-65504 turns into inf and the
+        sample into NaN.  One reduction per LOOP (the caller reads the sample back right after, sample/generate.py:163)
+        makes that loud and actionable.  MDM_CHECK_FINITE=0 skips it (fully asynchronous pipelines)."""
+        import os
+        if os.environ.get("MDM_CHECK_FINITE", "1") == "0" or bool(torch.isfinite(sample).all()):
+            return
+        raise FloatingPointError(
+            "the sampling loop produced non-finite values" + (
+                ": in the default precision='f16x3' the GEMM operands live as fp16 hi+lo planes (|x| <= 65504); this "
+                "checkpoint's activations probably leave that range -- construct the model with precision='f32' "
+                "(or MDM_PRECISION=f32)" if mdm.precision != "f32" else " in the exact-fp32 mode: check the checkpoint / inputs"))
 
     def _loop_stepwise(self, model, mdm, shape, coefs, noise, clip_denoised, model_kwargs, device, skip_timesteps,
                        init_image, dump_steps, noise_sequence, seed, const_noise=False):
@@ -446,6 +461,7 @@ class GaussianDiffusion:
                 img = out["sample"]
                 if dump_steps is not None and k in dump_steps:       # the loop's enumerate index (:637-655), not t
                     dumps.append(img.clone())
+        self._check_finite(img, mdm)
         return dumps if dump_steps is not None else img
 
     # ---- progressive generators (the reference yields per step; kept for callers that iterate) ---------

@@ -196,9 +196,10 @@ def test_hostile_weights_forward_and_loop(golden_dir, prec):
 # ---------------------------------------------------------------------------------------------------
 # the fp16 operand planes: subnormals, range
 # ---------------------------------------------------------------------------------------------------
-def test_fp16_planes_keep_subnormals_and_saturate(sd):
+def test_fp16_planes_keep_subnormals_and_fail_loudly_out_of_range(sd):
     """mdm_linear_x3 against fp64 on operands far outside the comfortable range: tiny activations (the lo plane is entirely
-    fp16-subnormal: the MFMA must not flush it) and large ones (up to 1e5 > 65504: hi saturates, lo carries the rest)."""
+    fp16-subnormal: the MFMA must not flush it), large ones inside fp16's range -- and beyond it (|x| > 65504) the result
+    must be non-finite, not a plausible wrong number; the sampler seam turns that into an actionable error."""
     from mdm_amd import _native
     lib = _native.load_native()
     M, N, K = 197 * 4, 512, 512
@@ -207,17 +208,32 @@ def test_fp16_planes_keep_subnormals_and_saturate(sd):
     b = torch.zeros(N)
     nb = lib.mdm_linear_x3_scratch_bytes(M, N, K)
     scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
-    for scale, rel in ((1.0, 2e-6), (1e-3, 2e-5), (3e-5, 1e-3), (3e4, 2e-4)):   # (flushed subnormals would give 3e-5 / 1 / -)
-        a = torch.randn(M, K, generator=g) * scale
-        if scale > 1e3:
-            a[::7, ::5] = 1.0e5                                   # beyond fp16's largest finite value
+
+    def run(a):
         out = torch.empty(M, N, device=DEV)
         lib.check(lib.mdm_linear_x3(a.to(DEV).data_ptr(), w.to(DEV).data_ptr(), b.to(DEV).data_ptr(), None, out.data_ptr(),
                                     M, N, K, 0, scratch.data_ptr(), nb, torch.cuda.current_stream().cuda_stream), "mdm_linear_x3")
+        return out.cpu()
+
+    for scale, rel in ((1.0, 2e-6), (1e-3, 3e-5), (3e-5, 1.5e-3), (1e4, 2e-6)):   # (flushed subnormals would give 3e-5 / 1)
+        a = torch.randn(M, K, generator=g) * scale
+        out = run(a)
         ref = a.double() @ w.double().t()
-        err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+        err = float((out.double() - ref).abs().max() / ref.abs().max())
         print(f"[parity] mdm_linear_x3 operand scale {scale:g}: max error / max|out| = {err:.2e}")
         assert torch.isfinite(out).all() and err < rel
+    a = torch.randn(M, K, generator=g)
+    a[5, 7] = 1.0e5                                           # beyond fp16's largest finite value
+    assert not torch.isfinite(run(a)[5]).all()
+    # ... and through the seams: a checkpoint whose activations overflow is reported, with the way out
+    bad = {k: v.clone() for k, v in sd.items()}
+    bad["input_process.poseEmbedding.bias"][3] = 2.0e5
+    model, diffusion = make_pair(bad, 4, DEV, guided=True)
+    y = synth_y(2, 16, seed=1)
+    with pytest.raises(FloatingPointError, match="precision='f32'"):
+        diffusion.p_sample_loop(model, (2, 263, 1, 16), clip_denoised=False, model_kwargs={"y": dict(y)}, seed=1)
+    model, diffusion = make_pair(bad, 4, DEV, guided=True, precision="f32")
+    assert torch.isfinite(diffusion.p_sample_loop(model, (2, 263, 1, 16), clip_denoised=False, model_kwargs={"y": dict(y)}, seed=1)).all()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -19,5 +19,5 @@ d = json.load(open(sys.argv[1]))
 print("bench", d["value"], d["unit"], "kernel_ms", d["kernel_ms"]); print("f32_mode", d.get("f32_mode")); print("dip", {k: d["dip"][k] for k in ("value", "ms_per_step", "dtype", "kernel_ms", "roofline")})
 PY
 tail -3 $OUT/bench.err
-BENCH_ARGS="--no-extras" bash tools/gpu_ab.sh $TAG/ab 2 default build/ab/libmdm_f16nc.so build/ab/libmdm_bf16.so env:MDM_ENC_GROUPS=2
+BENCH_ARGS="--no-extras" bash tools/gpu_ab.sh $TAG/ab 2 default build/ab/libmdm_f16nc.so build/ab/libmdm_bf16.so
 ls $OUT
