@@ -120,13 +120,17 @@ struct LinearEpilogue {
   struct Col { int n; float bias, mult; };
   __device__ __forceinline__ Row row(int m) const { return Row{(size_t)m * ld}; }
   __device__ __forceinline__ Col col(int n) const { return Col{n, bias[n], n < scale_cols ? col_scale : 1.f}; }
-  __device__ __forceinline__ void store(const Row& r, const Col& c, float acc) const {
+  // pre(): what store() needs from memory for this element, fetched for ALL of a lane's elements before the first store --
+  // `res` may alias `out` (in-place residual), so a load behind a store cannot be hoisted by the compiler and the epilogue
+  // degenerated into 16 serial load -> store round trips per lane (the DiP decoder's small GEMMs spent most of their time there)
+  __device__ __forceinline__ float pre(const Row& r, const Col& c) const { return res != nullptr ? res[r.base + c.n] : 0.f; }
+  __device__ __forceinline__ void store(const Row& r, const Col& c, float acc, float resv) const {
     float v = acc + c.bias;
     if (act == ACT_GELU) v = gelu_erf(v);
     else if (act == ACT_SILU) v = silu(v);
     v *= c.mult;
     const size_t o = r.base + c.n;
-    if (res != nullptr) v += res[o];
+    v += resv;
     if (out != nullptr) out[o] = v;
     if (oh != nullptr) split_p16(v, oh[o], ol[o]);
   }
@@ -149,8 +153,9 @@ struct EmbedEpilogue {
     return Row{((size_t)b * S + lead + t) * D, (size_t)(lead + t) * D};
   }
   __device__ __forceinline__ Col col(int n) const { return Col{n, bias[n]}; }
-  __device__ __forceinline__ void store(const Row& r, const Col& c, float acc) const {
-    const float v = acc + c.bias + pe[r.pe_off + c.n];
+  __device__ __forceinline__ float pre(const Row& r, const Col& c) const { return pe[r.pe_off + c.n]; }
+  __device__ __forceinline__ void store(const Row& r, const Col& c, float acc, float pev) const {
+    const float v = acc + c.bias + pev;
     tok[r.tok_off + c.n] = v;
     if (nbranch == 2) tok[r.tok_off + (size_t)B * S * D + c.n] = v;
     if (th != nullptr) {
@@ -203,13 +208,16 @@ struct OutProjEpilogue {
     const int b = n / T, t = n - b * T;
     return Col{(size_t)b * JF * T + t};
   }
-  __device__ __forceinline__ void store(const Row& r, const Col& c, float acc) const {
+  __device__ __forceinline__ float pre(const Row& r, const Col& c) const {
+    return (mode != 0) ? x_t[c.base + r.off] : 0.f;     // x_t aliases out in the fused loop (in-place update)
+  }
+  __device__ __forceinline__ void store(const Row& r, const Col& c, float acc, float xt) const {
     const size_t off = c.base + r.off;
     float x0 = acc + r.bias;
     if (mode == 0) { out[off] = x0; return; }
     if (inpaint_mask != nullptr && inpaint_mask[off]) x0 = inpaint_motion[off];
     if (co.clip_denoised) x0 = fminf(1.f, fmaxf(-1.f, x0));
-    float v = co.a_x0 * x0 + co.a_xt * x_t[off];
+    float v = co.a_x0 * x0 + co.a_xt * xt;
     if (noise != nullptr) v += co.sigma * noise[off];
     if (x0_out != nullptr) x0_out[off] = x0;
     out[off] = v;
@@ -362,6 +370,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
     nv[j] = n < N;
     cc[j] = ep.col(nv[j] ? n : 0);
   }
+  // two passes: everything the stores need from memory first (see LinearEpilogue::pre), then the stores
+  float pv[NA][16][NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * WT + i * 32 + mfma_row(e, h);
+#pragma unroll
+      for (int j = 0; j < NA; ++j) pv[i][e][j] = (m < M && nv[j]) ? ep.pre(ep.row(m), cc[j]) : 0.f;
+    }
 #pragma unroll
   for (int i = 0; i < NA; ++i)
 #pragma unroll
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
         const typename EP::Row rc = ep.row(m);
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-          if (nv[j]) ep.store(rc, cc[j], X3 ? acc[i][j][e] * kX3AccScale : acc[i][j][e]);
+          if (nv[j]) ep.store(rc, cc[j], X3 ? acc[i][j][e] * kX3AccScale : acc[i][j][e], pv[i][e][j]);
       }
     }
 }

@@ -161,9 +161,11 @@ def test_const_noise_matches_reference_and_broadcasts_sample_zero(golden_dir, sd
 def test_hostile_weights_forward_and_loop(golden_dir, prec):
     """Outlier channels (|beta|, bias 50-300x), LayerNorm gamma in [0.05, 8], 10x weight rows, 20x text embedding
     (oracle/synth.py synth_state_dict_hostile).  These weights amplify rounding noise, so the fixtures record the reference
-    arithmetic's OWN noise `floor` = |reference fp32 - fp64 oracle|; the bars are the unchanged tolerances or three floors,
-    whichever is larger -- measured against fp64 truth for the loop.  (The round-1 bf16 split is 10x the floor here:
-    tools/precision_probe.py --hostile; the folded LayerNorm's statistics are merged Chan-style, gemm_x3.h.)"""
+    arithmetic's OWN noise `floor` = |reference fp32 - fp64 oracle|; the bars are the unchanged tolerances or a multiple of
+    that floor, whichever is larger -- measured against fp64 truth for the loop: 3 floors for the exact-fp32 mode, 6 for the
+    split mode (22-bit products against fp32's 24: a factor 4 by construction).  The round-1 bf16 split is ~100 floors here
+    (tools/precision_probe.py --hostile); the folded LayerNorm's statistics are merged Chan-style (gemm_x3.h)."""
+    K = {"f32": 3.0, "f16x3": 6.0}[prec]
     sdh = synth_state_dict_hostile(0)
     g = _g(golden_dir, "hostile_fwd_B2_T196")
     B, T = 2, 196
@@ -175,8 +177,8 @@ def test_hostile_weights_forward_and_loop(golden_dir, prec):
     og = model(x.to(DEV), t.to(DEV), y=dict(y)).cpu()
     e_c, e_g = maxabs(oc, g["out_cond"]), maxabs(og, g["out_cfg"])
     print(f"[parity] hostile fwd {prec}: cond {e_c:.3e} (floor {float(g['floor_cond']):.1e}), cfg {e_g:.3e} (floor {float(g['floor_cfg']):.1e})")
-    assert e_c < max(TOL_FWD[prec], 3 * float(g["floor_cond"]))
-    assert e_g < max(4 * TOL_FWD[prec], 3 * float(g["floor_cfg"]))
+    assert e_c < max(TOL_FWD[prec], K * float(g["floor_cond"]))
+    assert e_g < max(4 * TOL_FWD[prec], K * float(g["floor_cfg"]))
     g = _g(golden_dir, "hostile_loop50_B2_T196")
     steps, seed = int(g["steps"]), int(g["seed"])
     shape = (B, 263, 1, T)
@@ -190,7 +192,8 @@ def test_hostile_weights_forward_and_loop(golden_dir, prec):
     e_ref, e_64 = maxabs(out, g["final"]), maxabs(out, truth)
     print(f"[parity] hostile loop50 {prec}: vs reference {e_ref:.3e}, vs fp64 {e_64:.3e} (reference's own {floor:.1e}; |x0| max "
           f"{float(np.abs(g['final']).max()):.1f})")
-    assert e_64 < max(TOL_LOOP[prec], 3 * floor) and e_ref < max(TOL_LOOP[prec], 4 * floor)
+    assert e_64 < max(TOL_LOOP[prec], K * floor) and e_ref < max(TOL_LOOP[prec], (K + 1) * floor)
+    assert e_64 < 1e-3                                           # BASELINE's bar, even on these weights
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -209,10 +212,13 @@ def test_fp16_planes_keep_subnormals_and_fail_loudly_out_of_range(sd):
     nb = lib.mdm_linear_x3_scratch_bytes(M, N, K)
     scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
 
+    wd, bd = w.to(DEV), b.to(DEV)
+
     def run(a):
-        out = torch.empty(M, N, device=DEV)
-        lib.check(lib.mdm_linear_x3(a.to(DEV).data_ptr(), w.to(DEV).data_ptr(), b.to(DEV).data_ptr(), None, out.data_ptr(),
+        ad, out = a.to(DEV), torch.empty(M, N, device=DEV)        # (kept alive across the asynchronous call)
+        lib.check(lib.mdm_linear_x3(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, out.data_ptr(),
                                     M, N, K, 0, scratch.data_ptr(), nb, torch.cuda.current_stream().cuda_stream), "mdm_linear_x3")
+        torch.cuda.synchronize()
         return out.cpu()
 
     for scale, rel in ((1.0, 2e-6), (1e-3, 3e-5), (3e-5, 1.5e-3), (1e4, 2e-6)):   # (flushed subnormals would give 3e-5 / 1)
