@@ -60,6 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the f32_mode and dip sub-records")
     # test infrastructure (tests/test_bench_launcher.py): the same launcher / sharding / gather / JSON code on CPU --
     # gloo ranks, kernels in the CPU emulator, a tiny model.  Never a measurement.
+    ap.add_argument("--force-pg", action="store_true",
+                    help="N = 1 only: still create the (one-rank) RCCL process group and run the gather through it")
     ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--layers", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--latent-dim", type=int, default=512, help=argparse.SUPPRESS)
@@ -181,7 +183,7 @@ def main(argv=None):
     from mdm_amd.cfg_sampler import ClassifierFreeSampleModel
 
     backend = "gloo" if a.emulate else "nccl"
-    rank, world, local = mdist.init_from_env(backend)
+    rank, world, local = mdist.init_from_env(backend, force=a.force_pg and a.gpus == 1)
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}")
     native_lib = None
@@ -218,7 +220,7 @@ def main(argv=None):
 
     def fence():
         sync()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         sync()
 
@@ -311,7 +313,7 @@ def main(argv=None):
         if world == 1 and not a.no_cpu_baseline and not a.emulate:
             line["cpu_baseline"] = cpu_baseline(state, T, DS)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

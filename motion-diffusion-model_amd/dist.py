@@ -14,12 +14,18 @@ import torch.distributed as dist
 _SHARDED_KEYS = ("mask", "lengths", "scale", "inpainting_mask", "inpainted_motion")
 
 
-def init_from_env(backend=None):
-    """Join the process group torchrun describes (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*); no-op single-process."""
+def init_from_env(backend=None, force=False):
+    """Join the process group torchrun describes (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*); no-op single-process unless
+    `force` (a one-rank group: exercises the RCCL bring-up and the collective on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -54,7 +60,7 @@ def shard_y(y, lo, hi):
 
 def all_gather_samples(local, B, world):
     """Gather the per-rank shards into the full batch on every rank (shards may be ragged by one sample)."""
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return local
     sizes = [shard_bounds(B, r, world)[1] - shard_bounds(B, r, world)[0] for r in range(world)]
     if len(set(sizes)) == 1:

@@ -188,7 +188,7 @@ def test_emulated_recover_from_ric(lib):
         assert maxabs(got, want) < 2e-6 * float(np.abs(want).max())
 
 
-@pytest.mark.parametrize("masked,prec", [(False, "f16x3"), (True, "f16x3"), (True, "f32")])
+@pytest.mark.parametrize("masked,prec", [(False, "f16x3"), (True, "f32")])
 def test_emulated_dip_decoder_forward(lib, masked, prec):
     """trans_dec denoiser: prefix completion, token-level text memory with ragged lengths, cross-attention
     with a different key count than queries, both CFG branches, through MDM.forward / ClassifierFreeSampleModel."""
