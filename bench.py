@@ -243,6 +243,15 @@ def main(argv=None):
 
     dt = timed(a.steps, a.warmup, 100)
 
+    def flush_c_stdio():
+        # RCCL printf()s a version banner into C stdio's buffer at communicator creation; flushed only at exit it would land
+        # BEHIND the JSON line.  Push it out now so that the JSON line is the last line of stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+
     # ---- per-kernel-class timing of one more pass (rank 0's GPU), hipEvents on the launch stream
     eng = mdm.engine()
     eng.profile(True)
@@ -312,10 +321,12 @@ def main(argv=None):
             line["dip"] = dip
         if world == 1 and not a.no_cpu_baseline and not a.emulate:
             line["cpu_baseline"] = cpu_baseline(state, T, DS)
-        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

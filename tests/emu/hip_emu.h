@@ -49,8 +49,28 @@ namespace emu {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short p16x8 __attribute__((ext_vector_type(8)));
 
+// Context switches: ucontext's swapcontext() makes two sigprocmask system calls per switch, and a lock-step emulation of a
+// 512-thread workgroup switches at every barrier / wave collective -- a third of the suite's time was kernel time.  On x86-64
+// the fibers switch through a six-register stack swap instead; other hosts keep ucontext.
+#if defined(__x86_64__)
+#define MDM_EMU_FASTCTX 1
+struct LightCtx { void* sp = nullptr; };
+extern "C" __attribute__((naked, noinline)) inline void mdm_emu_switch(LightCtx* /*from: rdi*/, LightCtx* /*to: rsi*/) {
+  asm volatile(
+      "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+      "movq %rsp, (%rdi)\n\t"
+      "movq (%rsi), %rsp\n\t"
+      "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\t"
+      "ret");
+}
+#endif
+
 struct Fiber {
+#ifdef MDM_EMU_FASTCTX
+  LightCtx ctx;
+#else
   ucontext_t ctx;
+#endif
   char* stack = nullptr;
   bool done = false;
   dim3 tid;
@@ -77,7 +97,11 @@ struct Block {
   unsigned bar_gen = 0;
   dim3 bid, bdim, gdim;
   char* dyn = nullptr;
+#ifdef MDM_EMU_FASTCTX
+  LightCtx sched;
+#else
   ucontext_t sched;
+#endif
   int cur = 0;
   const std::function<void()>* body = nullptr;
 };
@@ -88,7 +112,11 @@ inline Fiber& cur() { return blk().fibers[blk().cur]; }
 inline int lane_id() { return blk().cur & 63; }
 inline int wave_id() { return blk().cur >> 6; }
 
+#ifdef MDM_EMU_FASTCTX
+inline void yield() { Block& b = blk(); mdm_emu_switch(&b.fibers[b.cur].ctx, &b.sched); }
+#else
 inline void yield() { Block& b = blk(); swapcontext(&b.fibers[b.cur].ctx, &b.sched); }
+#endif
 
 inline void block_barrier() {
   Block& b = blk();
@@ -289,7 +317,12 @@ inline void fiber_entry() {
   Block& b = blk();
   (*b.body)();
   b.fibers[b.cur].done = true;
+#ifdef MDM_EMU_FASTCTX
+  mdm_emu_switch(&b.fibers[b.cur].ctx, &b.sched);
+  __builtin_trap();      // a finished fiber is never resumed
+#else
   swapcontext(&b.fibers[b.cur].ctx, &b.sched);
+#endif
 }
 
 inline void run_block(Block& b) {
@@ -299,18 +332,32 @@ inline void run_block(Block& b) {
     Fiber& f = b.fibers[t];
     f.done = false;
     if (!f.stack) f.stack = (char*)malloc(STK);
+#ifdef MDM_EMU_FASTCTX
+    // initial frame: six zeroed callee-saved registers, then fiber_entry as the return address, placed so that the stack is
+    // 16-byte aligned + 8 at fiber_entry's first instruction (as after a call)
+    uintptr_t top = ((uintptr_t)f.stack + STK) & ~(uintptr_t)15;
+    void** sp = (void**)(top - 16);
+    *sp = (void*)(void (*)())fiber_entry;
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    f.ctx.sp = sp;
+#else
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = f.stack;
     f.ctx.uc_stack.ss_size = STK;
     f.ctx.uc_link = &b.sched;
     makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+#endif
   }
   int remaining = b.nthreads;
   while (remaining > 0) {
     for (int t = 0; t < b.nthreads; ++t) {
       if (b.fibers[t].done) continue;
       b.cur = t;
+#ifdef MDM_EMU_FASTCTX
+      mdm_emu_switch(&b.sched, &b.fibers[t].ctx);
+#else
       swapcontext(&b.sched, &b.fibers[t].ctx);
+#endif
       if (b.fibers[t].done) --remaining;
     }
   }

@@ -267,3 +267,24 @@ def test_non_prefix_frame_mask_raises_and_broadcast_inpainting_mask_works(sd):
     yi["inpainted_motion"] = torch.randn(B, 263, 1, T)
     o = diffusion.p_sample(model, x, t, clip_denoised=False, model_kwargs={"y": yi})
     assert torch.equal(o["pred_xstart"][:, :4].cpu(), yi["inpainted_motion"][:, :4])
+
+
+def test_dip_dump_steps_are_loop_indices():
+    """p_sample_loop(dump_steps=...) on the step-at-a-time (trans_dec) path must snapshot by the loop's enumerate
+    index k (gaussian_diffusion.py:637-655), like the fused loop -- not by the descending timestep."""
+    from helpers import synth_dip_state_dict, synth_dip_y, to_dev
+    sdd = synth_dip_state_dict(seed=0)
+    steps, B = 10, 2
+    model, diffusion = make_pair(sdd, steps, DEV, guided=True, context_len=20, pred_len=40)
+    y = to_dev(synth_dip_y(B, 40, 20, seed=4, text_lengths=[7, 12]), DEV)
+    shape = (B, 263, 1, 40)
+    x_T, noises = orc.make_noise(shape, steps, 5)
+    seq = [x_T] + [n.contiguous() for n in noises]
+    traj = [o["sample"].clone() for o in diffusion.p_sample_loop_progressive(model, shape, clip_denoised=False,
+                                                                              model_kwargs={"y": y}, noise_sequence=seq)]
+    dumps = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, noise_sequence=seq,
+                                    dump_steps=[0, 3, 9])
+    assert len(dumps) == 3
+    for d, k in zip(dumps, (0, 3, 9)):
+        assert torch.equal(d, traj[k])
+    assert not torch.equal(dumps[0], traj[-1])
