@@ -1,12 +1,12 @@
-// Fused multi-head self-attention for the MDM encoder in split precision (three bf16 MFMA products per fp32
-// product, fp32 accumulate -- the same arithmetic class as gemm_x3.h), fed by the bf16 hi/lo planes that the
+// Fused multi-head self-attention for the MDM encoder in split precision (three 16-bit MFMA products per fp32
+// product, fp32 accumulate -- the same arithmetic class as gemm_x3.h), fed by the fp16 hi/lo planes that the
 // in_proj GEMM's epilogue writes in exactly the layouts this kernel wants.
 //
 // Replaces, per layer, torch's head split / scaled_dot_product_attention / head merge
 // (F.multi_head_attention_forward under nn.TransformerEncoderLayer, model/mdm.py:77-84, :253) and
 // the key-padding mask of mdm.py:241-247.  The exact-fp32 kernel (attention_f32.h) remains the `f32` mode.
 //
-// Operand planes (all bf16, hi and lo; SP = tokens padded to a multiple of 32, NKT = SP/32):
+// Operand planes (all 16-bit -- fp16 by default, common.h kSplitF16 --, hi and lo; SP = tokens padded to a multiple of 32, NKT = SP/32):
 //   Q, K   [nseq][H][SP][128]            row = token, Q pre-scaled by 1/sqrt(128); pad rows (>= S): never read
 //   V^T    [nseq][H][NKT][128][32]       per 32-key tile: row = d, 32 keys of that tile in MFMA ORDER: inside each
 //                                        group of 16 keys, position p holds key (p&3) + 8*((p>>2)&1) + 4*(p>>3).

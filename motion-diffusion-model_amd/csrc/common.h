@@ -340,7 +340,7 @@ template <int N> __device__ __forceinline__ void vmem_wait(f32x4& a, f32x4& b, f
 }
 #endif
 
-// 8-byte flavour (four bf16 of one plane): the residual stream of the f16x3 mode lives only as hi/lo planes
+// 8-byte flavour (four 16-bit elements of one plane): the residual stream of the f16x3 mode lives only as hi/lo planes
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifdef MDM_EMU
 __device__ __forceinline__ void gload8_async(u32x2& dst, const void* p) { memcpy(&dst, p, 8); }

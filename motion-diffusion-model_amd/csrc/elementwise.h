@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void outproj_finish_kernel(const float* __rest
   }
 }
 
-// InputProcess operand for the split-precision GEMM: poses x [B][JF][T] (frames contiguous) -> bf16 hi/lo planes
+// InputProcess operand for the split-precision GEMM: poses x [B][JF][T] (frames contiguous) -> 16-bit hi/lo planes
 // [B*T][KP] (row = (b, t), features contiguous, zero-padded from JF to KP) -- the permute of mdm.py:345 as a 32x32 LDS
 // tile transpose.  grid (ceil(T/32), KP/32, B), 256 threads.
 __global__ __launch_bounds__(256) void pose_to_planes_kernel(const float* __restrict__ x, p16_t* __restrict__ ph,
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __rest
   if (lane == 0) { colsum[n] = csf; biasf[n] = bias[n] + bsf; }
 }
 
-// hi/lo bf16 planes of a fp32 array (weights at mdm_prepare; test inputs).  n must be a multiple of 4.
+// hi/lo 16-bit planes of a fp32 array (weights at mdm_prepare; test inputs).  n must be a multiple of 4.
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, p16_t* __restrict__ hi,
                                                            p16_t* __restrict__ lo, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)

@@ -3,7 +3,7 @@
 // ah = fp16(a), al = a - ah (same for w); q6 = MX-FP6 (OCP Microscaling E2M3) with one power-of-two scale (E8M0) per 32
 // consecutive k.  The main term is ONE v_mfma_f32_32x32x16_f16 pass; the two cross terms -- 2^-11 of it, so ~5 bits do -- run on
 // v_mfma_scale_f32_32x32x64_f8f6f4, which gfx950 executes at four times the fp16 rate: 1.5 pass-equivalents instead of the
-// three bf16 passes of gemm_x3.h (measured at the matrix pipe: 1.75x; 50-step trajectory error 9.8e-5 vs 4.4e-5, bar 1e-3:
+// three 16-bit passes of gemm_x3.h (measured at the matrix pipe: 1.75x; 50-step trajectory error 9.8e-5 vs 4.4e-5 for bf16x3, bar 1e-3:
 // tools/precision_probe.py, tools/mx/, profiles/r01h_*).  Replaces nothing in the reference that gemm_x3.h does not
 // already replace (the `addmm`s of model/mdm.py:77-84).
 //
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void pack_f16f6_kernel(const float* __restrict
 }
 
 // Weights fp32 [N][K] -> the fragment-ordered planes the production k-loop streams straight into registers (gemm_x3.h
-// header: [n/32][k/16][lane][16 B], rows >= N zero): plane `hi` holds fp16 values where f16x3 holds bf16; plane `lo` holds,
+// header: [n/32][k/16][lane][16 B], rows >= N zero): plane `hi` holds fp16 values (unscaled: gemm_x3.h's own planes hold w * 2^8); plane `lo` holds,
 // per 32-k block, for B-operand lane half 0 the codes of LO and for half 1 the codes of HI (the scaled MFMA pairs them with
 // the A operand's hi / lo codes): k16 slot 2 kb: code dwords c0-c3, slot 2 kb + 1: [c4, c5, scale, 0].  One thread per (n, block).
 __global__ __launch_bounds__(256) void pack_weight_f16f6_kernel(const float* __restrict__ w, p16_t* __restrict__ hi,

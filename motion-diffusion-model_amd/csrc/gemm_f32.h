@@ -105,7 +105,7 @@ struct CfgTokenLoader {
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
 
 // v = act(acc + bias[n]) * (n < scale_cols ? col_scale : 1) + (res ? res[m][n] : 0);
-// out[m][n] = v (if out) and/or the bf16 split planes oh/ol[m][n] = hi/lo(v) (if oh) for a following f16x3 GEMM.
+// out[m][n] = v (if out) and/or the 16-bit split planes oh/ol[m][n] = hi/lo(v) (if oh) for a following f16x3 GEMM.
 struct LinearEpilogue {
   float* out;        // may be null when only the planes are wanted
   const float* bias;

@@ -1,16 +1,17 @@
-// Split-precision ("f16x3") MFMA GEMM for the encoder's dense contractions:
-//     C[m][n] = sum_k A[m][k] * W[n][k],   A = Ah + Al,  W = Wh + Wl  (bf16 planes, see common.h split_p16)
-//             ~ sum_k  Ah*Wh + Ah*Wl + Al*Wh            three v_mfma_f32_32x32x16_bf16 passes, fp32 accumulate.
+// Split-precision ("f16x3"; round 1: "bf16x3") MFMA GEMM for the encoder's dense contractions:
+//     C[m][n] = sum_k A[m][k] * W[n][k],   A = Ah + Al,  W = Wh + Wl  (16-bit planes: fp16 by default, common.h kSplitF16 / split_p16)
+//             ~ sum_k  Ah*Wh + Ah*Wl + Al*Wh            three v_mfma_f32_32x32x16_f16 passes, fp32 accumulate.
 //
 // Why: the reference computes these `addmm`s in fp32 (model/mdm.py:77-84 -> torch TransformerEncoderLayer) and
 // BASELINE's parity bar is 1e-3 max-abs over a 50-step guided trajectory.  gfx950 has no TF32; exact-fp32 MFMA
-// peaks at 157 TFLOP/s, bf16 MFMA at 2.5 PFLOP/s, so three bf16 passes carry a ~2^-16-relative fp32 product at up to
+// peaks at 157 TFLOP/s, fp16 / bf16 MFMA at 2.5 PFLOP/s, so three 16-bit passes carry a ~2^-22- (fp16) / ~2^-16- (bf16) relative fp32 product at up to
 // ~5x the fp32 rate.  Replaces in_proj / out_proj / linear1 / linear2 and,
 // with K / N padded, InputProcess and OutputProcess (rows a12, a16); the LayerNorms between them are folded into the
 // epilogues (X3Epilogue).  The exact-fp32 kernel (gemm_f32.h) remains the `f32` mode.
 //
-// Data layout.  Activations: two bf16 planes [rows][K] (hi, lo), K contiguous, written by the PRODUCING kernel's
-// epilogue.  Weights: split ONCE (mdm_prepare) and stored in MFMA-FRAGMENT order
+// Data layout.  Activations: two 16-bit planes [rows][K] (hi, lo), K contiguous, written by the PRODUCING kernel's
+// epilogue.  Weights: split ONCE (mdm_prepare), as hi / lo of w * 2^8 (common.h kX3WeightScale; the epilogue scales the
+// accumulators back), and stored in MFMA-FRAGMENT order
 //     Wp[plane][n/32][k/16][lane 0..63][8]      lane = (n%32) + 32*((k%16)/8),  element j = k%8
 // so the B-operand fragment of one wave for one 16-deep k sub-step is ONE contiguous, perfectly coalesced 1 KB
 // global_load_dwordx4 -- weights never pass through LDS (a wave's 32 output columns are private to it, so staging them
@@ -189,7 +190,7 @@ struct X3Cursor {
   uint32_t off[PIECES];
 };
 
-// RES: 0 = no residual, 1 = fp32 residual, 2 = residual held as bf16 hi/lo planes.
+// RES: 0 = no residual, 1 = fp32 residual, 2 = residual held as 16-bit hi/lo planes.
 // ABL (profiling experiments only, 0 in production): 1 = no epilogue stores, 2 = no loads after the prologue,
 // 4 = no MFMAs, 8 = loads issued but not waited for, 16 / 32 / 64 / 256 = timing probes described where they are used.
 // FOLD / OSTAT / RES == 3: LayerNorm folded into the GEMMs (X3Epilogue).

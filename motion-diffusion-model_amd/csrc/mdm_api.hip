@@ -119,7 +119,7 @@ struct mdm_model {
   int jf = 0, jf_pad = 0;
   int precision = MDM_PREC_F16X3;
   struct LayerPlanes { X3Weights in_proj, out_proj, linear1, linear2; };
-  std::vector<LayerPlanes> planes;  // fragment-ordered bf16 hi/lo planes of the encoder weights (mdm_prepare)
+  std::vector<LayerPlanes> planes;  // fragment-ordered hi/lo planes of the encoder weights (mdm_prepare)
   // LayerNorm folded into its consumers (gemm_x3.h X3Epilogue): gamma-scaled weight planes, column sums, folded biases
   struct LayerFold { X3Weights in_proj, linear1; float *c_qkv, *b_qkv, *c_1, *b_1; };
   std::vector<LayerFold> fold;
@@ -163,11 +163,11 @@ Workspace carve(const mdm_model* m, int nseq, int T, void* base) {
   Workspace w;
   w.tok = take(M * D);
   const size_t NKT = (S + 31) / 32, SP = 32 * NKT;
-  w.qkv = take((size_t)nseq * SP * 3 * D);  // fp32 [M][3D] (f32 mode) or six bf16 planes of nseq*SP*D (f16x3 mode)
+  w.qkv = take((size_t)nseq * SP * 3 * D);  // fp32 [M][3D] (f32 mode) or six 16-bit planes of nseq*SP*D (f16x3 mode)
   w.att = take(M * D);
   w.ffn = take(M * FF);
   w.cond = take((size_t)nseq * D);
-  float* tp = take(M * D);  // two bf16 planes = one fp32 array's worth of bytes
+  float* tp = take(M * D);  // two 16-bit planes = one fp32 array's worth of bytes
   w.tokh = reinterpret_cast<p16_t*>(tp);
   w.tokl = tp ? w.tokh + M * D : nullptr;
   w.atth = reinterpret_cast<p16_t*>(w.att);
@@ -692,7 +692,7 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
     m->prepared = true;
     return MDM_OK;
   }
-  // bf16 hi/lo planes of the encoder weights (always built: the precision mode can be switched afterwards)
+  // hi/lo planes of the encoder weights (always built: the precision mode can be switched afterwards)
   base += align_up((size_t)R * D * sizeof(float), 256);
   const size_t FF = m->cfg.ff_size;
   m->planes.assign(m->cfg.num_layers, mdm_model::LayerPlanes{});

@@ -38,7 +38,7 @@ def classify(name):
             if b(f32) and b(fold):
                 return "gemm", "OutputProcess"
             return "gemm", "other<" + ",".join(args[-11:]) + ">"
-    for pat, k in (("attention_x3_kernel", "attention"), ("pose_to_planes_kernel", "pose_to_planes"), ("layernorm_kernel", "layernorm"),
+    for pat, k in (("fold_layernorm_kernel", "fold_layernorm (mdm_prepare)"), ("attention_x3_kernel", "attention"), ("pose_to_planes_kernel", "pose_to_planes"), ("layernorm_kernel", "layernorm"),
                    ("outproj_finish_kernel", "outproj_finish"), ("cond_token_kernel", "cond_token")):
         if pat in name:
             return "other", k
