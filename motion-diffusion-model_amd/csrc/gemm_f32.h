@@ -237,13 +237,14 @@ struct OutProjEpilogue {
 // stages BK = 128 k per step (4 steps for K = 512 instead of 16): 8 float4 per operand and thread in flight.
 // LDS image of a plane: [rows][BK + 8] halfs (row stride = 4 dwords mod 64: the 16-byte fragment reads of 16 consecutive
 // rows fall on 16 distinct bank quads).
-constexpr int GEMM_X3_BK = 128;
-constexpr int GEMM_X3_LD = GEMM_X3_BK + 8;   // halfs per LDS row of a split plane
-constexpr int gemm_f32_lds_bytes(int bt, bool x3) { return 2 * (x3 ? 2 * bt * GEMM_X3_LD * 2 : bt * (GEMM_BK + 4) * 4); }
+constexpr int gemm_x3_bk(int bt) { return bt == 64 ? 128 : 64; }      // k per staging step (8 float4 per operand and thread either way)
+constexpr int gemm_x3_ld(int bt) { return gemm_x3_bk(bt) + 8; }       // halfs per LDS row of a split plane
+constexpr int gemm_f32_lds_bytes(int bt, bool x3) { return 2 * (x3 ? 2 * bt * gemm_x3_ld(bt) * 2 : bt * (GEMM_BK + 4) * 4); }
 template <class AL, class BL, class EP, int BT, bool X3 = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl, EP ep, int M, int N, int K,
                                                                     int tiles_n, int weight_is_a) {
-  constexpr int BK = X3 ? GEMM_X3_BK : GEMM_BK;
+  constexpr int BK = X3 ? gemm_x3_bk(BT) : GEMM_BK;
+  constexpr int GEMM_X3_LD = gemm_x3_ld(BT);
   constexpr int WT = BT / 2;          // wave tile edge
   constexpr int NA = WT / 32;         // 32x32 accumulators per wave tile edge
   constexpr int NST = BT * BK / 4 / GEMM_THREADS;   // float4 per operand per thread while staging
@@ -407,6 +408,9 @@ inline void gemm_f32_allow_lds(KF kfn, int bytes) {
   (void)kfn; (void)bytes;
 #endif
 }
+// (X3 tile choice, measured on the DiP bench: taking 128x128 tiles from 100 / 200 workgroups on instead of 512 is 30 % / 23 %
+// SLOWER -- 227.6 / 248.1 vs 322.0 motions/s on one box: these GEMMs are per-workgroup latency chains, not L2-traffic-bound,
+// and fewer, longer chains lose; profiles/r02_ab.md.)
 template <bool X3, class AL, class BL, class EP>
 inline void launch_gemm_f32_t(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream,
                               int weight_is_a) {

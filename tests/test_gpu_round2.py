@@ -288,3 +288,23 @@ def test_dip_dump_steps_are_loop_indices():
     for d, k in zip(dumps, (0, 3, 9)):
         assert torch.equal(d, traj[k])
     assert not torch.equal(dumps[0], traj[-1])
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_kit_shape_251_features(prec):
+    """dataset='kit' (utils/model_util.py:47-49): 251 pose features instead of 263 -- other K / N paddings of the 263-wide
+    projections, other tail tiles in the transposing kernels.  Forward and a short guided loop against the oracle."""
+    sdk = synth_state_dict(seed=0, input_feats=251)
+    B, T, steps = 3, 50, 6
+    model, diffusion = make_pair(sdk, steps, DEV, guided=True, precision=prec, dataset="kit")
+    assert model.njoints == 251
+    y = synth_y(B, T, seed=8, lengths=[50, 17, 33])
+    x = torch.randn(B, 251, 1, T, generator=torch.Generator().manual_seed(2))
+    t = torch.tensor([5, 0, 3])
+    assert maxabs(model(x.to(DEV), t.to(DEV), y=dict(y)).cpu(), orc.cfg_forward(sdk, x, t, y)) < 4 * TOL_FWD[prec]
+    shape = (B, 251, 1, T)
+    g = torch.Generator().manual_seed(4)
+    seq = [torch.randn(shape, generator=g) for _ in range(steps + 1)]
+    out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": dict(y)}, noise_sequence=seq)
+    want = orc.sample_loop(sdk, orc.Tables(orc.named_betas("cosine", steps)), shape, y, seq[0], seq[1:], cfg=True)
+    assert maxabs(out.cpu(), want) < TOL_LOOP[prec]

@@ -94,7 +94,7 @@ def test_bench_self_launches_two_ranks_from_a_bare_shell():
     from emu_lib import emu
     emu()                                              # build the emulator once, before the ranks race for it
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--emulate", "--layers", "1", "--latent-dim", "256",
-           "--batch", "2", "--frames", "6", "--diffusion-steps", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+           "--batch", "2", "--frames", "6", "--diffusion-steps", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=_clean_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
