@@ -107,6 +107,7 @@ enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
 // v = act(acc + bias[n]) * (n < scale_cols ? col_scale : 1) + (res ? res[m][n] : 0);
 // out[m][n] = v (if out) and/or the 16-bit split planes oh/ol[m][n] = hi/lo(v) (if oh) for a following f16x3 GEMM.
 struct LinearEpilogue {
+  static constexpr bool kVec4 = true;   // has the row-major 4-column form (pre4 / store4) the kernel prefers when ld % 4 == 0
   float* out;        // may be null when only the planes are wanted
   const float* bias;
   const float* res;  // may alias out (each element is read then written by the same lane)
@@ -134,11 +135,31 @@ struct LinearEpilogue {
     if (out != nullptr) out[o] = v;
     if (oh != nullptr) split_p16(v, oh[o], ol[o]);
   }
+  // the same for 4 consecutive columns n .. n+3 of row m (n % 4 == 0, ld % 4 == 0): 16-byte loads / stores
+  __device__ __forceinline__ bool vec4_ok() const { return (ld & 3) == 0; }
+  __device__ __forceinline__ float4 pre4(int m, int n) const { return res != nullptr ? ld4(res + (size_t)m * ld + n) : zero4(); }
+  __device__ __forceinline__ void store4(int m, int n, float4 a, float4 rv) const {
+    const float4 b4 = ld4(bias + n);
+    float v[4] = {a.x + b4.x, a.y + b4.y, a.z + b4.z, a.w + b4.w};
+    const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (act == ACT_GELU) v[q] = gelu_erf(v[q]);
+      else if (act == ACT_SILU) v[q] = silu(v[q]);
+      if (n + q < scale_cols) v[q] *= col_scale;
+      v[q] += rr[q];
+    }
+    const size_t o = (size_t)m * ld + n;
+    const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
+    if (out != nullptr) st4(out + o, v4);
+    if (oh != nullptr) split4_store(oh + o, ol + o, v4);
+  }
 };
 
 // InputProcess epilogue: token (b, s = 1 + t) of every branch gets  acc + b_in[n] + pe[s][n]
 // (mdm.py:348, :251-252); the frame tokens are identical in the cond and uncond branches.
 struct EmbedEpilogue {
+  static constexpr bool kVec4 = false;
   float* tok;          // [nbranch*B*S, D]
   const float* bias;   // [D]
   const float* pe;     // [max_len, D]
@@ -192,6 +213,7 @@ struct NoiseSource {
 // mode 1: fused p_sample/ddim_sample tail (inpainting blend, clamp, posterior mean, noise add); the
 // step's noise is a buffer (injected by the caller, or filled by randn_kernel just before).
 struct OutProjEpilogue {
+  static constexpr bool kVec4 = false;
   const float* bias;   // [JF]
   float* out;          // mode 0: model output [nb, JF, T];  mode 1: x_prev [B, JF, T]
   float* x0_out;       // mode 1: optional pred_xstart [B, JF, T]
@@ -237,19 +259,29 @@ struct OutProjEpilogue {
 // stages BK = 128 k per step (4 steps for K = 512 instead of 16): 8 float4 per operand and thread in flight.
 // LDS image of a plane: [rows][BK + 8] halfs (row stride = 4 dwords mod 64: the 16-byte fragment reads of 16 consecutive
 // rows fall on 16 distinct bank quads).
+#ifdef MDM_X3S_KSPLIT1      // A/B builds: four waves per workgroup
+constexpr int GEMM_X3_KSPLIT = 1;
+#else
+constexpr int GEMM_X3_KSPLIT = 2;
+#endif
 constexpr int gemm_x3_bk(int bt) { return bt == 64 ? 128 : 64; }      // k per staging step (8 float4 per operand and thread either way)
 constexpr int gemm_x3_ld(int bt) { return gemm_x3_bk(bt) + 8; }       // halfs per LDS row of a split plane
 constexpr int gemm_f32_lds_bytes(int bt, bool x3) { return 2 * (x3 ? 2 * bt * gemm_x3_ld(bt) * 2 : bt * (GEMM_BK + 4) * 4); }
-template <class AL, class BL, class EP, int BT, bool X3 = false>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl, EP ep, int M, int N, int K,
-                                                                    int tiles_n, int weight_is_a) {
+// KS = 2 (X3, 64x64 tiles): EIGHT waves per workgroup -- waves 4-7 take the odd 16-deep k sub-steps of every staged tile (a
+// two-way split-K inside the workgroup, summed through LDS before the epilogue) and every thread stages half as much: the
+// serial per-thread work of a step (loads, split conversions, LDS writes, MFMAs) halves.
+template <class AL, class BL, class EP, int BT, bool X3 = false, int KS = 1>
+__global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL al, BL bl, EP ep, int M, int N, int K,
+                                                                         int tiles_n, int weight_is_a) {
+  constexpr int NT = GEMM_THREADS * KS;
   constexpr int BK = X3 ? gemm_x3_bk(BT) : GEMM_BK;
   constexpr int GEMM_X3_LD = gemm_x3_ld(BT);
   constexpr int WT = BT / 2;          // wave tile edge
   constexpr int NA = WT / 32;         // 32x32 accumulators per wave tile edge
-  constexpr int NST = BT * BK / 4 / GEMM_THREADS;   // float4 per operand per thread while staging
+  constexpr int NST = BT * BK / 4 / NT;   // float4 per operand per thread while staging
   constexpr int TPR = BK / 4;         // threads sweeping the k's of one row (row-major staging)
-  constexpr int RPP = GEMM_THREADS / TPR;           // rows per staging pass
+  constexpr int RPP = NT / TPR;       // rows per staging pass
+  static_assert(KS == 1 || (X3 && BT == 64), "the in-workgroup split-K form exists for the small X3 tile only");
   // fp32 tiles (exact mode) or hi | lo fp16 planes of the same tiles (X3)
   constexpr int OP_BYTES = gemm_f32_lds_bytes(BT, X3) / 2;
   MDM_DYN_SMEM(unsigned char, lds_raw);   // 2 * OP_BYTES (the X3 image of a 64-row tile pair is 68 KB: beyond static LDS)
@@ -263,7 +295,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = (wid & 3) >> 1, wn = wid & 1;
+  const int kgrp = wid >> 2;          // 0, or 1 for the second wave quartet of the KS = 2 form
 
   const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
@@ -273,9 +306,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
   int a_row[NST], a_k[NST], b_row[NST], b_k[NST];
 #pragma unroll
   for (int i = 0; i < NST; ++i) {
-    if (AL::kColumnStaging) { a_row[i] = tid & (BT - 1); a_k[i] = (tid / BT + (GEMM_THREADS / BT) * i) * 4; }
+    if (AL::kColumnStaging) { a_row[i] = tid & (BT - 1); a_k[i] = (tid / BT + (NT / BT) * i) * 4; }
     else { a_row[i] = tid / TPR + RPP * i; a_k[i] = (tid % TPR) * 4; }
-    if (BL::kColumnStaging) { b_row[i] = tid & (BT - 1); b_k[i] = (tid / BT + (GEMM_THREADS / BT) * i) * 4; }
+    if (BL::kColumnStaging) { b_row[i] = tid & (BT - 1); b_k[i] = (tid / BT + (NT / BT) * i) * 4; }
     else { b_row[i] = tid / TPR + RPP * i; b_k[i] = (tid % TPR) * 4; }
   }
 
@@ -287,41 +320,42 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[NST], rb[NST];
-#pragma unroll
-  for (int i = 0; i < NST; ++i) {
-    ra[i] = al.load4(m0 + a_row[i], a_k[i]);
-    rb[i] = bl.load4(n0 + b_row[i], b_k[i]);
-  }
-
+  // Register staging TWO k tiles ahead: the loads of tile kt + 2 are issued right after tile kt has been handed to LDS, so
+  // each has a whole step to land (one tile ahead, a load had only the few MFMAs of a step to hide behind: the small X3
+  // tiles spent most of a step waiting for memory).  Tile kt lives in register set kt & 1.
+  float4 ra[2][NST], rb[2][NST];
   const int nk = (K + BK - 1) / BK;
-  for (int kt = 0; kt < nk; ++kt) {
+  auto fetch = [&](auto set_tag, int kt) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_tag)::value;
+    const int kb = kt * BK;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      ra[SET][i] = al.load4(m0 + a_row[i], kb + a_k[i]);
+      rb[SET][i] = bl.load4(n0 + b_row[i], kb + b_k[i]);
+    }
+  };
+  auto step = [&](auto set_tag, int kt) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_tag)::value;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       if constexpr (X3) {
         // the WEIGHT operand (B; A for the transposed OutputProcess) is split as hi / lo of w * 2^8 (common.h kX3WeightScale)
         const float sa = weight_is_a ? kX3WeightScale : 1.f, sb = weight_is_a ? 1.f : kX3WeightScale;
         split4_store(&Ah[a_row[i] * GEMM_X3_LD + a_k[i]], &Al[a_row[i] * GEMM_X3_LD + a_k[i]],
-                     make_float4(ra[i].x * sa, ra[i].y * sa, ra[i].z * sa, ra[i].w * sa));
+                     make_float4(ra[SET][i].x * sa, ra[SET][i].y * sa, ra[SET][i].z * sa, ra[SET][i].w * sa));
         split4_store(&Bh[b_row[i] * GEMM_X3_LD + b_k[i]], &Bl[b_row[i] * GEMM_X3_LD + b_k[i]],
-                     make_float4(rb[i].x * sb, rb[i].y * sb, rb[i].z * sb, rb[i].w * sb));
+                     make_float4(rb[SET][i].x * sb, rb[SET][i].y * sb, rb[SET][i].z * sb, rb[SET][i].w * sb));
       } else {
-        st4(&As[a_row[i] * GEMM_LDS_LD + a_k[i]], ra[i]);
-        st4(&Bs[b_row[i] * GEMM_LDS_LD + b_k[i]], rb[i]);
+        st4(&As[a_row[i] * GEMM_LDS_LD + a_k[i]], ra[SET][i]);
+        st4(&Bs[b_row[i] * GEMM_LDS_LD + b_k[i]], rb[SET][i]);
       }
     }
     __syncthreads();
-    if (kt + 1 < nk) {
-      const int kb = (kt + 1) * BK;
-#pragma unroll
-      for (int i = 0; i < NST; ++i) {
-        ra[i] = al.load4(m0 + a_row[i], kb + a_k[i]);
-        rb[i] = bl.load4(n0 + b_row[i], kb + b_k[i]);
-      }
-    }
+    if (kt + 2 < nk) fetch(set_tag, kt + 2);
     if constexpr (X3) {
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {   // 16-deep k sub-steps: lane (r, h) holds k = 16 ks + 8 h .. + 7 of row r
+      for (int kq = 0; kq < BK / 16 / KS; ++kq) {   // 16-deep k sub-steps: lane (r, h) holds k = 16 ks + 8 h .. + 7 of row r
+        const int ks = KS * kq + kgrp;              // (KS = 2: even sub-steps for waves 0-3, odd ones for waves 4-7)
         p16x8 ah[NA], al_[NA], bh[NA], bl_[NA];
 #pragma unroll
         for (int t = 0; t < NA; ++t) {
@@ -361,6 +395,60 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(AL al, BL bl,
         }
     }
     __syncthreads();
+  };
+  fetch(std::integral_constant<int, 0>{}, 0);
+  if (nk > 1) fetch(std::integral_constant<int, 1>{}, 1);
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
+  }
+
+  if constexpr (KS == 2) {
+    // the second quartet's partial tile -> LDS (the staging image is dead: the k loop ended with a barrier) -> added by the
+    // first quartet, which owns the epilogue; lane-major [wave][reg][lane] so that both sides are conflict-free
+    float* const part = reinterpret_cast<float*>(lds_raw);
+    if (kgrp == 1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) part[((wid & 3) * 16 + e) * 64 + lane] = acc[0][0][e];
+    }
+    __syncthreads();
+    if (kgrp == 1) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] += part[(wid * 16 + e) * 64 + lane];
+  }
+
+  if constexpr (EP::kVec4) {
+    if (ep.vec4_ok()) {
+      // Row-major epilogue: in the accumulator layout a lane owns ONE column, i.e. 16 four-byte stores per 32x32 tile -- a
+      // store-ISSUE-bound tail that was ~6 of a small GEMM's ~24 us.  Each wave turns its tiles through a private LDS patch
+      // ([32][36] floats; the staging image is dead) into (row, 4 consecutive columns) per lane: 4 sixteen-byte stores.
+      // (no barrier: the k loop ended with one, and the patches sit behind the split-K buffer of the KS = 2 form)
+      float* const patch = reinterpret_cast<float*>(lds_raw) + (KS == 2 ? 4 * 16 * 64 : 0) + (wid & 3) * (32 * 36);
+      const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const int mb = m0 + wm * WT + i * 32, nb = n0 + wn * WT + j * 32 + pc4;
+          float4 rv[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int m = mb + 8 * p + prow;
+            rv[p] = (m < M && nb < N) ? ep.pre4(m, nb) : zero4();
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) patch[mfma_row(e, h) * 36 + r] = X3 ? acc[i][j][e] * kX3AccScale : acc[i][j][e];
+          wave_lds_fence();
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int m = mb + 8 * p + prow;
+            const float4 a4 = ld4(&patch[(8 * p + prow) * 36 + pc4]);
+            if (m < M && nb < N) ep.store4(m, nb, a4, rv[p]);
+          }
+          wave_lds_fence();
+        }
+      return;
+    }
   }
 
   typename EP::Col cc[NA];
@@ -417,9 +505,10 @@ inline void launch_gemm_f32_t(const AL& al, const BL& bl, const EP& ep, int M, i
   const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   if (tiles_m * tiles_n < 512 && (size_t)M * N >= 64 * 64 * 4) {
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
-    auto kfn = &gemm_f32_kernel<AL, BL, EP, 64, X3>;
+    constexpr int KS = X3 ? GEMM_X3_KSPLIT : 1;
+    auto kfn = &gemm_f32_kernel<AL, BL, EP, 64, X3, KS>;
     gemm_f32_allow_lds(kfn, gemm_f32_lds_bytes(64, X3));
-    MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS), gemm_f32_lds_bytes(64, X3), stream, al, bl, ep, M, N, K, tn, weight_is_a);
+    MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS * KS), gemm_f32_lds_bytes(64, X3), stream, al, bl, ep, M, N, K, tn, weight_is_a);
     return;
   }
   auto kfn = &gemm_f32_kernel<AL, BL, EP, 128, X3>;
