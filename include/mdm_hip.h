@@ -33,7 +33,7 @@ extern "C" {
 #define MDM_EHIP (-4)     /* a HIP runtime call failed                         */
 #define MDM_EUNSUPPORTED (-5)
 
-#define MDM_ABI_VERSION 4
+#define MDM_ABI_VERSION 5
 
 typedef struct mdm_model mdm_model_t;
 
@@ -186,6 +186,22 @@ typedef struct mdm_sample_params {
 /* x_dev [B,J,F,T]: in = x at index start_index (x_T, or q_sample(init) -- see mdm_randn), out = sample. */
 int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x_dev, void* ws_dev, size_t ws_bytes,
                     void* stream);
+
+/* The same loop over the MDM_ARCH_TRANS_DEC (DiP) denoiser: one call = one p_sample_loop over a prediction window
+ * (sample/generate.py's autoregressive loop calls it once per window with the previous window's tail as y['prefix']).
+ * `loop.T` is pred_len and `loop.text_embed_dev` the token-major text tokens [ntok, B, clip_dim] of mdm_forward_dec.
+ * What does not change over the steps of a window is computed once per call: embed_text over the tokens and, per layer,
+ * the key | value projections of the text part of the cross-attention memory; a step adds its projected timestep
+ * embedding (one [2D] row per layer) while the attention kernel stages K / V.  The sampler update runs in place on x. */
+typedef struct mdm_sample_dec_params {
+  mdm_sample_params_t loop;
+  int32_t ntok;
+  const float* prefix_dev;           /* [B, njoints, nfeats, context_len]; NULL iff context_len == 0 */
+  const int32_t* text_lengths_dev;   /* [B] tokens per prompt                                        */
+} mdm_sample_dec_params_t;
+size_t mdm_workspace_bytes_dec_loop(const mdm_model_t* m, int32_t nseq, int32_t pred_len, int32_t ntok, int32_t nsteps);
+int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* p, float* x_dev, void* ws_dev, size_t ws_bytes,
+                        void* stream);
 
 /* Opt-in per-launch timing, for bench.py's roofline line.  While enabled, every kernel the model launches is
  * bracketed by a hipEvent pair on the launch stream and bucketed by kernel class; mdm_profile_read waits for

@@ -175,28 +175,24 @@ class Engine:
                                           sample_base, draw, self.stream()), "mdm_randn")
         return out
 
-    @_on_own_device
-    def sample_loop(self, x, *, a_x0, a_xt, sigma, timestep_map, start_index, text_embed, scale, lengths,
-                    inpaint_mask=None, inpaint_motion=None, noise=None, seed=0, sample_base=0, clip_denoised=False,
-                    force_uncond=False, want_x0=False, dump_steps=None, const_noise=False):
-        """In-place loop on x [B,J,F,T] (x at index start_index).  Returns (x, x0 or None, dumps or None)."""
-        B, J, Fe, T = x.shape
-        self._check_device(x)
+    @staticmethod
+    def _loop_params(x, T, a_x0, a_xt, sigma, timestep_map, start_index, text_embed, scale, lengths, inpaint_mask,
+                     inpaint_motion, noise, seed, sample_base, clip_denoised, force_uncond, want_x0, dump_steps,
+                     const_noise):
+        """-> (MdmSampleParams, x0, dumps, keepalive): the block mdm_sample_loop and mdm_sample_loop_dec share."""
         n = len(a_x0)
         a0 = np.ascontiguousarray(a_x0, dtype=np.float32)
         at = np.ascontiguousarray(a_xt, dtype=np.float32)
         sg = np.ascontiguousarray(sigma, dtype=np.float32)
         tm = np.ascontiguousarray(timestep_map, dtype=np.int32)
         assert len(at) == n and len(sg) == n and len(tm) == n
-        nb = 2 if scale is not None else 1
-        ws = self.workspace(nb * B, T)
         x0 = torch.empty_like(x) if want_x0 else None
         dumps = dsteps = None
         if dump_steps:
             dsteps = np.ascontiguousarray(sorted(dump_steps), dtype=np.int32)
             dumps = torch.empty((len(dsteps),) + tuple(x.shape), dtype=torch.float32, device=x.device)
         p = nat.MdmSampleParams(
-            B=B, T=T, num_timesteps=n, start_index=int(start_index),
+            B=x.shape[0], T=T, num_timesteps=n, start_index=int(start_index),
             a_x0=a0.ctypes.data, a_xt=at.ctypes.data, sigma=sg.ctypes.data, timestep_map=tm.ctypes.data,
             text_embed_dev=_ptr(text_embed), scale_dev=_ptr(scale), lengths_dev=_ptr(lengths),
             inpaint_mask_dev=_ptr(inpaint_mask), inpaint_motion_dev=_ptr(inpaint_motion), noise_dev=_ptr(noise),
@@ -205,6 +201,43 @@ class Engine:
             dump_steps=(dsteps.ctypes.data if dsteps is not None else None),
             num_dump=(len(dsteps) if dsteps is not None else 0), dump_dev=_ptr(dumps),
             const_noise=int(bool(const_noise)))
+        return p, x0, dumps, (a0, at, sg, tm, dsteps)
+
+    @_on_own_device
+    def sample_loop_dec(self, x, *, prefix, text_tokens, text_lengths, a_x0, a_xt, sigma, timestep_map, start_index, scale,
+                        lengths, inpaint_mask=None, inpaint_motion=None, noise=None, seed=0, sample_base=0,
+                        clip_denoised=False, force_uncond=False, want_x0=False, dump_steps=None, const_noise=False):
+        """In-place window loop of the trans_dec (DiP) denoiser on x [B,J,F,pred_len]; inputs as forward_dec."""
+        B, J, Fe, P = x.shape
+        self._check_device(x)
+        ntok = int(text_tokens.shape[0])
+        p, x0, dumps, keep = self._loop_params(x, P, a_x0, a_xt, sigma, timestep_map, start_index, text_tokens, scale,
+                                               lengths, inpaint_mask, inpaint_motion, noise, seed, sample_base,
+                                               clip_denoised, force_uncond, want_x0, dump_steps, const_noise)
+        pd = nat.MdmSampleDecParams(loop=p, ntok=ntok, prefix_dev=_ptr(prefix), text_lengths_dev=_ptr(text_lengths))
+        nb = 2 if scale is not None else 1
+        need = self.lib.mdm_workspace_bytes_dec_loop(self.handle, nb * B, P, ntok, int(start_index) + 1)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.lib.check(self.lib.mdm_sample_loop_dec(self.handle, C.byref(pd), x.data_ptr(), self._ws.data_ptr(),
+                                                    self._ws.numel(), self.stream()), "mdm_sample_loop_dec")
+        del keep
+        return x, x0, dumps
+
+    @_on_own_device
+    def sample_loop(self, x, *, a_x0, a_xt, sigma, timestep_map, start_index, text_embed, scale, lengths,
+                    inpaint_mask=None, inpaint_motion=None, noise=None, seed=0, sample_base=0, clip_denoised=False,
+                    force_uncond=False, want_x0=False, dump_steps=None, const_noise=False):
+        """In-place loop on x [B,J,F,T] (x at index start_index).  Returns (x, x0 or None, dumps or None)."""
+        B, J, Fe, T = x.shape
+        self._check_device(x)
+        p, x0, dumps, keep = self._loop_params(x, T, a_x0, a_xt, sigma, timestep_map, start_index, text_embed, scale,
+                                               lengths, inpaint_mask, inpaint_motion, noise, seed, sample_base,
+                                               clip_denoised, force_uncond, want_x0, dump_steps, const_noise)
+        nb = 2 if scale is not None else 1
+        ws = self.workspace(nb * B, T)
         self.lib.check(self.lib.mdm_sample_loop(self.handle, C.byref(p), x.data_ptr(), ws.data_ptr(), ws.numel(),
                                                 self.stream()), "mdm_sample_loop")
+        del keep
         return x, x0, dumps

@@ -23,11 +23,12 @@ EXPORTED_SYMBOLS = [
     "mdm_prepare", "mdm_workspace_bytes", "mdm_forward", "mdm_sampler_step", "mdm_randn", "mdm_sample_loop",
     "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset",
     "mdm_set_precision", "mdm_linear_x3", "mdm_linear_x3_scratch_bytes", "mdm_attention_x3", "mdm_attention_x3_scratch_bytes",
-    "mdm_recover_from_ric", "mdm_workspace_bytes_dec", "mdm_forward_dec",
+    "mdm_recover_from_ric", "mdm_workspace_bytes_dec", "mdm_forward_dec", "mdm_workspace_bytes_dec_loop",
+    "mdm_sample_loop_dec",
 ]
 # include/mdm_hip_probe.h: exported by the probe build only
 PROBE_SYMBOLS = ["mdm_debug_set", "mdm_debug_get", "mdm_linear_f16f6", "mdm_linear_f16f6_scratch_bytes"]
-ABI_VERSION = 4
+ABI_VERSION = 5
 ARCH = {"trans_enc": 0, "trans_dec": 1}
 
 
@@ -51,6 +52,12 @@ class MdmSampleParams(C.Structure):
         ("force_uncond", C.c_int32), ("x0_dev", C.c_void_p), ("dump_steps", C.c_void_p), ("num_dump", C.c_int32),
         ("dump_dev", C.c_void_p), ("const_noise", C.c_int32),
     ]
+
+
+class MdmSampleDecParams(C.Structure):
+    """mdm_sample_dec_params_t: the loop block (T = pred_len, text_embed_dev = token-major text tokens) + the DiP inputs."""
+    _fields_ = [("loop", MdmSampleParams), ("ntok", C.c_int32), ("prefix_dev", C.c_void_p),
+                ("text_lengths_dev", C.c_void_p)]
 
 
 class MdmError(RuntimeError):
@@ -93,6 +100,8 @@ class MdmLib:
             "mdm_recover_from_ric": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
             "mdm_workspace_bytes_dec": (sz, [vp, i32, i32, i32]),
             "mdm_forward_dec": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+            "mdm_workspace_bytes_dec_loop": (sz, [vp, i32, i32, i32, i32]),
+            "mdm_sample_loop_dec": (C.c_int, [vp, P(MdmSampleDecParams), vp, vp, sz, vp]),
             "mdm_profile_enable": (C.c_int, [vp, C.c_int]),
             "mdm_profile_read": (C.c_int, [vp, i32, P(C.c_double), P(i64), P(C.c_double)]),
             "mdm_profile_reset": (C.c_int, [vp]),

@@ -44,6 +44,10 @@ struct AttnF32Args {
   const int* lengths;  // [B] or null: valid keys = min(Sk, lead + lengths[seq % B])
   int lead;
   int B;
+  // optional rows [D] added to every key / value row while it is staged: the DiP window loop keeps the text part of the
+  // projected memory (constant over a window's steps) and adds the step's projected time embedding here (mdm_api.hip)
+  const float* kadd = nullptr;
+  const float* vadd = nullptr;
 };
 
 // blockDim.x = 64 * ceil(Sq / 32): wave w owns query rows [32w, 32w + 32); NKT = ceil(Sk / 32) key tiles.
@@ -82,6 +86,7 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
   for (int idx = tid; idx < ROWS * 32; idx += NT) {
     const int key = idx >> 5, c4 = idx & 31;
     float4 v = (key < S) ? ld4(kbase + (size_t)key * ld + 4 * c4) : zero4();
+    if (a.kadd != nullptr && key < S) v = add4(v, ld4(a.kadd + head * ATT_HD + 4 * c4));
     st4(&smem[key * ATT_KLD + 4 * c4], v);
   }
   __syncthreads();
@@ -138,6 +143,7 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
   for (int idx = tid; idx < ROWS * 32; idx += NT) {
     const int key = idx >> 5, c4 = idx & 31;
     float4 v = (key < S) ? ld4(vbase + (size_t)key * ld + 4 * c4) : zero4();
+    if (a.vadd != nullptr && key < S) v = add4(v, ld4(a.vadd + head * ATT_HD + 4 * c4));
     st4(&smem[key * ATT_HD + 4 * c4], v);
   }
   __syncthreads();

@@ -185,6 +185,7 @@ __device__ __forceinline__ float sum_lanes8(float v) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // ---------------------------------------------------------------------------------------------
 // Split-precision helpers: x = hi + lo, hi = rne16(x), lo = rne16(x - hi)  (fp16: +O(2^-22 |x|); bf16 build: +O(2^-17 |x|)).

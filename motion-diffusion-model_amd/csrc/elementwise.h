@@ -87,13 +87,14 @@ __global__ __launch_bounds__(256) void text_memory_kernel(float* __restrict__ me
                                                           const long long* __restrict__ timesteps, int B, int ntok, int D,
                                                           int uncond_from_branch, int table_rows) {
   const int row = blockIdx.x, seq = row / ntok, j = row - seq * ntok, b = seq % B, br = seq / B;
-  long long t = timesteps[b];
+  // timesteps == null: the text part alone (the window loop adds the projected time row inside the attention kernel)
+  long long t = timesteps != nullptr ? timesteps[b] : 0;
   if (t < 0) t = 0;
   if (t >= table_rows) t = table_rows - 1;
   for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
     const float4 e = (br >= uncond_from_branch || proj == nullptr) ? ld4(text_bias + c)
                                                                   : ld4(proj + ((size_t)j * B + b) * D + c);
-    const float4 tt = ld4(time_table + (size_t)t * D + c);
+    const float4 tt = timesteps != nullptr ? ld4(time_table + (size_t)t * D + c) : zero4();
     st4(mem + (size_t)row * D + c, make_float4(e.x + tt.x, e.y + tt.y, e.z + tt.z, e.w + tt.w));
   }
 }

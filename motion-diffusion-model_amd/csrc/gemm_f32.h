@@ -109,7 +109,7 @@ enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
 struct LinearEpilogue {
   static constexpr bool kVec4 = true;   // has the row-major 4-column form (pre4 / store4) the kernel prefers when ld % 4 == 0
   float* out;        // may be null when only the planes are wanted
-  const float* bias;
+  const float* bias;  // [N] or null (no bias)
   const float* res;  // may alias out (each element is read then written by the same lane)
   int ld;
   int act;
@@ -120,7 +120,7 @@ struct LinearEpilogue {
   struct Row { size_t base; };
   struct Col { int n; float bias, mult; };
   __device__ __forceinline__ Row row(int m) const { return Row{(size_t)m * ld}; }
-  __device__ __forceinline__ Col col(int n) const { return Col{n, bias[n], n < scale_cols ? col_scale : 1.f}; }
+  __device__ __forceinline__ Col col(int n) const { return Col{n, bias != nullptr ? bias[n] : 0.f, n < scale_cols ? col_scale : 1.f}; }
   // pre(): what store() needs from memory for this element, fetched for ALL of a lane's elements before the first store --
   // `res` may alias `out` (in-place residual), so a load behind a store cannot be hoisted by the compiler and the epilogue
   // degenerated into 16 serial load -> store round trips per lane (the DiP decoder's small GEMMs spent most of their time there)
@@ -139,7 +139,7 @@ struct LinearEpilogue {
   __device__ __forceinline__ bool vec4_ok() const { return (ld & 3) == 0; }
   __device__ __forceinline__ float4 pre4(int m, int n) const { return res != nullptr ? ld4(res + (size_t)m * ld + n) : zero4(); }
   __device__ __forceinline__ void store4(int m, int n, float4 a, float4 rv) const {
-    const float4 b4 = ld4(bias + n);
+    const float4 b4 = bias != nullptr ? ld4(bias + n) : zero4();
     float v[4] = {a.x + b4.x, a.y + b4.y, a.z + b4.z, a.w + b4.w};
     const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll

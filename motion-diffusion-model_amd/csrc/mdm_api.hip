@@ -818,9 +818,14 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
 namespace {
 struct DecWorkspace {
   float *tok, *qkv, *att, *ffn, *mem, *kv, *proj;
+  // window loop only (nsteps > 0): what is constant over the steps of one p_sample_loop
+  float *out;        // [nseq][J*F*pred_len] model output of the current step
+  float *kv_text;    // [L][nseq*ntok][2D]   Wkv_l . (text part of the memory)            (no bias)
+  float *kv_time;    // [L][nsteps][2D]      Wkv_l . time_table[timestep of step k] + b_kv_l
+  float *time_rows;  // [nsteps][D]          the gathered time-embedding rows
   size_t bytes;
 };
-DecWorkspace carve_dec(const mdm_model* m, int nseq, int S, int ntok, int B, void* base) {
+DecWorkspace carve_dec(const mdm_model* m, int nseq, int S, int ntok, int B, void* base, int nsteps = 0, int pred_len = 0) {
   const size_t D = m->cfg.latent_dim, FF = m->cfg.ff_size, M = (size_t)nseq * S, Mm = (size_t)nseq * ntok;
   size_t off = 0;
   auto take = [&](size_t floats) {
@@ -836,6 +841,14 @@ DecWorkspace carve_dec(const mdm_model* m, int nseq, int S, int ntok, int B, voi
   w.mem = take(Mm * D);           // text memory [nseq][ntok][D]
   w.kv = take(Mm * 2 * D);        // its key | value projections of the current layer
   w.proj = take((size_t)ntok * B * D);   // embed_text(enc_text), token-major
+  w.out = w.kv_text = w.kv_time = w.time_rows = nullptr;
+  if (nsteps > 0) {
+    const size_t L = m->cfg.num_layers;
+    w.out = take((size_t)nseq * m->jf * pred_len);
+    w.kv_text = take(L * Mm * 2 * D);
+    w.kv_time = take(L * nsteps * 2 * D);
+    w.time_rows = take((size_t)nsteps * D);
+  }
   w.bytes = off;
   return w;
 }
@@ -846,35 +859,43 @@ size_t mdm_workspace_bytes_dec(const mdm_model_t* m, int32_t nseq, int32_t pred_
   return carve_dec(m, nseq, m->cfg.context_len + pred_len, ntok, nseq, nullptr).bytes;
 }
 
-int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const int64_t* timesteps, const float* text_tokens,
-                    const int32_t* text_lengths, const int32_t* lengths, int32_t B, int32_t pred_len, int32_t ntok,
-                    int32_t branches, float* out, void* ws_dev, size_t ws_bytes, void* stream) {
-  if (int rc = check_ready(m)) return rc;
-  if (m->cfg.arch != MDM_ARCH_TRANS_DEC) return fail(MDM_ESTATE, "mdm_forward_dec: the model was created as trans_enc");
+size_t mdm_workspace_bytes_dec_loop(const mdm_model_t* m, int32_t nseq, int32_t pred_len, int32_t ntok, int32_t nsteps) {
+  if (m == nullptr || nseq <= 0 || pred_len <= 0 || ntok <= 0 || nsteps <= 0) return 0;
+  return carve_dec(m, nseq, m->cfg.context_len + pred_len, ntok, nseq, nullptr, nsteps, pred_len).bytes;
+}
+
+namespace {
+int check_dec_shapes(const mdm_model_t* m, const char* who, const float* prefix, int B, int pred_len, int ntok) {
+  const int C = m->cfg.context_len, S = C + pred_len;
+  const std::string w(who);
+  if (m->cfg.arch != MDM_ARCH_TRANS_DEC) return fail(MDM_ESTATE, w + ": the model was created as trans_enc");
+  if ((C > 0) != (prefix != nullptr)) return fail(MDM_EINVAL, w + ": prefix must be given iff context_len > 0");
+  if (B <= 0 || pred_len <= 0 || S > 224) return fail(MDM_EINVAL, w + ": need B >= 1 and context_len + pred_len <= 224");
+  if (ntok <= 0 || ntok > 224) return fail(MDM_EINVAL, w + ": 1 <= text tokens <= 224");
+  if (S > m->cfg.max_len) return fail(MDM_EINVAL, w + ": window longer than the positional table");
+  return MDM_OK;
+}
+
+// One evaluation of the trans_dec denoiser.  hoist_step < 0: the stand-alone forward (memory = text + time built here from
+// `timesteps`, projected per layer).  hoist_step = k >= 0: step k of a window loop -- ws.kv_text / ws.kv_time are filled,
+// the memory is never materialised and the per-layer memory projection is skipped.
+int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const float* prefix, const int64_t* timesteps,
+                 const float* text_tokens, const int32_t* text_lengths, const int32_t* lengths, int B, int pred_len,
+                 int ntok, int branches, float* out, hipStream_t s, int hoist_step, int nsteps) {
   const int C = m->cfg.context_len, S = C + pred_len, D = m->cfg.latent_dim, H = m->cfg.num_heads, FF = m->cfg.ff_size;
-  if (x == nullptr || timesteps == nullptr || out == nullptr || ws_dev == nullptr || text_lengths == nullptr)
-    return fail(MDM_EINVAL, "mdm_forward_dec: null pointer");
-  if ((C > 0) != (prefix != nullptr)) return fail(MDM_EINVAL, "mdm_forward_dec: prefix must be given iff context_len > 0");
-  if (B <= 0 || pred_len <= 0 || S > 224) return fail(MDM_EINVAL, "mdm_forward_dec: need B >= 1 and context_len + pred_len <= 224");
-  if (ntok <= 0 || ntok > 224) return fail(MDM_EINVAL, "mdm_forward_dec: 1 <= text tokens <= 224");
-  if (S > m->cfg.max_len) return fail(MDM_EINVAL, "mdm_forward_dec: window longer than the positional table");
-  if (branches < 0 || branches > 2) return fail(MDM_EINVAL, "mdm_forward_dec: bad branches");
-  if (branches != MDM_BRANCH_UNCOND && text_tokens == nullptr) return fail(MDM_EINVAL, "mdm_forward_dec: text tokens required");
-  hipStream_t s = static_cast<hipStream_t>(stream);
   const int nbranch = (branches == MDM_BRANCH_BOTH) ? 2 : 1;
   const int nseq = nbranch * B, M = nseq * S, Mm = nseq * ntok;
-  DecWorkspace ws = carve_dec(m, nseq, S, ntok, B, ws_dev);
-  if (ws_bytes < ws.bytes) return fail(MDM_ENOSPC, "mdm_forward_dec: workspace too small");
   Profiler* pf = &m->prof;
   const int* len = m->cfg.mask_frames ? lengths : nullptr;
   const float qscale = 1.0f / sqrtf((float)ATT_HD);
   const bool x3 = m->precision == MDM_PREC_F16X3;   // GEMM arithmetic (gemm_f32.h X3); attention, LayerNorm stay fp32
+  const bool hoisted = hoist_step >= 0;
 
   // ---- text memory: embed_text over every token (cond branch), + time embedding (mdm.py:217-219)
-  if (branches != MDM_BRANCH_UNCOND)
+  if (!hoisted && branches != MDM_BRANCH_UNCOND)
     if (int rc = launch_linear(nullptr, text_tokens, m->cfg.clip_dim, m->W("embed_text.weight"), m->W("embed_text.bias"),
                                nullptr, ws.proj, ntok * B, D, m->cfg.clip_dim, ACT_NONE, 0, 1.f, s)) return rc;
-  {
+  if (!hoisted) {
     ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
     MDM_LAUNCH(text_memory_kernel, dim3(Mm), dim3(128), 0, s, ws.mem, (const float*)ws.proj, m->W("embed_text.bias"),
                (const float*)m->time_table, reinterpret_cast<const long long*>(timesteps), B, ntok, D,
@@ -904,9 +925,16 @@ int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const i
     const float* wc = m->L(l, "multihead_attn.in_proj_weight");
     const float* bc = m->L(l, "multihead_attn.in_proj_bias");
     if (int rc = launch_linear(pf, ws.tok, D, wc, bc, nullptr, ws.qkv, M, D, D, ACT_NONE, D, qscale, s, x3)) return rc;
-    if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
-    {
+    if (!hoisted) {
+      if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
       const AttnF32Args a{ws.qkv, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
+      if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s)) return rc;
+    } else {
+      const float* kvt = ws.kv_text + (size_t)l * Mm * 2 * D;
+      const float* row = ws.kv_time + ((size_t)l * nsteps + hoist_step) * 2 * D;
+      AttnF32Args a{ws.qkv, D, kvt, kvt + D, 2 * D, S, ntok, text_lengths, 0, B};
+      a.kadd = row;
+      a.vadd = row + D;
       if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s)) return rc;
     }
     if (int rc = launch_linear(pf, ws.att, D, m->L(l, "multihead_attn.out_proj.weight"), m->L(l, "multihead_attn.out_proj.bias"),
@@ -929,6 +957,23 @@ int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const i
   ProfScope ps(pf, MDM_PROF_OUTPROJ, 2.0 * nseq * pred_len * (double)D * m->jf, s);
   launch_gemm_f32(al, bl, ep, m->jf, nseq * pred_len, D, s, x3, /*weight_is_a=*/true);
   return rt_launch_status();
+}
+}  // namespace
+
+int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const int64_t* timesteps, const float* text_tokens,
+                    const int32_t* text_lengths, const int32_t* lengths, int32_t B, int32_t pred_len, int32_t ntok,
+                    int32_t branches, float* out, void* ws_dev, size_t ws_bytes, void* stream) {
+  if (int rc = check_ready(m)) return rc;
+  if (x == nullptr || timesteps == nullptr || out == nullptr || ws_dev == nullptr || text_lengths == nullptr)
+    return fail(MDM_EINVAL, "mdm_forward_dec: null pointer");
+  if (int rc = check_dec_shapes(m, "mdm_forward_dec", prefix, B, pred_len, ntok)) return rc;
+  if (branches < 0 || branches > 2) return fail(MDM_EINVAL, "mdm_forward_dec: bad branches");
+  if (branches != MDM_BRANCH_UNCOND && text_tokens == nullptr) return fail(MDM_EINVAL, "mdm_forward_dec: text tokens required");
+  const int nseq = ((branches == MDM_BRANCH_BOTH) ? 2 : 1) * B;
+  DecWorkspace ws = carve_dec(m, nseq, m->cfg.context_len + pred_len, ntok, B, ws_dev);
+  if (ws_bytes < ws.bytes) return fail(MDM_ENOSPC, "mdm_forward_dec: workspace too small");
+  return decoder_pass(m, ws, x, prefix, timesteps, text_tokens, text_lengths, lengths, B, pred_len, ntok, branches, out,
+                      static_cast<hipStream_t>(stream), -1, 0);
 }
 
 int mdm_sampler_step(const float* x_t, const float* out_cond, const float* out_uncond, const float* scale,
@@ -1054,6 +1099,85 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
       ep.noise = step_noise;
       ProfScope ps(&m->prof, MDM_PROF_OUTPROJ, 2.0 * B * T * (double)D * m->jf, s);
       launch_gemm_f32(al, bl, ep, m->jf, B * T, D, s);
+      if (int rc = rt_launch_status()) return rc;
+    }
+    if (dump_i < p->num_dump && p->dump_steps[dump_i] == k) {
+      if (int rc = rt_copy(p->dump_dev + (size_t)dump_i * B * per_sample, x, (size_t)B * per_sample * sizeof(float), s)) return rc;
+      ++dump_i;
+    }
+  }
+  return MDM_OK;
+}
+
+int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float* x, void* ws_dev, size_t ws_bytes,
+                        void* stream) {
+  if (int rc = check_ready(m)) return rc;
+  if (pd == nullptr || x == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop_dec: null pointer");
+  const mdm_sample_params_t* p = &pd->loop;
+  const int B = p->B, P = p->T, ntok = pd->ntok;
+  if (int rc = check_dec_shapes(m, "mdm_sample_loop_dec", pd->prefix_dev, B, P, ntok)) return rc;
+  if (pd->text_lengths_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop_dec: text_lengths required");
+  if (p->num_timesteps <= 0 || p->start_index < 0 || p->start_index >= p->num_timesteps)
+    return fail(MDM_EINVAL, "mdm_sample_loop_dec: bad start_index / num_timesteps");
+  if (!p->a_x0 || !p->a_xt || !p->sigma || !p->timestep_map) return fail(MDM_EINVAL, "mdm_sample_loop_dec: null schedule table");
+  if ((p->inpaint_mask_dev == nullptr) != (p->inpaint_motion_dev == nullptr))
+    return fail(MDM_EINVAL, "mdm_sample_loop_dec: inpainting needs mask and motion");
+  const bool cfg = p->scale_dev != nullptr;
+  const bool uncond_only = !cfg && (p->force_uncond || p->text_embed_dev == nullptr);
+  if (cfg && p->text_embed_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop_dec: CFG needs the text tokens");
+  if (p->num_dump > 0 && (p->dump_steps == nullptr || p->dump_dev == nullptr)) return fail(MDM_EINVAL, "mdm_sample_loop_dec: dump buffers missing");
+  for (int i = 0; i <= p->start_index; ++i)
+    if (p->timestep_map[i] < 0 || p->timestep_map[i] >= m->cfg.max_len) return fail(MDM_EINVAL, "mdm_sample_loop_dec: timestep outside the positional table");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int branches = cfg ? MDM_BRANCH_BOTH : (uncond_only ? MDM_BRANCH_UNCOND : MDM_BRANCH_COND);
+  const int nbranch = cfg ? 2 : 1, nseq = nbranch * B, D = m->cfg.latent_dim, L = m->cfg.num_layers;
+  const int nsteps = p->start_index + 1, Mm = nseq * ntok;
+  DecWorkspace ws = carve_dec(m, nseq, m->cfg.context_len + P, ntok, B, ws_dev, nsteps, P);
+  if (ws_bytes < ws.bytes) return fail(MDM_ENOSPC, "mdm_sample_loop_dec: workspace too small");
+  const size_t per_sample = (size_t)m->jf * P;
+  const bool x3 = m->precision == MDM_PREC_F16X3;
+  Profiler* pf = &m->prof;
+
+  // ---- once per window: what the steps share.  memory = embed_text(tokens) (cond) | bias (uncond)  +  time_emb[t]
+  // (mdm.py:217-219, :262); its key | value projection of layer l is linear in the two parts:
+  //   Wkv_l . memory + b = [Wkv_l . text part]  +  [Wkv_l . time_emb[t] + b]      (per token)   (per step)
+  if (branches != MDM_BRANCH_UNCOND)
+    if (int rc = launch_linear(nullptr, p->text_embed_dev, m->cfg.clip_dim, m->W("embed_text.weight"), m->W("embed_text.bias"),
+                               nullptr, ws.proj, ntok * B, D, m->cfg.clip_dim, ACT_NONE, 0, 1.f, s)) return rc;
+  {
+    ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
+    MDM_LAUNCH(text_memory_kernel, dim3(Mm), dim3(128), 0, s, ws.mem, (const float*)ws.proj, m->W("embed_text.bias"),
+               (const float*)m->time_table, (const long long*)nullptr, B, ntok, D,
+               (branches == MDM_BRANCH_UNCOND) ? 0 : 1, (int)m->cfg.max_len);
+    if (int rc = rt_launch_status()) return rc;
+  }
+  for (int k = 0; k < nsteps; ++k)
+    if (int rc = rt_copy(ws.time_rows + (size_t)k * D, m->time_table + (size_t)p->timestep_map[p->start_index - k] * D,
+                         (size_t)D * sizeof(float), s)) return rc;
+  for (int l = 0; l < L; ++l) {
+    const float* wkv = m->L(l, "multihead_attn.in_proj_weight") + (size_t)D * D;
+    const float* bkv = m->L(l, "multihead_attn.in_proj_bias") + D;
+    if (int rc = launch_linear(pf, ws.mem, D, wkv, nullptr, nullptr, ws.kv_text + (size_t)l * Mm * 2 * D, Mm, 2 * D, D,
+                               ACT_NONE, 0, 1.f, s, x3)) return rc;
+    if (int rc = launch_linear(pf, ws.time_rows, D, wkv, bkv, nullptr, ws.kv_time + (size_t)l * nsteps * 2 * D, nsteps, 2 * D, D,
+                               ACT_NONE, 0, 1.f, s, x3)) return rc;
+  }
+
+  int dump_i = 0, k = 0;
+  for (int i = p->start_index; i >= 0; --i, ++k) {
+    if (int rc = decoder_pass(m, ws, x, pd->prefix_dev, nullptr, p->text_embed_dev, pd->text_lengths_dev, p->lengths_dev, B, P,
+                              ntok, branches, ws.out, s, k, nsteps)) return rc;
+    // CFG combine + posterior / DDIM update, in place on x (each element is read, then written, by the same lane)
+    StepCoefs co{p->a_x0[i], p->a_xt[i], p->sigma[i], p->clip_denoised};
+    const float* step_noise = (p->noise_dev != nullptr && p->sigma[i] != 0.f) ? p->noise_dev + (size_t)k * B * per_sample : nullptr;
+    NoiseSource ns{step_noise, p->seed, p->sample_base, (uint32_t)(1 + k), (uint32_t)(p->const_noise != 0)};
+    const size_t total = (size_t)B * per_sample;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 2048);
+    {
+      ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
+      MDM_LAUNCH(sampler_step_kernel, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)ws.out,
+                 cfg ? (const float*)(ws.out + (size_t)B * per_sample) : (const float*)nullptr, p->scale_dev,
+                 p->inpaint_mask_dev, p->inpaint_motion_dev, x, (i == 0) ? p->x0_dev : (float*)nullptr, (int)per_sample, B, co, ns);
       if (int rc = rt_launch_status()) return rc;
     }
     if (dump_i < p->num_dump && p->dump_steps[dump_i] == k) {

@@ -20,6 +20,7 @@ model it is given step by step; without the reference on the path those calls ra
 import enum
 import importlib
 import math
+import os
 
 import numpy as np
 import torch
@@ -354,7 +355,9 @@ class GaussianDiffusion:
         if 'text' in y.keys() and 'text_embed' not in y.keys():
             # encoding once instead of each iteration (gaussian_diffusion.py:633-635); caches into the caller's dict
             y['text_embed'] = model.encode_text(y['text'])
-        if mdm.arch == 'trans_dec':
+        if mdm.arch == 'trans_dec' and os.environ.get("MDM_DIP_STEPWISE", "0") == "1":
+            # the window loop one native forward + one step kernel at a time (what p_sample composes); kept as the
+            # cross-check of the native window loop below
             return self._loop_stepwise(model, mdm, shape, coefs, noise, clip_denoised, model_kwargs, device,
                                        skip_timesteps, init_image, dump_steps, noise_sequence, seed, const_noise)
 
@@ -380,14 +383,22 @@ class GaussianDiffusion:
             elif img is None:
                 img = eng.randn(shape, device, seed, base, 0)
 
-            te = mdm.text_embedding(y, device) if 'text' in mdm.cond_mode and not y.get('uncond', False) else None
+            dec = mdm.arch == 'trans_dec'
+            if dec:
+                for k in ('target_cond', 'action'):
+                    if k in y:
+                        raise NotImplementedError(f"y[{k!r}] is outside the MI355X hot path")
+                prefix, tokens, tok_lengths, lengths = mdm._dec_inputs(img, y)
+            else:
+                te = mdm.text_embedding(y, device) if 'text' in mdm.cond_mode and not y.get('uncond', False) else None
             scale = None
             if guided:
                 scale = y['scale'].to(device=device, dtype=torch.float32).reshape(-1).contiguous()
                 assert scale.numel() == B
-            lengths = mdm.lengths_from_mask(y, T)
-            if lengths is not None:
-                lengths = lengths.to(device)
+            if not dec:
+                lengths = mdm.lengths_from_mask(y, T)
+                if lengths is not None:
+                    lengths = lengths.to(device)
             im = imo = None
             if 'inpainting_mask' in y.keys() and 'inpainted_motion' in y.keys():      # :300-304
                 im = y['inpainting_mask'].to(device=device).expand(shape).to(torch.uint8).contiguous()
@@ -403,12 +414,15 @@ class GaussianDiffusion:
                 nz = nz.contiguous()
             a_x0, a_xt, sigma = coefs
             kept = sorted(set(int(k) for k in dump_steps if 0 <= int(k) <= start)) if dump_steps is not None else None
-            out, _, dumps = eng.sample_loop(
-                img, a_x0=a_x0, a_xt=a_xt, sigma=sigma, timestep_map=self.timestep_map, start_index=start,
-                text_embed=te, scale=scale, lengths=lengths, inpaint_mask=im, inpaint_motion=imo, noise=nz,
-                seed=seed, sample_base=base, clip_denoised=clip_denoised,
-                force_uncond=bool(y.get('uncond', False)) or mdm.cond_mode == 'no_cond',
-                dump_steps=kept, const_noise=const_noise)
+            common = dict(a_x0=a_x0, a_xt=a_xt, sigma=sigma, timestep_map=self.timestep_map, start_index=start,
+                          scale=scale, lengths=lengths, inpaint_mask=im, inpaint_motion=imo, noise=nz, seed=seed,
+                          sample_base=base, clip_denoised=clip_denoised, dump_steps=kept, const_noise=const_noise)
+            if dec:      # one DiP prediction window (sample/generate.py's autoregressive loop calls this per window)
+                out, _, dumps = eng.sample_loop_dec(img, prefix=prefix, text_tokens=tokens, text_lengths=tok_lengths,
+                                                    force_uncond=bool(y.get('uncond', False)), **common)
+            else:
+                out, _, dumps = eng.sample_loop(
+                    img, text_embed=te, force_uncond=bool(y.get('uncond', False)) or mdm.cond_mode == 'no_cond', **common)
         self._check_finite(out, mdm)
         if dump_steps is not None:      # the reference appends in loop order (:654-657)
             return [dumps[j] for j in range(len(kept))] if kept else []
@@ -419,7 +433,6 @@ class GaussianDiffusion:
         """The fp16 operand planes of the default mode do not saturate: an activation beyond +-65504 turns into inf and the
         sample into NaN.  One reduction per LOOP (the caller reads the sample back right after, sample/generate.py:163)
         makes that loud and actionable.  MDM_CHECK_FINITE=0 skips it (fully asynchronous pipelines)."""
-        import os
         if os.environ.get("MDM_CHECK_FINITE", "1") == "0" or bool(torch.isfinite(sample).all()):
             return
         raise FloatingPointError(
@@ -430,8 +443,8 @@ class GaussianDiffusion:
 
     def _loop_stepwise(self, model, mdm, shape, coefs, noise, clip_denoised, model_kwargs, device, skip_timesteps,
                        init_image, dump_steps, noise_sequence, seed, const_noise=False):
-        """The same loop, one native forward + one fused step kernel per iteration: the DiP decoder (10 steps x 60 tokens
-        per window) is not in the fused trans_enc loop of mdm_sample_loop."""
+        """The trans_dec window loop as p_sample composes it: one native forward + one fused step kernel per iteration
+        (MDM_DIP_STEPWISE=1).  The default is mdm_sample_loop_dec, which hoists the step-invariant text work."""
         eng = mdm.engine()
         with torch.no_grad():
             seed = self.reseed(seed)

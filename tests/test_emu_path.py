@@ -203,3 +203,28 @@ def test_emulated_dip_decoder_forward(lib, masked, prec):
     assert maxabs(model.model(x, t, y=dict(y)), dip.dip_forward(sd, x, t, y, **kw)) < 2e-5
     assert maxabs(model.model(x, t, y={**y, "uncond": True}), dip.dip_forward(sd, x, t, {**y, "uncond": True}, **kw)) < 2e-5
     assert maxabs(model(x, t, y=dict(y)), dip.dip_cfg_forward(sd, x, t, y, **kw)) < 5e-5
+
+
+@pytest.mark.parametrize("guided,prec", [(True, "f16x3"), (False, "f32")])
+def test_emulated_dip_window_loop(lib, monkeypatch, guided, prec):
+    """mdm_sample_loop_dec (one p_sample_loop over a DiP prediction window: text projections hoisted out of the steps, the
+    step's projected time row added while the attention kernel stages K / V) against the oracle's loop, and against the
+    same loop composed step by step from mdm_forward_dec + mdm_sampler_step (MDM_DIP_STEPWISE=1); dump_steps included."""
+    B, C, P, steps = 2, 5, 12, 3
+    sd = dip_small_state_dict(num_layers=2)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=guided, native_lib=lib, context_len=C, pred_len=P, precision=prec)
+    y = synth_dip_y(B, P, C, seed=4, text_lengths=[6, 3], scale=2.5)
+    g = torch.Generator().manual_seed(8)
+    seq = [torch.randn(B, 263, 1, P, generator=g) for _ in range(1 + steps)]
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    want = dip.dip_sample_loop(sd, tab, (B, 263, 1, P), y, seq[0], seq[1:], context_len=C, cfg=guided, num_heads=2)
+    run = lambda **kw: diffusion.p_sample_loop(model, (B, 263, 1, P), clip_denoised=False,   # noqa: E731
+                                               model_kwargs={"y": dict(y)}, noise_sequence=seq, **kw)
+    got = run()
+    assert maxabs(got, want) < 5e-5
+    dumps = run(dump_steps=[0, 2])
+    assert len(dumps) == 2 and torch.equal(dumps[1], got)
+    monkeypatch.setenv("MDM_DIP_STEPWISE", "1")
+    step = run()
+    assert maxabs(got, step) < 2e-5
+    assert maxabs(run(dump_steps=[0, 2])[0], dumps[0]) < 2e-5
