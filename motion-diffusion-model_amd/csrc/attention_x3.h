@@ -39,14 +39,6 @@ struct QkvPlanes {
 // position p (0..15) inside a 16-key group  <->  key offset, the MFMA accumulator row order (see header)
 __host__ __device__ __forceinline__ int ax_key_of_pos(int p) { return (p & 3) + 8 * ((p >> 2) & 1) + 4 * (p >> 3); }
 
-__device__ __forceinline__ void split8(const float* v, p16x8& hi, p16x8& lo) {
-  uint32_t h[4], l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) split2_p16(v[2 * j], v[2 * j + 1], h[j], l[j]);
-  hi = __builtin_bit_cast(p16x8, u32x4{h[0], h[1], h[2], h[3]});
-  lo = __builtin_bit_cast(p16x8, u32x4{l[0], l[1], l[2], l[3]});
-}
-
 // Streaming form.  256 threads = 4 waves per workgroup, TWO workgroups per (sequence, head) -- query tiles 0-3 and 4-6 --
 // and two workgroups resident per CU (<= 68 KB of LDS, <= 256 VGPRs each), so that one workgroup's load / softmax /
 // store phases hide behind the other's MFMAs (the one-workgroup-per-CU predecessor held all of K in LDS and exposed a

@@ -252,6 +252,15 @@ __device__ __forceinline__ void split2_p16(float a, float b, uint32_t& hi2, uint
 }
 
 // 4 consecutive values -> 8-byte packed hi and lo groups
+// 8 consecutive fp32 values -> one MFMA operand fragment each of hi and lo
+__device__ __forceinline__ void split8(const float* v, p16x8& hi, p16x8& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split2_p16(v[2 * j], v[2 * j + 1], h[j], l[j]);
+  hi = __builtin_bit_cast(p16x8, u32x4{h[0], h[1], h[2], h[3]});
+  lo = __builtin_bit_cast(p16x8, u32x4{l[0], l[1], l[2], l[3]});
+}
+
 __device__ __forceinline__ void split4_store(p16_t* hi_p, p16_t* lo_p, float4 v) {
   uint32_t h01, l01, h23, l23;
   split2_p16(v.x, v.y, h01, l01);

@@ -36,8 +36,47 @@ constexpr int GEMM_THREADS = 256;
 // 32 k's of one row (row-major sources), true = consecutive threads take consecutive rows (sources
 // that are contiguous along the row index, e.g. the [B, J, 1, T] pose tensor).
 // ------------------------------------------------------------------------------------------------
+// LayerNorm folded into the GEMMs around it (the DiP decoder's post-norm layers; the same idea as gemm_x3.h's FOLD / OSTAT /
+// RES 3 on this skeleton): the GEMM that produces a pre-norm sum y = x + f(x) (out_proj, linear2) writes y itself plus, per
+// row and 32-column block, the partial statistics (sum y, sum (y - block mean)^2); whoever reads LN(y) merges the partials of
+// its tile's rows once (Chan's update: no E[y^2] - mean^2 cancellation):
+//   * the next GEMM, whose A operand is LN(y), runs on y itself with weights pre-multiplied by gamma (mdm_prepare):
+//       W . LN(y) + b = rstd * (W' . y - mean * colsum(W')) + (b + W . beta)          applied per row in the epilogue;
+//   * the next residual rebuilds (y - mean) * rstd * gamma + beta from the y it was loading anyway.
+// No LayerNorm launch, no normalised copy of the residual stream (LnLinearEpilogue).
+constexpr int LN_PART_COLS = 32;
+struct LnFold {
+  const float* stat = nullptr;   // [M][parts][2]; null = the tensor is not pre-norm (read as it is)
+  const float* gamma = nullptr;  // [D]
+  const float* beta = nullptr;
+  int parts = 0;                 // D / 32
+  float inv_dim = 0.f;           // 1 / D
+};
+__device__ __forceinline__ float2 ln_row_stats(const LnFold& f, int row, int M) {   // -> (mean, rstd), eps 1e-5
+  if (row >= M) return make_float2(0.f, 1.f);
+  const float* q = f.stat + (size_t)row * f.parts * 2;
+  float sum = 0.f;
+  for (int i = 0; i < f.parts; i += 2) {
+    const float4 v = ld4(q + 2 * i);
+    sum += v.x + v.z;
+  }
+  const float mean = sum * f.inv_dim;
+  float m2 = 0.f;
+  for (int i = 0; i < f.parts; i += 2) {
+    const float4 v = ld4(q + 2 * i);
+    const float d0 = v.x * (1.0f / LN_PART_COLS) - mean, d1 = v.z * (1.0f / LN_PART_COLS) - mean;
+    m2 += (v.y + LN_PART_COLS * d0 * d0) + (v.w + LN_PART_COLS * d1 * d1);
+  }
+  return make_float2(mean, 1.0f / sqrtf(m2 * f.inv_dim + 1e-5f));
+}
+__device__ __forceinline__ float4 ln_apply4(float4 y, float2 st, float4 g, float4 b) {
+  return make_float4((y.x - st.x) * st.y * g.x + b.x, (y.y - st.x) * st.y * g.y + b.y, (y.z - st.x) * st.y * g.z + b.z,
+                     (y.w - st.x) * st.y * g.w + b.w);
+}
+
 struct RowMajorLoader {
   static constexpr bool kColumnStaging = false;
+  static constexpr bool kGather = false;
   const float* p;
   int ld;    // floats between rows (multiple of 4)
   int rows;  // valid rows
@@ -54,6 +93,7 @@ struct RowMajorLoader {
 // the remaining T - C from x [B, J*F, T - C] -- the torch.cat along the frame axis is fused away.
 struct PoseGatherLoader {
   static constexpr bool kColumnStaging = true;
+  static constexpr bool kGather = true;
   const float* x;
   int T, JF, rows;
   const float* prefix = nullptr;
@@ -80,6 +120,7 @@ struct PoseGatherLoader {
 // which halves this GEMM and removes the separate combine pass.
 struct CfgTokenLoader {
   static constexpr bool kColumnStaging = false;
+  static constexpr bool kGather = true;
   const float* tok;    // [nbranch*B*S, D]
   const float* scale;  // [B] or nullptr (single branch)
   int B, T, S, D, rows;
@@ -108,6 +149,7 @@ enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
 // out[m][n] = v (if out) and/or the 16-bit split planes oh/ol[m][n] = hi/lo(v) (if oh) for a following f16x3 GEMM.
 struct LinearEpilogue {
   static constexpr bool kVec4 = true;   // has the row-major 4-column form (pre4 / store4) the kernel prefers when ld % 4 == 0
+  static constexpr bool kLn = false;
   float* out;        // may be null when only the planes are wanted
   const float* bias;  // [N] or null (no bias)
   const float* res;  // may alias out (each element is read then written by the same lane)
@@ -156,10 +198,75 @@ struct LinearEpilogue {
   }
 };
 
+// v = act(A-fold(acc) + bias[n]) * (n < scale_cols ? col_scale : 1) + R[m][n]
+//   A-fold(acc) = rstd[m] * (acc - mean[m] * a_colsum[n])   when a_ln.stat is set (the A operand was a pre-norm sum, see LnFold)
+//   R = LN(res) (res_ln.stat set: res is itself a pre-norm sum), res as it is, or nothing (res == null)
+// v -> out (which may alias res: each element is read, then written, by the same lane) and, when ostat is set, per row and
+// 32-column block (sum v, sum (v - block mean)^2) -> ostat [M][ld/32][2] for the readers of LN(v).  Row-major form only
+// (ld % 32 == 0); the kernel builds the (mean, rstd) tables of the tile's rows and performs the 8-lane reductions.
+struct LnLinearEpilogue {
+  static constexpr bool kVec4 = true;
+  static constexpr bool kLn = true;
+  float* out;
+  const float* bias;
+  int ld;
+  int act;
+  int scale_cols;
+  float col_scale;
+  LnFold a_ln;             // gamma / beta unused: they live in the weights and the bias
+  const float* a_colsum;   // [N]
+  const float* res;
+  LnFold res_ln;
+  float* ostat;
+  struct Row { size_t base; };
+  struct Col { int n; };
+  __device__ __forceinline__ Row row(int m) const { return Row{(size_t)m * ld}; }          // (the per-element form is
+  __device__ __forceinline__ Col col(int n) const { return Col{n}; }                        //  never taken: vec4_ok())
+  __device__ __forceinline__ float pre(const Row&, const Col&) const { return 0.f; }
+  __device__ __forceinline__ void store(const Row&, const Col&, float, float) const {}
+  __device__ __forceinline__ bool vec4_ok() const { return true; }
+  __device__ __forceinline__ float4 pre4(int m, int n) const { return res != nullptr ? ld4(res + (size_t)m * ld + n) : zero4(); }
+  __device__ __forceinline__ void store4(int, int, float4, float4) const {}
+  // the per-column vectors of columns n .. n+3, fetched once per 32-row sub-tile (the stores to `out` in between would
+  // otherwise keep the compiler from hoisting them)
+  struct Cols { float4 bias, colsum, gamma, beta; };
+  __device__ __forceinline__ Cols cols4(int n) const {
+    Cols c;
+    c.bias = ld4(bias + n);
+    c.colsum = a_ln.stat != nullptr ? ld4(a_colsum + n) : zero4();
+    const bool rl = res != nullptr && res_ln.stat != nullptr;
+    c.gamma = rl ? ld4(res_ln.gamma + n) : zero4();
+    c.beta = rl ? ld4(res_ln.beta + n) : zero4();
+    return c;
+  }
+  // the value of (m, n .. n+3); sa / sr = (mean, rstd) of A row m / residual row m
+  __device__ __forceinline__ float4 value4(int n, const Cols& c, float4 a, float4 rv, float2 sa, float2 sr) const {
+    const float4 b4 = c.bias;
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (a_ln.stat != nullptr) {
+      const float4 c4 = c.colsum;
+      const float ms = sa.x * sa.y;
+      v[0] = v[0] * sa.y - ms * c4.x; v[1] = v[1] * sa.y - ms * c4.y; v[2] = v[2] * sa.y - ms * c4.z; v[3] = v[3] * sa.y - ms * c4.w;
+    }
+    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    if (res != nullptr && res_ln.stat != nullptr) rv = ln_apply4(rv, sr, c.gamma, c.beta);
+    const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (act == ACT_GELU) v[q] = gelu_erf(v[q]);
+      else if (act == ACT_SILU) v[q] = silu(v[q]);
+      if (n + q < scale_cols) v[q] *= col_scale;
+      v[q] += rr[q];
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
 // InputProcess epilogue: token (b, s = 1 + t) of every branch gets  acc + b_in[n] + pe[s][n]
 // (mdm.py:348, :251-252); the frame tokens are identical in the cond and uncond branches.
 struct EmbedEpilogue {
   static constexpr bool kVec4 = false;
+  static constexpr bool kLn = false;
   float* tok;          // [nbranch*B*S, D]
   const float* bias;   // [D]
   const float* pe;     // [max_len, D]
@@ -214,6 +321,7 @@ struct NoiseSource {
 // step's noise is a buffer (injected by the caller, or filled by randn_kernel just before).
 struct OutProjEpilogue {
   static constexpr bool kVec4 = false;
+  static constexpr bool kLn = false;
   const float* bias;   // [JF]
   float* out;          // mode 0: model output [nb, JF, T];  mode 1: x_prev [B, JF, T]
   float* x0_out;       // mode 1: optional pred_xstart [B, JF, T]
@@ -267,6 +375,8 @@ constexpr int GEMM_X3_KSPLIT = 2;
 constexpr int gemm_x3_bk(int bt) { return bt == 64 ? 128 : 64; }      // k per staging step (8 float4 per operand and thread either way)
 constexpr int gemm_x3_ld(int bt) { return gemm_x3_bk(bt) + 8; }       // halfs per LDS row of a split plane
 constexpr int gemm_f32_lds_bytes(int bt, bool x3) { return 2 * (x3 ? 2 * bt * gemm_x3_ld(bt) * 2 : bt * (GEMM_BK + 4) * 4); }
+// + behind the operand images: (mean, rstd) of the tile's A rows and of its residual rows (LayerNorm fold, LnFold)
+constexpr int gemm_f32_lds_total(int bt, bool x3) { return gemm_f32_lds_bytes(bt, x3) + 2 * bt * 8; }
 // KS = 2 (X3, 64x64 tiles): EIGHT waves per workgroup -- waves 4-7 take the odd 16-deep k sub-steps of every staged tile (a
 // two-way split-K inside the workgroup, summed through LDS before the epilogue) and every thread stages half as much: the
 // serial per-thread work of a step (loads, split conversions, LDS writes, MFMAs) halves.
@@ -323,7 +433,10 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
   // Register staging TWO k tiles ahead: the loads of tile kt + 2 are issued right after tile kt has been handed to LDS, so
   // each has a whole step to land (one tile ahead, a load had only the few MFMAs of a step to hide behind: the small X3
   // tiles spent most of a step waiting for memory).  Tile kt lives in register set kt & 1.
-  float4 ra[2][NST], rb[2][NST];
+  // (the gathering loaders keep ONE tile in flight instead of two: with their address arithmetic two did not fit the 128 VGPRs
+  // that two resident workgroups leave a wave -- InputProcess spilled 263 registers, OutputProcess 101)
+  constexpr int AHEAD = (AL::kGather || BL::kGather) ? 1 : 2;
+  float4 ra[AHEAD][NST], rb[AHEAD][NST];
   const int nk = (K + BK - 1) / BK;
   auto fetch = [&](auto set_tag, int kt) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_tag)::value;
@@ -351,7 +464,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
       }
     }
     __syncthreads();
-    if (kt + 2 < nk) fetch(set_tag, kt + 2);
+    if (kt + AHEAD < nk) fetch(set_tag, kt + AHEAD);
     if constexpr (X3) {
 #pragma unroll
       for (int kq = 0; kq < BK / 16 / KS; ++kq) {   // 16-deep k sub-steps: lane (r, h) holds k = 16 ks + 8 h .. + 7 of row r
@@ -397,10 +510,22 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
     __syncthreads();
   };
   fetch(std::integral_constant<int, 0>{}, 0);
-  if (nk > 1) fetch(std::integral_constant<int, 1>{}, 1);
-  for (int kt = 0; kt < nk; kt += 2) {
-    step(std::integral_constant<int, 0>{}, kt);
-    if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
+  if constexpr (AHEAD == 2) { if (nk > 1) fetch(std::integral_constant<int, 1>{}, 1); }
+  // LayerNorm fold (LnLinearEpilogue): (mean, rstd) of the tile's rows, merged once from the producers' per-block partial sums
+  // by one thread per row, under the first operand loads; first read in the epilogue, i.e. behind the barriers of the k loop
+  float2* const ln_tab = reinterpret_cast<float2*>(lds_raw + 2 * OP_BYTES);   // [0, BT) A rows, [BT, 2 BT) residual rows
+  if constexpr (EP::kLn) {
+    static_assert(NT >= 2 * BT, "one thread per table row");
+    if (ep.a_ln.stat != nullptr && tid < BT) ln_tab[tid] = ln_row_stats(ep.a_ln, m0 + tid, M);
+    if (ep.res_ln.stat != nullptr && tid >= BT && tid < 2 * BT) ln_tab[tid] = ln_row_stats(ep.res_ln, m0 + tid - BT, M);
+  }
+  if constexpr (AHEAD == 2) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      step(std::integral_constant<int, 0>{}, kt);
+      if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) step(std::integral_constant<int, 0>{}, kt);
   }
 
   if constexpr (KS == 2) {
@@ -415,6 +540,51 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
     if (kgrp == 1) return;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[0][0][e] += part[(wid * 16 + e) * 64 + lane];
+  }
+
+  if constexpr (EP::kLn) {
+    // LnLinearEpilogue: the row-major form below with the folded LayerNorms + the per-row partial statistics of what it writes.  A lane holds 4 columns
+    // of row 8 p + (lane >> 3); the 8 lanes of a row cover the 32 columns of one statistics block.
+    float* const patch = reinterpret_cast<float*>(lds_raw) + (KS == 2 ? 4 * 16 * 64 : 0) + (wid & 3) * (32 * 36);
+    const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+    const int parts = ep.ld / LN_PART_COLS;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int mb = m0 + wm * WT + i * 32, nb = n0 + wn * WT + j * 32 + pc4;
+        float4 rv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int m = mb + 8 * p + prow;
+          rv[p] = (m < M && nb < N) ? ep.pre4(m, nb) : zero4();
+        }
+        const typename EP::Cols cv = ep.cols4(nb < N ? nb : 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) patch[mfma_row(e, h) * 36 + r] = X3 ? acc[i][j][e] * kX3AccScale : acc[i][j][e];
+        wave_lds_fence();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int lrow = wm * WT + i * 32 + 8 * p + prow, m = m0 + lrow;
+          const float4 a4 = ld4(&patch[(8 * p + prow) * 36 + pc4]);
+          const bool ok = m < M && nb < N;
+          const float4 y = ok ? ep.value4(nb, cv, a4, rv[p], ln_tab[lrow], ln_tab[BT + lrow]) : zero4();
+          if (ok) st4(ep.out + (size_t)m * ep.ld + nb, y);
+          if (ep.ostat != nullptr) {
+            float sum = (y.x + y.y) + (y.z + y.w);
+#pragma unroll
+            for (int msk = 1; msk <= 4; msk <<= 1) sum += shfl_xor_f32(sum, msk);
+            const float bm = sum * (1.0f / LN_PART_COLS);
+            float m2 = ((y.x - bm) * (y.x - bm) + (y.y - bm) * (y.y - bm)) + ((y.z - bm) * (y.z - bm) + (y.w - bm) * (y.w - bm));
+#pragma unroll
+            for (int msk = 1; msk <= 4; msk <<= 1) m2 += shfl_xor_f32(m2, msk);
+            if (ok && (lane & 7) == 0)
+              *reinterpret_cast<float2*>(ep.ostat + ((size_t)m * parts + (nb / LN_PART_COLS)) * 2) = make_float2(sum, m2);
+          }
+        }
+        wave_lds_fence();
+      }
+    return;
   }
 
   if constexpr (EP::kVec4) {
@@ -507,13 +677,13 @@ inline void launch_gemm_f32_t(const AL& al, const BL& bl, const EP& ep, int M, i
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
     constexpr int KS = X3 ? GEMM_X3_KSPLIT : 1;
     auto kfn = &gemm_f32_kernel<AL, BL, EP, 64, X3, KS>;
-    gemm_f32_allow_lds(kfn, gemm_f32_lds_bytes(64, X3));
-    MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS * KS), gemm_f32_lds_bytes(64, X3), stream, al, bl, ep, M, N, K, tn, weight_is_a);
+    gemm_f32_allow_lds(kfn, gemm_f32_lds_total(64, X3));
+    MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS * KS), gemm_f32_lds_total(64, X3), stream, al, bl, ep, M, N, K, tn, weight_is_a);
     return;
   }
   auto kfn = &gemm_f32_kernel<AL, BL, EP, 128, X3>;
-  gemm_f32_allow_lds(kfn, gemm_f32_lds_bytes(128, X3));
-  MDM_LAUNCH(kfn, dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), gemm_f32_lds_bytes(128, X3), stream, al, bl, ep, M, N, K, tiles_n, weight_is_a);
+  gemm_f32_allow_lds(kfn, gemm_f32_lds_total(128, X3));
+  MDM_LAUNCH(kfn, dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), gemm_f32_lds_total(128, X3), stream, al, bl, ep, M, N, K, tiles_n, weight_is_a);
 }
 template <class AL, class BL, class EP>
 inline void launch_gemm_f32(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream,

@@ -123,6 +123,10 @@ struct mdm_model {
   // LayerNorm folded into its consumers (gemm_x3.h X3Epilogue): gamma-scaled weight planes, column sums, folded biases
   struct LayerFold { X3Weights in_proj, linear1; float *c_qkv, *b_qkv, *c_1, *b_1; };
   std::vector<LayerFold> fold;
+  // trans_dec: the same fold on fp32 weights (gemm_f32.h LnFold): in_proj(l >= 1) <- norm3(l-1), cross-attention q <- norm1(l),
+  // linear1 <- norm2(l); w = W . diag(gamma), c = row sums of w, b = bias + W . beta
+  struct DecFold { float *w_in, *c_in, *b_in, *w_q, *c_q, *b_q, *w_1, *c_1, *b_1; };
+  std::vector<DecFold> dec_fold;
   X3Weights in_planes{nullptr, nullptr};   // poseEmbedding.weight, K zero-padded to jf_k (f16x3 InputProcess)
   int jf_k = 0;                             // njoints*nfeats rounded up to a multiple of 32
   X3Weights out_planes_f{nullptr, nullptr};
@@ -203,9 +207,9 @@ int launch_layernorm(Profiler* pf, float* x, const float* g, const float* b, int
   return rt_launch_status();
 }
 
-template <int NKT>
+template <int NKT, bool X3 = false>
 int launch_attention_t(const AttnF32Args& a, float* out, int nseq, int D, int H, p16_t* oh, p16_t* ol, hipStream_t s) {
-  auto k = &attention_f32_kernel<NKT>;
+  auto k = &attention_f32_kernel<NKT, X3>;
   const int nqt = (a.Sq + 31) / 32;
   const size_t lds = attention_lds_bytes(NKT, nqt);
   if (int rc = rt_allow_lds(k, lds)) return rc;
@@ -213,13 +217,24 @@ int launch_attention_t(const AttnF32Args& a, float* out, int nseq, int D, int H,
   return rt_launch_status();
 }
 
-// exact-fp32 attention with separate query / key-value sources (attention_f32.h AttnF32Args)
+// attention with separate query / key-value sources (attention_f32.h AttnF32Args): exact fp32, or (x3) the split-precision
+// contractions on the same skeleton
 int launch_attention_args(Profiler* pf, const AttnF32Args& a, float* out, int nseq, int D, int H, p16_t* oh, p16_t* ol,
-                          hipStream_t s) {
+                          hipStream_t s, bool x3 = false) {
   ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * H * (double)a.Sq * a.Sk * ATT_HD, s);
   if (D != H * ATT_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
   if (a.Sq < 1 || a.Sq > 224 || a.Sk < 1 || a.Sk > 224)
     return fail(MDM_EUNSUPPORTED, "attention: 1 <= tokens <= 224 on both sides (T <= 223 frames)");
+  if (x3)
+    switch ((a.Sk + 31) / 32) {
+      case 1: return launch_attention_t<1, true>(a, out, nseq, D, H, oh, ol, s);
+      case 2: return launch_attention_t<2, true>(a, out, nseq, D, H, oh, ol, s);
+      case 3: return launch_attention_t<3, true>(a, out, nseq, D, H, oh, ol, s);
+      case 4: return launch_attention_t<4, true>(a, out, nseq, D, H, oh, ol, s);
+      case 5: return launch_attention_t<5, true>(a, out, nseq, D, H, oh, ol, s);
+      case 6: return launch_attention_t<6, true>(a, out, nseq, D, H, oh, ol, s);
+      default: return launch_attention_t<7, true>(a, out, nseq, D, H, oh, ol, s);
+    }
   switch ((a.Sk + 31) / 32) {
     case 1: return launch_attention_t<1>(a, out, nseq, D, H, oh, ol, s);
     case 2: return launch_attention_t<2>(a, out, nseq, D, H, oh, ol, s);
@@ -233,9 +248,9 @@ int launch_attention_args(Profiler* pf, const AttnF32Args& a, float* out, int ns
 
 // self-attention over packed qkv rows [nseq*S][3D]; `lead` tokens in front of the frames are never masked
 int launch_attention(Profiler* pf, const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D,
-                     int H, p16_t* oh, p16_t* ol, hipStream_t s, int lead = 1) {
+                     int H, p16_t* oh, p16_t* ol, hipStream_t s, int lead = 1, bool x3 = false) {
   const AttnF32Args a{qkv, 3 * D, qkv + D, qkv + 2 * D, 3 * D, S, S, lengths, lead, B};
-  return launch_attention_args(pf, a, out, nseq, D, H, oh, ol, s);
+  return launch_attention_args(pf, a, out, nseq, D, H, oh, ol, s, x3);
 }
 
 #ifdef MDM_PROBES
@@ -343,6 +358,21 @@ int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, cons
   RowMajorLoader al{in, ld_in, M, K};
   RowMajorLoader bl{w, K, N, K};
   LinearEpilogue ep{out, bias, res, N, act, scale_cols, col_scale, nullptr, nullptr};
+  launch_gemm_f32(al, bl, ep, M, N, K, s, x3);
+  return rt_launch_status();
+}
+
+// linear with LayerNorms folded in (gemm_f32.h LnLinearEpilogue): `a_ln` set = the A operand is a pre-norm sum and w / bias are
+// the gamma-folded ones with column sums `colsum`; res_ln set = the residual is LN(res); ostat = where the partial statistics
+// of the written rows go (or null)
+int launch_linear_lnfold(Profiler* pf, const float* in, int ld_in, const LnFold& a_ln, const float* w, const float* bias,
+                         const float* colsum, const float* res, const LnFold& res_ln, float* out, float* ostat, int M, int N,
+                         int K, int act, int scale_cols, float col_scale, hipStream_t s, bool x3) {
+  ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
+  if (K % 4 != 0 || ld_in % 4 != 0 || N % LN_PART_COLS != 0) return fail(MDM_EINVAL, "linear (LayerNorm fold): bad K / N");
+  RowMajorLoader al{in, ld_in, M, K};
+  RowMajorLoader bl{w, K, N, K};
+  LnLinearEpilogue ep{out, bias, N, act, scale_cols, col_scale, a_ln, colsum, res, res_ln, ostat};
   launch_gemm_f32(al, bl, ep, M, N, K, s, x3);
   return rt_launch_status();
 }
@@ -689,6 +719,30 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
                              1.f, s))
     return rc;
   if (m->cfg.arch == MDM_ARCH_TRANS_DEC) {   // the DiP decoder splits its fp32 operands inside the GEMM (gemm_f32.h X3): no planes
+    // LayerNorm folded into the consumers of its output (gemm_f32.h LnFold)
+    base += align_up((size_t)R * D * sizeof(float), 256);
+    const int L = m->cfg.num_layers, FFd = m->cfg.ff_size;
+    auto take = [&](size_t n) { float* p = reinterpret_cast<float*>(base); base += align_up(n * 4, 256); return p; };
+    auto fold_one = [&](const float* w, const float* bias, const float* gamma, const float* beta, int N, float*& wf, float*& cvec,
+                        float*& bvec) -> int {
+      wf = take((size_t)N * D);
+      cvec = take(N);
+      bvec = take(N);
+      MDM_LAUNCH(fold_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w, gamma, beta, bias, wf, cvec, bvec, N, D, N);
+      return rt_launch_status();
+    };
+    m->dec_fold.assign(L, mdm_model::DecFold{});
+    for (int l = 0; l < L; ++l) {
+      mdm_model::DecFold& F = m->dec_fold[l];
+      if (l >= 1)
+        if (int rc = fold_one(m->L(l, "self_attn.in_proj_weight"), m->L(l, "self_attn.in_proj_bias"), m->L(l - 1, "norm3.weight"),
+                              m->L(l - 1, "norm3.bias"), 3 * D, F.w_in, F.c_in, F.b_in)) return rc;
+      if (int rc = fold_one(m->L(l, "multihead_attn.in_proj_weight"), m->L(l, "multihead_attn.in_proj_bias"), m->L(l, "norm1.weight"),
+                            m->L(l, "norm1.bias"), D, F.w_q, F.c_q, F.b_q)) return rc;
+      if (int rc = fold_one(m->L(l, "linear1.weight"), m->L(l, "linear1.bias"), m->L(l, "norm2.weight"), m->L(l, "norm2.bias"),
+                            FFd, F.w_1, F.c_1, F.b_1)) return rc;
+    }
+    if ((size_t)(base - static_cast<char*>(const_ws)) > const_ws_bytes) return fail(MDM_ENOSPC, "mdm_prepare: const workspace too small");
     m->prepared = true;
     return MDM_OK;
   }
@@ -818,6 +872,7 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
 namespace {
 struct DecWorkspace {
   float *tok, *qkv, *att, *ffn, *mem, *kv, *proj;
+  float *stat[2];    // [M][D/32][2] partial LayerNorm statistics of the residual stream (gemm_f32.h LnFold), ping-pong
   // window loop only (nsteps > 0): what is constant over the steps of one p_sample_loop
   float *out;        // [nseq][J*F*pred_len] model output of the current step
   float *kv_text;    // [L][nseq*ntok][2D]   Wkv_l . (text part of the memory)            (no bias)
@@ -841,6 +896,8 @@ DecWorkspace carve_dec(const mdm_model* m, int nseq, int S, int ntok, int B, voi
   w.mem = take(Mm * D);           // text memory [nseq][ntok][D]
   w.kv = take(Mm * 2 * D);        // its key | value projections of the current layer
   w.proj = take((size_t)ntok * B * D);   // embed_text(enc_text), token-major
+  w.stat[0] = take(M * (D / LN_PART_COLS) * 2);
+  w.stat[1] = take(M * (D / LN_PART_COLS) * 2);
   w.out = w.kv_text = w.kv_time = w.time_rows = nullptr;
   if (nsteps > 0) {
     const size_t L = m->cfg.num_layers;
@@ -888,7 +945,7 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
   Profiler* pf = &m->prof;
   const int* len = m->cfg.mask_frames ? lengths : nullptr;
   const float qscale = 1.0f / sqrtf((float)ATT_HD);
-  const bool x3 = m->precision == MDM_PREC_F16X3;   // GEMM arithmetic (gemm_f32.h X3); attention, LayerNorm stay fp32
+  const bool x3 = m->precision == MDM_PREC_F16X3;   // GEMM and attention arithmetic (gemm_f32.h / attention_f32.h X3); the rest fp32
   const bool hoisted = hoist_step >= 0;
 
   // ---- text memory: embed_text over every token (cond branch), + time embedding (mdm.py:217-219)
@@ -912,41 +969,68 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
     launch_gemm_f32(al, bl, ep, B * S, D, m->jf_pad, s, x3);
     if (int rc = rt_launch_status()) return rc;
   }
-  // ---- nn.TransformerDecoder (mdm.py:265; post-norm layers, no final norm)
+  // ---- nn.TransformerDecoder (mdm.py:265; post-norm layers, no final norm).  The three LayerNorms of a layer are folded
+  // into the GEMMs around them (gemm_f32.h LnFold): ws.tok holds the PRE-norm sums y, `pend` says which LayerNorm its readers
+  // have to apply (none for the embedded tokens entering layer 0); only the last norm3 runs as a kernel, for OutputProcess.
+  LnFold pend{};
+  int sp = 0;
+  auto fold_of = [&](int l, const char* norm) {
+    LnFold f;
+    f.stat = ws.stat[sp];
+    f.gamma = m->L(l, (std::string(norm) + ".weight").c_str());
+    f.beta = m->L(l, (std::string(norm) + ".bias").c_str());
+    f.parts = D / LN_PART_COLS;
+    f.inv_dim = 1.0f / (float)D;
+    return f;
+  };
+  const LnFold none{};
   for (int l = 0; l < m->cfg.num_layers; ++l) {
+    const mdm_model::DecFold& F = m->dec_fold[l];
     // x = norm1(x + self_attn(x))
-    if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "self_attn.in_proj_weight"), m->L(l, "self_attn.in_proj_bias"), nullptr,
-                               ws.qkv, M, 3 * D, D, ACT_NONE, D, qscale, s, x3)) return rc;
-    if (int rc = launch_attention(pf, ws.qkv, ws.att, len, nseq, B, S, D, H, nullptr, nullptr, s, /*lead=*/0)) return rc;
-    if (int rc = launch_linear(pf, ws.att, D, m->L(l, "self_attn.out_proj.weight"), m->L(l, "self_attn.out_proj.bias"),
-                               ws.tok, ws.tok, M, D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
-    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), M, D, nullptr, nullptr, s)) return rc;
+    if (pend.stat != nullptr) {
+      if (int rc = launch_linear_lnfold(pf, ws.tok, D, pend, F.w_in, F.b_in, F.c_in, nullptr, none, ws.qkv, nullptr, M, 3 * D, D,
+                                        ACT_NONE, D, qscale, s, x3)) return rc;
+    } else {
+      if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "self_attn.in_proj_weight"), m->L(l, "self_attn.in_proj_bias"), nullptr,
+                                 ws.qkv, M, 3 * D, D, ACT_NONE, D, qscale, s, x3)) return rc;
+    }
+    if (int rc = launch_attention(pf, ws.qkv, ws.att, len, nseq, B, S, D, H, nullptr, nullptr, s, /*lead=*/0, x3)) return rc;
+    if (int rc = launch_linear_lnfold(pf, ws.att, D, none, m->L(l, "self_attn.out_proj.weight"), m->L(l, "self_attn.out_proj.bias"),
+                                      nullptr, ws.tok, pend, ws.tok, ws.stat[sp ^ 1], M, D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
+    sp ^= 1;
+    pend = fold_of(l, "norm1");
     // x = norm2(x + multihead_attn(x, memory, memory)): q from the tokens, k | v from the memory (packed in_proj rows)
     const float* wc = m->L(l, "multihead_attn.in_proj_weight");
     const float* bc = m->L(l, "multihead_attn.in_proj_bias");
-    if (int rc = launch_linear(pf, ws.tok, D, wc, bc, nullptr, ws.qkv, M, D, D, ACT_NONE, D, qscale, s, x3)) return rc;
+    if (int rc = launch_linear_lnfold(pf, ws.tok, D, pend, F.w_q, F.b_q, F.c_q, nullptr, none, ws.qkv, nullptr, M, D, D, ACT_NONE,
+                                      D, qscale, s, x3)) return rc;
     if (!hoisted) {
       if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
       const AttnF32Args a{ws.qkv, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
-      if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s)) return rc;
+      if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s, x3)) return rc;
     } else {
       const float* kvt = ws.kv_text + (size_t)l * Mm * 2 * D;
       const float* row = ws.kv_time + ((size_t)l * nsteps + hoist_step) * 2 * D;
       AttnF32Args a{ws.qkv, D, kvt, kvt + D, 2 * D, S, ntok, text_lengths, 0, B};
       a.kadd = row;
       a.vadd = row + D;
-      if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s)) return rc;
+      if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s, x3)) return rc;
     }
-    if (int rc = launch_linear(pf, ws.att, D, m->L(l, "multihead_attn.out_proj.weight"), m->L(l, "multihead_attn.out_proj.bias"),
-                               ws.tok, ws.tok, M, D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
-    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm2.weight"), m->L(l, "norm2.bias"), M, D, nullptr, nullptr, s)) return rc;
+    if (int rc = launch_linear_lnfold(pf, ws.att, D, none, m->L(l, "multihead_attn.out_proj.weight"),
+                                      m->L(l, "multihead_attn.out_proj.bias"), nullptr, ws.tok, pend, ws.tok, ws.stat[sp ^ 1], M,
+                                      D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
+    sp ^= 1;
+    pend = fold_of(l, "norm2");
     // x = norm3(x + linear2(gelu(linear1(x))))
-    if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "linear1.weight"), m->L(l, "linear1.bias"), nullptr, ws.ffn, M, FF, D,
-                               ACT_GELU, 0, 1.f, s, x3)) return rc;
-    if (int rc = launch_linear(pf, ws.ffn, FF, m->L(l, "linear2.weight"), m->L(l, "linear2.bias"), ws.tok, ws.tok, M, D, FF,
-                               ACT_NONE, 0, 1.f, s, x3)) return rc;
-    if (int rc = launch_layernorm(pf, ws.tok, m->L(l, "norm3.weight"), m->L(l, "norm3.bias"), M, D, nullptr, nullptr, s)) return rc;
+    if (int rc = launch_linear_lnfold(pf, ws.tok, D, pend, F.w_1, F.b_1, F.c_1, nullptr, none, ws.ffn, nullptr, M, FF, D, ACT_GELU,
+                                      0, 1.f, s, x3)) return rc;
+    if (int rc = launch_linear_lnfold(pf, ws.ffn, FF, none, m->L(l, "linear2.weight"), m->L(l, "linear2.bias"), nullptr, ws.tok,
+                                      pend, ws.tok, ws.stat[sp ^ 1], M, D, FF, ACT_NONE, 0, 1.f, s, x3)) return rc;
+    sp ^= 1;
+    pend = fold_of(l, "norm3");
   }
+  if (pend.stat != nullptr)
+    if (int rc = launch_layernorm(pf, ws.tok, pend.gamma, pend.beta, M, D, nullptr, nullptr, s)) return rc;
   // ---- OutputProcess over the completed suffix (mdm.py:278-282): token rows context_len .. S-1 of every sequence
   RowMajorLoader al{m->W("output_process.poseFinal.weight"), D, m->jf, D};
   CfgTokenLoader bl{ws.tok, nullptr, nseq, pred_len, S, D, nseq * pred_len, C};
