@@ -77,6 +77,7 @@ __device__ __forceinline__ float4 ln_apply4(float4 y, float2 st, float4 g, float
 struct RowMajorLoader {
   static constexpr bool kColumnStaging = false;
   static constexpr bool kGather = false;
+  static constexpr bool kFragments = false;
   const float* p;
   int ld;    // floats between rows (multiple of 4)
   int rows;  // valid rows
@@ -87,6 +88,21 @@ struct RowMajorLoader {
   }
 };
 
+// B operand (weights) of the small X3 GEMM as PRE-SPLIT planes in MFMA-fragment order (gemm_x3.h header: Wp[plane][n/32][k/16]
+// [lane][8], values w * 2^8, packed once by mdm_prepare): a wave's B fragment of one 16-deep k sub-step is ONE coalesced 1 KB
+// load straight into registers.  The weights then never pass through LDS (half of the kernel's LDS traffic: 32 KB written and
+// 64 KB read per 128-deep k tile) and are not re-split by every one of the M/64 row tiles.
+struct X3FragB {
+  static constexpr bool kColumnStaging = false;
+  static constexpr bool kGather = false;
+  static constexpr bool kFragments = true;
+  const p16_t* hi;
+  const p16_t* lo;
+  int nblocks;   // 32-row blocks (rows padded)
+  int K;
+  __device__ __forceinline__ float4 load4(int, int) const { return zero4(); }
+};
+
 // A-operand of InputProcess: logical row m = b*T + t, logical k = feature jf in [0, J*F):
 // element = x[b][jf][t] of the contiguous [B, J*F, T] pose tensor (mdm.py:345 permute+reshape fused away).
 // Prefix completion (mdm.py:203-206, DiP): the first C of the T frames of a row batch come from `prefix` [B, J*F, C],
@@ -94,6 +110,7 @@ struct RowMajorLoader {
 struct PoseGatherLoader {
   static constexpr bool kColumnStaging = true;
   static constexpr bool kGather = true;
+  static constexpr bool kFragments = false;
   const float* x;
   int T, JF, rows;
   const float* prefix = nullptr;
@@ -121,6 +138,7 @@ struct PoseGatherLoader {
 struct CfgTokenLoader {
   static constexpr bool kColumnStaging = false;
   static constexpr bool kGather = true;
+  static constexpr bool kFragments = false;
   const float* tok;    // [nbranch*B*S, D]
   const float* scale;  // [B] or nullptr (single branch)
   int B, T, S, D, rows;
@@ -376,7 +394,9 @@ constexpr int gemm_x3_bk(int bt) { return bt == 64 ? 128 : 64; }      // k per s
 constexpr int gemm_x3_ld(int bt) { return gemm_x3_bk(bt) + 8; }       // halfs per LDS row of a split plane
 constexpr int gemm_f32_lds_bytes(int bt, bool x3) { return 2 * (x3 ? 2 * bt * gemm_x3_ld(bt) * 2 : bt * (GEMM_BK + 4) * 4); }
 // + behind the operand images: (mean, rstd) of the tile's A rows and of its residual rows (LayerNorm fold, LnFold)
-constexpr int gemm_f32_lds_total(int bt, bool x3) { return gemm_f32_lds_bytes(bt, x3) + 2 * bt * 8; }
+constexpr int gemm_f32_lds_total(int bt, bool x3, bool wfrag = false) {
+  return gemm_f32_lds_bytes(bt, x3) / (wfrag ? 2 : 1) + 2 * bt * 8;   // (fragment-ordered weights bypass the LDS: X3FragB)
+}
 // KS = 2 (X3, 64x64 tiles): EIGHT waves per workgroup -- waves 4-7 take the odd 16-deep k sub-steps of every staged tile (a
 // two-way split-K inside the workgroup, summed through LDS before the epilogue) and every thread stages half as much: the
 // serial per-thread work of a step (loads, split conversions, LDS writes, MFMAs) halves.
@@ -392,8 +412,11 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
   constexpr int TPR = BK / 4;         // threads sweeping the k's of one row (row-major staging)
   constexpr int RPP = NT / TPR;       // rows per staging pass
   static_assert(KS == 1 || (X3 && BT == 64), "the in-workgroup split-K form exists for the small X3 tile only");
+  constexpr bool WF = BL::kFragments;   // B = fragment-ordered weight planes, global -> registers (X3FragB)
+  static_assert(!WF || (X3 && BT == 64), "fragment-ordered weights: the small X3 tile only");
   // fp32 tiles (exact mode) or hi | lo fp16 planes of the same tiles (X3)
   constexpr int OP_BYTES = gemm_f32_lds_bytes(BT, X3) / 2;
+  constexpr int IMG_BYTES = WF ? OP_BYTES : 2 * OP_BYTES;
   MDM_DYN_SMEM(unsigned char, lds_raw);   // 2 * OP_BYTES (the X3 image of a 64-row tile pair is 68 KB: beyond static LDS)
   float* const As = reinterpret_cast<float*>(lds_raw);
   float* const Bs = reinterpret_cast<float*>(lds_raw + OP_BYTES);
@@ -444,7 +467,24 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       ra[SET][i] = al.load4(m0 + a_row[i], kb + a_k[i]);
-      rb[SET][i] = bl.load4(n0 + b_row[i], kb + b_k[i]);
+      if constexpr (!WF) rb[SET][i] = bl.load4(n0 + b_row[i], kb + b_k[i]);
+    }
+  };
+  // WF: this wave's B fragments of the k tile in flight, one (hi, lo) pair per 16-deep sub-step it owns; pair kq is re-fetched
+  // for the NEXT tile right behind the MFMAs that consumed it (a rolling prefetch one tile deep in the same registers)
+  constexpr int NQ = X3 ? BK / 16 / KS : 1;
+  p16x8 wfh[WF ? NQ : 1], wfl[WF ? NQ : 1];
+  auto fetch_w = [&](int kq, int kt) __attribute__((always_inline)) {
+    if constexpr (WF) {
+      const int nb = (n0 + wn * WT) >> 5, kk = kt * (BK / 16) + KS * kq + kgrp;
+      if (nb < bl.nblocks && kk * 16 < K) {
+        const size_t o = (((size_t)nb * (size_t)(bl.K / 16) + kk) * 64 + lane) * 8;
+        wfh[kq] = *reinterpret_cast<const p16x8*>(bl.hi + o);
+        wfl[kq] = *reinterpret_cast<const p16x8*>(bl.lo + o);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wfh[kq][j] = 0; wfl[kq][j] = 0; }
+      }
     }
   };
   auto step = [&](auto set_tag, int kt) __attribute__((always_inline)) {
@@ -456,8 +496,9 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
         const float sa = weight_is_a ? kX3WeightScale : 1.f, sb = weight_is_a ? 1.f : kX3WeightScale;
         split4_store(&Ah[a_row[i] * GEMM_X3_LD + a_k[i]], &Al[a_row[i] * GEMM_X3_LD + a_k[i]],
                      make_float4(ra[SET][i].x * sa, ra[SET][i].y * sa, ra[SET][i].z * sa, ra[SET][i].w * sa));
-        split4_store(&Bh[b_row[i] * GEMM_X3_LD + b_k[i]], &Bl[b_row[i] * GEMM_X3_LD + b_k[i]],
-                     make_float4(rb[SET][i].x * sb, rb[SET][i].y * sb, rb[SET][i].z * sb, rb[SET][i].w * sb));
+        if constexpr (!WF)
+          split4_store(&Bh[b_row[i] * GEMM_X3_LD + b_k[i]], &Bl[b_row[i] * GEMM_X3_LD + b_k[i]],
+                       make_float4(rb[SET][i].x * sb, rb[SET][i].y * sb, rb[SET][i].z * sb, rb[SET][i].w * sb));
       } else {
         st4(&As[a_row[i] * GEMM_LDS_LD + a_k[i]], ra[SET][i]);
         st4(&Bs[b_row[i] * GEMM_LDS_LD + b_k[i]], rb[SET][i]);
@@ -476,8 +517,11 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
           const int bo = (wn * WT + t * 32 + r) * GEMM_X3_LD + 16 * ks + 8 * h;
           ah[t] = *reinterpret_cast<const p16x8*>(&Ah[ao]);
           al_[t] = *reinterpret_cast<const p16x8*>(&Al[ao]);
-          bh[t] = *reinterpret_cast<const p16x8*>(&Bh[bo]);
-          bl_[t] = *reinterpret_cast<const p16x8*>(&Bl[bo]);
+          if constexpr (WF) { bh[t] = wfh[kq]; bl_[t] = wfl[kq]; }
+          else {
+            bh[t] = *reinterpret_cast<const p16x8*>(&Bh[bo]);
+            bl_[t] = *reinterpret_cast<const p16x8*>(&Bl[bo]);
+          }
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i)
@@ -487,6 +531,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
             acc[i][j] = mfma_p16(ah[i], bl_[j], acc[i][j]);
             acc[i][j] = mfma_p16(ah[i], bh[j], acc[i][j]);
           }
+        if constexpr (WF) { if (kt + 1 < nk) fetch_w(kq, kt + 1); }
       }
     } else
 #pragma unroll
@@ -510,10 +555,14 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
     __syncthreads();
   };
   fetch(std::integral_constant<int, 0>{}, 0);
+  if constexpr (WF) {
+#pragma unroll
+    for (int kq = 0; kq < NQ; ++kq) fetch_w(kq, 0);
+  }
   if constexpr (AHEAD == 2) { if (nk > 1) fetch(std::integral_constant<int, 1>{}, 1); }
   // LayerNorm fold (LnLinearEpilogue): (mean, rstd) of the tile's rows, merged once from the producers' per-block partial sums
   // by one thread per row, under the first operand loads; first read in the epilogue, i.e. behind the barriers of the k loop
-  float2* const ln_tab = reinterpret_cast<float2*>(lds_raw + 2 * OP_BYTES);   // [0, BT) A rows, [BT, 2 BT) residual rows
+  float2* const ln_tab = reinterpret_cast<float2*>(lds_raw + IMG_BYTES);   // [0, BT) A rows, [BT, 2 BT) residual rows
   if constexpr (EP::kLn) {
     static_assert(NT >= 2 * BT, "one thread per table row");
     if (ep.a_ln.stat != nullptr && tid < BT) ln_tab[tid] = ln_row_stats(ep.a_ln, m0 + tid, M);
@@ -528,6 +577,7 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
     for (int kt = 0; kt < nk; ++kt) step(std::integral_constant<int, 0>{}, kt);
   }
 
+  static_assert(!WF || (KS == 2 ? 4 * 16 * 64 * 4 : 0) + 4 * 32 * 36 * 4 <= IMG_BYTES, "split-K buffer + epilogue patches must fit the A image");
   if constexpr (KS == 2) {
     // the second quartet's partial tile -> LDS (the staging image is dead: the k loop ended with a barrier) -> added by the
     // first quartet, which owns the epilogue; lane-major [wave][reg][lane] so that both sides are conflict-free
@@ -673,23 +723,31 @@ template <bool X3, class AL, class BL, class EP>
 inline void launch_gemm_f32_t(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream,
                               int weight_is_a) {
   const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-  if (tiles_m * tiles_n < 512 && (size_t)M * N >= 64 * 64 * 4) {
+  if (BL::kFragments || (tiles_m * tiles_n < 512 && (size_t)M * N >= 64 * 64 * 4)) {
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
     constexpr int KS = X3 ? GEMM_X3_KSPLIT : 1;
+    constexpr int LDS = gemm_f32_lds_total(64, X3, BL::kFragments);
     auto kfn = &gemm_f32_kernel<AL, BL, EP, 64, X3, KS>;
-    gemm_f32_allow_lds(kfn, gemm_f32_lds_total(64, X3));
-    MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS * KS), gemm_f32_lds_total(64, X3), stream, al, bl, ep, M, N, K, tn, weight_is_a);
+    gemm_f32_allow_lds(kfn, LDS);
+    MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS * KS), LDS, stream, al, bl, ep, M, N, K, tn, weight_is_a);
     return;
   }
+  if constexpr (!BL::kFragments) {
   auto kfn = &gemm_f32_kernel<AL, BL, EP, 128, X3>;
   gemm_f32_allow_lds(kfn, gemm_f32_lds_total(128, X3));
   MDM_LAUNCH(kfn, dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), gemm_f32_lds_total(128, X3), stream, al, bl, ep, M, N, K, tiles_n, weight_is_a);
+  }
 }
 template <class AL, class BL, class EP>
 inline void launch_gemm_f32(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream,
                             bool x3 = false, bool weight_is_a = false) {
-  if (x3) launch_gemm_f32_t<true>(al, bl, ep, M, N, K, stream, (int)weight_is_a);
-  else launch_gemm_f32_t<false>(al, bl, ep, M, N, K, stream, 0);
+  if constexpr (BL::kFragments) {
+    (void)x3;   // pre-split weights: the split arithmetic by construction
+    launch_gemm_f32_t<true>(al, bl, ep, M, N, K, stream, 0);
+  } else {
+    if (x3) launch_gemm_f32_t<true>(al, bl, ep, M, N, K, stream, (int)weight_is_a);
+    else launch_gemm_f32_t<false>(al, bl, ep, M, N, K, stream, 0);
+  }
 }
 
 }  // namespace mdm

@@ -127,6 +127,10 @@ struct mdm_model {
   // linear1 <- norm2(l); w = W . diag(gamma), c = row sums of w, b = bias + W . beta
   struct DecFold { float *w_in, *c_in, *b_in, *w_q, *c_q, *b_q, *w_1, *c_1, *b_1; };
   std::vector<DecFold> dec_fold;
+  // trans_dec: fragment-ordered fp16 hi/lo planes of the layer weights for the small X3 GEMM (gemm_f32.h X3FragB); in_proj,
+  // q and linear1 from the gamma-folded copies where a LayerNorm is folded (in_proj of layer 0: the plain weight)
+  struct DecPlanes { X3Weights in_proj, out_proj, q, out_proj2, linear1, linear2; };
+  std::vector<DecPlanes> dec_planes;
   X3Weights in_planes{nullptr, nullptr};   // poseEmbedding.weight, K zero-padded to jf_k (f16x3 InputProcess)
   int jf_k = 0;                             // njoints*nfeats rounded up to a multiple of 32
   X3Weights out_planes_f{nullptr, nullptr};
@@ -365,15 +369,22 @@ int launch_linear(Profiler* pf, const float* in, int ld_in, const float* w, cons
 // linear with LayerNorms folded in (gemm_f32.h LnLinearEpilogue): `a_ln` set = the A operand is a pre-norm sum and w / bias are
 // the gamma-folded ones with column sums `colsum`; res_ln set = the residual is LN(res); ostat = where the partial statistics
 // of the written rows go (or null)
-int launch_linear_lnfold(Profiler* pf, const float* in, int ld_in, const LnFold& a_ln, const float* w, const float* bias,
-                         const float* colsum, const float* res, const LnFold& res_ln, float* out, float* ostat, int M, int N,
-                         int K, int act, int scale_cols, float col_scale, hipStream_t s, bool x3) {
+// (x3: the weights come as the fragment-ordered planes `wp` of the same matrix, gemm_f32.h X3FragB)
+int launch_linear_lnfold(Profiler* pf, const float* in, int ld_in, const LnFold& a_ln, const float* w, X3Weights wp,
+                         const float* bias, const float* colsum, const float* res, const LnFold& res_ln, float* out,
+                         float* ostat, int M, int N, int K, int act, int scale_cols, float col_scale, hipStream_t s, bool x3) {
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
-  if (K % 4 != 0 || ld_in % 4 != 0 || N % LN_PART_COLS != 0) return fail(MDM_EINVAL, "linear (LayerNorm fold): bad K / N");
+  if (K % 16 != 0 || ld_in % 4 != 0 || N % LN_PART_COLS != 0) return fail(MDM_EINVAL, "linear (LayerNorm fold): bad K / N");
   RowMajorLoader al{in, ld_in, M, K};
-  RowMajorLoader bl{w, K, N, K};
   LnLinearEpilogue ep{out, bias, N, act, scale_cols, col_scale, a_ln, colsum, res, res_ln, ostat};
-  launch_gemm_f32(al, bl, ep, M, N, K, s, x3);
+  static const bool fragb = [] { const char* e = getenv("MDM_DEC_FRAGB"); return e == nullptr || e[0] != '0'; }();   // A/B switch
+  if (x3 && wp.hi != nullptr && fragb) {
+    X3FragB bl{wp.hi, wp.lo, (N + 31) / 32, K};
+    launch_gemm_f32(al, bl, ep, M, N, K, s, true);
+  } else {
+    RowMajorLoader bl{w, K, N, K};
+    launch_gemm_f32(al, bl, ep, M, N, K, s, x3);
+  }
   return rt_launch_status();
 }
 
@@ -682,6 +693,15 @@ size_t mdm_const_bytes(const mdm_model_t* m) {
   if (m == nullptr) return 0;
   const size_t D = m->cfg.latent_dim;
   const size_t FF = m->cfg.ff_size;
+  if (m->cfg.arch == MDM_ARCH_TRANS_DEC) {
+    // padded poseEmbedding, time table + its MLP scratch; per layer the gamma-folded in_proj / q / linear1 (fp32 + 2 vectors
+    // each) and the fragment-ordered planes of in_proj, out_proj, q, cross out_proj, linear1, linear2 (4 bytes per weight)
+    const size_t fold = align_up(3 * D * D * 4, 256) + align_up(D * D * 4, 256) + align_up(FF * D * 4, 256) +
+                        2 * (align_up(3 * D * 4, 256) + align_up(D * 4, 256) + align_up(FF * 4, 256));
+    const size_t planes = align_up(3 * D * D * 4, 256) + 3 * align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
+    return align_up(D * m->jf_pad * sizeof(float), 256) + 2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) +
+           (size_t)m->cfg.num_layers * (fold + planes);
+  }
   const size_t per_layer = align_up(3 * D * D * 4, 256) + align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
   return align_up(D * m->jf_pad * sizeof(float), 256) + 2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) +
          (size_t)m->cfg.num_layers * per_layer + align_up(x3_packed_weight_elems(m->jf_out, (int)D) * 4, 256) +
@@ -741,6 +761,24 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
                             m->L(l, "norm1.bias"), D, F.w_q, F.c_q, F.b_q)) return rc;
       if (int rc = fold_one(m->L(l, "linear1.weight"), m->L(l, "linear1.bias"), m->L(l, "norm2.weight"), m->L(l, "norm2.bias"),
                             FFd, F.w_1, F.c_1, F.b_1)) return rc;
+    }
+    auto make_planes = [&](const float* src, int N, int K, X3Weights& op) -> int {
+      const size_t n = x3_packed_weight_elems(N, K);
+      p16_t* hi = reinterpret_cast<p16_t*>(base);
+      base += align_up(n * 4, 256);
+      op = X3Weights{hi, hi + n};
+      return launch_pack_weights(src, hi, hi + n, N, K, s);
+    };
+    m->dec_planes.assign(L, mdm_model::DecPlanes{});
+    for (int l = 0; l < L; ++l) {
+      const mdm_model::DecFold& F = m->dec_fold[l];
+      mdm_model::DecPlanes& P = m->dec_planes[l];
+      if (int rc = make_planes(l >= 1 ? F.w_in : m->L(l, "self_attn.in_proj_weight"), 3 * D, D, P.in_proj)) return rc;
+      if (int rc = make_planes(m->L(l, "self_attn.out_proj.weight"), D, D, P.out_proj)) return rc;
+      if (int rc = make_planes(F.w_q, D, D, P.q)) return rc;
+      if (int rc = make_planes(m->L(l, "multihead_attn.out_proj.weight"), D, D, P.out_proj2)) return rc;
+      if (int rc = make_planes(F.w_1, FFd, D, P.linear1)) return rc;
+      if (int rc = make_planes(m->L(l, "linear2.weight"), D, FFd, P.linear2)) return rc;
     }
     if ((size_t)(base - static_cast<char*>(const_ws)) > const_ws_bytes) return fail(MDM_ENOSPC, "mdm_prepare: const workspace too small");
     m->prepared = true;
@@ -986,24 +1024,23 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
   const LnFold none{};
   for (int l = 0; l < m->cfg.num_layers; ++l) {
     const mdm_model::DecFold& F = m->dec_fold[l];
+    const mdm_model::DecPlanes& P = m->dec_planes[l];
+    const bool folded = pend.stat != nullptr;   // false only for the embedded tokens entering layer 0
     // x = norm1(x + self_attn(x))
-    if (pend.stat != nullptr) {
-      if (int rc = launch_linear_lnfold(pf, ws.tok, D, pend, F.w_in, F.b_in, F.c_in, nullptr, none, ws.qkv, nullptr, M, 3 * D, D,
-                                        ACT_NONE, D, qscale, s, x3)) return rc;
-    } else {
-      if (int rc = launch_linear(pf, ws.tok, D, m->L(l, "self_attn.in_proj_weight"), m->L(l, "self_attn.in_proj_bias"), nullptr,
-                                 ws.qkv, M, 3 * D, D, ACT_NONE, D, qscale, s, x3)) return rc;
-    }
+    if (int rc = launch_linear_lnfold(pf, ws.tok, D, pend, folded ? F.w_in : m->L(l, "self_attn.in_proj_weight"), P.in_proj,
+                                      folded ? F.b_in : m->L(l, "self_attn.in_proj_bias"), folded ? F.c_in : nullptr, nullptr,
+                                      none, ws.qkv, nullptr, M, 3 * D, D, ACT_NONE, D, qscale, s, x3)) return rc;
     if (int rc = launch_attention(pf, ws.qkv, ws.att, len, nseq, B, S, D, H, nullptr, nullptr, s, /*lead=*/0, x3)) return rc;
-    if (int rc = launch_linear_lnfold(pf, ws.att, D, none, m->L(l, "self_attn.out_proj.weight"), m->L(l, "self_attn.out_proj.bias"),
-                                      nullptr, ws.tok, pend, ws.tok, ws.stat[sp ^ 1], M, D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
+    if (int rc = launch_linear_lnfold(pf, ws.att, D, none, m->L(l, "self_attn.out_proj.weight"), P.out_proj,
+                                      m->L(l, "self_attn.out_proj.bias"), nullptr, ws.tok, pend, ws.tok, ws.stat[sp ^ 1], M, D, D,
+                                      ACT_NONE, 0, 1.f, s, x3)) return rc;
     sp ^= 1;
     pend = fold_of(l, "norm1");
     // x = norm2(x + multihead_attn(x, memory, memory)): q from the tokens, k | v from the memory (packed in_proj rows)
     const float* wc = m->L(l, "multihead_attn.in_proj_weight");
     const float* bc = m->L(l, "multihead_attn.in_proj_bias");
-    if (int rc = launch_linear_lnfold(pf, ws.tok, D, pend, F.w_q, F.b_q, F.c_q, nullptr, none, ws.qkv, nullptr, M, D, D, ACT_NONE,
-                                      D, qscale, s, x3)) return rc;
+    if (int rc = launch_linear_lnfold(pf, ws.tok, D, pend, F.w_q, P.q, F.b_q, F.c_q, nullptr, none, ws.qkv, nullptr, M, D, D,
+                                      ACT_NONE, D, qscale, s, x3)) return rc;
     if (!hoisted) {
       if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
       const AttnF32Args a{ws.qkv, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
@@ -1016,16 +1053,16 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
       a.vadd = row + D;
       if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s, x3)) return rc;
     }
-    if (int rc = launch_linear_lnfold(pf, ws.att, D, none, m->L(l, "multihead_attn.out_proj.weight"),
+    if (int rc = launch_linear_lnfold(pf, ws.att, D, none, m->L(l, "multihead_attn.out_proj.weight"), P.out_proj2,
                                       m->L(l, "multihead_attn.out_proj.bias"), nullptr, ws.tok, pend, ws.tok, ws.stat[sp ^ 1], M,
                                       D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
     sp ^= 1;
     pend = fold_of(l, "norm2");
     // x = norm3(x + linear2(gelu(linear1(x))))
-    if (int rc = launch_linear_lnfold(pf, ws.tok, D, pend, F.w_1, F.b_1, F.c_1, nullptr, none, ws.ffn, nullptr, M, FF, D, ACT_GELU,
-                                      0, 1.f, s, x3)) return rc;
-    if (int rc = launch_linear_lnfold(pf, ws.ffn, FF, none, m->L(l, "linear2.weight"), m->L(l, "linear2.bias"), nullptr, ws.tok,
-                                      pend, ws.tok, ws.stat[sp ^ 1], M, D, FF, ACT_NONE, 0, 1.f, s, x3)) return rc;
+    if (int rc = launch_linear_lnfold(pf, ws.tok, D, pend, F.w_1, P.linear1, F.b_1, F.c_1, nullptr, none, ws.ffn, nullptr, M, FF,
+                                      D, ACT_GELU, 0, 1.f, s, x3)) return rc;
+    if (int rc = launch_linear_lnfold(pf, ws.ffn, FF, none, m->L(l, "linear2.weight"), P.linear2, m->L(l, "linear2.bias"), nullptr,
+                                      ws.tok, pend, ws.tok, ws.stat[sp ^ 1], M, D, FF, ACT_NONE, 0, 1.f, s, x3)) return rc;
     sp ^= 1;
     pend = fold_of(l, "norm3");
   }
