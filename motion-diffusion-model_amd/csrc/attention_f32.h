@@ -48,6 +48,10 @@ struct AttnF32Args {
   // projected memory (constant over a window's steps) and adds the step's projected time embedding here (mdm_api.hip)
   const float* kadd = nullptr;
   const float* vadd = nullptr;
+  // the K / V source may hold MORE samples than this launch covers (a sample group of a larger batch, mdm_sample_loop_dec):
+  // local sequence (branch br, sample bl) reads source sequence br * kv_B + kv_b0 + bl; kv_B = 0: the source is local
+  int kv_B = 0;
+  int kv_b0 = 0;
 };
 
 // blockDim.x = 64 * ceil(Sq / 32): wave w owns query rows [32w, 32w + 32); NKT = ceil(Sk / 32) key tiles.
@@ -70,8 +74,13 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
   const int seq = blockIdx.x / H, head = blockIdx.x - seq * H;
   const int ld = a.ldkv;
   const float* qbase = a.q + (size_t)seq * Sq * a.ldq + head * ATT_HD;
-  const float* kbase = a.k + (size_t)seq * S * ld + head * ATT_HD;
-  const float* vbase = a.v + (size_t)seq * S * ld + head * ATT_HD;
+  int kseq = seq;
+  if (a.kv_B > 0) {
+    const int br = seq / a.B;
+    kseq = br * a.kv_B + a.kv_b0 + (seq - br * a.B);
+  }
+  const float* kbase = a.k + (size_t)kseq * S * ld + head * ATT_HD;
+  const float* vbase = a.v + (size_t)kseq * S * ld + head * ATT_HD;
 
   int nvalid = S;
   if (a.lengths != nullptr) nvalid = min(S, a.lead + a.lengths[seq % a.B]);

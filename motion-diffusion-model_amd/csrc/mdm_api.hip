@@ -108,9 +108,35 @@ struct ProfScope {   // records start on construction, stop on destruction (both
 #endif
 };
 
+// Side streams of a model handle (the DiP window loop runs independent sample groups concurrently): created on first use on
+// the handle's device, joined back into the caller's stream with events before the call returns control of the results.
+struct AuxStreams {
+  static constexpr int kMax = 3;
+#ifndef MDM_EMU
+  hipStream_t s[kMax] = {};
+  hipEvent_t fork = nullptr, join[kMax] = {};
+  int n = 0;
+  int ensure(int want) {
+    if (fork == nullptr && hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return fail(MDM_EHIP, "hipEventCreate failed");
+    for (; n < want && n < kMax; ++n)
+      if (hipStreamCreateWithFlags(&s[n], hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&join[n], hipEventDisableTiming) != hipSuccess) return fail(MDM_EHIP, "hipStreamCreate failed");
+    return MDM_OK;
+  }
+  ~AuxStreams() {
+    for (int i = 0; i < kMax; ++i) {
+      if (join[i] != nullptr) (void)hipEventDestroy(join[i]);
+      if (s[i] != nullptr) (void)hipStreamDestroy(s[i]);
+    }
+    if (fork != nullptr) (void)hipEventDestroy(fork);
+  }
+#endif
+};
+
 struct mdm_model {
   mdm_config_t cfg;
   Profiler prof;
+  AuxStreams aux;
   std::map<std::string, const float*> w;
   std::map<std::string, int64_t> expect;  // name -> numel
   bool prepared = false;
@@ -974,9 +1000,16 @@ int check_dec_shapes(const mdm_model_t* m, const char* who, const float* prefix,
 // One evaluation of the trans_dec denoiser.  hoist_step < 0: the stand-alone forward (memory = text + time built here from
 // `timesteps`, projected per layer).  hoist_step = k >= 0: step k of a window loop -- ws.kv_text / ws.kv_time are filled,
 // the memory is never materialised and the per-layer memory projection is skipped.
+struct DecHoist {         // step k of a window loop: where the hoisted projections of the (whole) batch live
+  int step = -1;          // < 0: not hoisted
+  int nsteps = 0;
+  const float* kv_text = nullptr;   // [L][nbranch * kv_B * ntok][2D]
+  const float* kv_time = nullptr;   // [L][nsteps][2D]
+  int kv_B = 0, kv_b0 = 0;          // this pass covers samples kv_b0 .. kv_b0 + B - 1 of kv_B
+};
 int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const float* prefix, const int64_t* timesteps,
                  const float* text_tokens, const int32_t* text_lengths, const int32_t* lengths, int B, int pred_len,
-                 int ntok, int branches, float* out, hipStream_t s, int hoist_step, int nsteps) {
+                 int ntok, int branches, float* out, hipStream_t s, const DecHoist& hz) {
   const int C = m->cfg.context_len, S = C + pred_len, D = m->cfg.latent_dim, H = m->cfg.num_heads, FF = m->cfg.ff_size;
   const int nbranch = (branches == MDM_BRANCH_BOTH) ? 2 : 1;
   const int nseq = nbranch * B, M = nseq * S, Mm = nseq * ntok;
@@ -984,7 +1017,7 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
   const int* len = m->cfg.mask_frames ? lengths : nullptr;
   const float qscale = 1.0f / sqrtf((float)ATT_HD);
   const bool x3 = m->precision == MDM_PREC_F16X3;   // GEMM and attention arithmetic (gemm_f32.h / attention_f32.h X3); the rest fp32
-  const bool hoisted = hoist_step >= 0;
+  const bool hoisted = hz.step >= 0;
 
   // ---- text memory: embed_text over every token (cond branch), + time embedding (mdm.py:217-219)
   if (!hoisted && branches != MDM_BRANCH_UNCOND)
@@ -1046,11 +1079,13 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
       const AttnF32Args a{ws.qkv, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
       if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s, x3)) return rc;
     } else {
-      const float* kvt = ws.kv_text + (size_t)l * Mm * 2 * D;
-      const float* row = ws.kv_time + ((size_t)l * nsteps + hoist_step) * 2 * D;
+      const float* kvt = hz.kv_text + (size_t)l * ((size_t)nbranch * hz.kv_B * ntok) * 2 * D;
+      const float* row = hz.kv_time + ((size_t)l * hz.nsteps + hz.step) * 2 * D;
       AttnF32Args a{ws.qkv, D, kvt, kvt + D, 2 * D, S, ntok, text_lengths, 0, B};
       a.kadd = row;
       a.vadd = row + D;
+      a.kv_B = hz.kv_B;
+      a.kv_b0 = hz.kv_b0;
       if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s, x3)) return rc;
     }
     if (int rc = launch_linear_lnfold(pf, ws.att, D, none, m->L(l, "multihead_attn.out_proj.weight"), P.out_proj2,
@@ -1094,7 +1129,7 @@ int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const i
   DecWorkspace ws = carve_dec(m, nseq, m->cfg.context_len + pred_len, ntok, B, ws_dev);
   if (ws_bytes < ws.bytes) return fail(MDM_ENOSPC, "mdm_forward_dec: workspace too small");
   return decoder_pass(m, ws, x, prefix, timesteps, text_tokens, text_lengths, lengths, B, pred_len, ntok, branches, out,
-                      static_cast<hipStream_t>(stream), -1, 0);
+                      static_cast<hipStream_t>(stream), DecHoist{});
 }
 
 int mdm_sampler_step(const float* x_t, const float* out_cond, const float* out_uncond, const float* scale,
@@ -1284,29 +1319,76 @@ int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float
                                ACT_NONE, 0, 1.f, s, x3)) return rc;
   }
 
-  int dump_i = 0, k = 0;
-  for (int i = p->start_index; i >= 0; --i, ++k) {
-    if (int rc = decoder_pass(m, ws, x, pd->prefix_dev, nullptr, p->text_embed_dev, pd->text_lengths_dev, p->lengths_dev, B, P,
-                              ntok, branches, ws.out, s, k, nsteps)) return rc;
-    // CFG combine + posterior / DDIM update, in place on x (each element is read, then written, by the same lane)
-    StepCoefs co{p->a_x0[i], p->a_xt[i], p->sigma[i], p->clip_denoised};
-    const float* step_noise = (p->noise_dev != nullptr && p->sigma[i] != 0.f) ? p->noise_dev + (size_t)k * B * per_sample : nullptr;
-    NoiseSource ns{step_noise, p->seed, p->sample_base, (uint32_t)(1 + k), (uint32_t)(p->const_noise != 0)};
-    const size_t total = (size_t)B * per_sample;
-    const int grid = (int)std::min<size_t>((total + 255) / 256, 2048);
-    {
-      ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
-      MDM_LAUNCH(sampler_step_kernel, dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)ws.out,
-                 cfg ? (const float*)(ws.out + (size_t)B * per_sample) : (const float*)nullptr, p->scale_dev,
-                 p->inpaint_mask_dev, p->inpaint_motion_dev, x, (i == 0) ? p->x0_dev : (float*)nullptr, (int)per_sample, B, co, ns);
-      if (int rc = rt_launch_status()) return rc;
-    }
-    if (dump_i < p->num_dump && p->dump_steps[dump_i] == k) {
-      if (int rc = rt_copy(p->dump_dev + (size_t)dump_i * B * per_sample, x, (size_t)B * per_sample * sizeof(float), s)) return rc;
-      ++dump_i;
+  // ---- the steps.  Samples are independent chains, and at these sizes a launch is mostly fixed cost (dispatch, cold first
+  // loads, a short tail: ~11 of ~20 us for a 3840-row GEMM): the batch is cut into G groups of B / G samples whose loops run
+  // CONCURRENTLY on side streams (forked behind the hoisted projections, joined before returning), so that one group's
+  // fixed costs hide behind another's matrix work.  Every output element sees the same arithmetic whatever G is (bit-identical
+  // results in the f32 mode; in f16x3 up to re-association where a GEMM's tile shape follows its row count).  Each group owns
+  // the rows [g * Mg, (g + 1) * Mg) of the activation buffers.
+  int G = 1;
+  {
+    const char* e = getenv("MDM_DIP_GROUPS");   // A/B switch and tests; read per window
+    const int forced = e != nullptr ? atoi(e) : 0;
+    const int want = forced > 0 ? forced : (B >= 16 ? 2 : 1);
+    for (int g = std::min(want, AuxStreams::kMax + 1); g >= 1; --g)
+      if (B % g == 0) { G = g; break; }
+  }
+  hipStream_t gs[AuxStreams::kMax + 1] = {s, s, s, s};
+#ifndef MDM_EMU
+  if (G > 1) {
+    if (int rc = m->aux.ensure(G - 1)) return rc;
+    if (hipEventRecord(m->aux.fork, s) != hipSuccess) return fail(MDM_EHIP, "mdm_sample_loop_dec: hipEventRecord failed");
+    for (int g = 1; g < G; ++g) {
+      gs[g] = m->aux.s[g - 1];
+      if (hipStreamWaitEvent(gs[g], m->aux.fork, 0) != hipSuccess) return fail(MDM_EHIP, "mdm_sample_loop_dec: hipStreamWaitEvent failed");
     }
   }
-  return MDM_OK;
+#endif
+  const int Bg = B / G, nseq_g = nbranch * Bg, S = m->cfg.context_len + P;
+  const size_t Mg = (size_t)nseq_g * S, FFs = m->cfg.ff_size;
+  int dump_i = 0, k = 0, rc_loop = MDM_OK;
+  for (int i = p->start_index; i >= 0 && rc_loop == MDM_OK; --i, ++k) {
+    const bool dump = dump_i < p->num_dump && p->dump_steps[dump_i] == k;
+    for (int g = 0; g < G && rc_loop == MDM_OK; ++g) {
+      const int b0 = g * Bg;
+      const size_t xo = (size_t)b0 * per_sample;
+      DecWorkspace wg = ws;
+      wg.tok += g * Mg * D; wg.qkv += g * Mg * 3 * D; wg.att += g * Mg * D; wg.ffn += g * Mg * FFs;
+      wg.stat[0] += g * Mg * (D / LN_PART_COLS) * 2; wg.stat[1] += g * Mg * (D / LN_PART_COLS) * 2;
+      wg.out += (size_t)g * nseq_g * per_sample;
+      DecHoist hz;
+      hz.step = k; hz.nsteps = nsteps; hz.kv_text = ws.kv_text; hz.kv_time = ws.kv_time; hz.kv_B = B; hz.kv_b0 = b0;
+      const float* prefix_g = pd->prefix_dev != nullptr ? pd->prefix_dev + (size_t)b0 * m->jf * m->cfg.context_len : nullptr;
+      rc_loop = decoder_pass(m, wg, x + xo, prefix_g, nullptr, p->text_embed_dev, pd->text_lengths_dev + b0,
+                             p->lengths_dev != nullptr ? p->lengths_dev + b0 : nullptr, Bg, P, ntok, branches, wg.out, gs[g], hz);
+      if (rc_loop != MDM_OK) break;
+      // CFG combine + posterior / DDIM update, in place on x (each element is read, then written, by the same lane)
+      StepCoefs co{p->a_x0[i], p->a_xt[i], p->sigma[i], p->clip_denoised};
+      const float* step_noise = (p->noise_dev != nullptr && p->sigma[i] != 0.f) ? p->noise_dev + (size_t)k * B * per_sample + xo : nullptr;
+      NoiseSource ns{step_noise, p->seed, p->sample_base + (uint32_t)b0, (uint32_t)(1 + k), (uint32_t)(p->const_noise != 0)};
+      const size_t total = (size_t)Bg * per_sample;
+      const int grid = (int)std::min<size_t>((total + 255) / 256, 2048);
+      {
+        ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, gs[g]);
+        MDM_LAUNCH(sampler_step_kernel, dim3(grid), dim3(256), 0, gs[g], (const float*)(x + xo), (const float*)wg.out,
+                   cfg ? (const float*)(wg.out + (size_t)Bg * per_sample) : (const float*)nullptr,
+                   cfg ? p->scale_dev + b0 : (const float*)nullptr,
+                   p->inpaint_mask_dev != nullptr ? p->inpaint_mask_dev + xo : (const uint8_t*)nullptr,
+                   p->inpaint_motion_dev != nullptr ? p->inpaint_motion_dev + xo : (const float*)nullptr, x + xo,
+                   (i == 0 && p->x0_dev != nullptr) ? p->x0_dev + xo : (float*)nullptr, (int)per_sample, Bg, co, ns);
+        rc_loop = rt_launch_status();
+      }
+      if (rc_loop == MDM_OK && dump)
+        rc_loop = rt_copy(p->dump_dev + (size_t)dump_i * B * per_sample + xo, x + xo, (size_t)Bg * per_sample * sizeof(float), gs[g]);
+    }
+    if (dump) ++dump_i;
+  }
+#ifndef MDM_EMU
+  for (int g = 1; g < G; ++g)   // join, also on the error path: the caller's stream must not run ahead of the side streams
+    if (hipEventRecord(m->aux.join[g - 1], gs[g]) != hipSuccess || hipStreamWaitEvent(s, m->aux.join[g - 1], 0) != hipSuccess)
+      return fail(MDM_EHIP, "mdm_sample_loop_dec: joining the side streams failed");
+#endif
+  return rc_loop;
 }
 
 #ifdef MDM_PROBES

@@ -227,3 +227,30 @@ def test_emulated_dip_window_loop(lib, monkeypatch, guided, prec):
     monkeypatch.setenv("MDM_DIP_STEPWISE", "1")
     step = run(dump_steps=[0, 1])
     assert maxabs(got, step[1]) < 2e-5 and maxabs(step[0], dumps[0]) < 2e-5
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_emulated_dip_window_loop_sample_groups(lib, monkeypatch, prec):
+    """mdm_sample_loop_dec cuts the batch into sample groups that run on concurrent streams (sequentially on the emulator):
+    per-group slices of every buffer, the hoisted text K / V of the WHOLE batch read through (branch, sample) remapping, per-group
+    Philox bases.  The result must not depend on the number of groups, with injected and with Philox noise: bit for bit in the
+    exact-fp32 mode; in f16x3 up to the re-association of a GEMM whose tile shape follows the row count (gemm_f32.h)."""
+    B, C, P, steps = 4, 5, 12, 2
+    sd = dip_small_state_dict(num_layers=1)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, precision=prec)
+    y = synth_dip_y(B, P, C, seed=6, text_lengths=[6, 3, 1, 5], lengths=None, scale=2.5)
+    g = torch.Generator().manual_seed(9)
+    seq = [torch.randn(B, 263, 1, P, generator=g) for _ in range(1 + steps)]
+    other = "2" if prec == "f32" else "4"
+    run = lambda **kw: diffusion.p_sample_loop(model, (B, 263, 1, P), clip_denoised=False,   # noqa: E731
+                                               model_kwargs={"y": dict(y)}, **kw)
+    kw = dict(noise_sequence=seq) if prec == "f32" else dict(seed=3)
+    monkeypatch.setenv("MDM_DIP_GROUPS", "1")
+    one = run(**kw)
+    monkeypatch.setenv("MDM_DIP_GROUPS", other)
+    many = run(**kw)
+    assert torch.equal(many, one) if prec == "f32" else maxabs(many, one) < 2e-5
+    if prec == "f32":
+        tab = orc.Tables(orc.named_betas("cosine", steps))
+        want = dip.dip_sample_loop(sd, tab, (B, 263, 1, P), y, seq[0], seq[1:], context_len=C, cfg=True, num_heads=2)
+        assert maxabs(many, want) < 5e-5
