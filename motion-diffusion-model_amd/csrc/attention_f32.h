@@ -55,12 +55,7 @@ struct AttnF32Args {
 };
 
 // blockDim.x = 64 * ceil(Sq / 32): wave w owns query rows [32w, 32w + 32); NKT = ceil(Sk / 32) key tiles.
-// X3: the two contractions in the split-precision arithmetic of attention_x3.h / gemm_x3.h on THIS skeleton (fp32 operands in
-// memory and in LDS, split into fp16 hi + lo fragments on their way into the MFMAs: three v_mfma_f32_32x32x16_f16 per 16 k
-// instead of eight v_mfma_f32_32x32x2_f32 -- 5.3x less matrix-pipe time).  The DiP decoder's attention runs so in the `f16x3`
-// mode: at 60 queries x 60 / 24 keys a (sequence, head) is two waves on one CU, and the serial chain of 256 / 128 fp32 MFMAs
-// (64 cycles each) was a third of the kernel's time.  The probabilities are split as hi / lo of p * 2^10 (attention_x3.h).
-template <int NKT, bool X3 = false>
+template <int NKT>
 __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float* __restrict__ out, int D, int H,
                                                              p16_t* __restrict__ oh, p16_t* __restrict__ ol) {
   MDM_DYN_SMEM(float, smem);  // max(NKT, query tiles) * 32 rows x ATT_KLD floats
@@ -107,30 +102,6 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
 
   // ---- phase 1: St tiles
   f32x16 p[NKT];
-  if constexpr (X3) {
-    // lane-half h owns d's [64 h, 64 h + 64) of both operands, in 8 blocks of 8: any pairing of k slots is a valid contraction
-    p16x8 qh[8], ql[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) split8(&qf[8 * c], qh[c], ql[c]);
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      f32x16 acc;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      const float* kp = &smem[(kt * 32 + r) * ATT_KLD + 64 * h];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float4 k0 = ld4(kp + 8 * c), k1 = ld4(kp + 8 * c + 4);
-        const float kf[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-        p16x8 kh, kl;
-        split8(kf, kh, kl);
-        acc = mfma_p16(kl, qh[c], acc);
-        acc = mfma_p16(kh, ql[c], acc);
-        acc = mfma_p16(kh, qh[c], acc);
-      }
-      p[kt] = acc;
-    }
-  } else
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
     f32x16 acc;
@@ -160,7 +131,6 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
       mx = fmaxf(mx, s);
     }
   mx = fmaxf(mx, shfl_xor_f32(mx, 32));
-  if constexpr (X3 && kSplitF16) mx -= 6.931471805599453f;   // p * 2^10: the lo part of p ~ 1/S stays a normal fp16; cancels in 1/sum
   float sum = 0.f;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
@@ -172,12 +142,10 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
     }
   sum += shfl_xor_f32(sum, 32);
   const float inv = 1.0f / sum;
-  if constexpr (!X3) {   // (X3: the 2^10-scaled probabilities go into the MFMAs as they are; 1 / sum is applied to O)
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+  for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) p[kt][e] *= inv;
-  }
+    for (int e = 0; e < 16; ++e) p[kt][e] *= inv;
 
   __syncthreads();  // every wave is done reading K
   // ---- stage V into the same buffer, row stride ATT_HD (rows >= S zero-filled)
@@ -195,31 +163,6 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
-  if constexpr (X3) {
-    // a lane's 16 probabilities of a key tile are keys mfma_row(e, h): two blocks of 8 (e = 0..7, 8..15) = the k slots of two
-    // 32x32x16 MFMAs; the V^T fragment of lane (d = r, h) gathers the same keys
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        float pf[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = p[kt][8 * b + j];
-        p16x8 ph, pl;
-        split8(pf, ph, pl);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          float vf[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) vf[j] = smem[(kt * 32 + mfma_row(8 * b + j, h)) * ATT_HD + 32 * dt + r];
-          p16x8 vh, vl;
-          split8(vf, vh, vl);
-          o[dt] = mfma_p16(vl, ph, o[dt]);
-          o[dt] = mfma_p16(vh, pl, o[dt]);
-          o[dt] = mfma_p16(vh, ph, o[dt]);
-        }
-      }
-  } else
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
@@ -238,8 +181,7 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int d0 = dt * 32 + 8 * g + 4 * h;  // rows mfma_row(4g..4g+3, h) are 4 consecutive d's
-      const float os = X3 ? inv : 1.f;
-      st4(&smem[q * ATT_KLD + d0], make_float4(o[dt][4 * g + 0] * os, o[dt][4 * g + 1] * os, o[dt][4 * g + 2] * os, o[dt][4 * g + 3] * os));
+      st4(&smem[q * ATT_KLD + d0], make_float4(o[dt][4 * g + 0], o[dt][4 * g + 1], o[dt][4 * g + 2], o[dt][4 * g + 3]));
     }
   __syncthreads();
   const size_t obase = (size_t)seq * Sq * D + head * ATT_HD;

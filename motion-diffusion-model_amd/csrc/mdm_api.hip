@@ -108,8 +108,8 @@ struct ProfScope {   // records start on construction, stop on destruction (both
 #endif
 };
 
-// Side streams of a model handle (the DiP window loop runs independent sample groups concurrently): created on first use on
-// the handle's device, joined back into the caller's stream with events before the call returns control of the results.
+// Side streams of a model handle (probe build: the DiP window loop's concurrent sample groups, see mdm_sample_loop_dec): created
+// on first use on the handle's device, joined back into the caller's stream with events before the call returns.
 struct AuxStreams {
   static constexpr int kMax = 3;
 #ifndef MDM_EMU
@@ -237,9 +237,9 @@ int launch_layernorm(Profiler* pf, float* x, const float* g, const float* b, int
   return rt_launch_status();
 }
 
-template <int NKT, bool X3 = false>
+template <int NKT>
 int launch_attention_t(const AttnF32Args& a, float* out, int nseq, int D, int H, p16_t* oh, p16_t* ol, hipStream_t s) {
-  auto k = &attention_f32_kernel<NKT, X3>;
+  auto k = &attention_f32_kernel<NKT>;
   const int nqt = (a.Sq + 31) / 32;
   const size_t lds = attention_lds_bytes(NKT, nqt);
   if (int rc = rt_allow_lds(k, lds)) return rc;
@@ -247,24 +247,13 @@ int launch_attention_t(const AttnF32Args& a, float* out, int nseq, int D, int H,
   return rt_launch_status();
 }
 
-// attention with separate query / key-value sources (attention_f32.h AttnF32Args): exact fp32, or (x3) the split-precision
-// contractions on the same skeleton
+// exact-fp32 attention with separate query / key-value sources (attention_f32.h AttnF32Args)
 int launch_attention_args(Profiler* pf, const AttnF32Args& a, float* out, int nseq, int D, int H, p16_t* oh, p16_t* ol,
-                          hipStream_t s, bool x3 = false) {
+                          hipStream_t s) {
   ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * H * (double)a.Sq * a.Sk * ATT_HD, s);
   if (D != H * ATT_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
   if (a.Sq < 1 || a.Sq > 224 || a.Sk < 1 || a.Sk > 224)
     return fail(MDM_EUNSUPPORTED, "attention: 1 <= tokens <= 224 on both sides (T <= 223 frames)");
-  if (x3)
-    switch ((a.Sk + 31) / 32) {
-      case 1: return launch_attention_t<1, true>(a, out, nseq, D, H, oh, ol, s);
-      case 2: return launch_attention_t<2, true>(a, out, nseq, D, H, oh, ol, s);
-      case 3: return launch_attention_t<3, true>(a, out, nseq, D, H, oh, ol, s);
-      case 4: return launch_attention_t<4, true>(a, out, nseq, D, H, oh, ol, s);
-      case 5: return launch_attention_t<5, true>(a, out, nseq, D, H, oh, ol, s);
-      case 6: return launch_attention_t<6, true>(a, out, nseq, D, H, oh, ol, s);
-      default: return launch_attention_t<7, true>(a, out, nseq, D, H, oh, ol, s);
-    }
   switch ((a.Sk + 31) / 32) {
     case 1: return launch_attention_t<1>(a, out, nseq, D, H, oh, ol, s);
     case 2: return launch_attention_t<2>(a, out, nseq, D, H, oh, ol, s);
@@ -278,9 +267,9 @@ int launch_attention_args(Profiler* pf, const AttnF32Args& a, float* out, int ns
 
 // self-attention over packed qkv rows [nseq*S][3D]; `lead` tokens in front of the frames are never masked
 int launch_attention(Profiler* pf, const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D,
-                     int H, p16_t* oh, p16_t* ol, hipStream_t s, int lead = 1, bool x3 = false) {
+                     int H, p16_t* oh, p16_t* ol, hipStream_t s, int lead = 1) {
   const AttnF32Args a{qkv, 3 * D, qkv + D, qkv + 2 * D, 3 * D, S, S, lengths, lead, B};
-  return launch_attention_args(pf, a, out, nseq, D, H, oh, ol, s, x3);
+  return launch_attention_args(pf, a, out, nseq, D, H, oh, ol, s);
 }
 
 #ifdef MDM_PROBES
@@ -1016,7 +1005,7 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
   Profiler* pf = &m->prof;
   const int* len = m->cfg.mask_frames ? lengths : nullptr;
   const float qscale = 1.0f / sqrtf((float)ATT_HD);
-  const bool x3 = m->precision == MDM_PREC_F16X3;   // GEMM and attention arithmetic (gemm_f32.h / attention_f32.h X3); the rest fp32
+  const bool x3 = m->precision == MDM_PREC_F16X3;   // GEMM arithmetic (gemm_f32.h X3); attention and LayerNorm statistics stay fp32
   const bool hoisted = hz.step >= 0;
 
   // ---- text memory: embed_text over every token (cond branch), + time embedding (mdm.py:217-219)
@@ -1063,7 +1052,7 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
     if (int rc = launch_linear_lnfold(pf, ws.tok, D, pend, folded ? F.w_in : m->L(l, "self_attn.in_proj_weight"), P.in_proj,
                                       folded ? F.b_in : m->L(l, "self_attn.in_proj_bias"), folded ? F.c_in : nullptr, nullptr,
                                       none, ws.qkv, nullptr, M, 3 * D, D, ACT_NONE, D, qscale, s, x3)) return rc;
-    if (int rc = launch_attention(pf, ws.qkv, ws.att, len, nseq, B, S, D, H, nullptr, nullptr, s, /*lead=*/0, x3)) return rc;
+    if (int rc = launch_attention(pf, ws.qkv, ws.att, len, nseq, B, S, D, H, nullptr, nullptr, s, /*lead=*/0)) return rc;
     if (int rc = launch_linear_lnfold(pf, ws.att, D, none, m->L(l, "self_attn.out_proj.weight"), P.out_proj,
                                       m->L(l, "self_attn.out_proj.bias"), nullptr, ws.tok, pend, ws.tok, ws.stat[sp ^ 1], M, D, D,
                                       ACT_NONE, 0, 1.f, s, x3)) return rc;
@@ -1077,7 +1066,7 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
     if (!hoisted) {
       if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
       const AttnF32Args a{ws.qkv, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
-      if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s, x3)) return rc;
+      if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s)) return rc;
     } else {
       const float* kvt = hz.kv_text + (size_t)l * ((size_t)nbranch * hz.kv_B * ntok) * 2 * D;
       const float* row = hz.kv_time + ((size_t)l * hz.nsteps + hz.step) * 2 * D;
@@ -1086,7 +1075,7 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
       a.vadd = row + D;
       a.kv_B = hz.kv_B;
       a.kv_b0 = hz.kv_b0;
-      if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s, x3)) return rc;
+      if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s)) return rc;
     }
     if (int rc = launch_linear_lnfold(pf, ws.att, D, none, m->L(l, "multihead_attn.out_proj.weight"), P.out_proj2,
                                       m->L(l, "multihead_attn.out_proj.bias"), nullptr, ws.tok, pend, ws.tok, ws.stat[sp ^ 1], M,
@@ -1319,22 +1308,27 @@ int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float
                                ACT_NONE, 0, 1.f, s, x3)) return rc;
   }
 
-  // ---- the steps.  Samples are independent chains, and at these sizes a launch is mostly fixed cost (dispatch, cold first
-  // loads, a short tail: ~11 of ~20 us for a 3840-row GEMM): the batch is cut into G groups of B / G samples whose loops run
-  // CONCURRENTLY on side streams (forked behind the hoisted projections, joined before returning), so that one group's
-  // fixed costs hide behind another's matrix work.  Every output element sees the same arithmetic whatever G is (bit-identical
-  // results in the f32 mode; in f16x3 up to re-association where a GEMM's tile shape follows its row count).  Each group owns
-  // the rows [g * Mg, (g + 1) * Mg) of the activation buffers.
+  // ---- the steps.  The loop is written over G sample groups (each owns the rows [g * Mg, (g + 1) * Mg) of the activation
+  // buffers and reads the hoisted text K / V of the whole batch through the attention kernel's (branch, sample) remap);
+  // production runs ONE group on the caller's stream.
+  // PROBE BUILD ONLY (MDM_DIP_GROUPS=G): the groups' loops run CONCURRENTLY on side streams (forked behind the hoisted
+  // projections, joined before returning).  Samples are independent chains and a launch at these sizes is mostly fixed cost,
+  // so one group's dispatch floor / cold loads / tail hide behind another's matrix work: +3 % (two groups) on the bench.
+  // It is NOT in the product because in the f16x3 mode two or four concurrent chains intermittently (a few % of the window
+  // loops at four groups, more with a split-precision attention kernel) return one sequence off by 1e-4 .. 1e-1 -- never in the
+  // f32 mode, never with one chain, never with the groups serialised on one stream; not root-caused (profiles/r02e_dip.md,
+  // reproducer tools/repro_dip_groups.py).
   int G = 1;
+#ifdef MDM_PROBES
   {
-    const char* e = getenv("MDM_DIP_GROUPS");   // A/B switch and tests; read per window
-    const int forced = e != nullptr ? atoi(e) : 0;
-    const int want = forced > 0 ? forced : (B >= 16 ? 2 : 1);
-    for (int g = std::min(want, AuxStreams::kMax + 1); g >= 1; --g)
+    const char* e = getenv("MDM_DIP_GROUPS");
+    const int want = e != nullptr ? atoi(e) : 1;
+    for (int g = std::min(std::max(want, 1), AuxStreams::kMax + 1); g >= 1; --g)
       if (B % g == 0) { G = g; break; }
   }
+#endif
   hipStream_t gs[AuxStreams::kMax + 1] = {s, s, s, s};
-#ifndef MDM_EMU
+#if !defined(MDM_EMU) && defined(MDM_PROBES)
   if (G > 1) {
     if (int rc = m->aux.ensure(G - 1)) return rc;
     if (hipEventRecord(m->aux.fork, s) != hipSuccess) return fail(MDM_EHIP, "mdm_sample_loop_dec: hipEventRecord failed");
@@ -1383,7 +1377,7 @@ int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float
     }
     if (dump) ++dump_i;
   }
-#ifndef MDM_EMU
+#if !defined(MDM_EMU) && defined(MDM_PROBES)
   for (int g = 1; g < G; ++g)   // join, also on the error path: the caller's stream must not run ahead of the side streams
     if (hipEventRecord(m->aux.join[g - 1], gs[g]) != hipSuccess || hipStreamWaitEvent(s, m->aux.join[g - 1], 0) != hipSuccess)
       return fail(MDM_EHIP, "mdm_sample_loop_dec: joining the side streams failed");

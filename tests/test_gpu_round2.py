@@ -319,34 +319,3 @@ def test_kit_shape_251_features(prec):
     out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": dict(y)}, noise_sequence=seq)
     want = orc.sample_loop(sdk, orc.Tables(orc.named_betas("cosine", steps)), shape, y, seq[0], seq[1:], cfg=True)
     assert maxabs(out.cpu(), want) < TOL_LOOP[prec]
-
-
-@pytest.mark.parametrize("prec", PRECISIONS)
-def test_dip_sample_groups_on_side_streams(prec):
-    """mdm_sample_loop_dec runs the batch as sample groups on concurrent side streams (fork behind the hoisted projections,
-    join before returning).  The sample must not depend on the number of groups: bit for bit in the f32 mode, up to the
-    re-association of GEMMs whose tile shape follows the row count in f16x3; checked with Philox noise (per-group bases) over a
-    whole autoregressive generation (3 windows: the join has to order window i's result before window i + 1's prefix)."""
-    from types import SimpleNamespace
-    from helpers import synth_dip_state_dict, synth_dip_y, to_dev
-    from mdm_amd.sampler_util import AutoRegressiveSampler
-    sdd = synth_dip_state_dict(seed=0)
-    B, frames = 8, 100
-    model, diffusion = make_pair(sdd, 10, DEV, guided=True, context_len=20, pred_len=40, precision=prec)
-    y = to_dev(synth_dip_y(B, 40, 20, seed=2, text_lengths=[4, 11, 25, 8, 1, 17, 9, 30]), DEV)
-    args = SimpleNamespace(pred_len=40, context_len=20, autoregressive_include_prefix=False)
-    outs = {}
-    for groups in ("1", "2", "4"):
-        os.environ["MDM_DIP_GROUPS"] = groups
-        try:
-            seeds = iter(range(50, 60))
-            fn = lambda mdl, shape, **kw: diffusion.p_sample_loop(mdl, shape, seed=next(seeds), **kw)   # noqa: E731
-            outs[groups] = AutoRegressiveSampler(args, fn, frames).sample(model, (B, 263, 1, frames), clip_denoised=False,
-                                                                          model_kwargs={"y": y}).cpu()
-        finally:
-            del os.environ["MDM_DIP_GROUPS"]
-    for groups in ("2", "4"):
-        if prec == "f32":
-            assert torch.equal(outs[groups], outs["1"])
-        else:
-            assert maxabs(outs[groups], outs["1"]) < 5e-5

@@ -1,0 +1,33 @@
+"""Reproducer (open issue, profiles/r02e_dip.md): the DiP window loop run as G concurrent sample groups (probe build only,
+MDM_DIP_GROUPS=G) intermittently differs from the one-group result in the f16x3 mode.  Counts the differing window loops out of
+80 and prints where each first difference appears (step, sample, frames, features).
+    MDM_HIP_LIB=$PWD/motion-diffusion-model_amd/csrc/libmdm_hip_probe.so python tools/repro_dip_groups.py [G] [f16x3|f32]"""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+from helpers import make_pair, synth_dip_state_dict, synth_dip_y, to_dev
+DEV = "cuda:0"
+sdd = synth_dip_state_dict(seed=0)
+B = 8
+model, diffusion = make_pair(sdd, 10, DEV, guided=True, context_len=20, pred_len=40, precision=(sys.argv[2] if len(sys.argv) > 2 else "f16x3"))
+y = to_dev(synth_dip_y(B, 40, 20, seed=2, text_lengths=[4, 11, 25, 8, 1, 17, 9, 30]), DEV)
+run = lambda: [d.cpu() for d in diffusion.p_sample_loop(model, (B, 263, 1, 40), clip_denoised=False, model_kwargs={"y": y}, seed=7,
+                                                         dump_steps=list(range(10)))]
+os.environ["MDM_DIP_GROUPS"] = "1"
+ref = run()
+os.environ["MDM_DIP_GROUPS"] = sys.argv[1] if len(sys.argv) > 1 else "2"
+for rep in range(80):
+    got = run()
+    bad = [k for k in range(10) if not torch.equal(got[k], ref[k])]
+    if not bad:
+        continue
+    k = bad[0]
+    d = (got[k] - ref[k]).abs()[:, :, 0, :]          # [B, 263, 40]
+    for b in range(B):
+        if float(d[b].max()) > 0:
+            fr = (d[b].max(dim=0).values > 0).nonzero().flatten().tolist()
+            ft = (d[b].max(dim=1).values > 0).nonzero().flatten().tolist()
+            print(f"  rep {rep} step {k} sample {b}: max {float(d[b].max()):.3e}, frames {fr[:6]}..{fr[-1]} ({len(fr)}), features {ft[:4]}..{ft[-1]} ({len(ft)})")
+    fails = globals().get("fails", 0) + 1
+    globals()["fails"] = fails
+print("FAILS", globals().get("fails", 0), "of 80")
