@@ -28,6 +28,15 @@ for rep in range(80):
             fr = (d[b].max(dim=0).values > 0).nonzero().flatten().tolist()
             ft = (d[b].max(dim=1).values > 0).nonzero().flatten().tolist()
             print(f"  rep {rep} step {k} sample {b}: max {float(d[b].max()):.3e}, frames {fr[:6]}..{fr[-1]} ({len(fr)}), features {ft[:4]}..{ft[-1]} ({len(ft)})")
+            # does the wrong block equal what ANOTHER sample (or this sample at the previous step) holds there?
+            blk = got[k][b, :, 0, fr]
+            for b2 in range(B):
+                for kk, tag in ((k, "same step"), (k - 1, "previous step")):
+                    if kk < 0 or (b2 == b and kk == k):
+                        continue
+                    e = float((blk - ref[kk][b2, :, 0, fr]).abs().max())
+                    if e < 1e-3 * max(1.0, float(blk.abs().max())):
+                        print(f"    == sample {b2} at the {tag} (max diff {e:.2e})")
     fails = globals().get("fails", 0) + 1
     globals()["fails"] = fails
 print("FAILS", globals().get("fails", 0), "of 80")
