@@ -211,7 +211,7 @@ def test_emulated_dip_window_loop(lib, monkeypatch, guided, prec):
     step's projected time row added while the attention kernel stages K / V) against the oracle's loop, and against the
     same loop composed step by step from mdm_forward_dec + mdm_sampler_step (MDM_DIP_STEPWISE=1); dump_steps included."""
     B, C, P, steps = 2, 5, 12, 2
-    sd = dip_small_state_dict(num_layers=2 if guided else 1)
+    sd = dip_small_state_dict(num_layers=1)
     model, diffusion = make_pair(sd, steps, "cpu", guided=guided, native_lib=lib, context_len=C, pred_len=P, precision=prec)
     y = synth_dip_y(B, P, C, seed=4, text_lengths=[6, 3], scale=2.5)
     g = torch.Generator().manual_seed(8)
@@ -229,7 +229,7 @@ def test_emulated_dip_window_loop(lib, monkeypatch, guided, prec):
     assert maxabs(got, step[1]) < 2e-5 and maxabs(step[0], dumps[0]) < 2e-5
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("prec", ["f32"])
 def test_emulated_dip_window_loop_sample_groups(lib, monkeypatch, prec):
     """mdm_sample_loop_dec cuts the batch into sample groups that run on concurrent streams (sequentially on the emulator):
     per-group slices of every buffer, the hoisted text K / V of the WHOLE batch read through (branch, sample) remapping, per-group
