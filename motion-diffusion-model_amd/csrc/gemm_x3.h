@@ -918,13 +918,17 @@ inline int launch_gemm_x3_ln_t(int kind, const X3Operand& A, const X3Weights& W,
     default: return -2;
   }
 }
-// 208-row tiles (T16) whenever the row extent of a tile fits (S = 197 does); MDM_X3_T16=0 keeps 224-row tiles (A/B runs)
+// 208-row tiles (T16) whenever the row extent of a tile fits (S = 197 does); probe library: MDM_X3_T16=0 keeps 224-row tiles
 inline bool x3_t16_setting() {
+#ifdef MDM_PROBES
   static const bool on = [] {
     const char* e = getenv("MDM_X3_T16");
     return !(e != nullptr && e[0] == '0');
   }();
   return on;
+#else
+  return true;
+#endif
 }
 inline int launch_gemm_x3_ln(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
                                  int K, int rpt, hipStream_t s) {

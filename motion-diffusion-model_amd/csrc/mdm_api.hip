@@ -392,7 +392,11 @@ int launch_linear_lnfold(Profiler* pf, const float* in, int ld_in, const LnFold&
   if (K % 16 != 0 || ld_in % 4 != 0 || N % LN_PART_COLS != 0) return fail(MDM_EINVAL, "linear (LayerNorm fold): bad K / N");
   RowMajorLoader al{in, ld_in, M, K};
   LnLinearEpilogue ep{out, bias, N, act, scale_cols, col_scale, a_ln, colsum, res, res_ln, ostat};
-  static const bool fragb = [] { const char* e = getenv("MDM_DEC_FRAGB"); return e == nullptr || e[0] != '0'; }();   // A/B switch
+#ifdef MDM_PROBES   // A/B switch of the probe library: MDM_DEC_FRAGB=0 sends the layer weights through the fp32 loader again
+  static const bool fragb = [] { const char* e = getenv("MDM_DEC_FRAGB"); return e == nullptr || e[0] != '0'; }();
+#else
+  constexpr bool fragb = true;
+#endif
   if (x3 && wp.hi != nullptr && fragb) {
     X3FragB bl{wp.hi, wp.lo, (N + 31) / 32, K};
     launch_gemm_f32(al, bl, ep, M, N, K, s, true);
@@ -864,8 +868,10 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
       m->in_planes = X3Weights{hi, hi + n};
       if (int rc = launch_pack_weights(scratch_w, hi, hi + n, D, m->jf_k, s)) return rc;
     }
-    const char* e = getenv("MDM_LNFOLD");
-    m->lnfold = !(e != nullptr && e[0] == '0');
+    m->lnfold = true;
+#ifdef MDM_PROBES   // A/B switch of the probe library: MDM_LNFOLD=0 runs the LayerNorms as kernels on the planes again
+    if (const char* e = getenv("MDM_LNFOLD")) m->lnfold = e[0] != '0';
+#endif
   }
   m->prepared = true;
   return MDM_OK;
