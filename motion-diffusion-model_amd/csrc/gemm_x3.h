@@ -367,6 +367,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         stats_dma(m0n, tile_parity ^ 1);
       }
       if (tid < X3_TM) {
+        // rows of the tile past the matrix (the last sequence's pad rows) have no statistics: their raw slots hold whatever the
+        // clamped DMA fetched -- for an odd M with one partial per row two floats BEHIND the buffer (uninitialised workspace:
+        // a NaN there went through these rows' V^T pad keys, 0 * NaN, into the whole sequence) -- so they get (0, 0): every
+        // folded value of such a row is then the finite constant b' / beta
+        int m0t, n0t;
+        tile_origin(v, m0t, n0t);
+        const bool pad_row = m0t + tid >= M;
         const float* sraw = reinterpret_cast<const float*>(lds + x3_raw_base(WAVES) + tile_parity * X3_RAW_BYTES);
         // partials are (sum, CENTRED sum of squares about the partial's own mean) of X3_TN columns each; merged by Chan's
         // formula -- no E[x^2] - mean^2 cancellation when a row's mean is large against its spread
@@ -380,9 +387,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         }
         const float var = m2 * ep.inv_dim;
 #ifdef MDM_EMU
-        stab[tid] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+        stab[tid] = pad_row ? make_float2(0.f, 0.f) : make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
 #else
-        stab[tid] = make_float2(mean, __builtin_amdgcn_rsqf(var + 1e-5f));   // v_rsq_f32, 1 ulp
+        stab[tid] = pad_row ? make_float2(0.f, 0.f) : make_float2(mean, __builtin_amdgcn_rsqf(var + 1e-5f));   // v_rsq_f32, 1 ulp
 #endif
       }
     }
