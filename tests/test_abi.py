@@ -88,3 +88,26 @@ def test_product_path_fails_loudly_without_the_extension(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "_LIB", None)
     with pytest.raises(_native.MdmError, match="no CPU fallback"):
         _native.load_native()
+
+
+def test_dip_window_loop_entry_points_validate_before_touching_the_device(lib):
+    """mdm_sample_loop_dec / mdm_workspace_bytes_dec_loop (ABI 5): host-side contract only -- sizes, and the refusals that
+    come before any launch (unprepared model, trans_enc handle, null pointers)."""
+    from mdm_amd import _native
+    h = C.c_void_p()
+    assert lib.mdm_create(C.byref(_cfg(arch=_native.ARCH["trans_dec"], context_len=20, clip_dim=768)), C.byref(h)) == 0
+    one = lib.mdm_workspace_bytes_dec(h, 64, 40, 24)
+    loop = lib.mdm_workspace_bytes_dec_loop(h, 64, 40, 24, 10)
+    # the loop adds the model-output buffer, the hoisted text K | V of 8 layers and the per-step time rows
+    assert loop >= one + 64 * 263 * 40 * 4 + 8 * 64 * 24 * 1024 * 4 + 8 * 10 * 1024 * 4
+    assert lib.mdm_workspace_bytes_dec_loop(h, 64, 40, 24, 0) == 0 and lib.mdm_workspace_bytes_dec_loop(None, 64, 40, 24, 10) == 0
+    p = _native.MdmSampleDecParams()
+    buf = (C.c_float * 16)()
+    assert lib.mdm_sample_loop_dec(h, C.byref(p), C.addressof(buf), C.addressof(buf), 64, None) == -2     # not prepared
+    assert lib.mdm_sample_loop_dec(None, C.byref(p), C.addressof(buf), C.addressof(buf), 64, None) < 0
+    assert lib.mdm_last_error()
+    lib.mdm_destroy(h)
+    h2 = C.c_void_p()
+    assert lib.mdm_create(C.byref(_cfg()), C.byref(h2)) == 0
+    assert lib.mdm_sample_loop_dec(h2, C.byref(p), C.addressof(buf), C.addressof(buf), 64, None) < 0      # trans_enc handle
+    lib.mdm_destroy(h2)
