@@ -18,8 +18,9 @@ Prints ONE JSON line on rank 0.  Besides the contract fields it carries
   kernel_ms     per-kernel-class totals of that loop,
   f32_mode      the same workload on the exact-fp32 MFMA kernels (one short extra pass; N = 1 only),
   dip           the DiP configuration (BASELINE.json configs[4] per GPU: trans_dec, 5 windows x 10 steps) -- N = 1 only,
-  cpu_baseline  the oracle (CPU restatement of the reference, pinned to it: tests/golden) timed on this box's host
-                cores on a bounded sample of the same workload (N = 1, rank 0 only),
+  steps1000     BASELINE.json configs[2] (1000-step DDPM, batch 64) -- one timed pass, N = 1 only,
+  cpu_baseline  BASELINE.json configs[0]: the whole 50-step CFG loop at batch 1 on this box's host cores, twice -- the
+                reference's own p_sample_loop where the upstream tree is mounted, else the oracle port (N = 1, rank 0),
   ranks         what the process group looked like (backend, world size) -- the evidence that RCCL carried the gather.
 """
 import argparse
@@ -57,7 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
                     help="arithmetic of the encoder GEMMs (include/mdm_hip.h mdm_set_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the f32_mode and dip sub-records")
+    ap.add_argument("--no-extras", action="store_true", help="skip the f32_mode, steps1000 and dip sub-records")
+    ap.add_argument("--no-steps1000", action="store_true", help="skip the 1000-step (BASELINE.json configs[2]) sub-record")
     # test infrastructure (tests/test_bench_launcher.py): the same launcher / sharding / gather / JSON code on CPU --
     # gloo ranks, kernels in the CPU emulator, a tiny model.  Never a measurement.
     ap.add_argument("--force-pg", action="store_true",
@@ -94,46 +96,100 @@ def synthetic_y(B, T, device, seed, clip_dim=512):
             "scale": torch.full((B,), 2.5, device=device)}
 
 
-def cpu_baseline(state, T, dsteps, budget_s=15.0):
-    """The oracle's p_sample_loop (CFG on) on the host cores: a bounded number of diffusion steps of a small batch,
-    scaled to whole 50-step motions.  Checker code used as a reported baseline only."""
+def cpu_baseline(state, T, dsteps, runs=2):
+    """BASELINE.json configs[0] as written: the 50-step CFG p_sample_loop at batch = 1, T = 196 on this box's host cores,
+    the WHOLE loop timed, `runs` times (both values reported; `value` is their mean).  When the upstream tree is mounted
+    (MDM_REFERENCE_ROOT / /root/reference -- the build container, never the GPU box) the reference's own
+    `SpacedDiffusion.p_sample_loop(ClassifierFreeSampleModel(MDM))` (diffusion/gaussian_diffusion.py:591-658) is what runs
+    and `kind` is "reference"; otherwise the oracle port of the same loop (oracle/mdm_oracle.py, pinned to the reference by
+    tests/golden).  Checker code used as a reported baseline only -- never the thing measured as `value` of the line."""
     import torch
     from oracle import mdm_oracle as orc
-    B = 4
+    from oracle import ref_harness
+    B = 1
     sd = {k: v.detach().cpu().float() for k, v in state.items()}
-    tab = orc.Tables(orc.named_betas("cosine", dsteps))
     g = torch.Generator().manual_seed(0)
     y = {"mask": torch.ones(B, 1, 1, T, dtype=torch.bool), "lengths": torch.full((B,), T),
          "text_embed": torch.randn(1, B, 512, generator=g), "scale": torch.full((B,), 2.5)}
-    x = torch.randn(B, 263, 1, T, generator=g)
-    pe = orc.positional_table(5000, 512)
-
-    def one_step(i, x):
-        t = torch.full((B,), i, dtype=torch.long)
-        x0 = orc.predict_x0(lambda a, b, c: orc.cfg_forward(sd, a, b, c, pe=pe), x, t, y)
-        return orc.ddpm_step(tab, x, x0, t, torch.randn(x.shape, generator=g))
-
-    with torch.no_grad():
-        x = one_step(dsteps - 1, x)                       # warm-up (thread pool, allocator)
-        t0 = time.perf_counter()
-        x = one_step(dsteps - 2, x)
-        per = time.perf_counter() - t0
-        n = int(max(2, min(dsteps - 2, budget_s / max(per, 1e-3))))
-        t0 = time.perf_counter()
-        for k in range(n):
-            x = one_step(dsteps - 3 - k, x)
-        per = (time.perf_counter() - t0) / n
+    shape = (B, 263, 1, T)
     thr = torch.get_num_threads()
-    return {"value": B / (per * dsteps), "unit": "motions/s", "cores": thr, "kind": "port",
-            "sample": f"oracle (torch-CPU restatement of the reference, {thr} intra-op threads) CFG p_sample: {n} of {dsteps} "
-                      f"diffusion steps at B={B} (NOT the GPU run's B=128: a bounded sample), T={T}, scaled to {dsteps}-step "
-                      f"motions ({per * 1e3:.0f} ms per batch-step); a reported baseline, not a target"}
+    kind, runner = "port", None
+    if ref_harness.reference_available():
+        try:
+            ref = ref_harness.build_reference_model(seed=0)
+            ref_harness.load_reference_weights(ref, sd)
+            cfg = ref_harness.reference_cfg(ref)
+            rdiff = ref_harness.build_reference_diffusion(steps=dsteps)
+
+            def runner():
+                return rdiff.p_sample_loop(cfg, shape, clip_denoised=False, model_kwargs={"y": dict(y)}, skip_timesteps=0,
+                                           init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False)
+            kind = "reference"
+        except Exception:   # an incomplete mount: fall back to the port, and say so through `kind`
+            kind, runner = "port", None
+    if runner is None:
+        tab = orc.Tables(orc.named_betas("cosine", dsteps))
+
+        def runner():
+            x_T = torch.randn(shape, generator=g)
+            noises = [torch.randn(shape, generator=g) for _ in range(dsteps)]
+            return orc.sample_loop(sd, tab, shape, y, x_T, noises, cfg=True)
+    times = []
+    with torch.no_grad():
+        # warm-up: a short loop through the same code (thread pool, allocator, oneDNN primitive caches)
+        if kind == "port":
+            tabw = orc.Tables(orc.named_betas("cosine", 2))
+            orc.sample_loop(sd, tabw, shape, y, torch.randn(shape, generator=g), [torch.randn(shape, generator=g)] * 2, cfg=True)
+        else:
+            ref_harness.build_reference_diffusion(steps=2).p_sample_loop(cfg, shape, clip_denoised=False,
+                                                                         model_kwargs={"y": dict(y)})
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            out = runner()
+            times.append(time.perf_counter() - t0)
+            assert bool(torch.isfinite(out).all())
+    mean = sum(times) / len(times)
+    what = ("the reference's own SpacedDiffusion.p_sample_loop(ClassifierFreeSampleModel(MDM)) (diffusion/gaussian_diffusion.py:591-658)"
+            if kind == "reference" else "oracle/mdm_oracle.sample_loop (torch-CPU restatement of the reference, pinned by tests/golden)")
+    return {"value": round(B / mean, 4), "unit": "motions/s", "cores": thr, "kind": kind,
+            "runs_motions_per_s": [round(B / t, 4) for t in times], "runs_s": [round(t, 3) for t in times],
+            "sample_steps_per_s": round(B * dsteps / mean, 2),
+            "sample": f"BASELINE.json configs[0]: {what}, CFG 2.5, batch={B}, T={T}, all {dsteps} diffusion steps, whole loop "
+                      f"timed {runs}x after a 2-step warm-up loop, torch.get_num_threads()={thr} intra-op threads on "
+                      f"{os.cpu_count()} logical host CPUs; a reported baseline, not a target"}
 
 
 # Mean ALGORITHMIC HBM bytes of one encoder-GEMM launch at the headline shape (256 sequences x 197 tokens, D=512, FF=1024;
 # DESIGN.md section 4): operand planes read once + weights once + output written once (+ residual planes), averaged over
 # the four GEMMs of a layer.  in_proj 103+3+352 MB, out_proj 103+1+103+103, linear1 103+2+207, linear2 207+2+103+103.
 ALGORITHMIC_GEMM_BYTES_PER_LAUNCH = int((458.9e6 + 310.9e6 + 311.9e6 + 415.2e6) / 4)
+
+
+def measure_steps1000(mdm, model, dev, sync, T, layers, latent_dim, B=64, dsteps=1000):
+    """BASELINE.json configs[2]: the 1000-step DDPM p_sample_loop at batch = 64 on this GPU (`step-fusion stress`:
+    diffusion/gaussian_diffusion.py:708 runs its loop body 1000x): one short warm-up loop (8-step schedule, same kernels
+    and shapes) + ONE timed pass of the whole 1000-step loop, same model / weights / arithmetic as the headline."""
+    import torch
+    from mdm_amd import model_util
+    diff = model_util.create_gaussian_diffusion(model_util.default_args(diffusion_steps=dsteps, layers=layers,
+                                                                        latent_dim=latent_dim))
+    warm = model_util.create_gaussian_diffusion(model_util.default_args(diffusion_steps=8, layers=layers,
+                                                                        latent_dim=latent_dim))
+    y = synthetic_y(B, T, dev, seed=2000)
+    shape = (B, 263, 1, T)
+    warm.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, seed=1)
+    sync()
+    t0 = time.perf_counter()
+    out = diff.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, seed=2)
+    sync()
+    dt = time.perf_counter() - t0
+    assert out.shape[0] == B and bool(torch.isfinite(out).all())
+    fwd = algorithmic_flops_per_forward(T)
+    return {"value": round(B / dt, 3), "unit": "motions/s", "sample_steps_per_s": round(B * dsteps / dt, 1),
+            "ms_per_step": round(dt * 1e3, 2), "steps": 1, "model_tflops": round(B * dsteps / dt * 2 * fwd / 1e12, 2),
+            "config": {"workload": f"BASELINE.json configs[2]: HumanML3D {dsteps}-step DDPM p_sample_loop with CFG 2.5, "
+                                   f"batch={B}, T={T}, same model and f16x3 arithmetic as the headline; one timed pass",
+                       "global_batch": B, "diffusion_steps": dsteps}}
 
 
 def csrc_sha256():
@@ -155,17 +211,20 @@ def pmc_traffic_per_gemm_launch():
     profile records the sha256 of the kernel sources it was taken on, and a profile of different sources yields null."""
     path = os.path.join(ROOT, PMC_PROFILE)
     if not os.path.isfile(path):
-        return None, f"{PMC_PROFILE} absent"
+        return None, False, f"{PMC_PROFILE} absent"
     try:
         with open(path) as f:
             d = json.load(f)
-        if d.get("csrc_sha256") != csrc_sha256():
-            return None, f"{PMC_PROFILE} was taken on other kernel sources (csrc_sha256 differs): stale, not quoted"
         per_layer = {"in_proj": 1, "out_proj|linear2": 2, "linear1": 1}
         tot = sum(d["gemm"][k]["hbm_bytes"] * n for k, n in per_layer.items())
-        return int(tot / sum(per_layer.values())), f"{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command)"
+        val = int(tot / sum(per_layer.values()))
+        if d.get("csrc_sha256") != csrc_sha256():
+            # quoted, but flagged: the kernels were edited after the PMC passes were taken (re-run tools/gpu_prof.sh pmc)
+            return val, True, (f"{PMC_PROFILE}: taken on OTHER kernel sources (csrc_sha256 differs) -- stale, see "
+                               f"roofline.traffic_stale")
+        return val, False, f"{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command)"
     except (KeyError, ValueError, OSError) as e:
-        return None, f"{PMC_PROFILE} unreadable ({type(e).__name__})"
+        return None, False, f"{PMC_PROFILE} unreadable ({type(e).__name__})"
 
 
 def main(argv=None):
@@ -272,12 +331,15 @@ def main(argv=None):
         f32_mode = {"value": round(GB / f32_dt, 3), "unit": "motions/s", "ms_per_step": round(f32_dt * 1e3, 3), "steps": 1,
                     "model_tflops": round(f32_tf, 2), "frac_of_157.3TF": round(f32_tf / 157.3, 4),
                     "dtype": "f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
+    steps1000 = None
+    if extras and a.precision != "f32" and not a.no_steps1000:
+        steps1000 = measure_steps1000(mdm, model, dev, sync, T, a.layers, a.latent_dim)
     if extras:
         import bench_dip
         dip = bench_dip.measure(dev, rank=0, world=1, B=32, steps=3, warmup=1, cpu=False)
 
     if rank == 0:
-        traffic, traffic_src = pmc_traffic_per_gemm_launch()
+        traffic, traffic_stale, traffic_src = pmc_traffic_per_gemm_launch()
         motions_s = GB * a.steps / dt
         lin = prof["linear"]
         ach = lin["flops"] / (lin["ms"] * 1e-3) / 1e12 if lin["ms"] > 0 else 0.0
@@ -304,7 +366,8 @@ def main(argv=None):
                          "kernel": ("gemm_x3_kernel" if x3 else "gemm_f32_kernel<RowMajor,RowMajor,Linear>")
                          + " (encoder GEMMs: in_proj, out_proj, linear1, linear2)",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_stale": traffic_stale, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes": ALGORITHMIC_GEMM_BYTES_PER_LAUNCH if x3 else None,
                          "launches": lin["launches"],
                          "avg_launch_us": round(lin["ms"] * 1e3 / max(lin["launches"], 1), 2),
@@ -317,6 +380,8 @@ def main(argv=None):
         }
         if f32_mode is not None:
             line["f32_mode"] = f32_mode
+        if steps1000 is not None:
+            line["steps1000"] = steps1000
         if dip is not None:
             line["dip"] = dip
         if world == 1 and not a.no_cpu_baseline and not a.emulate:

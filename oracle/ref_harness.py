@@ -82,6 +82,16 @@ def build_reference_model(seed=0, **over):
     return m
 
 
+def load_reference_weights(model, state_dict):
+    """Load a CLIP-less state dict (ours or the reference's) into the reference model the way
+    `utils/model_util.py:8-15 load_model_wo_clip` does: positional tables are recomputed, CLIP is absent."""
+    sd = {k: v for k, v in state_dict.items() if "sequence_pos_encoder" not in k and not k.startswith("clip_model.")}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert len(unexpected) == 0, unexpected
+    assert all(k.startswith("clip_model.") or "sequence_pos_encoder" in k for k in missing), missing
+    return model
+
+
 def reference_state_dict(model):
     """state_dict as `train/training_loop.py:404-410` saves it: CLIP keys stripped."""
     return {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("clip_model.")}
