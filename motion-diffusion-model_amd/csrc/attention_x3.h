@@ -160,9 +160,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
     constexpr int slot = t & (AX_RING - 1);
     // tile t landed?  tiles t+1, t+2 (4 pieces each of this wave) may stay in flight; LDS-DMA retires in order
     constexpr int ahead = (NTILES - 1 - t) < 2 ? (NTILES - 1 - t) : 2;
-#ifndef MDM_EMU
-    if constexpr (!(ABL & 16)) __builtin_amdgcn_s_waitcnt(0x0F70 | (4 * ahead));
-#endif
+    if constexpr (!(ABL & 16)) wait_vmem_upto<4 * ahead>();
     if constexpr (!(ABL & 32)) wg_barrier();  // tile t visible to every wave; every wave is done with tile t-1 (whose slot is refilled now)
     if constexpr (t + 3 < NTILES && !(ABL & 16)) issue_tile(sh, t + 3, lv);
     if constexpr (t == NTILES - 1) {

@@ -273,7 +273,7 @@ __device__ __forceinline__ void split4_store(p16_t* hi_p, p16_t* lo_p, float4 v)
 // `lds_wave_base + lane*16` (wave-uniform base, lane-linear image); the global source is per lane.
 __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_base) {
 #ifdef MDM_EMU
-  memcpy(static_cast<char*>(lds_wave_base) + 16 * emu::lane_id(), gsrc_lane, 16);
+  emu::vm_issue(static_cast<char*>(lds_wave_base) + 16 * emu::lane_id(), gsrc_lane, 16, false);
 #else
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -298,13 +298,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // above the wait, and any copy the compiler made earlier is dead.
 #ifdef MDM_EMU
 __device__ __forceinline__ void lds_read16(p16x8& dst, const unsigned char* base, uint32_t byte_off) {
-  dst = *reinterpret_cast<const p16x8*>(base + byte_off);
+  emu::lds_issue(&dst, base + byte_off, 16);   // EARLY mode: immediate; LATE mode: withheld until a covering lds_wait
 }
-template <int N> __device__ __forceinline__ void lds_wait(p16x8&, p16x8&) {}
-template <int N> __device__ __forceinline__ void lds_wait(p16x8&, p16x8&, p16x8&, p16x8&) {}
-template <int N> __device__ __forceinline__ void lds_wait(p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&) {}
+template <int N> __device__ __forceinline__ void lds_wait(p16x8&, p16x8&) { emu::lgkm_wait(N); }
+template <int N> __device__ __forceinline__ void lds_wait(p16x8&, p16x8&, p16x8&, p16x8&) { emu::lgkm_wait(N); }
+template <int N> __device__ __forceinline__ void lds_wait(p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&) { emu::lgkm_wait(N); }
 template <int N>
-__device__ __forceinline__ void lds_wait(p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&) {}
+__device__ __forceinline__ void lds_wait(p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&) { emu::lgkm_wait(N); }
 #else
 // `lds_addr` = 32-bit LDS byte address (lds_addr_of), IMM = compile-time byte offset < 65536
 template <int IMM> __device__ __forceinline__ void lds_read16(p16x8& dst, uint32_t lds_addr) {
@@ -337,10 +337,14 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 // residual tile through these instead, two row sub-tiles ahead, retired by a counted vmem_wait<N> where N = number of
 // LOADS issued after the ones awaited (loads return in order; stores in between can only make the wait stricter).
 #ifdef MDM_EMU
-__device__ __forceinline__ void gload16_async(f32x4& dst, const float* p) {
-  dst = f32x4{p[0], p[1], p[2], p[3]};
-}
-template <int N> __device__ __forceinline__ void vmem_wait(f32x4&, f32x4&, f32x4&, f32x4&) {}
+__device__ __forceinline__ void gload16_async(f32x4& dst, const float* p) { emu::vm_issue(&dst, p, 16, true); }
+template <int N> __device__ __forceinline__ void vmem_wait(f32x4&, f32x4&, f32x4&, f32x4&) { emu::vm_wait(N); }
+// 16-bit-plane flavour: one MFMA operand fragment (the pipelined k-loop's W stream, gemm_x3.h)
+__device__ __forceinline__ void gload16_async(p16x8& dst, const p16_t* p) { emu::vm_issue(&dst, p, 16, true); }
+template <int N> __device__ __forceinline__ void vmem_wait(p16x8&, p16x8&) { emu::vm_wait(N); }
+template <int N> __device__ __forceinline__ void vmem_wait(p16x8&, p16x8&, p16x8&, p16x8&) { emu::vm_wait(N); }
+template <int N>
+__device__ __forceinline__ void vmem_wait(p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&) { emu::vm_wait(N); }
 #else
 __device__ __forceinline__ void gload16_async(f32x4& dst, const float* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
@@ -348,14 +352,31 @@ __device__ __forceinline__ void gload16_async(f32x4& dst, const float* p) {
 template <int N> __device__ __forceinline__ void vmem_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
 }
+// 16-bit-plane flavour: one MFMA operand fragment (the pipelined k-loop's W stream, gemm_x3.h)
+__device__ __forceinline__ void gload16_async(p16x8& dst, const p16_t* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N> __device__ __forceinline__ void vmem_wait(p16x8& a, p16x8& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void vmem_wait(p16x8& a, p16x8& b, p16x8& c, p16x8& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vmem_wait(p16x8& a, p16x8& b, p16x8& c, p16x8& d, p16x8& e, p16x8& f, p16x8& g, p16x8& h) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)
+               : "i"(N)
+               : "memory");
+}
 #endif
 
 // 8-byte flavour (four 16-bit elements of one plane): the residual stream of the f16x3 mode lives only as hi/lo planes
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #ifdef MDM_EMU
-__device__ __forceinline__ void gload8_async(u32x2& dst, const void* p) { memcpy(&dst, p, 8); }
+__device__ __forceinline__ void gload8_async(u32x2& dst, const void* p) { emu::vm_issue(&dst, p, 8, true); }
 template <int N>
-__device__ __forceinline__ void vmem_wait(u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&) {}
+__device__ __forceinline__ void vmem_wait(u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&) { emu::vm_wait(N); }
 #else
 __device__ __forceinline__ void gload8_async(u32x2& dst, const void* p) {
   asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
@@ -373,9 +394,19 @@ __device__ __forceinline__ void vmem_wait(u32x2& a, u32x2& b, u32x2& c, u32x2& d
 // would wait vmcnt(0) while an LDS-DMA is in flight); pair it with an explicit wait where the data is consumed.
 __device__ __forceinline__ void wg_barrier() {
 #ifdef MDM_EMU
+  emu::lgkm_wait(0);
   emu::block_barrier();
 #else
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); the builtin (unlike inline asm) is visible to hipcc's waitcnt pass
+  __builtin_amdgcn_s_barrier();
+#endif
+}
+// The bare rendezvous: neither queue is drained -- untracked fragment reads (lds_read16) and LDS-DMA pieces stay in flight
+// across it.  What it orders is only what each wave retired with its own counted waits BEFORE arriving.
+__device__ __forceinline__ void wg_barrier_nodrain() {
+#ifdef MDM_EMU
+  emu::block_barrier();
+#else
   __builtin_amdgcn_s_barrier();
 #endif
 }
@@ -389,13 +420,25 @@ __device__ __forceinline__ void wave_lds_fence() {
 #endif
 }
 __device__ __forceinline__ void wait_vmem_upto3() {  // at most 3 vector-memory operations of this wave still pending
-#ifndef MDM_EMU
+#ifdef MDM_EMU
+  emu::vm_wait(3);
+#else
   __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(3)
 #endif
 }
 __device__ __forceinline__ void wait_vmem_all() {
-#ifndef MDM_EMU
+#ifdef MDM_EMU
+  emu::vm_wait(0);
+#else
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#endif
+}
+template <int N> __device__ __forceinline__ void wait_vmem_upto() {   // vmcnt(N), N <= 15 in this encoding
+  static_assert(N >= 0 && N <= 15, "vmcnt low bits only");
+#ifdef MDM_EMU
+  emu::vm_wait(N);
+#else
+  __builtin_amdgcn_s_waitcnt(0x0F70 | N);
 #endif
 }
 

@@ -54,23 +54,34 @@ constexpr int x3_tn(int waves) { return 32 * waves; }
 constexpr int X3_MSUB = X3_TM / 32;                              // 7 row sub-tiles
 constexpr int X3_A_BYTES = X3_TM * X3_BK * 2;                    // one A plane tile: 14336
 constexpr int X3_A_STAGE = 2 * X3_A_BYTES;                       // Ah|Al: 28672
-constexpr int X3_A_RING = 2;
-constexpr int X3_PATCH_BASE = X3_A_RING * X3_A_STAGE;            // 57344
+constexpr int X3_A_RING = 2;                                     // stages of the step-synchronous k-loop
+constexpr int X3_PIPE_RING = 4;                                  // stages of the pipelined k-loop (PIPE): A runs 3 steps ahead
+// -DMDM_X3_PIPE_BADWAIT: a deliberately too lenient middle-of-step wait -- the check that the emulator's LATE mode
+// (tests/emu/hip_emu.h) really catches a wrong count (profiles/r03a_pipe_emulator.md); never defined in a product build
+#ifdef MDM_X3_PIPE_BADWAIT
+constexpr int X3P_MID_SLACK = 8;
+#else
+constexpr int X3P_MID_SLACK = 0;
+#endif
+constexpr int x3_patch_base(int ring) { return ring * X3_A_STAGE; }   // 57344 (2 stages) / 114688 (4)
 constexpr int X3_PATCH_BYTES = 8 * 32 * 4;                       // per wave: 8 rows x 32 columns fp32
 constexpr int X3_TAB_BYTES = X3_TM * 8;                          // one (mean, rstd) table of the tile's rows
 // LDS after the patches: the (mean, rstd) table of the tile's rows (FOLD or RES == 3: a kernel has one of them) and the
 // raw partial sums it is built from (<= 4 partials per row: 7 KB, the LDS-DMA lands whole KBs), both double-buffered by
 // tile parity, then the per-wave partial sums of OSTAT
-constexpr int x3_tab_base(int waves) { return X3_PATCH_BASE + waves * X3_PATCH_BYTES; }
+constexpr int x3_tab_base(int waves, int ring = X3_A_RING) { return x3_patch_base(ring) + waves * X3_PATCH_BYTES; }
 constexpr int X3_RAW_BYTES = 7 * 1024;
-constexpr int x3_raw_base(int waves) { return x3_tab_base(waves) + 2 * X3_TAB_BYTES; }      // tables: 2 (tile parity)
-constexpr int x3_part_base(int waves) { return x3_raw_base(waves) + 2 * X3_RAW_BYTES; }    // raw partials: 2 (parity)
+constexpr int x3_raw_base(int waves, int ring = X3_A_RING) { return x3_tab_base(waves, ring) + 2 * X3_TAB_BYTES; }      // tables: 2 (tile parity)
+constexpr int x3_part_base(int waves, int ring = X3_A_RING) { return x3_raw_base(waves, ring) + 2 * X3_RAW_BYTES; }    // raw partials: 2 (parity)
 // last: the epilogue's per-column vectors of the tile (bias, folded column sums, residual gamma, beta: 4 x 256 floats),
 // fetched by LDS-DMA one tile ahead, double-buffered by tile parity
 constexpr int X3_CVEC_BYTES = 4 * 1024;
-constexpr int x3_cvec_base(int waves, bool ln) { return ln ? x3_part_base(waves) + waves * X3_TAB_BYTES : x3_tab_base(waves); }
-constexpr int x3_lds_bytes(int waves, bool ln) {   // 69632 (4 waves) / 73728 (8); with the LayerNorm tables 95232 (8)
-  return x3_cvec_base(waves, ln) + 2 * X3_CVEC_BYTES;
+constexpr int x3_cvec_base(int waves, bool ln, int ring = X3_A_RING) {
+  return ln ? x3_part_base(waves, ring) + waves * X3_TAB_BYTES : x3_tab_base(waves, ring);
+}
+// 69632 (4 waves) / 73728 (8); with the LayerNorm tables 95232 (8); the 4-stage pipelined form 131072 / 152576
+constexpr int x3_lds_bytes(int waves, bool ln, int ring = X3_A_RING) {
+  return x3_cvec_base(waves, ln, ring) + 2 * X3_CVEC_BYTES;
 }
 constexpr int X3_A_GROUPS = X3_A_STAGE / 1024;                   // 28 LDS-DMA wave-instructions per stage
 constexpr int x3_a_pieces(int waves) { return (X3_A_GROUPS + waves - 1) / waves; }  // 7 (4 waves) / 4 (8 waves)
@@ -202,10 +213,12 @@ struct X3Cursor {
 // records, the weight planes come from pack_weight_f16f6_kernel; units are ordered sub-tile-major so that a sub-tile's two
 // 16-byte record reads (k sub-steps 0 and 1) meet in ONE scaled MFMA; 2 + 1 MFMAs per sub-tile and step instead of 6.
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
-          bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false>
+          bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false, bool PIPE = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N,
                                                                      int K, int rows_per_tile, int tiles_n, int total) {
   MDM_DYN_SMEM(unsigned char, lds);
+  static_assert(!PIPE || (T16 && WAVES == 8 && !F6), "the pipelined k-loop exists for 8-wave, 208-row (T16) tiles");
+  constexpr int RINGN = PIPE ? X3_PIPE_RING : X3_A_RING;   // A stages in LDS
   constexpr int X3_WAVES = WAVES, X3_TN = x3_tn(WAVES), X3_A_PIECES = x3_a_pieces(WAVES);
   constexpr int NT32 = T16 ? X3_MSUB - 1 : X3_MSUB;     // 32-row sub-tiles
   constexpr int NROUNDS = 4 * NT32 + (T16 ? 2 : 0);     // epilogue rounds of 8 rows
@@ -238,7 +251,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     tile_origin(c.v, m0, n0);
 #pragma unroll
     for (int i = 0; i < X3_A_PIECES; ++i) {
-      const int q = min(wid + X3_WAVES * i, X3_A_GROUPS - 1);
+      // PIPE: the 26 groups a 208-row tile reads (13 per plane) are dealt round-robin: piece j = wid + 8 i -> group j (hi) /
+      // j + 1 (lo, stage groups 14..26); waves 0 and 1 issue four pieces per step, the others three
+      const int jj = min(wid + X3_WAVES * i, 25);
+      const int q = PIPE ? (jj < 13 ? jj : jj + 1) : min(wid + X3_WAVES * i, X3_A_GROUPS - 1);
       const int ga = (q < 14) ? q : q - 14;
       const int arow = min(m0 + ga * 16 + (lane >> 2), M - 1);
       if constexpr ((ABL & 16) != 0) {
@@ -251,9 +267,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     }
   };
   auto piece_a = [&](const Cursor& c, int i, int buf) {
-    const int q = wid + X3_WAVES * i;
-    if (q < X3_A_GROUPS && !(T16 && (q == 13 || q == 27)))   // T16: rows 208-223 of the stage are never read
-      glds16(((q < 14) ? A.hi : A.lo) + c.off[i] + c.k * ((ABL & 16) ? 512 : X3_BK), lds + buf * X3_A_STAGE + q * 1024);
+    if constexpr (PIPE) {
+      const int j = wid + X3_WAVES * i;
+      const int q = j < 13 ? j : j + 1;
+      if (j < 26) glds16(((q < 14) ? A.hi : A.lo) + c.off[i] + c.k * X3_BK, lds + buf * X3_A_STAGE + q * 1024);
+    } else {
+      const int q = wid + X3_WAVES * i;
+      if (q < X3_A_GROUPS && !(T16 && (q == 13 || q == 27)))   // T16: rows 208-223 of the stage are never read
+        glds16(((q < 14) ? A.hi : A.lo) + c.off[i] + c.k * ((ABL & 16) ? 512 : X3_BK), lds + buf * X3_A_STAGE + q * 1024);
+    }
   };
   // past its last tile the stream simply re-fetches that tile (one wasted stage per workgroup): no "anything left to
   // load" branches in the step body
@@ -307,7 +329,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
       const long long total_f = ((long long)M * ep.stat_parts * 2 + 3) / 4 * 4;
       long long fo = (long long)m0s * ep.stat_parts * 2 + 4LL * (64 * wid + lane);
       if (fo > total_f - 4) fo = total_f - 4;                          // rows past the matrix: any valid address
-      glds16(st + fo, lds + x3_raw_base(WAVES) + par * X3_RAW_BYTES + wid * 1024);
+      glds16(st + fo, lds + x3_raw_base(WAVES, RINGN) + par * X3_RAW_BYTES + wid * 1024);
     }
   };
   // the epilogue's per-column vectors of the tile starting at column n0c -> LDS buffer `par`: wave 0 bias, wave 1 folded
@@ -319,7 +341,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     if (wid == 0) src = ep.bias;
     if constexpr (FOLD) { if (wid == 1) src = ep.colsum; }
     if constexpr (RES == 3) { if (wid == 2) src = ep.rgamma; if (wid == 3) src = ep.rbeta; }
-    if (src != nullptr) glds16(src + min(n0c + 4 * lane, N - 4), lds + x3_cvec_base(WAVES, LN_ANY) + par * X3_CVEC_BYTES + wid * 1024);
+    if (src != nullptr) glds16(src + min(n0c + 4 * lane, N - 4), lds + x3_cvec_base(WAVES, LN_ANY, RINGN) + par * X3_CVEC_BYTES + wid * 1024);
   };
   {
     int m0f, n0f;
@@ -328,12 +350,54 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     cvec_dma(n0f, 0);
   }
   p16x8 wh[2], wl[2], wnh[2], wnl[2];
+  // PIPE: the W stream lives in four half-step slots (slot 2 * (step parity) + k sub-step; hi and lo plane fragment each),
+  // refilled IN PLACE for two steps later as soon as their last MFMA has been issued -- 32 VGPRs, 1.5 steps of cover
+  p16x8 wsh[4], wsl[4];
+  uint32_t wso = 0;           // element offset of the W stream's current step inside the fragment-ordered planes
+  uint32_t wtile = 0;         // ... of its tile's first step (wave-uniform): changes only when the stream enters a new tile
+  auto aim_w_tile = [&]() {
+    int m0w, n0w;
+    tile_origin(wv, m0w, n0w);
+    wtile = (uint32_t)((n0w >> 5) + wid) * (uint32_t)wk16 * 512u;
+  };
+  auto aim_w = [&]() { wso = wtile + (uint32_t)wkk * 1024u + (uint32_t)lane * 8u; };
+  auto advance_w = [&]() {
+    if (++wkk == nk) {
+      wkk = 0;
+      if (wv + gstride < total) { wv += gstride; aim_w_tile(); }
+    }
+  };
+  auto load_w_half = [&](int ks, p16x8& fh, p16x8& fl) {
+    gload16_async(fh, W.hi + wso + 512 * ks);
+    gload16_async(fl, W.lo + wso + 512 * ks);
+  };
+  int gs = 0;                 // PIPE: global k-step counter of this workgroup (stage of step g = g & 3)
+  if constexpr (PIPE) {
+    // A(0), A(1), A(2) into stages 0..2 and W(0), W(1) into the four slots; everything landed and visible before step 0
 #pragma unroll
-  for (int i = 0; i < X3_A_PIECES; ++i) piece_a(ca, i, 0);
-  advance_a(ca);
-  load_w(wv, wkk, wh, wl);
-  wait_vmem_all();
-  wg_barrier();
+    for (int st = 0; st < 3; ++st) {
+#pragma unroll
+      for (int i = 0; i < X3_A_PIECES; ++i) piece_a(ca, i, st);
+      advance_a(ca);
+    }
+    aim_w_tile();
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      aim_w();
+      load_w_half(0, wsh[2 * st], wsl[2 * st]);
+      load_w_half(1, wsh[2 * st + 1], wsl[2 * st + 1]);
+      advance_w();
+    }
+    vmem_wait<0>(wsh[0], wsl[0], wsh[1], wsl[1], wsh[2], wsl[2], wsh[3], wsl[3]);
+    wg_barrier();
+  } else {
+#pragma unroll
+    for (int i = 0; i < X3_A_PIECES; ++i) piece_a(ca, i, 0);
+    advance_a(ca);
+    load_w(wv, wkk, wh, wl);
+    wait_vmem_all();
+    wg_barrier();
+  }
 
   int abuf = 0;
   int tile_parity = 0;
@@ -351,7 +415,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     // global-load latency in front of the epilogue); the next tile's are requested in this tile's SECOND k step (below),
     // i.e. behind a workgroup barrier every wave reaches only after its epilogue of the previous tile -- whose vectors
     // live in the buffer being refilled -- and land under the rest of this tile's k-loop
-    const float* const cvec = reinterpret_cast<const float*>(lds + x3_cvec_base(WAVES, LN_ANY) + tile_parity * X3_CVEC_BYTES);
+    const float* const cvec = reinterpret_cast<const float*>(lds + x3_cvec_base(WAVES, LN_ANY, RINGN) + tile_parity * X3_CVEC_BYTES);
     const int kt_cvec = nk > 1 ? 1 : 0;
     if (nk == 1) wg_barrier();   // single-step contractions: no k-step barrier in front of the request
     // row statistics (mean, rstd) of this tile's rows, built HERE -- where the accumulators are not live yet -- from the
@@ -359,7 +423,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     // next tile's partials are requested now and land under this tile's k-loop.  Tables and raw buffers alternate with
     // the tile parity: a fast wave may build table j+1 while a slow one still reads table j in its epilogue.
     constexpr bool LN_TABS = FOLD || RES == 3;
-    float2* const stab = reinterpret_cast<float2*>(lds + x3_tab_base(WAVES) + tile_parity * X3_TAB_BYTES);
+    float2* const stab = reinterpret_cast<float2*>(lds + x3_tab_base(WAVES, RINGN) + tile_parity * X3_TAB_BYTES);
     if constexpr (LN_TABS) {
       if (v + gstride < total) {
         int m0n, n0n;
@@ -374,7 +438,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         int m0t, n0t;
         tile_origin(v, m0t, n0t);
         const bool pad_row = m0t + tid >= M;
-        const float* sraw = reinterpret_cast<const float*>(lds + x3_raw_base(WAVES) + tile_parity * X3_RAW_BYTES);
+        const float* sraw = reinterpret_cast<const float*>(lds + x3_raw_base(WAVES, RINGN) + tile_parity * X3_RAW_BYTES);
         // partials are (sum, CENTRED sum of squares about the partial's own mean) of X3_TN columns each; merged by Chan's
         // formula -- no E[x^2] - mean^2 cancellation when a row's mean is large against its spread
         float s1 = 0.f;
@@ -399,6 +463,158 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     unsigned long long dbg_t0 = 0, dbg_w0 = 0, dbg_w1 = 0, dbg_bar = 0;
     if constexpr ((ABL & 128) != 0) dbg_t0 = x3_now();
 #endif
+    if constexpr (PIPE) {
+      // ================= pipelined k-loop (round 3) =================
+      // What the step-synchronous loop below pays per 32-deep step -- a full vmcnt(0) drain of loads issued at most one step
+      // earlier, a rendezvous of all eight waves behind it, and a cold restart of the fragment-read pipeline (measured: a
+      // step takes ~2.8 us against 1.3 us of matrix work) -- is removed by running every stream AHEAD of the matrix work:
+      //   * A: four LDS stages.  During step g the pieces of A(g+3) are issued (into the stage A(g-1) lived in); each wave
+      //     retires its own pieces of A(g+1) with a COUNTED vmcnt at the step's middle, then one bare s_barrier -- no drain --
+      //     makes them visible, and from there on the fragment reads of step g+1 may begin: the unit pipeline never restarts
+      //     inside a tile.  cover: 1.5-2 steps.
+      //   * W: four half-step register slots refilled in place for step g+2 right behind their last MFMA (cover 1.5 steps),
+      //     by untracked loads retired with counted waits that name the slot (hipcc would drain the LDS-DMA queue for a
+      //     tracked load).
+      //   * the 16-row sub-tile ("X") sits between the two k sub-steps, right behind the barrier, where both W halves of the
+      //     step are valid; its two reads travel in the same in-order read queue as the units'.
+      // Per step and wave the vector-memory queue therefore holds, in program order,
+      //     W0(g+2) x2 | A(g+3) x nA | W1(g+2) x2          nA = 4 (waves 0, 1) or 3
+      // and the waits are: step start, slot W0(g): 2 nA + 6 younger operations; middle, A(g+1) and W1(g): nA + 4.
+      // Other operations that land in the queue (column vectors, row statistics, the previous tile's stores) only make
+      // these waits stricter: the queue retires in order.
+      constexpr int NU = 2 * NT32, NE = NU + 1, XP = NT32, DEPTH = 2, RING = DEPTH + 1;
+      static_assert(NU % RING == 0, "fragment ring slots must line up across steps");
+      p16x8 ah[RING], al[RING], a16h, a16l;
+#ifndef MDM_EMU
+      const uint32_t lane_a = lds_base + fa, lane_a16 = lds_base + fa16;
+      const uint32_t sw0 = (uint32_t)((h ^ sw) * 16), sw1 = (uint32_t)(((2 + h) ^ sw) * 16);
+#endif
+      // reads of element `ee` of the step whose A stage is `stg` (runtime, 0..3): a regular unit or the 16-row sub-tile
+      auto issue_reads = [&](auto ee_tag, uint32_t stg) __attribute__((always_inline)) {
+        constexpr int ee = decltype(ee_tag)::value;
+        if constexpr (ee == XP) {
+#ifdef MDM_EMU
+          lds_read16(a16h, lds + stg * X3_A_STAGE, fa16);
+          lds_read16(a16l, lds + stg * X3_A_STAGE, X3_A_BYTES + fa16);
+#else
+          lds_read16<0>(a16h, lane_a16 + stg * X3_A_STAGE);
+          lds_read16<X3_A_BYTES>(a16l, lane_a16 + stg * X3_A_STAGE);
+#endif
+        } else {
+          constexpr int u = ee < XP ? ee : ee - 1, ks = u / NT32, t = u - ks * NT32;
+#ifdef MDM_EMU
+          lds_read16(ah[u % RING], lds + stg * X3_A_STAGE, fa + t * 2048 + (((ks * 2 + h) ^ sw) * 16));
+          lds_read16(al[u % RING], lds + stg * X3_A_STAGE, X3_A_BYTES + fa + t * 2048 + (((ks * 2 + h) ^ sw) * 16));
+#else
+          const uint32_t ad = lane_a + stg * X3_A_STAGE + (ks ? sw1 : sw0);
+          lds_read16<t * 2048>(ah[u % RING], ad);
+          lds_read16<X3_A_BYTES + t * 2048>(al[u % RING], ad);
+#endif
+        }
+      };
+      auto pipe_step = [&](auto par_tag) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;
+        const uint32_t cur = (uint32_t)gs & 3u, nxt = (uint32_t)(gs + 1) & 3u, fill = (uint32_t)(gs + 3) & 3u;
+        p16x8 w16h[2], w16l[2];
+        // slot W0(g) landed?  (issued in the middle of step g-2)
+        vmem_wait<12>(wsh[2 * PAR], wsl[2 * PAR]);
+        static_for<NE>([&](auto e_tag) __attribute__((always_inline)) {
+          constexpr int e = decltype(e_tag)::value;
+          // ---- 1. reads of the element DEPTH ahead (past the step: units 0, 1 of step g+1, from the next stage)
+          if constexpr (e + DEPTH < NE) issue_reads(std::integral_constant<int, e + DEPTH>{}, cur);
+          else issue_reads(std::integral_constant<int, e + DEPTH - NE>{}, nxt);
+          // ---- 2. the middle of the step sits in front of the 16-row sub-tile
+          if constexpr (e == XP) {
+            // own pieces of A(g+1) and slot W1(g) (both issued during step g-2) landed
+            vmem_wait<7 + X3P_MID_SLACK>(wsh[2 * PAR + 1], wsl[2 * PAR + 1]);
+            w16h[0] = wsh[2 * PAR]; w16h[1] = wsh[2 * PAR + 1];
+            w16l[0] = wsl[2 * PAR]; w16l[1] = wsl[2 * PAR + 1];
+            frag32_to_frag16(w16h[0], w16h[1]);
+            frag32_to_frag16(w16l[0], w16l[1]);
+#ifndef MDM_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            // slot W0 is free (its last 32-row MFMA was issued with unit NT32-1, its lane-swapped copy is taken): refill for g+2
+            if constexpr (!(ABL & 2)) { aim_w(); load_w_half(0, wsh[2 * PAR], wsl[2 * PAR]); }
+            wg_barrier_nodrain();   // A(g+1) visible to every wave; every wave is past step g-1, whose stage A(g+3) refills
+#ifndef MDM_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+          }
+          // ---- 3. this element's reads retired (those of the DEPTH younger elements may stay in flight)
+          constexpr int issued_after = DEPTH;
+          if constexpr (e == XP) {
+            lds_wait<2 * issued_after>(a16h, a16l);
+          } else {
+            constexpr int u = e < XP ? e : e - 1;
+            lds_wait<2 * issued_after>(ah[u % RING], al[u % RING]);
+          }
+#ifndef MDM_EMU
+          __builtin_amdgcn_sched_barrier(0);  // the MFMAs below must not be hoisted above the wait (rule 18)
+#endif
+          // ---- 4. matrix work
+          if constexpr (e == XP) {
+            if constexpr ((ABL & 4) != 0) {
+#ifndef MDM_EMU
+              asm volatile("" ::"v"(a16h), "v"(a16l), "v"(w16h[0]), "v"(w16h[1]), "v"(w16l[0]), "v"(w16l[1]));
+#endif
+            } else {
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) {
+                acc16[cb] = mfma16_p16(a16l, w16h[cb], acc16[cb]);
+                acc16[cb] = mfma16_p16(a16h, w16l[cb], acc16[cb]);
+                acc16[cb] = mfma16_p16(a16h, w16h[cb], acc16[cb]);
+              }
+            }
+          } else {
+            constexpr int u = e < XP ? e : e - 1, ks = u / NT32, t = u - ks * NT32;
+            if constexpr ((ABL & 4) != 0) {
+#ifndef MDM_EMU
+              asm volatile("" ::"v"(al[u % RING]), "v"(ah[u % RING]), "v"(wsh[2 * PAR + ks]), "v"(wsl[2 * PAR + ks]));
+#endif
+            } else {
+              acc[t] = mfma_p16(al[u % RING], wsh[2 * PAR + ks], acc[t]);
+              acc[t] = mfma_p16(ah[u % RING], wsl[2 * PAR + ks], acc[t]);
+              acc[t] = mfma_p16(ah[u % RING], wsh[2 * PAR + ks], acc[t]);
+            }
+          }
+#ifndef MDM_EMU
+          __builtin_amdgcn_sched_barrier(0);  // keep the same-accumulator triple back to back (no filler inside)
+#endif
+          // ---- 5. one LDS-DMA piece of A(g+3) rides behind each of the four elements that follow the barrier
+          if constexpr (!(ABL & 2) && e >= XP && e < XP + X3_A_PIECES) piece_a(ca, e - XP, (int)fill);
+#ifndef MDM_EMU
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        });
+        // slot W1 is free: refill for g+2; then both streams move on
+        if constexpr (!(ABL & 2)) load_w_half(1, wsh[2 * PAR + 1], wsl[2 * PAR + 1]);
+        advance_w();
+        advance_a(ca);
+        ++gs;
+      };
+      // prime the fragment pipeline of this tile: its first stage was made visible by the previous step's barrier / the prologue
+      issue_reads(std::integral_constant<int, 0>{}, (uint32_t)gs & 3u);
+      issue_reads(std::integral_constant<int, 1>{}, (uint32_t)gs & 3u);
+      for (int kt = 0; kt < nk; kt += 2) {
+        pipe_step(std::integral_constant<int, 0>{});
+        // the next tile's per-column vectors: behind step 0's barrier, which every wave reaches only after its epilogue of
+        // the previous tile (whose vectors live in the buffer being refilled)
+        if (kt == 0 && v + gstride < total) {
+          int m0n, n0n;
+          tile_origin(v + gstride, m0n, n0n);
+          cvec_dma(n0n, tile_parity ^ 1);
+        }
+        pipe_step(std::integral_constant<int, 1>{});
+      }
+      // the tile's last step has run two elements ahead like every other (ONE step body: a separate "last step" instance made
+      // hipcc keep two copies of the accumulators, 192 VGPRs): those fragments belong to the next tile's first step, whose
+      // pipeline is primed afresh behind the epilogue -- retire and drop them
+      lds_wait<0>(ah[0], al[0], ah[1], al[1]);
+      // the epilogue must not meet a W slot whose load is still in flight (a spill would save the stale register); hipcc
+      // drains the queue in front of the epilogue's first LDS read anyway (LDS-DMA pending)
+      vmem_wait<0>(wsh[0], wsl[0], wsh[1], wsl[1], wsh[2], wsl[2], wsh[3], wsl[3]);
+    } else {
     for (int kt = 0; kt < nk; ++kt) {
       if (kt == kt_cvec && v + gstride < total) {
         int m0n, n0n;
@@ -542,6 +758,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         wh[0] = wnh[0]; wh[1] = wnh[1]; wl[0] = wnl[0]; wl[1] = wnl[1];
       }
     }
+    }   // !PIPE
 
     // ---- epilogue.  In the accumulator layout a lane owns ONE column and 16 rows of each 32x32 sub-tile, which would
     // mean 4-byte (fp32) / 2-byte (planes) stores: the store tail is issue-bound (cdna_hip_programming.md T21).  So
@@ -552,9 +769,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     unsigned long long dbg_t1 = 0;
     if constexpr ((ABL & 128) != 0) dbg_t1 = x3_now();
 #endif
+    {   // epilogue scope: every lane-derived index below is rebuilt from an OPAQUE copy of the lane id, so that hipcc cannot
+        // compute the epilogue's per-round offsets once, in front of the tile loop, and carry them (24 VGPRs of hoisted
+        // store offsets, spilled in the in_proj instantiation) through every k-loop
+    int lane_e = lane;
+#ifndef MDM_EMU
+    asm volatile("" : "+v"(lane_e));
+#endif
+    const int r = lane_e & 31, h = lane_e >> 5, r16 = lane_e & 15, g16 = lane_e >> 4;
     const int m_end = min(M, m0 + rows_per_tile);
-    float* patch = reinterpret_cast<float*>(lds + X3_PATCH_BASE) + wid * (X3_PATCH_BYTES / 4);  // [8][32] fp32
-    const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+    float* patch = reinterpret_cast<float*>(lds + x3_patch_base(RINGN)) + wid * (X3_PATCH_BYTES / 4);  // [8][32] fp32
+    const int prow = lane_e >> 3, pc4 = (lane_e & 7) * 4;
     const int n4 = ncol0 + pc4;                          // first of this lane's 4 columns in the row layout
     // per-lane column vectors of the row-major side: bias (or folded bias), Q scale, folded column sums, residual gamma/beta
     const int cl4 = wid * 32 + pc4;                      // this lane's first column inside the tile
@@ -743,7 +968,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         res_issue(std::integral_constant<int, 0>{});
         if constexpr (RR == 3) res_issue(std::integral_constant<int, 1>{});
       }
-      float2* part = reinterpret_cast<float2*>(lds + x3_part_base(WAVES)) + wid * X3_TM;   // OSTAT: this wave's partials
+      float2* part = reinterpret_cast<float2*>(lds + x3_part_base(WAVES, RINGN)) + wid * X3_TM;   // OSTAT: this wave's partials
       patch_write(std::integral_constant<int, 0>{});
       float2 st_cur = row_stats(std::integral_constant<int, 0>{});
       static_for<NROUNDS>([&](auto j_tag) __attribute__((always_inline)) {
@@ -786,7 +1011,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
           const float mw = s1 * (1.0f / 32.0f);
           const float dx = v4.x - mw, dy = v4.y - mw, dz = v4.z - mw, dw = v4.w - mw;
           const float m2 = sum_lanes8((dx * dx + dy * dy) + (dz * dz + dw * dw));
-          if ((lane & 7) == 0) part[row_in_tile] = make_float2(s1, m2);
+          if ((lane_e & 7) == 0) part[row_in_tile] = make_float2(s1, m2);
         }
         if (!(ABL & 1)) {
           const int m = m0 + row_in_tile;
@@ -808,7 +1033,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
       if constexpr (OSTAT) {   // rows x waves partials -> one (sum, sum^2) pair per row and column tile
         wg_barrier();
         if (tid < X3_TM && m0 + tid < m_end) {
-          const float2* pp = reinterpret_cast<const float2*>(lds + x3_part_base(WAVES));
+          const float2* pp = reinterpret_cast<const float2*>(lds + x3_part_base(WAVES, RINGN));
           float s1 = 0.f;
 #pragma unroll
           for (int w8 = 0; w8 < X3_WAVES; ++w8) s1 += pp[w8 * X3_TM + tid].x;
@@ -824,6 +1049,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         }
       }
     }
+    }   // epilogue scope
 #ifdef MDM_X3_DBG
     if constexpr ((ABL & 128) != 0) {
       const unsigned long long t2 = x3_now();
@@ -837,6 +1063,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
   wait_vmem_all();  // the stream's last (unused) LDS-DMA stage must land before this workgroup's LDS is released
 }
 
+#ifndef MDM_X3_KERNEL_ONLY   // (register-pressure studies compile single instantiations of the kernel without the launchers)
 // rows per block tile: a whole number of sequences when the row space is sequence-structured (keeps the tile count a
 // multiple of the sequence count -> no ragged last wave of workgroups), else the full 224.
 inline int x3_rows_per_tile(int M, int seq_len) {
@@ -878,31 +1105,43 @@ inline int x3_waves_setting() { return 8; }   // the 4-wave form is compiled int
 #endif
 
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
-          bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false>
+          bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false, bool PIPE = false>
 inline int launch_gemm_x3_w(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                                 int rpt, hipStream_t stream) {
   constexpr int TN = x3_tn(WAVES);
   constexpr bool LN = FOLD || OSTAT || RES == 3;
+  constexpr int RINGN = PIPE ? X3_PIPE_RING : X3_A_RING;
   const int tiles_m = (M + rpt - 1) / rpt, tiles_n = (N + TN - 1) / TN;
   const int total = tiles_m * tiles_n;
   static_assert(!(F6 && T16), "the f16f6 k-loop has no 16-row sub-tile yet");
-  auto kfn = &gemm_x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16, F6>;
+  auto kfn = &gemm_x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16, F6, PIPE>;
   if (T16 && rpt > X3_TM - 16) return -2;
+  if (PIPE && (K / X3_BK) % 2 != 0) return -2;   // the pipelined k-loop is unrolled over step pairs
 #ifndef MDM_EMU
-  if (x3_lds_bytes(WAVES, LN) > 65536) {
+  if (x3_lds_bytes(WAVES, LN, RINGN) > 65536) {
     static bool configured[kMaxDevices] = {};  // per instantiation and device (the attribute belongs to the device's code object)
     bool& done = configured[rt_device_ordinal()];
     if (!done) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              x3_lds_bytes(WAVES, LN)) != hipSuccess)
+                              x3_lds_bytes(WAVES, LN, RINGN)) != hipSuccess)
         return -1;
       done = true;
     }
   }
 #endif
   const int grid = std::min(total, x3_grid_limit(WAVES == 4 ? 2 : 1));
-  MDM_LAUNCH(kfn, dim3(grid), dim3(64 * WAVES), x3_lds_bytes(WAVES, LN), stream, A, W, ep, M, N, K, rpt, tiles_n, total);
+  MDM_LAUNCH(kfn, dim3(grid), dim3(64 * WAVES), x3_lds_bytes(WAVES, LN, RINGN), stream, A, W, ep, M, N, K, rpt, tiles_n, total);
   return 0;
+}
+
+// The pipelined k-loop (PIPE) is the default wherever it exists (208-row tiles, an even number of 32-deep k steps);
+// MDM_X3_PIPE=0 selects the step-synchronous loop for same-box A/B runs.
+inline bool x3_pipe_setting() {
+  static const bool on = [] {
+    const char* e = getenv("MDM_X3_PIPE");
+    return !(e != nullptr && e[0] == '0');
+  }();
+  return on;
 }
 
 // The GEMMs of the folded-LayerNorm encoder (8-wave workgroups only):
@@ -912,16 +1151,17 @@ inline int launch_gemm_x3_w(const X3Operand& A, const X3Weights& W, const X3Epil
 //   kind 3  linear1                             FOLD + GELU -> planes
 //   kind 4  OutputProcess                       FOLD -> fp32
 //   kind 5  InputProcess                        + positional rows, planes to the token rows of every branch (EMBED)
-template <bool T16>
+template <bool T16, bool PIPE = false>
 inline int launch_gemm_x3_ln_t(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
                                    int K, int rpt, hipStream_t s) {
   switch (kind) {
-    case 0: return launch_gemm_x3_w<8, ACT_NONE, 0, false, false, true, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
-    case 1: return launch_gemm_x3_w<8, ACT_NONE, 2, false, true, false, 0, false, true, false, T16>(A, W, ep, M, N, K, rpt, s);
-    case 2: return launch_gemm_x3_w<8, ACT_NONE, 3, false, true, false, 0, false, true, false, T16>(A, W, ep, M, N, K, rpt, s);
-    case 3: return launch_gemm_x3_w<8, ACT_GELU, 0, false, true, false, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
-    case 4: return launch_gemm_x3_w<8, ACT_NONE, 0, true, false, false, 0, true, false, false, T16>(A, W, ep, M, N, K, rpt, s);
-    case 5: return launch_gemm_x3_w<8, ACT_NONE, 1, false, true, false, 0, false, false, true, T16>(A, W, ep, M, N, K, rpt, s);
+    case 0: return launch_gemm_x3_w<8, ACT_NONE, 0, false, false, true, 0, true, false, false, T16, false, PIPE>(A, W, ep, M, N, K, rpt, s);
+    case 1: return launch_gemm_x3_w<8, ACT_NONE, 2, false, true, false, 0, false, true, false, T16, false, PIPE>(A, W, ep, M, N, K, rpt, s);
+    case 2: return launch_gemm_x3_w<8, ACT_NONE, 3, false, true, false, 0, false, true, false, T16, false, PIPE>(A, W, ep, M, N, K, rpt, s);
+    case 3: return launch_gemm_x3_w<8, ACT_GELU, 0, false, true, false, 0, true, false, false, T16, false, PIPE>(A, W, ep, M, N, K, rpt, s);
+    case 4: return launch_gemm_x3_w<8, ACT_NONE, 0, true, false, false, 0, true, false, false, T16, false, PIPE>(A, W, ep, M, N, K, rpt, s);
+    case 5:   // InputProcess: K = 288 is nine steps -- stays on the step-synchronous loop
+      return launch_gemm_x3_w<8, ACT_NONE, 1, false, true, false, 0, false, false, true, T16>(A, W, ep, M, N, K, rpt, s);
     default: return -2;
   }
 }
@@ -939,7 +1179,10 @@ inline bool x3_t16_setting() {
 }
 inline int launch_gemm_x3_ln(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
                                  int K, int rpt, hipStream_t s) {
-  if (rpt <= X3_TM - 16 && x3_t16_setting()) return launch_gemm_x3_ln_t<true>(kind, A, W, ep, M, N, K, rpt, s);
+  if (rpt <= X3_TM - 16 && x3_t16_setting()) {
+    if (kind != 5 && (K / X3_BK) % 2 == 0 && x3_pipe_setting()) return launch_gemm_x3_ln_t<true, true>(kind, A, W, ep, M, N, K, rpt, s);
+    return launch_gemm_x3_ln_t<true>(kind, A, W, ep, M, N, K, rpt, s);
+  }
   return launch_gemm_x3_ln_t<false>(kind, A, W, ep, M, N, K, rpt, s);
 }
 
@@ -1019,10 +1262,16 @@ inline int launch_gemm_f16f6(const X3Operand& A, const X3Weights& W, const X3Epi
 inline int launch_gemm_x3_qkv(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int nseq, int S, int D,
                                   hipStream_t s) {
   if (S > X3_TM) return -2;
-  if (x3_waves_setting() == 8 && S <= X3_TM - 16 && x3_t16_setting())
+  if (x3_waves_setting() == 8 && S <= X3_TM - 16 && x3_t16_setting()) {
+    if ((D / X3_BK) % 2 == 0 && x3_pipe_setting())
+      return launch_gemm_x3_w<8, ACT_NONE, 0, false, false, true, 0, false, false, false, true, false, true>(A, W, ep, nseq * S,
+                                                                                                              3 * D, D, S, s);
     return launch_gemm_x3_w<8, ACT_NONE, 0, false, false, true, 0, false, false, false, true>(A, W, ep, nseq * S, 3 * D, D,
                                                                                                  S, s);
+  }
   return launch_gemm_x3_t<ACT_NONE, 0, false, false, true>(A, W, ep, nseq * S, 3 * D, D, S, s);
 }
+
+#endif  // MDM_X3_KERNEL_ONLY
 
 }  // namespace mdm

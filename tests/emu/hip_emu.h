@@ -74,6 +74,10 @@ struct Fiber {
   char* stack = nullptr;
   bool done = false;
   dim3 tid;
+  // LATE mode (MDM_EMU_LATE=1): asynchronous operations of this lane that have been ISSUED but whose effect is withheld
+  // until a counted wait covers them -- vector-memory queue (LDS-DMA pieces, untracked global loads) and LDS-read queue
+  struct Pending { void* dst; const void* src; int bytes; };
+  std::vector<Pending> vmq, ldsq;
 };
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -313,9 +317,42 @@ inline void permlane16_swap(uint32_t& vdst, uint32_t& src) {
   src = ns;
 }
 
+// ---- LATE mode: the adversarial half of the asynchronous-operation model.  By default (EARLY) an LDS-DMA / untracked load /
+// untracked ds_read takes effect the moment it is issued -- the earliest the hardware could deliver it, which exposes
+// write-after-read hazards (a stage refilled while somebody still reads it).  With MDM_EMU_LATE=1 the effect is withheld
+// until the issuing lane executes a counted wait that covers the operation (`s_waitcnt vmcnt(N)` / `lgkmcnt(N)`: everything
+// but the N youngest operations of that queue) -- the latest the hardware may deliver it, which exposes read-after-write
+// hazards (data consumed before the wait + barrier that makes it valid) and wrong wait counts.  Registers awaiting a
+// withheld load hold a NaN pattern.  Operations the hardware also counts but the emulator executes synchronously (plain
+// loads, stores, compiler-tracked LDS accesses) only make the hardware's waits STRICTER than the model's.
+inline bool late_mode() {
+  static const bool on = [] { const char* e = getenv("MDM_EMU_LATE"); return e != nullptr && e[0] == '1'; }();
+  return on;
+}
+inline void apply_pending(std::vector<Fiber::Pending>& q, size_t keep) {
+  if (q.size() <= keep) return;
+  const size_t n = q.size() - keep;
+  for (size_t i = 0; i < n; ++i) memcpy(q[i].dst, q[i].src, (size_t)q[i].bytes);
+  q.erase(q.begin(), q.begin() + (long)n);
+}
+inline void vm_issue(void* dst, const void* src, int bytes, bool poison_dst) {
+  if (!late_mode()) { memcpy(dst, src, (size_t)bytes); return; }
+  if (poison_dst) memset(dst, 0xFF, (size_t)bytes);
+  cur().vmq.push_back(Fiber::Pending{dst, src, bytes});
+}
+inline void vm_wait(int n) { if (late_mode()) apply_pending(cur().vmq, (size_t)n); }
+inline void lds_issue(void* dst, const void* src, int bytes) {
+  if (!late_mode()) { memcpy(dst, src, (size_t)bytes); return; }
+  memset(dst, 0xFF, (size_t)bytes);
+  cur().ldsq.push_back(Fiber::Pending{dst, src, bytes});
+}
+inline void lgkm_wait(int n) { if (late_mode()) apply_pending(cur().ldsq, (size_t)n); }
+
 inline void fiber_entry() {
   Block& b = blk();
   (*b.body)();
+  apply_pending(b.fibers[b.cur].vmq, 0);   // s_endpgm: whatever is still in flight lands (LATE mode)
+  b.fibers[b.cur].ldsq.clear();            // a register load nobody waited for has no observer
   b.fibers[b.cur].done = true;
 #ifdef MDM_EMU_FASTCTX
   mdm_emu_switch(&b.fibers[b.cur].ctx, &b.sched);
