@@ -14,6 +14,14 @@
  *   - every function returns MDM_OK (0) or a negative MDM_E* code; mdm_last_error() gives the message of the
  *     calling thread's last failure.  No C++ exception crosses the ABI;
  *   - a model handle may be used from one thread / one stream at a time.
+ *   - CONCURRENCY: ONE chain of this library's kernels per device.  The library itself enforces it: every call that
+ *     enqueues kernels takes a per-device lock for the duration of the (asynchronous) enqueue and, when the previous call
+ *     on this device used a DIFFERENT stream, makes `stream` wait (hipStreamWaitEvent) for the event recorded behind
+ *     that call's kernels.  Two model handles, two streams or two host threads on one GPU therefore run their kernels
+ *     back to back, never side by side.  Why: two concurrent chains of the split-precision kernels were measured to
+ *     read stale cache lines of rows their own predecessor kernel had just rewritten (profiles/r02e_dip.md; root cause
+ *     not established).  Work of OTHER libraries may overlap freely.  Because of the event record, do not call into
+ *     this library while `stream` is being captured into a hipGraph together with an earlier call from another stream.
  *   - all tensors are fp32, dense, in the reference's layouts: poses [B, njoints, nfeats, T] (T contiguous).
  */
 #ifndef MDM_HIP_H
@@ -33,7 +41,7 @@ extern "C" {
 #define MDM_EHIP (-4)     /* a HIP runtime call failed                         */
 #define MDM_EUNSUPPORTED (-5)
 
-#define MDM_ABI_VERSION 5
+#define MDM_ABI_VERSION 6
 
 typedef struct mdm_model mdm_model_t;
 
@@ -75,6 +83,14 @@ int mdm_set_weight(mdm_model_t* m, const char* name, const float* dev_ptr, int64
 size_t mdm_const_bytes(const mdm_model_t* m);
 /* Validates that every weight is present and (re)builds the derived tables.  Call again after weights change. */
 int mdm_prepare(mdm_model_t* m, void* const_ws_dev, size_t const_ws_bytes, void* stream);
+
+/* Range check of the split-precision weight planes.  The f16x3 arithmetic carries every weight matrix (and every
+ * LayerNorm-gamma-folded weight matrix: gamma[k] * W[n][k]) as fp16 hi + lo planes of w * 2^8, i.e. it needs
+ * |w| < 255.9 (activations: |x| <= 65504, checked on the samples by the Python seam).  mdm_prepare's pack kernels record a
+ * violation in a device flag; this call reads it back (ONE stream synchronisation -- call it once after mdm_prepare).
+ * *in_range = 1: every plane is finite; 0: use MDM_PREC_F32 for this checkpoint (the Python seam raises and says so).
+ * No counterpart in the reference (its fp32 `addmm`s have fp32's range). */
+int mdm_weights_in_range(mdm_model_t* m, int32_t* in_range, void* stream);
 
 /* Arithmetic of the model's dense contractions:
  *   MDM_PREC_F32     exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere: bit-for-bit an fp32 fma chain; the on-device

@@ -17,7 +17,8 @@ extern "C" {
  * what = 1: mdm_linear_x3 reuses the operand planes already in scratch (kernel-only timing); what = 2: waves per GEMM
  * workgroup, 8 (default: 208/224 x 256 tiles, one workgroup per CU) or 4 (224 x 128 tiles, two per CU); what = 3: attention
  * ablation code; what = 4: mdm_linear_f16f6 on its reference kernel; what = 5: the `f32` mode's encoder GEMMs run unfused on
- * the f16f6 kernel, operands packed per call into a scratch this library allocates itself. */
+ * the f16f6 kernel, operands packed per call into a scratch this library allocates itself; what = 6: mdm_linear_x3's plain
+ * fp32-out variant runs on the pipelined k-loop (gemm_x3.h PIPE) with ablation codes 0..7. */
 int mdm_debug_set(int what, int value);
 /* Cycle counters of the split-precision GEMM's ABL = 128 build (idx 0..7; idx < 0 resets). */
 int mdm_debug_get(int idx, double* out);

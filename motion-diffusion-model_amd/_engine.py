@@ -56,6 +56,17 @@ class Engine:
             raise ValueError(f"precision must be one of {sorted(nat.PRECISIONS)}, got {precision!r}")
         self.lib.check(self.lib.mdm_set_precision(self.handle, nat.PRECISIONS[precision]), "mdm_set_precision")
         self.precision = precision
+        self._check_weight_range()
+
+    def _check_weight_range(self):
+        """The f16x3 operand planes hold w * 2^8 as fp16 hi + lo: a weight (or LayerNorm-gamma-folded weight) with
+        |w| >= 255.9 does not fit (include/mdm_hip.h mdm_weights_in_range).  Loud at bind / mode switch, not as NaN samples."""
+        if getattr(self, "ready", False) and self.precision != "f32" and not getattr(self, "weights_in_range", True):
+            raise nat.MdmError(
+                "this checkpoint does not fit the default precision='f16x3': a weight matrix (possibly scaled by the "
+                "LayerNorm gamma folded into it) has an entry of magnitude >= 255.9, beyond the fp16 operand planes "
+                "(w * 2^8 <= 65504).  Construct the model with precision='f32' (or set MDM_PRECISION=f32): the exact-fp32 "
+                "MFMA mode has fp32's range.")
 
     # ---- plumbing -------------------------------------------------------------------------
     def _check_device(self, t):
@@ -91,7 +102,11 @@ class Engine:
         nbytes = self.lib.mdm_const_bytes(self.handle)
         self._const_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self.lib.check(self.lib.mdm_prepare(self.handle, self._const_ws.data_ptr(), nbytes, self.stream()), "mdm_prepare")
+        ok = C.c_int32(1)
+        self.lib.check(self.lib.mdm_weights_in_range(self.handle, C.byref(ok), self.stream()), "mdm_weights_in_range")
+        self.weights_in_range = bool(ok.value)
         self.ready = True
+        self._check_weight_range()
 
     @_on_own_device
     def workspace(self, nseq, T):

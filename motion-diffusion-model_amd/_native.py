@@ -24,11 +24,11 @@ EXPORTED_SYMBOLS = [
     "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset",
     "mdm_set_precision", "mdm_linear_x3", "mdm_linear_x3_scratch_bytes", "mdm_attention_x3", "mdm_attention_x3_scratch_bytes",
     "mdm_recover_from_ric", "mdm_workspace_bytes_dec", "mdm_forward_dec", "mdm_workspace_bytes_dec_loop",
-    "mdm_sample_loop_dec",
+    "mdm_sample_loop_dec", "mdm_weights_in_range",
 ]
 # include/mdm_hip_probe.h: exported by the probe build only
 PROBE_SYMBOLS = ["mdm_debug_set", "mdm_debug_get", "mdm_linear_f16f6", "mdm_linear_f16f6_scratch_bytes"]
-ABI_VERSION = 5
+ABI_VERSION = 6
 ARCH = {"trans_enc": 0, "trans_dec": 1}
 
 
@@ -93,6 +93,7 @@ class MdmLib:
             "mdm_layernorm": (C.c_int, [vp, vp, vp, i32, i32, vp]),
             "mdm_attention": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
             "mdm_set_precision": (C.c_int, [vp, i32]),
+            "mdm_weights_in_range": (C.c_int, [vp, P(i32), vp]),
             "mdm_linear_x3_scratch_bytes": (sz, [i32, i32, i32]),
             "mdm_linear_x3": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
             "mdm_attention_x3_scratch_bytes": (sz, [i32, i32, i32]),

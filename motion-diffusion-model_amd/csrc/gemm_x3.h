@@ -63,6 +63,15 @@ constexpr int X3P_MID_SLACK = 8;
 #else
 constexpr int X3P_MID_SLACK = 0;
 #endif
+// Counted vmcnt waits of the pipelined loop.  ORDERED: the queue retires in issue order across both kinds of operation it
+// holds (LDS-DMA pieces of A, VGPR loads of W) -- the count is the number of YOUNGER operations of either kind.  STRICT
+// (-DMDM_X3_PIPE_STRICT): only operations of the SAME kind are assumed to retire in order -- the count is the number of younger
+// operations of the awaited kind alone, i.e. the wait also holds if every operation of the other kind has already retired.
+#ifdef MDM_X3_PIPE_STRICT
+constexpr int X3P_WAIT_WS = 6, X3P_WAIT_MID = 3;
+#else
+constexpr int X3P_WAIT_WS = 12, X3P_WAIT_MID = 7;
+#endif
 constexpr int x3_patch_base(int ring) { return ring * X3_A_STAGE; }   // 57344 (2 stages) / 114688 (4)
 constexpr int X3_PATCH_BYTES = 8 * 32 * 4;                       // per wave: 8 rows x 32 columns fp32
 constexpr int X3_TAB_BYTES = X3_TM * 8;                          // one (mean, rstd) table of the tile's rows
@@ -156,8 +165,10 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 }
 
 // fp32 [N][K] -> fragment-ordered hi/lo planes (rows >= N zero).  One thread per 8 consecutive k of one row.
+// `overflow` (device int, may be null): set to 1 when a hi element is not a finite 16-bit number, i.e. |w * 2^8| left the
+// plane format's range (fp16: |w| >= 255.9) -- such a matrix cannot be carried by the split arithmetic (mdm_weights_in_range).
 __global__ __launch_bounds__(256) void pack_weight_planes_kernel(const float* __restrict__ w, p16_t* __restrict__ hi,
-                                                                 p16_t* __restrict__ lo, int N, int K) {
+                                                                 p16_t* __restrict__ lo, int N, int K, int* overflow) {
   const int npad = (N + 31) / 32 * 32, k8n = K / 8;
   const size_t total = (size_t)npad * k8n;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -167,6 +178,15 @@ __global__ __launch_bounds__(256) void pack_weight_planes_kernel(const float* __
     for (int j = 0; j < 8; ++j) v[j] = (n < N) ? w[(size_t)n * K + 8 * k8 + j] * kX3WeightScale : 0.f;
     p16x8 h8, l8;
     split8(v, h8, l8);
+    if (overflow != nullptr) {
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float back = p16_to_f32((p16_t)h8[j]);
+        bad = bad || !(fabsf(back) <= 3.0e38f);   // inf or NaN (also when the fp32 weight itself is not finite)
+      }
+      if (bad) *overflow = 1;   // benign race: every writer stores the same value
+    }
     const int kstep = k8 >> 1, half = k8 & 1, lane = (n & 31) + 32 * half;
     const size_t o = (((size_t)(n >> 5) * (K / 16) + kstep) * 64 + lane) * 8;
     *reinterpret_cast<p16x8*>(hi + o) = h8;
@@ -516,17 +536,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         constexpr int PAR = decltype(par_tag)::value;
         const uint32_t cur = (uint32_t)gs & 3u, nxt = (uint32_t)(gs + 1) & 3u, fill = (uint32_t)(gs + 3) & 3u;
         p16x8 w16h[2], w16l[2];
+#ifdef MDM_X3_PIPE_NOLOOK
+        issue_reads(std::integral_constant<int, 0>{}, cur);
+        issue_reads(std::integral_constant<int, 1>{}, cur);
+#endif
         // slot W0(g) landed?  (issued in the middle of step g-2)
-        vmem_wait<12>(wsh[2 * PAR], wsl[2 * PAR]);
+        vmem_wait<X3P_WAIT_WS>(wsh[2 * PAR], wsl[2 * PAR]);
         static_for<NE>([&](auto e_tag) __attribute__((always_inline)) {
           constexpr int e = decltype(e_tag)::value;
           // ---- 1. reads of the element DEPTH ahead (past the step: units 0, 1 of step g+1, from the next stage)
           if constexpr (e + DEPTH < NE) issue_reads(std::integral_constant<int, e + DEPTH>{}, cur);
+#ifndef MDM_X3_PIPE_NOLOOK   // (bisection build: the fragment pipeline restarts at every step)
           else issue_reads(std::integral_constant<int, e + DEPTH - NE>{}, nxt);
+#endif
           // ---- 2. the middle of the step sits in front of the 16-row sub-tile
           if constexpr (e == XP) {
             // own pieces of A(g+1) and slot W1(g) (both issued during step g-2) landed
-            vmem_wait<7 + X3P_MID_SLACK>(wsh[2 * PAR + 1], wsl[2 * PAR + 1]);
+            vmem_wait<X3P_WAIT_MID + X3P_MID_SLACK>(wsh[2 * PAR + 1], wsl[2 * PAR + 1]);
             w16h[0] = wsh[2 * PAR]; w16h[1] = wsh[2 * PAR + 1];
             w16l[0] = wsl[2 * PAR]; w16l[1] = wsl[2 * PAR + 1];
             frag32_to_frag16(w16h[0], w16h[1]);
@@ -536,13 +562,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
 #endif
             // slot W0 is free (its last 32-row MFMA was issued with unit NT32-1, its lane-swapped copy is taken): refill for g+2
             if constexpr (!(ABL & 2)) { aim_w(); load_w_half(0, wsh[2 * PAR], wsl[2 * PAR]); }
+#ifdef MDM_X3_PIPE_DRAINBAR   // (bisection build: lgkmcnt(0) in front of the rendezvous)
+            lds_wait<0>(a16h, a16l);
+            wg_barrier();
+#else
             wg_barrier_nodrain();   // A(g+1) visible to every wave; every wave is past step g-1, whose stage A(g+3) refills
+#endif
 #ifndef MDM_EMU
             __builtin_amdgcn_sched_barrier(0);
 #endif
           }
           // ---- 3. this element's reads retired (those of the DEPTH younger elements may stay in flight)
+#ifdef MDM_X3_PIPE_NOLOOK
+          constexpr int issued_after = (NE - 1 - e) < DEPTH ? (NE - 1 - e) : DEPTH;
+#else
           constexpr int issued_after = DEPTH;
+#endif
           if constexpr (e == XP) {
             lds_wait<2 * issued_after>(a16h, a16l);
           } else {
@@ -593,9 +628,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         advance_a(ca);
         ++gs;
       };
+#ifdef MDM_X3_PIPE_SYNCTILE   // (bisection build: every tile starts from a drained, rendezvoused workgroup)
+      wait_vmem_all();
+      wg_barrier();
+#endif
       // prime the fragment pipeline of this tile: its first stage was made visible by the previous step's barrier / the prologue
+#ifndef MDM_X3_PIPE_NOLOOK
       issue_reads(std::integral_constant<int, 0>{}, (uint32_t)gs & 3u);
       issue_reads(std::integral_constant<int, 1>{}, (uint32_t)gs & 3u);
+#endif
       for (int kt = 0; kt < nk; kt += 2) {
         pipe_step(std::integral_constant<int, 0>{});
         // the next tile's per-column vectors: behind step 0's barrier, which every wave reaches only after its epilogue of
@@ -610,7 +651,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
       // the tile's last step has run two elements ahead like every other (ONE step body: a separate "last step" instance made
       // hipcc keep two copies of the accumulators, 192 VGPRs): those fragments belong to the next tile's first step, whose
       // pipeline is primed afresh behind the epilogue -- retire and drop them
+#ifndef MDM_X3_PIPE_NOLOOK
       lds_wait<0>(ah[0], al[0], ah[1], al[1]);
+#endif
       // the epilogue must not meet a W slot whose load is still in flight (a spill would save the stale register); hipcc
       // drains the queue in front of the epilogue's first LDS read anyway (LDS-DMA pending)
       vmem_wait<0>(wsh[0], wsl[0], wsh[1], wsl[1], wsh[2], wsl[2], wsh[3], wsl[3]);
@@ -1136,12 +1179,18 @@ inline int launch_gemm_x3_w(const X3Operand& A, const X3Weights& W, const X3Epil
 
 // The pipelined k-loop (PIPE) is the default wherever it exists (208-row tiles, an even number of 32-deep k steps);
 // MDM_X3_PIPE=0 selects the step-synchronous loop for same-box A/B runs.
-inline bool x3_pipe_setting() {
+inline bool x3_pipe_setting(int kind = 0) {
   static const bool on = [] {
     const char* e = getenv("MDM_X3_PIPE");
     return !(e != nullptr && e[0] == '0');
   }();
-  return on;
+  // MDM_X3_PIPE_KINDS: bit k = GEMM kind k of launch_gemm_x3_ln (0 in_proj, 1 out_proj layer 0, 2 out_proj / linear2,
+  // 3 linear1, 4 OutputProcess), bit 5 = layer 0's in_proj; default: all -- bisection of a misbehaving instantiation
+  static const int kinds = [] {
+    const char* e = getenv("MDM_X3_PIPE_KINDS");
+    return e != nullptr ? atoi(e) : 0x3f;
+  }();
+  return on && ((kinds >> kind) & 1);
 }
 
 // The GEMMs of the folded-LayerNorm encoder (8-wave workgroups only):
@@ -1180,11 +1229,15 @@ inline bool x3_t16_setting() {
 inline int launch_gemm_x3_ln(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
                                  int K, int rpt, hipStream_t s) {
   if (rpt <= X3_TM - 16 && x3_t16_setting()) {
-    if (kind != 5 && (K / X3_BK) % 2 == 0 && x3_pipe_setting()) return launch_gemm_x3_ln_t<true, true>(kind, A, W, ep, M, N, K, rpt, s);
+    if (kind != 5 && (K / X3_BK) % 2 == 0 && x3_pipe_setting(kind)) return launch_gemm_x3_ln_t<true, true>(kind, A, W, ep, M, N, K, rpt, s);
     return launch_gemm_x3_ln_t<true>(kind, A, W, ep, M, N, K, rpt, s);
   }
   return launch_gemm_x3_ln_t<false>(kind, A, W, ep, M, N, K, rpt, s);
 }
+
+#ifdef MDM_PROBES
+inline int& x3_pipe_probe() { static int on = 0; return on; }
+#endif
 
 template <int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL = 0>
 inline int launch_gemm_x3_t(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
@@ -1207,6 +1260,20 @@ inline int launch_gemm_x3(const X3Operand& A, const X3Weights& W, const X3Epilog
     return -2;
   }
 #ifdef MDM_PROBES
+  // mdm_debug_set(6, p): the plain fp32-out variant on 208-row (T16) tiles of 197-token sequences -- p = 1: the PIPELINED
+  // k-loop, p = 2: the step-synchronous one -- with the ablation codes both support (1 no epilogue stores, 2 no loads after
+  // the prologue, 4 no MFMAs, and their sums): tools/gemm_probe_pipe.py
+  if (x3_pipe_probe() != 0 && act == ACT_NONE && !res && f32 && !pl && M % 197 == 0 && (K / X3_BK) % 2 == 0) {
+#define X3_PIPE_PROBE_CASE(c) case c: return x3_pipe_probe() == 1 \
+      ? launch_gemm_x3_w<8, ACT_NONE, 0, true, false, false, c, false, false, false, true, false, true>(A, W, ep, M, N, K, 197, s) \
+      : launch_gemm_x3_w<8, ACT_NONE, 0, true, false, false, c, false, false, false, true, false, false>(A, W, ep, M, N, K, 197, s);
+    switch (ablate) {
+      X3_PIPE_PROBE_CASE(0) X3_PIPE_PROBE_CASE(1) X3_PIPE_PROBE_CASE(2) X3_PIPE_PROBE_CASE(3) X3_PIPE_PROBE_CASE(4)
+      X3_PIPE_PROBE_CASE(5) X3_PIPE_PROBE_CASE(6) X3_PIPE_PROBE_CASE(7)
+      default: return -2;
+    }
+#undef X3_PIPE_PROBE_CASE
+  }
   if (ablate != 0) {  // profiling experiments (mdm_debug_set): only the plain fp32-out variant is instantiated
     if (!(act == ACT_NONE && !res && f32 && !pl)) return -2;
     switch (ablate) {
@@ -1263,7 +1330,7 @@ inline int launch_gemm_x3_qkv(const X3Operand& A, const X3Weights& W, const X3Ep
                                   hipStream_t s) {
   if (S > X3_TM) return -2;
   if (x3_waves_setting() == 8 && S <= X3_TM - 16 && x3_t16_setting()) {
-    if ((D / X3_BK) % 2 == 0 && x3_pipe_setting())
+    if ((D / X3_BK) % 2 == 0 && x3_pipe_setting(5))
       return launch_gemm_x3_w<8, ACT_NONE, 0, false, false, true, 0, false, false, false, true, false, true>(A, W, ep, nseq * S,
                                                                                                               3 * D, D, S, s);
     return launch_gemm_x3_w<8, ACT_NONE, 0, false, false, true, 0, false, false, false, true>(A, W, ep, nseq * S, 3 * D, D,

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -140,6 +141,7 @@ struct mdm_model {
   std::map<std::string, const float*> w;
   std::map<std::string, int64_t> expect;  // name -> numel
   bool prepared = false;
+  int* range_flag = nullptr;    // device word in the const workspace: a weight left the 16-bit planes' range (mdm_prepare)
   float* w_in_pad = nullptr;    // [D][JFpad]
   float* time_table = nullptr;  // [max_len][D]
   int jf = 0, jf_pad = 0;
@@ -459,11 +461,11 @@ int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w,
 }
 
 // fp32 [N][K] weights -> fragment-ordered hi/lo planes (gemm_x3.h header); K % 16 == 0
-int launch_pack_weights(const float* src, p16_t* hi, p16_t* lo, int N, int K, hipStream_t s) {
+int launch_pack_weights(const float* src, p16_t* hi, p16_t* lo, int N, int K, hipStream_t s, int* overflow = nullptr) {
   if (K % 16 != 0) return fail(MDM_EINVAL, "pack_weights: K must be a multiple of 16");
   const size_t n = x3_packed_weight_elems(N, K) / 8;
   const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-  MDM_LAUNCH(pack_weight_planes_kernel, dim3(grid), dim3(256), 0, s, src, hi, lo, N, K);
+  MDM_LAUNCH(pack_weight_planes_kernel, dim3(grid), dim3(256), 0, s, src, hi, lo, N, K, overflow);
   return rt_launch_status();
 }
 
@@ -620,6 +622,41 @@ int outproj_x3(mdm_model* m, const Workspace& ws, int nseq, int B, int T, const 
   return rt_launch_status();
 }
 
+// ONE chain of this library's kernels per device.  Two chains of these kernels running concurrently on one GPU (two model
+// handles, two streams, two host threads) intermittently read stale cache lines of rows their own predecessor kernel had
+// rewritten (round 2: profiles/r02e_dip.md, DESIGN.md section 9 -- seen with the f16x3 kernels under two hardware queues,
+// cured by cache-bypassing loads in one loader, root cause not established).  Until it is, the library enforces what its
+// header states: every exported call that enqueues kernels holds this guard, which (i) serialises the host-side enqueue per
+// device and (ii) makes the caller's stream wait for the event recorded behind the previous call's kernels when that call
+// ran on ANOTHER stream.  Same-stream callers (every caller the reference has) pay one hipEventRecord per call.
+#ifdef MDM_EMU
+struct ChainGuard { explicit ChainGuard(void*) {} };
+#else
+struct DeviceChain {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+  hipStream_t last = nullptr;
+  bool has = false;
+};
+DeviceChain g_chain[kMaxDevices];
+struct ChainGuard {
+  DeviceChain& c;
+  hipStream_t s;
+  explicit ChainGuard(void* stream) : c(g_chain[rt_device_ordinal()]), s(static_cast<hipStream_t>(stream)) {
+    c.mu.lock();
+    if (c.has && c.last != s) (void)hipStreamWaitEvent(s, c.ev, 0);
+  }
+  ~ChainGuard() {
+    if (c.ev == nullptr && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) c.ev = nullptr;
+    if (c.ev != nullptr && hipEventRecord(c.ev, s) == hipSuccess) { c.last = s; c.has = true; }
+    else c.has = false;
+    c.mu.unlock();
+  }
+  ChainGuard(const ChainGuard&) = delete;
+  ChainGuard& operator=(const ChainGuard&) = delete;
+};
+#endif
+
 int check_ready(const mdm_model* m) {
   if (m == nullptr) return fail(MDM_EINVAL, "null model");
   if (!m->prepared) return fail(MDM_ESTATE, "mdm_prepare has not been called (or weights changed since)");
@@ -718,12 +755,12 @@ size_t mdm_const_bytes(const mdm_model_t* m) {
     const size_t fold = align_up(3 * D * D * 4, 256) + align_up(D * D * 4, 256) + align_up(FF * D * 4, 256) +
                         2 * (align_up(3 * D * 4, 256) + align_up(D * 4, 256) + align_up(FF * 4, 256));
     const size_t planes = align_up(3 * D * D * 4, 256) + 3 * align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
-    return align_up(D * m->jf_pad * sizeof(float), 256) + 2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) +
-           (size_t)m->cfg.num_layers * (fold + planes);
+    return 256 /* range flag */ + align_up(D * m->jf_pad * sizeof(float), 256) +
+           2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) + (size_t)m->cfg.num_layers * (fold + planes);
   }
   const size_t per_layer = align_up(3 * D * D * 4, 256) + align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
-  return align_up(D * m->jf_pad * sizeof(float), 256) + 2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) +
-         (size_t)m->cfg.num_layers * per_layer + align_up(x3_packed_weight_elems(m->jf_out, (int)D) * 4, 256) +
+  return 256 /* range flag */ + align_up(D * m->jf_pad * sizeof(float), 256) +
+         2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) + (size_t)m->cfg.num_layers * per_layer + align_up(x3_packed_weight_elems(m->jf_out, (int)D) * 4, 256) +
          align_up((size_t)m->jf_out * sizeof(float), 256) +
          // folded-LayerNorm constants: per layer gamma-scaled in_proj / linear1 planes + 2 vectors each; OutputProcess;
          // one fp32 scratch matrix for the scaled weights before they are packed
@@ -734,6 +771,7 @@ size_t mdm_const_bytes(const mdm_model_t* m) {
 }
 
 int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* stream) {
+  ChainGuard chain_guard(stream);
   if (m == nullptr || const_ws == nullptr) return fail(MDM_EINVAL, "mdm_prepare: null argument");
   for (const auto& kv : m->expect)
     if (m->w.find(kv.first) == m->w.end()) return fail(MDM_ESTATE, "missing weight: " + kv.first);
@@ -741,6 +779,14 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int D = m->cfg.latent_dim, R = m->cfg.max_len;
   char* base = static_cast<char*>(const_ws);
+  // word 0: "a weight left the range of the 16-bit operand planes" (set by the pack kernels below; mdm_weights_in_range)
+  m->range_flag = reinterpret_cast<int*>(base);
+  base += 256;
+#ifdef MDM_EMU
+  *m->range_flag = 0;
+#else
+  if (hipMemsetAsync(m->range_flag, 0, 4, s) != hipSuccess) return fail(MDM_EHIP, "mdm_prepare: hipMemsetAsync failed");
+#endif
   m->w_in_pad = reinterpret_cast<float*>(base);
   base += align_up((size_t)D * m->jf_pad * sizeof(float), 256);
   m->time_table = reinterpret_cast<float*>(base);
@@ -786,7 +832,7 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
       p16_t* hi = reinterpret_cast<p16_t*>(base);
       base += align_up(n * 4, 256);
       op = X3Weights{hi, hi + n};
-      return launch_pack_weights(src, hi, hi + n, N, K, s);
+      return launch_pack_weights(src, hi, hi + n, N, K, s, m->range_flag);
     };
     m->dec_planes.assign(L, mdm_model::DecPlanes{});
     for (int l = 0; l < L; ++l) {
@@ -813,7 +859,7 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
     p16_t* lo = hi + n;
     base += align_up(n * 4, 256);
     op = X3Weights{hi, lo};
-    return launch_pack_weights(src, hi, lo, N, K, s);
+    return launch_pack_weights(src, hi, lo, N, K, s, m->range_flag);
   };
   for (int l = 0; l < m->cfg.num_layers; ++l) {
     if (int rc = make_planes(m->L(l, "self_attn.in_proj_weight"), 3 * D, D, m->planes[l].in_proj)) return rc;
@@ -866,7 +912,7 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
       p16_t* hi = reinterpret_cast<p16_t*>(base);
       base += align_up(n * 4, 256);
       m->in_planes = X3Weights{hi, hi + n};
-      if (int rc = launch_pack_weights(scratch_w, hi, hi + n, D, m->jf_k, s)) return rc;
+      if (int rc = launch_pack_weights(scratch_w, hi, hi + n, D, m->jf_k, s, m->range_flag)) return rc;
     }
     m->lnfold = true;
 #ifdef MDM_PROBES   // A/B switch of the probe library: MDM_LNFOLD=0 runs the LayerNorms as kernels on the planes again
@@ -874,6 +920,22 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
 #endif
   }
   m->prepared = true;
+  return MDM_OK;
+}
+
+int mdm_weights_in_range(mdm_model_t* m, int32_t* in_range, void* stream) {
+  if (int rc = check_ready(m)) return rc;
+  if (in_range == nullptr) return fail(MDM_EINVAL, "mdm_weights_in_range: null argument");
+  int flag = 0;
+#ifdef MDM_EMU
+  (void)stream;
+  flag = *m->range_flag;
+#else
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(&flag, m->range_flag, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return fail(MDM_EHIP, "mdm_weights_in_range: reading the flag back failed");
+#endif
+  *in_range = flag == 0 ? 1 : 0;
   return MDM_OK;
 }
 
@@ -894,6 +956,7 @@ size_t mdm_workspace_bytes(const mdm_model_t* m, int32_t nseq, int32_t nframes) 
 int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const float* text_embed,
                 const int32_t* lengths, int32_t B, int32_t T, int32_t branches, float* out, void* ws_dev,
                 size_t ws_bytes, void* stream) {
+  ChainGuard chain_guard(stream);
   if (int rc = check_ready(m)) return rc;
   if (m->cfg.arch != MDM_ARCH_TRANS_ENC) return fail(MDM_ESTATE, "mdm_forward: trans_dec models go through mdm_forward_dec");
   if (x == nullptr || timesteps == nullptr || out == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_forward: null pointer");
@@ -1114,6 +1177,7 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
 int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const int64_t* timesteps, const float* text_tokens,
                     const int32_t* text_lengths, const int32_t* lengths, int32_t B, int32_t pred_len, int32_t ntok,
                     int32_t branches, float* out, void* ws_dev, size_t ws_bytes, void* stream) {
+  ChainGuard chain_guard(stream);
   if (int rc = check_ready(m)) return rc;
   if (x == nullptr || timesteps == nullptr || out == nullptr || ws_dev == nullptr || text_lengths == nullptr)
     return fail(MDM_EINVAL, "mdm_forward_dec: null pointer");
@@ -1130,6 +1194,7 @@ int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const i
 int mdm_sampler_step(const float* x_t, const float* out_cond, const float* out_uncond, const float* scale,
                      const uint8_t* inpaint_mask, const float* inpaint_motion, const float* noise, float* x_prev,
                      float* x0, int32_t B, int32_t per_sample, const mdm_step_t* st, void* stream) {
+  ChainGuard chain_guard(stream);
   if (x_t == nullptr || out_cond == nullptr || x_prev == nullptr || st == nullptr) return fail(MDM_EINVAL, "mdm_sampler_step: null pointer");
   if (out_uncond != nullptr && scale == nullptr) return fail(MDM_EINVAL, "mdm_sampler_step: scale required with out_uncond");
   if ((inpaint_mask == nullptr) != (inpaint_motion == nullptr)) return fail(MDM_EINVAL, "mdm_sampler_step: inpainting needs mask and motion");
@@ -1156,11 +1221,13 @@ static int launch_randn(float* out, const float* init, const float* eps, float a
 
 int mdm_randn(float* out, const float* init, const float* eps, float a, float s, int32_t B, int32_t per_sample,
               uint64_t seed, uint32_t sample_base, uint32_t draw, void* stream) {
+  ChainGuard chain_guard(stream);
   return launch_randn(out, init, eps, a, s, B, per_sample, seed, sample_base, draw, 0u, stream);
 }
 
 int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void* ws_dev, size_t ws_bytes,
                     void* stream) {
+  ChainGuard chain_guard(stream);
   if (int rc = check_ready(m)) return rc;
   if (m->cfg.arch != MDM_ARCH_TRANS_ENC) return fail(MDM_ESTATE, "mdm_sample_loop: the fused loop drives the trans_enc denoiser");
   if (p == nullptr || x == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop: null pointer");
@@ -1262,6 +1329,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
 
 int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float* x, void* ws_dev, size_t ws_bytes,
                         void* stream) {
+  ChainGuard chain_guard(stream);
   if (int rc = check_ready(m)) return rc;
   if (pd == nullptr || x == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop_dec: null pointer");
   const mdm_sample_params_t* p = &pd->loop;
@@ -1399,6 +1467,7 @@ int mdm_debug_set(int what, int value) {
   if (what == 3) g_ax_ablate = value;
   if (what == 4) g_f6_reference = value;
   if (what == 5) g_f6_linear = value;
+  if (what == 6) x3_pipe_probe() = value;
   return MDM_OK;
 }
 
@@ -1453,6 +1522,7 @@ int mdm_profile_reset(mdm_model_t* m) {
 
 int mdm_linear(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M, int32_t N,
                int32_t K, int32_t act, void* stream) {
+  ChainGuard chain_guard(stream);
   if (!in || !w || !bias || !out || M <= 0 || N <= 0 || K <= 0) return fail(MDM_EINVAL, "mdm_linear: bad argument");
   return launch_linear(nullptr, in, K, w, bias, res, out, M, N, K, act, 0, 1.f, static_cast<hipStream_t>(stream));
 }
@@ -1463,6 +1533,7 @@ size_t mdm_linear_x3_scratch_bytes(int32_t M, int32_t N, int32_t K) {
 
 int mdm_linear_x3(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M,
                       int32_t N, int32_t K, int32_t act, void* scratch, size_t scratch_bytes, void* stream) {
+  ChainGuard chain_guard(stream);
   if (!in || !w || !bias || !out || !scratch || M <= 0 || N <= 0 || K <= 0) return fail(MDM_EINVAL, "mdm_linear_x3: bad argument");
   if (K % X3_BK != 0) return fail(MDM_EINVAL, "mdm_linear_x3: K must be a multiple of 32");
   if (scratch_bytes < mdm_linear_x3_scratch_bytes(M, N, K)) return fail(MDM_ENOSPC, "mdm_linear_x3: scratch too small");
@@ -1488,6 +1559,7 @@ size_t mdm_linear_f16f6_scratch_bytes(int32_t M, int32_t N, int32_t K) {
 
 int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const float* res, float* out, int32_t M,
                      int32_t N, int32_t K, int32_t act, void* scratch, size_t scratch_bytes, void* stream) {
+  ChainGuard chain_guard(stream);
   if (!in || !w || !bias || !out || !scratch || M <= 0 || N <= 0 || K <= 0) return fail(MDM_EINVAL, "mdm_linear_f16f6: bad argument");
   if (K % 32 != 0) return fail(MDM_EINVAL, "mdm_linear_f16f6: K must be a multiple of 32");
   if (act != ACT_NONE && act != ACT_GELU && act != ACT_SILU) return fail(MDM_EINVAL, "mdm_linear_f16f6: bad activation");
@@ -1529,12 +1601,14 @@ int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const f
 #endif
 
 int mdm_layernorm(float* x, const float* gamma, const float* beta, int32_t rows, int32_t D, void* stream) {
+  ChainGuard chain_guard(stream);
   if (!x || !gamma || !beta || rows <= 0 || D % 256 != 0) return fail(MDM_EINVAL, "mdm_layernorm: bad argument");
   return launch_layernorm(nullptr, x, gamma, beta, rows, D, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int mdm_attention(const float* qkv, float* out, const int32_t* lengths, int32_t nseq, int32_t B, int32_t S, int32_t D,
                   int32_t H, void* stream) {
+  ChainGuard chain_guard(stream);
   if (!qkv || !out || nseq <= 0 || B <= 0) return fail(MDM_EINVAL, "mdm_attention: bad argument");
   return launch_attention(nullptr, qkv, out, lengths, nseq, B, S, D, H, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
@@ -1547,6 +1621,7 @@ size_t mdm_attention_x3_scratch_bytes(int32_t nseq, int32_t S, int32_t D) {
 
 int mdm_attention_x3(const float* qkv, float* out, const int32_t* lengths, int32_t nseq, int32_t B, int32_t S,
                          int32_t D, int32_t H, void* scratch, size_t scratch_bytes, void* stream) {
+  ChainGuard chain_guard(stream);
   if (!qkv || !out || !scratch || nseq <= 0 || B <= 0 || S <= 0 || H <= 0) return fail(MDM_EINVAL, "mdm_attention_x3: bad argument");
   if (D != H * AX_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
   if (scratch_bytes < mdm_attention_x3_scratch_bytes(nseq, S, D)) return fail(MDM_ENOSPC, "mdm_attention_x3: scratch too small");
@@ -1565,6 +1640,7 @@ int mdm_attention_x3(const float* qkv, float* out, const int32_t* lengths, int32
 
 int mdm_recover_from_ric(const float* x, const float* mean, const float* stdv, float* out, int32_t B, int32_t T,
                          int32_t njoints_feat, int32_t joints, void* stream) {
+  ChainGuard chain_guard(stream);
   if (!x || !mean || !stdv || !out || B <= 0 || T <= 0 || joints < 1) return fail(MDM_EINVAL, "mdm_recover_from_ric: bad argument");
   if (njoints_feat < 4 + 3 * (joints - 1)) return fail(MDM_EINVAL, "mdm_recover_from_ric: feature width too small for the joint count");
   if (T > 1024) return fail(MDM_EUNSUPPORTED, "mdm_recover_from_ric: at most 1024 frames");

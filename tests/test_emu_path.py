@@ -56,6 +56,34 @@ def test_emulated_forward_branches(lib, prec, tol, layers, B, T, lengths):
     assert maxabs(model(x, t, y=yu), orc.mdm_forward(sd, x, t, yu, num_heads=2)) < tol
 
 
+def test_weight_beyond_the_fp16_planes_is_refused_at_bind_time(lib):
+    """include/mdm_hip.h mdm_weights_in_range: the f16x3 planes hold w * 2^8 as fp16, so a weight (or a LayerNorm-gamma-folded
+    weight) of magnitude >= 255.9 cannot be carried.  The pack kernels of mdm_prepare flag it; the Python seam raises at bind
+    time in the default mode -- not NaN samples later -- and the same checkpoint runs in the exact-fp32 mode."""
+    from mdm_amd._native import MdmError
+    T = 9
+    y = synth_y(1, T, seed=5, lengths=[T])
+    x, t = torch.randn(1, 263, 1, T, generator=torch.Generator().manual_seed(0)), torch.tensor([3])
+    # (a) a raw weight entry out of range
+    sd = small_state_dict(num_layers=1)
+    sd["seqTransEncoder.layers.0.linear2.weight"] = sd["seqTransEncoder.layers.0.linear2.weight"].clone()
+    sd["seqTransEncoder.layers.0.linear2.weight"][3, 7] = 300.0
+    model, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib, precision="f16x3")
+    with pytest.raises(MdmError, match="precision='f32'"):
+        model(x, t, y=dict(y))
+    model32, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib, precision="f32")
+    assert maxabs(model32(x, t, y=dict(y)), orc.mdm_forward(sd, x, t, y, num_heads=2)) < 2e-4
+    model32.precision = "f16x3"                                  # switching the mode afterwards is refused as well
+    with pytest.raises(MdmError, match="precision='f32'"):
+        model32(x, t, y=dict(y))
+    # (b) only the gamma-FOLDED weight leaves the range: |W| ~ 0.1 but the LayerNorm gamma it is folded with is 5000
+    sd = small_state_dict(num_layers=1)
+    sd["seqTransEncoder.layers.0.norm1.weight"] = torch.full_like(sd["seqTransEncoder.layers.0.norm1.weight"], 5000.0)
+    model, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib, precision="f16x3")
+    with pytest.raises(MdmError, match="precision='f32'"):
+        model(x, t, y=dict(y))
+
+
 @pytest.mark.parametrize("M,N,K,act,res", [(70, 130, 36, 0, True), (129, 64, 8, 1, False), (3, 5, 4, 2, False)])
 def test_emulated_linear(lib, M, N, K, act, res):
     rng = np.random.default_rng(M)

@@ -517,6 +517,52 @@ def test_dip_autoregressive_philox_is_deterministic(sd_dip):
     assert torch.equal(outs[0][..., :20], y["prefix"])            # autoregressive_include_prefix (sampler_util.py:54-55)
 
 
+def test_dip_config4_B32_F196_philox_replayed_through_the_oracle(sd_dip):
+    """BASELINE.json configs[4] at its per-GPU shape: B = 32 motions, 196 frames = 5 prediction windows x 10 steps, CFG 7.5,
+    ragged text lengths, the PRODUCTION Philox noise (one stream per window, as bench_dip.py runs it).  Three samples spread
+    over the batch are recomputed by oracle/dip_oracle.autoregressive_sample on the library's own noise (utils/sampler_util.py
+    :47-81 over model/mdm.py:255-270), and the two independent arithmetic modes must agree over all 32.  The native window
+    loop hoists the text K / V projections per call -- a size-dependent path the B = 2 golden does not reach."""
+    from mdm_amd.sampler_util import AutoRegressiveSampler
+    from types import SimpleNamespace
+    B, frames, steps, C, P, nwin = 32, 196, 10, 20, 40, 5
+    g = torch.Generator().manual_seed(321)
+    tl = [int(v) for v in torch.randint(3, 25, (B,), generator=g)]
+    tl[0], tl[31] = 24, 1
+    y_cpu = synth_dip_y(B, P, C, seed=41, text_lengths=tl, scale=7.5)
+    y = to_dev(y_cpu, DEV)
+    seeds = [9000 + w for w in range(nwin)]
+    args = SimpleNamespace(pred_len=P, context_len=C, autoregressive_include_prefix=False)
+    outs = {}
+    for prec in PRECISIONS:
+        model, diffusion = make_pair(sd_dip, steps, DEV, guided=True, context_len=C, pred_len=P, precision=prec)
+        it = iter(seeds)
+        fn = lambda mdl, shape, **kw: diffusion.p_sample_loop(mdl, shape, seed=next(it), **kw)   # noqa: E731
+        outs[prec] = AutoRegressiveSampler(args, fn, frames).sample(model, (B, 263, 1, frames), clip_denoised=False,
+                                                                     model_kwargs={"y": y}).cpu()
+        assert outs[prec].shape == (B, 263, 1, frames) and torch.isfinite(outs[prec]).all()
+    cross = maxabs(outs["f16x3"], outs["f32"])
+    print(f"[parity] DiP configs[4] B=32 F=196, all samples, f16x3 vs f32 mode: max-abs = {cross:.3e}")
+    assert cross < TOL_DIP_AR
+    # replay of samples idx on the library's own noise: window w, draw 0 = x_T, draws 1..10 = the steps' noise
+    idx = [0, 13, 31]
+    eng = model.model.engine()
+    chunks = []
+    for s in seeds:
+        draws = [torch.cat([eng.randn((1, 263, 1, P), DEV, s, i, k).cpu() for i in idx]) for k in range(steps + 1)]
+        chunks.append((draws[0], draws[1:]))
+    te, pad = y_cpu["text_embed"]
+    ys = {**{k: v for k, v in y_cpu.items() if k not in ("text_embed", "prefix", "mask", "lengths", "scale", "text")},
+          "text_embed": (te[:, idx], pad[idx]), "prefix": y_cpu["prefix"][idx], "mask": y_cpu["mask"][idx],
+          "lengths": y_cpu["lengths"][idx], "scale": y_cpu["scale"][idx]}
+    want = dip.autoregressive_sample(sd_dip, orc.Tables(orc.named_betas("cosine", steps)), (len(idx), 263, 1, frames), ys,
+                                     chunks, context_len=C, pred_len=P, required_frames=frames)
+    for prec in PRECISIONS:
+        err = maxabs(outs[prec][idx], want)
+        print(f"[parity] DiP configs[4] B=32 F=196, 3 samples replayed, {prec}: max-abs vs oracle = {err:.3e}")
+        assert err < TOL_DIP_AR
+
+
 def test_eval_caller_call_sequence(sd):
     """the second production caller, CompMDMGeneratedDataset (data_loaders/humanml/motion_loaders/
     comp_v6_model_dataset.py:148-257): batches of 32 variable-length motions, `scale` added to y by the caller, the exact

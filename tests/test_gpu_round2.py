@@ -59,6 +59,10 @@ def test_config1_B128_T196_50_steps_eight_samples_replayed_through_the_oracle(sd
         err = maxabs(outs[prec][idx], want)
         print(f"[parity] configs[1] B=128 T=196 50 steps, 8 samples replayed, {prec}: max-abs vs oracle = {err:.3e}")
         assert err < TOL_LOOP[prec]
+    # the other 120 samples: the two independent arithmetic modes (exact-fp32 MFMA vs the fp16 split) agree over the WHOLE batch
+    cross = maxabs(outs["f16x3"], outs["f32"])
+    print(f"[parity] configs[1] all 128 samples, f16x3 vs f32 mode: max-abs = {cross:.3e}")
+    assert cross < TOL_LOOP["f16x3"]
 
 
 def test_config2_B64_T196_1000_steps_replayed_through_the_oracle(sd):
