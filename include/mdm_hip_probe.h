@@ -33,6 +33,12 @@ int mdm_linear_f16f6(const float* in_dev, const float* w_dev, const float* bias_
                      float* out_dev, int32_t M, int32_t N, int32_t K, int32_t act, void* scratch_dev,
                      size_t scratch_bytes, void* stream);
 
+/* in_proj alone (layer 0's instantiation: no folded LayerNorm): fp32 tokens [nseq * S][D], weights [3D][D] -> the six attention
+ * operand planes (nseq * 32 * ceil(S / 32) * D 16-bit elements each: qh ql kh kl vh vl) in `planes_dev`; `scratch_dev`:
+ * 4 * nseq * S * D + 12 * D * D bytes.  Determinism screens of the GEMM k-loops (tools/in_proj_determinism.py). */
+int mdm_probe_in_proj(const float* tokens, const float* w, const float* bias, void* planes_dev, int32_t nseq, int32_t S,
+                      int32_t D, void* scratch_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "mdm_sample_loop_dec", "mdm_weights_in_range",
 ]
 # include/mdm_hip_probe.h: exported by the probe build only
-PROBE_SYMBOLS = ["mdm_debug_set", "mdm_debug_get", "mdm_linear_f16f6", "mdm_linear_f16f6_scratch_bytes"]
+PROBE_SYMBOLS = ["mdm_debug_set", "mdm_debug_get", "mdm_linear_f16f6", "mdm_linear_f16f6_scratch_bytes", "mdm_probe_in_proj"]
 ABI_VERSION = 6
 ARCH = {"trans_enc": 0, "trans_dec": 1}
 
@@ -112,6 +112,7 @@ class MdmLib:
             "mdm_debug_get": (C.c_int, [C.c_int, P(C.c_double)]),
             "mdm_linear_f16f6_scratch_bytes": (sz, [i32, i32, i32]),
             "mdm_linear_f16f6": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+            "mdm_probe_in_proj": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
         }
         self.has_probes = hasattr(lib, "mdm_debug_set")   # libmdm_hip_probe.so / the emulator build
         if self.has_probes:

@@ -341,20 +341,31 @@ __device__ __forceinline__ void gload16_async(f32x4& dst, const float* p) { emu:
 template <int N> __device__ __forceinline__ void vmem_wait(f32x4&, f32x4&, f32x4&, f32x4&) { emu::vm_wait(N); }
 // 16-bit-plane flavour: one MFMA operand fragment (the pipelined k-loop's W stream, gemm_x3.h)
 __device__ __forceinline__ void gload16_async(p16x8& dst, const p16_t* p) { emu::vm_issue(&dst, p, 16, true); }
+__device__ __forceinline__ void gload16_refill(p16x8& slot, const p16_t* p) { emu::vm_issue(&slot, p, 16, true); }
 template <int N> __device__ __forceinline__ void vmem_wait(p16x8&, p16x8&) { emu::vm_wait(N); }
 template <int N> __device__ __forceinline__ void vmem_wait(p16x8&, p16x8&, p16x8&, p16x8&) { emu::vm_wait(N); }
 template <int N>
 __device__ __forceinline__ void vmem_wait(p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&) { emu::vm_wait(N); }
 #else
+// ("=&v": the destination never doubles as the address pair -- see gload16_refill below)
 __device__ __forceinline__ void gload16_async(f32x4& dst, const float* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
 }
 template <int N> __device__ __forceinline__ void vmem_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
 }
 // 16-bit-plane flavour: one MFMA operand fragment (the pipelined k-loop's W stream, gemm_x3.h)
 __device__ __forceinline__ void gload16_async(p16x8& dst, const p16_t* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+// IN-PLACE refill of a register slot whose previous value was an MFMA operand until just now.  The slot is an input AND the
+// output ("+v"): its old value stays live -- in these very registers -- up to this instruction, so hipcc can neither recycle
+// the registers as scratch behind the last MFMA that read them (address arithmetic, lane swaps done "in place"), nor let the
+// destination double as the address pair.  Found on the MI355X (profiles/r03b_pipe_determinism.md): with a plain "=v"
+// destination hipcc wrote the refill's own address into the slot one instruction behind the last of three dependent MFMAs
+// that read it, and one launch in ~6 returned 4-lane groups of one wave's 32 columns computed on a half-rewritten fragment.
+__device__ __forceinline__ void gload16_refill(p16x8& slot, const p16_t* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(slot) : "v"(p) : "memory");
 }
 template <int N> __device__ __forceinline__ void vmem_wait(p16x8& a, p16x8& b) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
@@ -379,7 +390,7 @@ template <int N>
 __device__ __forceinline__ void vmem_wait(u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&) { emu::vm_wait(N); }
 #else
 __device__ __forceinline__ void gload8_async(u32x2& dst, const void* p) {
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void vmem_wait(u32x2& a, u32x2& b, u32x2& c, u32x2& d, u32x2& e, u32x2& f, u32x2& g, u32x2& h) {

@@ -67,7 +67,9 @@ constexpr int X3P_MID_SLACK = 0;
 // holds (LDS-DMA pieces of A, VGPR loads of W) -- the count is the number of YOUNGER operations of either kind.  STRICT
 // (-DMDM_X3_PIPE_STRICT): only operations of the SAME kind are assumed to retire in order -- the count is the number of younger
 // operations of the awaited kind alone, i.e. the wait also holds if every operation of the other kind has already retired.
-#ifdef MDM_X3_PIPE_STRICT
+#if defined(MDM_X3_PIPE_WDRAIN)     // (bisection build: both waits drain the whole queue)
+constexpr int X3P_WAIT_WS = 0, X3P_WAIT_MID = 0;
+#elif defined(MDM_X3_PIPE_STRICT)
 constexpr int X3P_WAIT_WS = 6, X3P_WAIT_MID = 3;
 #else
 constexpr int X3P_WAIT_WS = 12, X3P_WAIT_MID = 7;
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
   p16x8 wh[2], wl[2], wnh[2], wnl[2];
   // PIPE: the W stream lives in four half-step slots (slot 2 * (step parity) + k sub-step; hi and lo plane fragment each),
   // refilled IN PLACE for two steps later as soon as their last MFMA has been issued -- 32 VGPRs, 1.5 steps of cover
-  p16x8 wsh[4], wsl[4];
+  p16x8 wsh[4] = {}, wsl[4] = {};   // (zero: the first refill formally reads its slot)
   uint32_t wso = 0;           // element offset of the W stream's current step inside the fragment-ordered planes
   uint32_t wtile = 0;         // ... of its tile's first step (wave-uniform): changes only when the stream enters a new tile
   auto aim_w_tile = [&]() {
@@ -387,9 +389,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
       if (wv + gstride < total) { wv += gstride; aim_w_tile(); }
     }
   };
-  auto load_w_half = [&](int ks, p16x8& fh, p16x8& fl) {
+  auto load_w_half = [&](int ks, p16x8& fh, p16x8& fl) {   // in-place refill of a slot (common.h gload16_refill)
+#ifdef MDM_X3_PIPE_NOGUARD
     gload16_async(fh, W.hi + wso + 512 * ks);
     gload16_async(fl, W.lo + wso + 512 * ks);
+#else
+    gload16_refill(fh, W.hi + wso + 512 * ks);
+    gload16_refill(fl, W.lo + wso + 512 * ks);
+#endif
   };
   int gs = 0;                 // PIPE: global k-step counter of this workgroup (stage of step g = g & 3)
   if constexpr (PIPE) {
@@ -553,6 +560,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
           if constexpr (e == XP) {
             // own pieces of A(g+1) and slot W1(g) (both issued during step g-2) landed
             vmem_wait<X3P_WAIT_MID + X3P_MID_SLACK>(wsh[2 * PAR + 1], wsl[2 * PAR + 1]);
+#if (defined(MDM_X3_PIPE_SNOP) || defined(MDM_X3_PIPE_SNOP2)) && !defined(MDM_EMU)   // (bisection build: the matrix pipe drains before slot W0 is rewritten)
+            asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
+#endif
             w16h[0] = wsh[2 * PAR]; w16h[1] = wsh[2 * PAR + 1];
             w16l[0] = wsl[2 * PAR]; w16l[1] = wsl[2 * PAR + 1];
             frag32_to_frag16(w16h[0], w16h[1]);
@@ -623,6 +633,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
 #endif
         });
         // slot W1 is free: refill for g+2; then both streams move on
+#if defined(MDM_X3_PIPE_SNOP2) && !defined(MDM_EMU)   // (bisection build: the matrix pipe drains before slot W1 is rewritten)
+        asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
+#endif
         if constexpr (!(ABL & 2)) load_w_half(1, wsh[2 * PAR + 1], wsl[2 * PAR + 1]);
         advance_w();
         advance_a(ca);

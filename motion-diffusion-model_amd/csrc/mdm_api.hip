@@ -1638,6 +1638,32 @@ int mdm_attention_x3(const float* qkv, float* out, const int32_t* lengths, int32
   return launch_attention_x3(nullptr, qp, lengths, nseq, B, S, D, out, nullptr, nullptr, s);
 }
 
+#ifdef MDM_PROBES
+// in_proj alone (the non-folded instantiation of layer 0): fp32 tokens [nseq * S][D] and in_proj weights [3D][D] -> the
+// attention operand planes, written to `planes_dev` (6 planes of nseq * SP * D 16-bit elements: qh ql kh kl vh vl).
+// `scratch_dev`: 4 * nseq * S * D + 12 * D * D bytes.  tools/in_proj_determinism.py compares repeated runs bit for bit.
+int mdm_probe_in_proj(const float* tokens, const float* w, const float* bias, void* planes_dev, int32_t nseq, int32_t S,
+                      int32_t D, void* scratch_dev, void* stream) {
+  ChainGuard chain_guard(stream);
+  if (!tokens || !w || !bias || !planes_dev || !scratch_dev || nseq <= 0 || S <= 0 || D % 256 != 0) return fail(MDM_EINVAL, "mdm_probe_in_proj");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t n = (size_t)nseq * S * D;
+  p16_t* ah = static_cast<p16_t*>(scratch_dev);
+  p16_t* al = ah + n;
+  p16_t* wh = al + n;
+  p16_t* wl = wh + (size_t)3 * D * D;
+  if (!g_x3_reuse_planes) {
+    if (int rc = launch_split(tokens, ah, al, n, s)) return rc;
+    if (int rc = launch_pack_weights(w, wh, wl, 3 * D, D, s)) return rc;
+  }
+  const int H = D / AX_HD, NKT = (S + 31) / 32, SP = 32 * NKT;
+  const size_t plane = (size_t)nseq * SP * D;
+  p16_t* q = static_cast<p16_t*>(planes_dev);
+  QkvPlanes qp{q, q + plane, q + 2 * plane, q + 3 * plane, q + 4 * plane, q + 5 * plane, SP, NKT, H};
+  return launch_in_proj_x3(nullptr, X3Operand{ah, al}, X3Weights{wh, wl}, bias, qp, nseq, S, D, 0.08838834764831845f, s);
+}
+#endif
+
 int mdm_recover_from_ric(const float* x, const float* mean, const float* stdv, float* out, int32_t B, int32_t T,
                          int32_t njoints_feat, int32_t joints, void* stream) {
   ChainGuard chain_guard(stream);

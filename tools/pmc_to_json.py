@@ -25,7 +25,12 @@ def classify(name):
         args = [a.strip() for a in name[name.rfind("<") + 1:name.rfind(">")].split(",")] if "<" in name else \
             [a.strip() for a in name[:name.rfind(">")].split(",")]
         if len(args) >= 11:
-            f6, t16, embed, ostat, fold, abl, qkv, planes, f32, res, act = args[::-1][:11]
+            # round 3 appended a 13th template argument (PIPE): names arrive truncated on the LEFT, so count from the right --
+            # 13 arguments (or 12 + a cut one) are told from 12 by whether the kernel name carries all of <8, ...>
+            full = name[name.rfind("<") + 1:name.rfind(">")].split(",") if "<" in name else []
+            has_pipe = len(full) == 13 or ("<" not in name and os.environ.get("PMC_PIPE_ARG", "1") == "1")
+            tail = args[::-1][1:12] if has_pipe else args[::-1][:11]
+            f6, t16, embed, ostat, fold, abl, qkv, planes, f32, res, act = tail
             b = lambda v: v == "true"   # noqa: E731
             if b(embed):
                 return "gemm", "InputProcess"
