@@ -41,7 +41,7 @@ extern "C" {
 #define MDM_EHIP (-4)     /* a HIP runtime call failed                         */
 #define MDM_EUNSUPPORTED (-5)
 
-#define MDM_ABI_VERSION 6
+#define MDM_ABI_VERSION 7
 
 typedef struct mdm_model mdm_model_t;
 
@@ -119,8 +119,13 @@ size_t mdm_workspace_bytes(const mdm_model_t* m, int32_t nseq, int32_t nframes);
  *   x_dev          [B, njoints, nfeats, T]
  *   timesteps_dev  [B] int64
  *   text_embed_dev [B, clip_dim] = y['text_embed'][0]; may be NULL for MDM_BRANCH_UNCOND
- *   lengths_dev    [B] int32 = number of valid frames (y['mask'] rows are prefixes: data_loaders/tensors.py:3-8);
- *                  NULL = no key-padding mask (all frames valid, or mask_frames == 0)
+ *   lengths_dev    the key-padding mask of model/mdm.py:241-247 (`~y['mask']` -> src_key_padding_mask), in one of two forms:
+ *                  [B] int32 valid-FRAME COUNTS when every y['mask'] row is a prefix mask (what data_loaders/tensors.py:3-8
+ *                  builds; the kernels' fast path), or -- since ABI 7 -- [9 B] int32 for arbitrary masks: lengths[b] >= 0 is
+ *                  sample b's count as before, lengths[b] == -1 says that its mask is the BITMAP in the eight words
+ *                  lengths[B + 8 b .. B + 8 b + 7] (bit j of word i set: frame 32 i + j is a valid key; frames >= T ignored);
+ *                  the condition token is always a valid key.  NULL = no key-padding mask (all frames valid, or
+ *                  mask_frames == 0).  The same two forms hold wherever this header says `lengths_dev`
  *   out_dev        [B or 2B, njoints, nfeats, T]                                                   */
 int mdm_forward(mdm_model_t* m, const float* x_dev, const int64_t* timesteps_dev, const float* text_embed_dev,
                 const int32_t* lengths_dev, int32_t B, int32_t T, int32_t branches, float* out_dev, void* ws_dev,

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
 ]
 # include/mdm_hip_probe.h: exported by the probe build only
 PROBE_SYMBOLS = ["mdm_debug_set", "mdm_debug_get", "mdm_linear_f16f6", "mdm_linear_f16f6_scratch_bytes", "mdm_probe_in_proj"]
-ABI_VERSION = 6
+ABI_VERSION = 7
 ARCH = {"trans_enc": 0, "trans_dec": 1}
 
 

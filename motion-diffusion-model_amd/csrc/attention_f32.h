@@ -78,7 +78,12 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
   const float* vbase = a.v + (size_t)kseq * S * ld + head * ATT_HD;
 
   int nvalid = S;
-  if (a.lengths != nullptr) nvalid = min(S, a.lead + a.lengths[seq % a.B]);
+  const uint32_t* kbits = nullptr;   // arbitrary frame mask of this sequence (common.h key_valid_bits), else a count
+  if (a.lengths != nullptr) {
+    const int cnt = a.lengths[seq % a.B];
+    if (cnt >= 0) nvalid = min(S, a.lead + cnt);
+    else kbits = reinterpret_cast<const uint32_t*>(a.lengths + a.B + 8 * (seq % a.B));
+  }
 
   // ---- Q fragment: query row q = 32w + r, this lane-half's 64 d's
   const int q = 32 * w + r;
@@ -121,15 +126,31 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
 
   // ---- softmax over keys (lane-local + one cross-half exchange)
   float mx = -INFINITY;
+  if (kbits == nullptr) {
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = kt * 32 + mfma_row(e, h);
-      const float s = (key < nvalid) ? p[kt][e] : -INFINITY;
-      p[kt][e] = s;
-      mx = fmaxf(mx, s);
-    }
+      for (int e = 0; e < 16; ++e) {
+        const int key = kt * 32 + mfma_row(e, h);
+        const float s = (key < nvalid) ? p[kt][e] : -INFINITY;
+        p[kt][e] = s;
+        mx = fmaxf(mx, s);
+      }
+  } else {
+    uint32_t wb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wb[i] = kbits[i];
+    static_for<NKT>([&](auto kt_tag) __attribute__((always_inline)) {
+      constexpr int kt = decltype(kt_tag)::value;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = mfma_row(e, h), key = kt * 32 + row;
+        const float s = (key < S && key_valid_bits<kt>(wb, row, a.lead)) ? p[kt][e] : -INFINITY;
+        p[kt][e] = s;
+        mx = fmaxf(mx, s);
+      }
+    });
+  }
   mx = fmaxf(mx, shfl_xor_f32(mx, 32));
   float sum = 0.f;
 #pragma unroll

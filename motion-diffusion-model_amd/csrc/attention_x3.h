@@ -128,7 +128,12 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
   const int vb_next = vb + vb_step;
   const bool has_next = vb_next < vb_total && item_of(vb_next) < items;
   int nvalid = S;  // token 0 (the condition token) is never masked; frame j-1 must be < length (mdm.py:241-247)
-  if (lengths != nullptr) nvalid = min(S, 1 + lengths[seq % B]);
+  const uint32_t* kbits = nullptr;   // arbitrary frame mask of this sequence (common.h key_valid_bits), else a count
+  if (lengths != nullptr) {
+    const int cnt = lengths[seq % B];
+    if (cnt >= 0) nvalid = min(S, 1 + cnt);
+    else kbits = reinterpret_cast<const uint32_t*>(lengths + B + 8 * (seq % B));
+  }
   int lv = lane;
 #ifndef MDM_EMU
   asm volatile("" : "+v"(lv));   // opaque per item: nothing derived from it is hoisted out of the item loop
@@ -214,15 +219,31 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
       if constexpr (t == NKT - 1 && !(ABL & 4)) {
         // ---- softmax over keys: lane-local + one cross-half exchange; 1/sum is applied to the output
         float mx = -INFINITY;
+        if (kbits == nullptr) {
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+          for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + mfma_row(e, h);
-            const float sc = (key < nvalid) ? p[kt][e] : -INFINITY;
-            p[kt][e] = sc;
-            mx = fmaxf(mx, sc);
-          }
+            for (int e = 0; e < 16; ++e) {
+              const int key = kt * 32 + mfma_row(e, h);
+              const float sc = (key < nvalid) ? p[kt][e] : -INFINITY;
+              p[kt][e] = sc;
+              mx = fmaxf(mx, sc);
+            }
+        } else {   // a mask with holes: the frame bitmap decides (rare path: the words are fetched here, not kept live)
+          uint32_t wb[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) wb[i] = kbits[i];
+          static_for<NKT>([&](auto kt_tag) __attribute__((always_inline)) {
+            constexpr int kt = decltype(kt_tag)::value;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = mfma_row(e, h), key = kt * 32 + row;
+              const float sc = (key < S && key_valid_bits<kt>(wb, row, 1)) ? p[kt][e] : -INFINITY;
+              p[kt][e] = sc;
+              mx = fmaxf(mx, sc);
+            }
+          });
+        }
         mx = fmaxf(mx, shfl_xor_f32(mx, 32));
         // fp16 planes: the probabilities are split as hi / lo of p * 2^10 -- free, by lowering the subtracted maximum by
         // 10 ln 2; the factor cancels in 1 / sum.  Unscaled, a typical p ~ 1/S = 0.005 has an fp16-SUBNORMAL lo part

@@ -182,6 +182,20 @@ __device__ __forceinline__ float sum_lanes8(float v) {
 #endif
 }
 
+// ---- key-padding masks (model/mdm.py:241-247).  A sample's frame mask reaches the attention kernels through the `lengths` array:
+// lengths[b] >= 0 is a valid-FRAME COUNT (a prefix mask: every mask data_loaders/tensors.py builds); lengths[b] == -1 says
+// that the sample's mask is an arbitrary BITMAP in the eight words lengths[B + 8 b .. B + 8 b + 7] (bit j of word i: frame
+// 32 i + j is valid), the array then holding 9 B ints (include/mdm_hip.h).  Keys in front of the frames (`lead`: the
+// condition token of trans_enc) are always valid.  key = 32 * KT + row; KT is a compile-time key-tile index.
+template <int KT>
+__device__ __forceinline__ bool key_valid_bits(const uint32_t* __restrict__ w, int row, int lead) {
+  const int f = row - lead;                        // frame index inside key tile KT (may be -1: the last frame of tile KT - 1)
+  uint32_t word;
+  if (f >= 0) word = w[KT];
+  else word = (KT > 0) ? w[KT > 0 ? KT - 1 : 0] : 0xffffffffu;   // KT == 0: key < lead, always valid
+  return (word >> (f & 31)) & 1u;
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }

@@ -399,6 +399,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
 #endif
   };
   int gs = 0;                 // PIPE: global k-step counter of this workgroup (stage of step g = g & 3)
+#if defined(MDM_X3_PIPE_PRIO) && !defined(MDM_EMU)
+  if constexpr (PIPE) { if (wid >= 4) __builtin_amdgcn_s_setprio(1); }   // (A/B build: static priority for the younger half)
+#endif
   if constexpr (PIPE) {
     // A(0), A(1), A(2) into stages 0..2 and W(0), W(1) into the four slots; everything landed and visible before step 0
 #pragma unroll
@@ -452,11 +455,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     constexpr bool LN_TABS = FOLD || RES == 3;
     float2* const stab = reinterpret_cast<float2*>(lds + x3_tab_base(WAVES, RINGN) + tile_parity * X3_TAB_BYTES);
     if constexpr (LN_TABS) {
-      if (v + gstride < total) {
-        int m0n, n0n;
-        tile_origin(v + gstride, m0n, n0n);
-        stats_dma(m0n, tile_parity ^ 1);
-      }
       if (tid < X3_TM) {
         // rows of the tile past the matrix (the last sequence's pad rows) have no statistics: their raw slots hold whatever the
         // clamped DMA fetched -- for an odd M with one partial per row two floats BEHIND the buffer (uninitialised workspace:
@@ -482,6 +480,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
 #else
         stab[tid] = pad_row ? make_float2(0.f, 0.f) : make_float2(mean, __builtin_amdgcn_rsqf(var + 1e-5f));   // v_rsq_f32, 1 ulp
 #endif
+      }
+      // the NEXT tile's partials are requested BEHIND the table build: hipcc drains the vector-memory queue in front of the
+      // build's LDS reads (an LDS-DMA may be pending), and issued first, this request -- a fresh HBM / L2 round trip -- was what
+      // it waited for at every tile start (round 3; the other raw buffer is the target, the build does not touch it)
+      if (v + gstride < total) {
+        int m0n, n0n;
+        tile_origin(v + gstride, m0n, n0n);
+        stats_dma(m0n, tile_parity ^ 1);
       }
     }
     float2* const atab = stab;   // FOLD: statistics of the A rows;  RES == 3: of the residual rows (a kernel has one)
@@ -509,7 +515,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
       // and the waits are: step start, slot W0(g): 2 nA + 6 younger operations; middle, A(g+1) and W1(g): nA + 4.
       // Other operations that land in the queue (column vectors, row statistics, the previous tile's stores) only make
       // these waits stricter: the queue retires in order.
-      constexpr int NU = 2 * NT32, NE = NU + 1, XP = NT32, DEPTH = 2, RING = DEPTH + 1;
+#ifndef MDM_X3_PIPE_DEPTH
+#define MDM_X3_PIPE_DEPTH 2
+#endif
+      constexpr int NU = 2 * NT32, NE = NU + 1, XP = NT32, DEPTH = MDM_X3_PIPE_DEPTH, RING = DEPTH + 1;
       static_assert(NU % RING == 0, "fragment ring slots must line up across steps");
       p16x8 ah[RING], al[RING], a16h, a16l;
 #ifndef MDM_EMU
@@ -544,8 +553,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         const uint32_t cur = (uint32_t)gs & 3u, nxt = (uint32_t)(gs + 1) & 3u, fill = (uint32_t)(gs + 3) & 3u;
         p16x8 w16h[2], w16l[2];
 #ifdef MDM_X3_PIPE_NOLOOK
-        issue_reads(std::integral_constant<int, 0>{}, cur);
-        issue_reads(std::integral_constant<int, 1>{}, cur);
+        static_for<DEPTH>([&](auto d_tag) __attribute__((always_inline)) { issue_reads(d_tag, cur); });
 #endif
         // slot W0(g) landed?  (issued in the middle of step g-2)
         vmem_wait<X3P_WAIT_WS>(wsh[2 * PAR], wsl[2 * PAR]);
@@ -647,8 +655,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
 #endif
       // prime the fragment pipeline of this tile: its first stage was made visible by the previous step's barrier / the prologue
 #ifndef MDM_X3_PIPE_NOLOOK
-      issue_reads(std::integral_constant<int, 0>{}, (uint32_t)gs & 3u);
-      issue_reads(std::integral_constant<int, 1>{}, (uint32_t)gs & 3u);
+      static_for<DEPTH>([&](auto d_tag) __attribute__((always_inline)) { issue_reads(d_tag, (uint32_t)gs & 3u); });
 #endif
       for (int kt = 0; kt < nk; kt += 2) {
         pipe_step(std::integral_constant<int, 0>{});
@@ -665,7 +672,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
       // hipcc keep two copies of the accumulators, 192 VGPRs): those fragments belong to the next tile's first step, whose
       // pipeline is primed afresh behind the epilogue -- retire and drop them
 #ifndef MDM_X3_PIPE_NOLOOK
-      lds_wait<0>(ah[0], al[0], ah[1], al[1]);
+      if constexpr (DEPTH == 2) lds_wait<0>(ah[0], al[0], ah[1], al[1]);
+      else lds_wait<0>(ah[0], al[0], ah[1], al[1], ah[2], al[2]);
 #endif
       // the epilogue must not meet a W slot whose load is still in flight (a spill would save the stale register); hipcc
       // drains the queue in front of the epilogue's first LDS read anyway (LDS-DMA pending)

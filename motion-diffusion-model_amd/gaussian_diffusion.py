@@ -233,10 +233,10 @@ class GaussianDiffusion:
         return torch.tensor(self.timestep_map, device=t.device, dtype=t.dtype)[t]      # respace.py:125-130
 
     def _uniform_index(self, t):
+        """The common timestep index of the batch, or None when the samples sit at different timesteps (the reference's
+        p_sample takes any `t`: gaussian_diffusion.py:489-541 gathers its coefficients per sample)."""
         i = int(t[0])
-        if not bool((t == i).all()):
-            raise NotImplementedError("per-sample timesteps inside one sampler step are not supported")
-        return i
+        return i if bool((t == i).all()) else None
 
     def _step(self, model, x, t, coefs, clip_denoised, denoised_fn, cond_fn, model_kwargs, noise, draw, index=None,
               const_noise=False):
@@ -260,10 +260,27 @@ class GaussianDiffusion:
             noise = noise.contiguous()
         a_x0, a_xt, sigma = coefs
         seed, base = self._rng_state()
-        x_prev, x0 = eng.sampler_step(x.contiguous(), oc, ou, scale, im, imo, noise,
-                                      float(a_x0[i]), float(a_xt[i]), float(sigma[i]), clip_denoised,
-                                      seed=seed, sample_base=base, draw=draw, want_x0=True, const_noise=const_noise)
-        return {"sample": x_prev, "pred_xstart": x0}
+        if i is not None:
+            x_prev, x0 = eng.sampler_step(x.contiguous(), oc, ou, scale, im, imo, noise,
+                                          float(a_x0[i]), float(a_xt[i]), float(sigma[i]), clip_denoised,
+                                          seed=seed, sample_base=base, draw=draw, want_x0=True, const_noise=const_noise)
+            return {"sample": x_prev, "pred_xstart": x0}
+        # per-sample timesteps (never on a loop's path): ONE denoiser evaluation of the whole batch above (the forward takes
+        # mixed t), then the fused step kernel sample by sample with that sample's coefficients; sample b keeps its own
+        # Philox stream (global index base + b), const_noise keeps sample 0's
+        xs, x0s = [], []
+        xc = x.contiguous()
+        for b, ib in enumerate(t.tolist()):
+            sl = slice(b, b + 1)
+            xp, x0 = eng.sampler_step(xc[sl], oc[sl], None if ou is None else ou[sl], None if scale is None else scale[sl],
+                                      None if im is None else im[sl], None if imo is None else imo[sl],
+                                      None if noise is None else noise[sl].contiguous(),
+                                      float(a_x0[ib]), float(a_xt[ib]), float(sigma[ib]), clip_denoised, seed=seed,
+                                      sample_base=base if const_noise else base + b, draw=draw, want_x0=True,
+                                      const_noise=const_noise)
+            xs.append(xp)
+            x0s.append(x0)
+        return {"sample": torch.cat(xs), "pred_xstart": torch.cat(x0s)}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                  const_noise=False, noise=None):

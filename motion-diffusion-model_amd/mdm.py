@@ -216,12 +216,32 @@ class MDM(nn.Module):
             self._engine, self._engine_key = eng, key
         return self._engine
 
+    @staticmethod
+    def frame_mask_lengths(valid):
+        """bool [B, F] (True = the frame is a key the reference attends to, model/mdm.py:241-247) -> the int32 `lengths` array
+        of the C ABI (include/mdm_hip.h): [B] valid-frame counts when every row is a PREFIX mask -- what
+        data_loaders/tensors.py:3-8 builds, the kernels' fast path --, else [9 B]: counts, with -1 for the rows that have
+        holes, followed by eight bitmap words per sample (bit j of word i: frame 32 i + j is valid)."""
+        B, F = valid.shape
+        if F > 256:
+            raise NotImplementedError(f"frame masks of more than 256 frames ({F}) do not fit the kernels' bitmap")
+        counts = valid.sum(dim=1)
+        prefix = (valid == (torch.arange(F, device=valid.device)[None, :] < counts[:, None])).all(dim=1)
+        if bool(prefix.all()):
+            return counts.to(torch.int32).contiguous()
+        bits = torch.zeros(B, 256, dtype=torch.int64, device=valid.device)
+        bits[:, :F] = valid.to(torch.int64)
+        words = (bits.view(B, 8, 32) << torch.arange(32, device=valid.device)).sum(dim=-1)     # < 2^32
+        words = torch.where(words >= 2 ** 31, words - 2 ** 32, words)                         # two's complement int32
+        counts = torch.where(prefix, counts, torch.full_like(counts, -1))
+        return torch.cat([counts, words.reshape(-1)]).to(torch.int32).contiguous()
+
     def lengths_from_mask(self, y, T):
         """y['mask'] [B,1,1,T] bool -> int32 valid-frame counts, or None when the reference would not mask
-        (model/mdm.py:241-247).  collate builds prefix masks (data_loaders/tensors.py:3-8, :22-40) and the attention
-        kernels take the mask as a valid-frame count, so a mask that is NOT a prefix mask raises instead of being
-        silently reduced to its popcount.  The (host-synchronising) check runs once per mask tensor: a sampling loop
-        hands over the same `y` every step; the cache entry keeps the mask alive so that its address cannot be recycled."""
+        (model/mdm.py:241-247).  collate builds prefix masks (data_loaders/tensors.py:3-8, :22-40): those reach the
+        attention kernels as valid-frame counts; any other mask as per-sample bitmaps (frame_mask_lengths).  The
+        (host-synchronising) classification runs once per mask tensor: a sampling loop hands over the same `y` every step;
+        the cache entry keeps the mask alive so that its address cannot be recycled."""
         mask = y.get('mask', None) if y is not None else None
         if not self.mask_frames or mask is None or mask.shape[-1] <= 1:
             return None
@@ -230,11 +250,7 @@ class MDM(nn.Module):
         if cached is not None and cached[0] == key and cached[1] is mask:
             return cached[2]
         m = mask[..., :T].reshape(mask.shape[0], -1).to(torch.bool)
-        lengths = m.sum(dim=1)
-        if not bool((m == (torch.arange(m.shape[1], device=m.device)[None, :] < lengths[:, None])).all()):
-            raise NotImplementedError("y['mask'] must be a prefix mask (valid frames first, data_loaders/tensors.py:3-8): "
-                                      "the MI355X attention kernels mask by valid-frame count")
-        lengths = lengths.to(torch.int32).contiguous()
+        lengths = self.frame_mask_lengths(m)
         self._len_cache = (key, mask, lengths)
         return lengths
 
@@ -284,10 +300,10 @@ class MDM(nn.Module):
             assert tok.dim() == 3 and tok.shape[1] == bs and tok.shape[2] == self.clip_dim, tok.shape
             lengths = None
             if use_mask:
-                m2 = mask[..., :x.shape[-1]].reshape(bs, -1).to(dev)
-                if not bool((m2 == (torch.arange(m2.shape[1], device=dev)[None, :] < m2.sum(dim=1)[:, None])).all()):
-                    raise NotImplementedError("frame masks must be prefix masks (data_loaders/tensors.py:3-8)")
-                lengths = (self.context_len + m2.sum(dim=1)).to(torch.int32).contiguous()
+                m2 = mask[..., :x.shape[-1]].reshape(bs, -1).to(dev).to(torch.bool)
+                # keys of the decoder's self-attention: the context_len prefix frames (always valid) + the window's frames
+                lengths = self.frame_mask_lengths(torch.cat([torch.ones(bs, self.context_len, dtype=torch.bool, device=dev),
+                                                             m2], dim=1))
             # the entry keeps the SOURCE tensors alive: a later batch of the same shape must not be able to land on a
             # recycled address with _version 0 and hit this entry
             self._dec_cache = (key, (tok, tl.to(torch.int32).contiguous(), lengths), (enc, mask))

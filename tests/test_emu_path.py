@@ -56,6 +56,47 @@ def test_emulated_forward_branches(lib, prec, tol, layers, B, T, lengths):
     assert maxabs(model(x, t, y=yu), orc.mdm_forward(sd, x, t, yu, num_heads=2)) < tol
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_emulated_frame_masks_with_holes(lib, prec):
+    """Arbitrary key-padding masks (model/mdm.py:241-247) through the bitmap form of `lengths` (include/mdm_hip.h, ABI 7):
+    S = 41 (two key tiles): a prefix-mask sample, a sample with holes at frame 0 / across the tile boundary, a sparse sample."""
+    B, T = 3, 40
+    sd = small_state_dict(num_layers=1)
+    model, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib, precision=prec)
+    y = synth_y(B, T, seed=2, lengths=[T, 33, T])
+    y["mask"] = y["mask"].clone()
+    y["mask"][1, 0, 0, [0, 5, 30, 31, 32]] = False
+    y["mask"][2] = False
+    y["mask"][2, 0, 0, [2, 31, 39]] = True
+    from mdm_amd.mdm import MDM
+    ext = MDM.frame_mask_lengths(y["mask"].reshape(B, T))
+    assert ext.numel() == 9 * B and ext[:B].tolist() == [T, -1, -1]
+    g = torch.Generator().manual_seed(0)
+    x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 0, 13])
+    assert maxabs(model(x, t, y=dict(y)), orc.mdm_forward(sd, x, t, y, num_heads=2)) < 2e-5
+
+
+def test_p_sample_takes_per_sample_timesteps(lib):
+    """gaussian_diffusion.py:489-541: p_sample gathers its coefficients per sample, so `t` may differ inside a batch (a loop
+    never does that; the public method may be called so).  One guided denoiser evaluation of the mixed-t batch + the fused step
+    per sample, against the oracle with the same injected noise; and the t = 0 sample receives no noise."""
+    steps, B, T = 50, 3, 9
+    sd = small_state_dict(num_layers=1)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib)
+    y = synth_y(B, T, seed=3, lengths=[T, 5, 7])
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 263, 1, T, generator=g)
+    eps = torch.randn(B, 263, 1, T, generator=g)
+    t = torch.tensor([49, 0, 17])
+    got = diffusion.p_sample(model, x, t, clip_denoised=False, model_kwargs={"y": dict(y)}, noise=eps)
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    x0 = orc.predict_x0(lambda a, b, c: orc.cfg_forward(sd, a, b, c, num_heads=2), x, t, y)
+    want = orc.ddpm_step(tab, x, x0, t, eps)
+    assert maxabs(got["pred_xstart"], x0) < 2e-5
+    assert maxabs(got["sample"], want) < 2e-5
+    assert maxabs(got["sample"][1], x0[1]) < 2e-5          # t = 0: the sample IS the predicted x0 (coef1 = 1, no noise)
+
+
 def test_weight_beyond_the_fp16_planes_is_refused_at_bind_time(lib):
     """include/mdm_hip.h mdm_weights_in_range: the f16x3 planes hold w * 2^8 as fp16, so a weight (or a LayerNorm-gamma-folded
     weight) of magnitude >= 255.9 cannot be carried.  The pack kernels of mdm_prepare flag it; the Python seam raises at bind

@@ -253,17 +253,35 @@ def test_fp16_planes_keep_subnormals_and_fail_loudly_out_of_range(sd):
 # ---------------------------------------------------------------------------------------------------
 # seams: masks
 # ---------------------------------------------------------------------------------------------------
-def test_non_prefix_frame_mask_raises_and_broadcast_inpainting_mask_works(sd):
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_frame_masks_with_holes_are_honoured(sd, prec):
+    """model/mdm.py:241-247 hands ANY `~y['mask']` to src_key_padding_mask; masks that are not prefix masks reach the attention
+    kernels as per-sample bitmaps (include/mdm_hip.h lengths_dev, ABI 7).  T = 196 (seven key tiles), three samples: a prefix
+    mask, a mask with holes incl. frame 0 and a tile boundary, a mask with only scattered frames; cond, uncond and guided."""
+    B, T = 3, 196
+    y = synth_y(B, T, seed=2, lengths=[196, 150, 196])
+    y["mask"] = y["mask"].clone()
+    y["mask"][1, 0, 0, [0, 3, 31, 32, 63, 64, 95, 100, 149]] = False
+    y["mask"][2] = False
+    y["mask"][2, 0, 0, [1, 30, 33, 127, 128, 190, 195]] = True
+    model, _ = make_pair(sd, 50, DEV, guided=True, precision=prec)
+    g = torch.Generator().manual_seed(4)
+    x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 7, 0])
+    yd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in y.items()}
+    want_c = orc.mdm_forward(sd, x, t, y)
+    want_u = orc.mdm_forward(sd, x, t, {**y, "uncond": True})
+    assert maxabs(model.model(x.to(DEV), t.to(DEV), y=dict(yd)).cpu(), want_c) < TOL_FWD[prec]
+    assert maxabs(model.model(x.to(DEV), t.to(DEV), y={**yd, "uncond": True}).cpu(), want_u) < TOL_FWD[prec]
+    want_g = want_u + y["scale"].view(-1, 1, 1, 1) * (want_c - want_u)
+    assert maxabs(model(x.to(DEV), t.to(DEV), y=dict(yd)).cpu(), want_g) < 3 * TOL_FWD[prec]
+
+
+def test_broadcast_inpainting_mask_works(sd):
     B, T = 2, 16
     y = synth_y(B, T, seed=2, lengths=[16, 9])
     model, diffusion = make_pair(sd, 50, DEV, guided=True)
     x = torch.randn(B, 263, 1, T).to(DEV)
     t = torch.tensor([10, 10], device=DEV)
-    bad = dict(y)
-    bad["mask"] = y["mask"].clone()
-    bad["mask"][1, 0, 0, 3] = False                           # a hole: not a prefix mask (model/mdm.py:243-247 would honour it)
-    with pytest.raises(NotImplementedError, match="prefix mask"):
-        model(x, t, y=bad)
     yi = dict(y)
     m = torch.zeros(1, 263, 1, T, dtype=torch.bool)
     m[:, :4] = True
