@@ -60,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the f32_mode, steps1000 and dip sub-records")
     ap.add_argument("--no-steps1000", action="store_true", help="skip the 1000-step (BASELINE.json configs[2]) sub-record")
-    # test infrastructure (tests/test_bench_launcher.py): the same launcher / sharding / gather / JSON code on CPU --
+    # test infrastructure (tests/test_round2_cpu.py::test_bench_self_launches_two_ranks_from_a_bare_shell): the same launcher / sharding / gather / JSON code on CPU --
     # gloo ranks, kernels in the CPU emulator, a tiny model.  Never a measurement.
     ap.add_argument("--force-pg", action="store_true",
                     help="N = 1 only: still create the (one-rank) RCCL process group and run the gather through it")

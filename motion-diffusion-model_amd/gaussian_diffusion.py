@@ -286,6 +286,7 @@ class GaussianDiffusion:
                  const_noise=False, noise=None):
         """gaussian_diffusion.py:489-541.  `noise` (extra kwarg) injects eps; otherwise the Philox stream is used."""
         if denoised_fn is not None or cond_fn is not None or _unwrap(model)[0] is None:
+            self._no_stream_kwargs("p_sample", noise=noise)
             return self._reference("p_sample with cond_fn / denoised_fn / a foreign model").p_sample(
                 model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
                 model_kwargs=model_kwargs, const_noise=const_noise)
@@ -296,6 +297,7 @@ class GaussianDiffusion:
                     noise=None):
         """gaussian_diffusion.py:729-779."""
         if denoised_fn is not None or cond_fn is not None or _unwrap(model)[0] is None:
+            self._no_stream_kwargs("ddim_sample", noise=noise)
             return self._reference("ddim_sample with cond_fn / denoised_fn / a foreign model").ddim_sample(
                 model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
                 model_kwargs=model_kwargs, eta=eta)
@@ -329,6 +331,7 @@ class GaussianDiffusion:
                       noise_sequence=None, seed=None):
         """gaussian_diffusion.py:591-658.  Returns the final sample (or the list of dumped steps)."""
         if self._needs_reference(model, denoised_fn, cond_fn, cond_fn_with_grad, randomize_class):
+            self._no_stream_kwargs("p_sample_loop", noise_sequence=noise_sequence, seed=seed)
             return self._reference("p_sample_loop with cond_fn / denoised_fn / randomize_class / a foreign model").p_sample_loop(
                 model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
                 model_kwargs=model_kwargs, device=device, progress=progress, skip_timesteps=skip_timesteps,
@@ -336,6 +339,17 @@ class GaussianDiffusion:
                 dump_steps=dump_steps, const_noise=const_noise)
         return self._loop(model, shape, self.ddpm_coefficients(), noise, clip_denoised, model_kwargs, device,
                           skip_timesteps, init_image, dump_steps, const_noise, noise_sequence, seed)
+
+    @staticmethod
+    def _no_stream_kwargs(where, **given):
+        """`noise_sequence=` / `seed=` / p_sample's `noise=` are extensions of THIS implementation (injected or Philox noise
+        streams).  A call that is handed to the reference's sampler draws from torch's global generator instead, so these
+        arguments cannot be honoured there: refuse them loudly instead of returning an unrelated trajectory."""
+        bad = [k for k, v in given.items() if v is not None]
+        if bad:
+            raise ValueError(f"{where}: {', '.join(bad)} cannot be combined with cond_fn / denoised_fn / randomize_class / a "
+                             f"foreign model -- that call is executed by the reference's sampler, whose noise comes from "
+                             f"torch's global generator (seed it with torch.manual_seed)")
 
     @staticmethod
     def _needs_reference(model, denoised_fn, cond_fn, cond_fn_with_grad, randomize_class):
@@ -352,6 +366,7 @@ class GaussianDiffusion:
         if const_noise == True:                  # noqa: E712  (:902-903)
             raise NotImplementedError()
         if self._needs_reference(model, denoised_fn, cond_fn, cond_fn_with_grad, randomize_class):
+            self._no_stream_kwargs("ddim_sample_loop", noise_sequence=noise_sequence, seed=seed)
             return self._reference("ddim_sample_loop with cond_fn / denoised_fn / randomize_class / a foreign model").ddim_sample_loop(
                 model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
                 model_kwargs=model_kwargs, device=device, progress=progress, eta=eta, skip_timesteps=skip_timesteps,
@@ -503,6 +518,7 @@ class GaussianDiffusion:
         step kernel per iteration; use p_sample_loop for the fully-fused loop).  `noise_sequence` = [x_T, eps_0, ...]
         (extra kwarg) injects the noise stream, as in p_sample_loop."""
         if self._needs_reference(model, denoised_fn, cond_fn, cond_fn_with_grad, randomize_class):
+            self._no_stream_kwargs("p_sample_loop_progressive", noise_sequence=noise_sequence)
             ref = self._reference("progressive sampling with cond_fn / denoised_fn / randomize_class / a foreign model")
             kw = dict(noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
                       model_kwargs=model_kwargs, device=device, progress=progress, skip_timesteps=skip_timesteps,

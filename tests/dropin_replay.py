@@ -98,6 +98,14 @@ def main():
     got = diffusion.p_sample_loop(model, motion_shape, clip_denoised=False, model_kwargs=model_kwargs,
                                   cond_fn=lambda x, t, **kw: torch.zeros_like(x))
     res["cond_fn_handover_vs_oracle"] = maxabs(got, want_cpu)
+    # this implementation's noise-stream arguments cannot be honoured by the reference's sampler: refused, not dropped
+    for bad in (dict(seed=5), dict(noise_sequence=[x_T] + list(noises))):
+        try:
+            diffusion.p_sample_loop(model, motion_shape, clip_denoised=False, model_kwargs=model_kwargs,
+                                    cond_fn=lambda x, t, **kw: torch.zeros_like(x), **bad)
+            raise AssertionError(f"{list(bad)} was silently dropped on a reference-routed call")
+        except ValueError:
+            pass
     assert type(diffusion._reference("test").base).__module__ == "diffusion.gaussian_diffusion"
     # a foreign model: the reference's own torch MDM through OUR diffusion object
     import contextlib
