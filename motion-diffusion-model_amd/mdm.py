@@ -112,6 +112,8 @@ class MDM(nn.Module):
 
         if arch not in ('trans_enc', 'trans_dec'):
             raise NotImplementedError(f"arch={arch!r}: trans_enc and trans_dec (DiP) only (SURVEY.md 8f)")
+        if arch == 'trans_dec' and self.total_len > self.MAX_TOKENS:
+            raise NotImplementedError(f"context_len + pred_len = {self.total_len} tokens: {self._cap_reason}")
         if activation != "gelu":
             raise NotImplementedError("only activation='gelu' (the reference's fixed choice, utils/model_util.py:64)")
         if data_rep == 'rot_vel' or self.multi_target_cond or self.emb_policy != 'add':
@@ -150,6 +152,7 @@ class MDM(nn.Module):
         self.rot2xyz = _IdentityRot2xyz()
         self._engine = None
         self._engine_key = None
+        self._engine_params = self._engine_quick = None
 
     # ---- text encoder (outside the hot path: runs once per prompt batch on the host side) ------------
     @staticmethod
@@ -193,6 +196,19 @@ class MDM(nn.Module):
         return cond
 
     # ---- native engine management ---------------------------------------------------------------------
+    # ---- the one size limit of the seam: a sequence is at most 224 tokens.  The attention kernels keep all scores of a query
+    # row in registers (seven 32-key tiles: the softmax is exact, no online rescaling) and the encoder GEMMs put one
+    # sequence in one 208 / 224-row tile.  HumanML3D / KIT motions are <= 196 frames (sample/generate.py:32); the reference
+    # itself is bounded by its positional table only (5000 rows, model/mdm.py:55).  Longer inputs raise (MdmError), loudly.
+    MAX_TOKENS = 224
+    MAX_FRAMES = 223          # trans_enc: the condition token takes one of the 224
+    _cap_reason = ("the MI355X path holds a sequence in one GEMM tile and its attention scores in registers: at most 224 tokens "
+                   "(trans_enc: 223 frames + the condition token; trans_dec: context_len + pred_len <= 224)")
+
+    def _check_frames(self, T):
+        if (T + 1 if self.arch == 'trans_enc' else self.context_len + T) > self.MAX_TOKENS:
+            raise nat.MdmError(f"{T} frames: {self._cap_reason}")
+
     def _native_state(self):
         sd = {k: v for k, v in self.state_dict().items()
               if not k.startswith('clip_model.') and k != 'embed_timestep.sequence_pos_encoder.pe'}
@@ -203,9 +219,19 @@ class MDM(nn.Module):
         return sd
 
     def engine(self):
-        """Native handle bound to the current parameters (rebuilt when they move or change)."""
+        """Native handle bound to the current parameters (rebuilt when they move or change).  The per-call check is one pass
+        over the parameters' in-place version counters (load_state_dict / optimizer steps bump them; .to() / .half() go through
+        _apply, which drops the engine); the full (data_ptr, version) key of ~150 tensors is only rebuilt when that sum, the
+        first parameter's address or the precision changed."""
+        params = self._engine_params
+        if params is None:
+            params = self._engine_params = list(self.parameters_wo_clip())
+        quick = (self.precision, params[0].data_ptr(), sum(q._version for q in params))
+        if self._engine is not None and self._engine_quick == quick:
+            return self._engine
         p = self.input_process.poseEmbedding.weight
-        key = (str(p.device), self.precision) + tuple((q.data_ptr(), q._version) for q in self.parameters_wo_clip())
+        params = self._engine_params = list(self.parameters_wo_clip())       # (a parameter may have been re-assigned)
+        key = (str(p.device), self.precision) + tuple((q.data_ptr(), q._version) for q in params)
         if self._engine is None or self._engine_key != key:
             cfg = dict(njoints=self.njoints, nfeats=self.nfeats, latent_dim=self.latent_dim, ff_size=self.ff_size,
                        num_layers=self.num_layers, num_heads=self.num_heads, clip_dim=self.clip_dim,
@@ -214,6 +240,7 @@ class MDM(nn.Module):
             eng = Engine(cfg, lib=self._native_lib, precision=self.precision)
             eng.bind(self._native_state(), p.device)
             self._engine, self._engine_key = eng, key
+        self._engine_quick = (self.precision, params[0].data_ptr(), sum(q._version for q in params))
         return self._engine
 
     @staticmethod
@@ -334,6 +361,7 @@ class MDM(nn.Module):
                 raise NotImplementedError(f"y[{k!r}] is outside the MI355X hot path")
         bs, njoints, nfeats, nframes = x.shape
         assert njoints == self.njoints and nfeats == self.nfeats
+        self._check_frames(nframes)
         eng = self.engine()
         x = x.to(torch.float32).contiguous()
         ts = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
@@ -352,6 +380,7 @@ class MDM(nn.Module):
         if self.arch == 'trans_dec':
             out = self._forward_dec(x, timesteps, y, nat.BRANCH_BOTH)
             return out[:bs], out[bs:]
+        self._check_frames(x.shape[-1])
         eng = self.engine()
         x = x.to(torch.float32).contiguous()
         ts = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
@@ -365,5 +394,6 @@ class MDM(nn.Module):
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._engine = None   # parameters moved: rebind lazily
+        self._engine_params = self._engine_quick = None
         self._len_cache = self._dec_cache = None
         return r
