@@ -52,7 +52,8 @@ __host__ __device__ __forceinline__ int ax_key_of_pos(int p) { return (p & 3) + 
 //     latency at the start of an item and the output phase at its end were 26 + 19 of the kernel's 105 us otherwise.
 constexpr int AX_SLOT = 16384, AX_RING = 4;
 constexpr int AX_OST = 64 + 4;   // output staging row stride (floats): 32 queries x 64 d per wave and pass, in ring slots 1-3
-constexpr int ax_lds_bytes(int) { return AX_RING * AX_SLOT; }
+constexpr int AX_KMASK_BYTES = 1024;   // per-key additive mask (0 / -inf) of the current item: only written for bitmap masks
+constexpr int ax_lds_bytes(int) { return AX_RING * AX_SLOT + AX_KMASK_BYTES; }
 static_assert(AX_SLOT + 4 * 32 * AX_OST * 4 <= AX_RING * AX_SLOT, "output staging must fit behind ring slot 0");
 
 // ABL (timing experiments only, 0 in production; results are garbage): 1 = no MFMAs, 2 = no LDS fragment reads,
@@ -133,6 +134,14 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
     const int cnt = lengths[seq % B];
     if (cnt >= 0) nvalid = min(S, 1 + cnt);
     else kbits = reinterpret_cast<const uint32_t*>(lengths + B + 8 * (seq % B));
+  }
+  if (tid < 32 * NKT) {
+    // additive key mask of this item, key `tid`: the condition token (key 0) is always valid; frame f = key - 1 by the count
+    // or by its bitmap bit; keys >= S never.  Read at the softmax, NKT workgroup barriers from here; the previous item's
+    // softmax is at least NKT barriers in the past.
+    const int f = tid - 1;
+    const bool ok = kbits == nullptr ? tid < nvalid : (tid < S && (tid == 0 || ((kbits[f >> 5] >> (f & 31)) & 1u)));
+    reinterpret_cast<float*>(lds + AX_RING * AX_SLOT)[tid] = ok ? 0.f : -INFINITY;
   }
   int lv = lane;
 #ifndef MDM_EMU
@@ -219,30 +228,22 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
       if constexpr (t == NKT - 1 && !(ABL & 4)) {
         // ---- softmax over keys: lane-local + one cross-half exchange; 1/sum is applied to the output
         float mx = -INFINITY;
-        if (kbits == nullptr) {
+        {
+          // key-padding mask: the item's per-key additive mask (0 or -inf; count or bitmap form of `lengths`, built at the
+          // item start) is read as four 16-byte groups per key tile -- a lane's sixteen scores of a tile are keys
+          // 8 g + 4 h .. + 3, g = 0..3 (common.h mfma_row).  One code path for both mask forms: bitmap words in registers at
+          // this kernel's register peak cost 147 spilled VGPRs (round 3, measured: the kernel twice as slow).
+          const float* km = reinterpret_cast<const float*>(lds + AX_RING * AX_SLOT) + 4 * h;
 #pragma unroll
           for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int key = kt * 32 + mfma_row(e, h);
-              const float sc = (key < nvalid) ? p[kt][e] : -INFINITY;
-              p[kt][e] = sc;
-              mx = fmaxf(mx, sc);
+            for (int g = 0; g < 4; ++g) {
+              const float4 m4 = ld4(km + kt * 32 + 8 * g);
+              const float s0 = p[kt][4 * g] + m4.x, s1 = p[kt][4 * g + 1] + m4.y, s2 = p[kt][4 * g + 2] + m4.z,
+                          s3 = p[kt][4 * g + 3] + m4.w;
+              p[kt][4 * g] = s0; p[kt][4 * g + 1] = s1; p[kt][4 * g + 2] = s2; p[kt][4 * g + 3] = s3;
+              mx = fmaxf(mx, fmaxf(fmaxf(s0, s1), fmaxf(s2, s3)));
             }
-        } else {   // a mask with holes: the frame bitmap decides (rare path: the words are fetched here, not kept live)
-          uint32_t wb[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) wb[i] = kbits[i];
-          static_for<NKT>([&](auto kt_tag) __attribute__((always_inline)) {
-            constexpr int kt = decltype(kt_tag)::value;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int row = mfma_row(e, h), key = kt * 32 + row;
-              const float sc = (key < S && key_valid_bits<kt>(wb, row, 1)) ? p[kt][e] : -INFINITY;
-              p[kt][e] = sc;
-              mx = fmaxf(mx, sc);
-            }
-          });
         }
         mx = fmaxf(mx, shfl_xor_f32(mx, 32));
         // fp16 planes: the probabilities are split as hi / lo of p * 2^10 -- free, by lowering the subtracted maximum by
