@@ -134,29 +134,45 @@ def cpu_baseline(state, T, dsteps, runs=2):
             x_T = torch.randn(shape, generator=g)
             noises = [torch.randn(shape, generator=g) for _ in range(dsteps)]
             return orc.sample_loop(sd, tab, shape, y, x_T, noises, cfg=True)
-    times = []
-    with torch.no_grad():
-        # warm-up: a short loop through the same code (thread pool, allocator, oneDNN primitive caches)
+    def warm():
+        # a short loop through the same code (thread pool, allocator, oneDNN primitive caches)
         if kind == "port":
             tabw = orc.Tables(orc.named_betas("cosine", 2))
             orc.sample_loop(sd, tabw, shape, y, torch.randn(shape, generator=g), [torch.randn(shape, generator=g)] * 2, cfg=True)
         else:
             ref_harness.build_reference_diffusion(steps=2).p_sample_loop(cfg, shape, clip_denoised=False,
                                                                          model_kwargs={"y": dict(y)})
-        for _ in range(runs):
-            t0 = time.perf_counter()
-            out = runner()
-            times.append(time.perf_counter() - t0)
-            assert bool(torch.isfinite(out).all())
-    mean = sum(times) / len(times)
+
+    # torch's default intra-op thread count is every hardware thread of the box; at batch 1 (197-row GEMMs) that
+    # over-subscription is SLOWER than a few cores (128 threads: ~17 s per motion on the GPU box, the 8-vCPU build container:
+    # 2.3 s).  Both settings are timed -- all threads once, a moderate count `runs` times -- and the better one is the value.
+    all_thr = torch.get_num_threads()
+    settings = [(all_thr, 1), (16, runs)] if all_thr > 16 else [(all_thr, runs)]
+    results = []
+    with torch.no_grad():
+        for nthr, n in settings:
+            torch.set_num_threads(nthr)
+            warm()
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                out = runner()
+                ts.append(time.perf_counter() - t0)
+                assert bool(torch.isfinite(out).all())
+            results.append((nthr, ts))
+        torch.set_num_threads(all_thr)
+    best_thr, best_ts = min(results, key=lambda r: sum(r[1]) / len(r[1]))
+    mean = sum(best_ts) / len(best_ts)
     what = ("the reference's own SpacedDiffusion.p_sample_loop(ClassifierFreeSampleModel(MDM)) (diffusion/gaussian_diffusion.py:591-658)"
             if kind == "reference" else "oracle/mdm_oracle.sample_loop (torch-CPU restatement of the reference, pinned by tests/golden)")
-    return {"value": round(B / mean, 4), "unit": "motions/s", "cores": thr, "kind": kind,
-            "runs_motions_per_s": [round(B / t, 4) for t in times], "runs_s": [round(t, 3) for t in times],
+    return {"value": round(B / mean, 4), "unit": "motions/s", "cores": best_thr, "kind": kind,
+            "runs_motions_per_s": {str(nthr): [round(B / t, 4) for t in ts] for nthr, ts in results},
+            "runs_s": {str(nthr): [round(t, 3) for t in ts] for nthr, ts in results},
             "sample_steps_per_s": round(B * dsteps / mean, 2),
             "sample": f"BASELINE.json configs[0]: {what}, CFG 2.5, batch={B}, T={T}, all {dsteps} diffusion steps, whole loop "
-                      f"timed {runs}x after a 2-step warm-up loop, torch.get_num_threads()={thr} intra-op threads on "
-                      f"{os.cpu_count()} logical host CPUs; a reported baseline, not a target"}
+                      f"timed after a 2-step warm-up loop at {' and '.join(str(r[0]) for r in results)} intra-op threads "
+                      f"({os.cpu_count()} logical host CPUs; keys of runs_*); value = the faster setting ({best_thr} threads, "
+                      f"mean of {len(best_ts)}); a reported baseline, not a target"}
 
 
 # Mean ALGORITHMIC HBM bytes of one encoder-GEMM launch at the headline shape (256 sequences x 197 tokens, D=512, FF=1024;
