@@ -415,6 +415,74 @@ __device__ __forceinline__ void vmem_wait(u32x2& a, u32x2& b, u32x2& c, u32x2& d
 }
 #endif
 
+// (float)(fp16 half HALF of `packed`) + c in ONE instruction: v_fma_mix_f32 converts its 16-bit source on the fly (h * 1.0 + c),
+// where the plain form is a v_cvt_f32_f16 and an add per element.  fp16 planes only (kSplitF16).
+template <int HALF> __device__ __forceinline__ float f16_half_plus(uint32_t packed, float c) {
+#ifdef MDM_EMU
+  return (float)__builtin_bit_cast(f16x2, packed)[HALF] + c;
+#else
+  float d;
+  if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(c));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(c));
+  return d;
+#endif
+}
+
+// A window of `bytes` bytes of global memory addressed through a raw buffer descriptor (V#, stride 0) by 32-bit byte offsets:
+// the buffer unit drops stores and returns 0 for loads whose offset lies past the window, so a GEMM tile's pad rows and the
+// columns past the matrix cost neither a predicate (exec-mask branch) nor a clamp, and a round's address is ONE 32-bit add
+// instead of a 64-bit multiply-add per plane.  (The range check covers VGPR offset + immediate, not the SGPR offset: the row
+// term has to be in the VGPR.)  `CLIP_OFF` is an offset that is out of every window.
+constexpr uint32_t CLIP_OFF = 0x80000000u;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct ClipWin {
+#ifdef MDM_EMU
+  char* base;
+  uint32_t bytes;
+#else
+  i32x4 d;
+#endif
+};
+__device__ __forceinline__ ClipWin clip_win(const void* base, uint32_t bytes) {
+  ClipWin w;
+#ifdef MDM_EMU
+  w.base = const_cast<char*>(static_cast<const char*>(base));
+  w.bytes = bytes;
+#else
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  w.d[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  w.d[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((b >> 32) & 0xffffu));   // stride 0, no swizzle
+  w.d[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  w.d[3] = 0x00020000;                                                              // raw buffer, 32-bit data format
+#endif
+  return w;
+}
+__device__ __forceinline__ void clip_store8(const ClipWin& w, uint32_t off, u32x2 v) {
+#ifdef MDM_EMU
+  if (off < w.bytes && off + 8 <= w.bytes) *reinterpret_cast<u32x2*>(w.base + off) = v;
+#else
+  // 8 bytes of store data: no VMEM-store-data hazard window on gfx9 (that one starts above 8 bytes)
+  asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(v), "v"(off), "s"(w.d) : "memory");
+#endif
+}
+__device__ __forceinline__ void split4_store_clip(const ClipWin& hi_w, const ClipWin& lo_w, uint32_t off, float4 v) {
+  uint32_t h01, l01, h23, l23;
+  split2_p16(v.x, v.y, h01, l01);
+  split2_p16(v.z, v.w, h23, l23);
+  clip_store8(hi_w, off, u32x2{h01, h23});
+  clip_store8(lo_w, off, u32x2{l01, l23});
+}
+// untracked load (cf. gload8_async): retire it with vmem_wait
+__device__ __forceinline__ void clip_load8_async(u32x2& dst, const ClipWin& w, uint32_t off) {
+#ifdef MDM_EMU
+  static const uint32_t zeros[2] = {0u, 0u};
+  const bool in = off < w.bytes && off + 8 <= w.bytes;
+  emu::vm_issue(&dst, in ? static_cast<const void*>(w.base + off) : static_cast<const void*>(zeros), 8, true);
+#else
+  asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(off), "s"(w.d) : "memory");
+#endif
+}
+
 // Workgroup barrier that does NOT drain the vector-memory queue (cdna_hip_programming.md section 5: __syncthreads()
 // would wait vmcnt(0) while an LDS-DMA is in flight); pair it with an explicit wait where the data is consumed.
 __device__ __forceinline__ void wg_barrier() {

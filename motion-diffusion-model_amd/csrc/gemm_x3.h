@@ -143,8 +143,12 @@ struct X3Epilogue {
   float acc_scale = kX3AccScale;   // accumulators -> value: undoes the 2^8 the weight planes carry (common.h kX3WeightScale)
 };
 
+constexpr bool x3_has_col_scale(int act, int res) { return act == 0 && (res == 0 || res == 1); }
+
 // exact-GELU with erf from Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, i.e. fp32-rounding class): one v_exp, one v_rcp
-// and a 5-term Horner chain instead of the ~40-instruction libm erff; used only in this split-precision path.
+// and a 5-term Horner chain instead of the ~40-instruction libm erff; used only in this split-precision path.  (Round 3 tried
+// the odd rational x P(x^2) / Q(x^2) on |x| <= 4 -- ten packed FMAs and a single v_rcp per element, |err| < 4.5e-7: same-box
+// A/B 0.35 % SLOWER over the whole sampling loop, profiles/r03c_ab.md; not kept.)
 __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
 #ifdef MDM_EMU
@@ -848,7 +852,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     // per-lane column vectors of the row-major side: bias (or folded bias), Q scale, folded column sums, residual gamma/beta
     const int cl4 = wid * 32 + pc4;                      // this lane's first column inside the tile
     const float4 b4 = ld4(cvec + cl4);
-    const float mult4 = (n4 < ep.scale_cols) ? ep.col_scale : 1.f;   // scale_cols is a multiple of the tile width
+    // column scale (in_proj's Q columns; scale_cols is a multiple of the tile width): only the instantiations without an
+    // activation and without a plane residual carry one (the launcher refuses it elsewhere) -- two packed multiplies per round
+    constexpr bool COL_SCALE = x3_has_col_scale(ACT, RES);
+    const float mult4 = (COL_SCALE && n4 < ep.scale_cols) ? ep.col_scale : 1.f;
     float4 c4 = zero4(), g4 = zero4(), be4 = zero4();
     if constexpr (FOLD) c4 = ld4(cvec + 256 + cl4);
     if constexpr (RES == 3) {
@@ -861,17 +868,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     if constexpr (FOLD) csum = cvec[256 + wid * 32 + r];
     // accumulator values of one round, row-major, -> the GEMM's value:  fold / bias, activation, Q scale
     const float accs = ep.acc_scale;
+    // RES == 3: the rebuilt LayerNorm residual's beta is a per-column constant like the bias -- added with it
+    const float4 bb4 = RES == 3 ? make_float4(b4.x + be4.x, b4.y + be4.y, b4.z + be4.z, b4.w + be4.w) : b4;
     auto finish4 = [&](float4 v4, float2 st) __attribute__((always_inline)) {
       v4.x *= accs; v4.y *= accs; v4.z *= accs; v4.w *= accs;
       if constexpr (FOLD) {
-        v4.x = st.y * (v4.x - st.x * c4.x) + b4.x; v4.y = st.y * (v4.y - st.x * c4.y) + b4.y;
-        v4.z = st.y * (v4.z - st.x * c4.z) + b4.z; v4.w = st.y * (v4.w - st.x * c4.w) + b4.w;
+        v4.x = st.y * (v4.x - st.x * c4.x) + bb4.x; v4.y = st.y * (v4.y - st.x * c4.y) + bb4.y;
+        v4.z = st.y * (v4.z - st.x * c4.z) + bb4.z; v4.w = st.y * (v4.w - st.x * c4.w) + bb4.w;
       } else {
-        v4.x += b4.x; v4.y += b4.y; v4.z += b4.z; v4.w += b4.w;
+        v4.x += bb4.x; v4.y += bb4.y; v4.z += bb4.z; v4.w += bb4.w;
       }
       if (ACT == ACT_GELU) { v4.x = gelu_erf_fast(v4.x); v4.y = gelu_erf_fast(v4.y); v4.z = gelu_erf_fast(v4.z); v4.w = gelu_erf_fast(v4.w); }
       else if (ACT == ACT_SILU) { v4.x = silu(v4.x); v4.y = silu(v4.y); v4.z = silu(v4.z); v4.w = silu(v4.w); }
-      v4.x *= mult4; v4.y *= mult4; v4.z *= mult4; v4.w *= mult4;
+      if constexpr (COL_SCALE) { v4.x *= mult4; v4.y *= mult4; v4.z *= mult4; v4.w *= mult4; }
       return v4;
     };
     // row statistics of the rows a lane finishes in round j (FOLD: of the A rows, RES == 3: of the residual rows).  Read ONE
@@ -998,6 +1007,30 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
       // rows past the matrix are clamped (loaded, never stored)
       constexpr bool HAS_RES = RES != 0;
       constexpr bool RES_PLANES = RES == 2 || RES == 3;
+      // plane rows of this tile (output and residual) are addressed through clipped windows (common.h ClipWin): byte offset
+      // of a lane's 4 columns in tile row `prow`, plus a wave-uniform row term per round
+      static_assert(!(EMBED && RES_PLANES), "the EMBED epilogue takes an fp32 residual");
+      constexpr bool CLIP_OUT = OUT_PLANES && !EMBED;
+      const uint32_t pitch2 = (uint32_t)ep.ld * 2u;
+      const uint32_t voff0 = n4 < N ? ((uint32_t)prow * (uint32_t)ep.ld + (uint32_t)n4) * 2u : CLIP_OFF;
+      ClipWin w_oh = {}, w_ol = {}, w_rh = {}, w_rl = {};
+      {
+        int m0_e = m0;
+#ifndef MDM_EMU
+        asm volatile("" : "+s"(m0_e));   // (opaque: keeps the windows from being built, and carried, in front of the k-loop)
+#endif
+        const size_t row0 = (size_t)m0_e * ep.ld;
+        if constexpr (CLIP_OUT) {
+          const uint32_t bytes = (uint32_t)(m_end - m0_e) * pitch2;
+          w_oh = clip_win(ep.oh + row0, bytes);
+          w_ol = clip_win(ep.ol + row0, bytes);
+        }
+        if constexpr (RES_PLANES) {
+          const uint32_t bytes = (uint32_t)min(M - m0_e, X3_TM) * pitch2;
+          w_rh = clip_win(ep.resh + row0, bytes);
+          w_rl = clip_win(ep.resl + row0, bytes);
+        }
+      }
       constexpr int RR = (RES == 3) ? 2 : 3;   // residual sub-tiles in flight + in use (RES == 3 sits at the VGPR limit)
       f32x4 rr[RR][4];       // RES == 1
       u32x2 rh[RR][4], rl[RR][4];  // RES == 2 / 3
@@ -1006,13 +1039,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         if constexpr (HAS_RES && t < X3_MSUB) {
 #pragma unroll
           for (int g = 0; g < x3_res_rounds(t, T16); ++g) {
-            const int m = min(m0 + t * 32 + 8 * g + prow, M - 1);
-            const size_t o = (size_t)(EMBED ? 1 + m % ep.emb_T : m) * ep.ld + (n4 < N ? n4 : 0);   // EMBED: positional row
             if constexpr (RES == 1) {
+              const int m = min(m0 + t * 32 + 8 * g + prow, M - 1);
+              const size_t o = (size_t)(EMBED ? 1 + m % ep.emb_T : m) * ep.ld + (n4 < N ? n4 : 0);   // EMBED: positional row
               gload16_async(rr[t % RR][g], ep.res + o);
             } else {
-              gload8_async(rh[t % RR][g], ep.resh + o);
-              gload8_async(rl[t % RR][g], ep.resl + o);
+              const uint32_t o = voff0 + (uint32_t)(t * 32 + 8 * g) * pitch2;   // past the matrix: reads 0, never stored
+              clip_load8_async(rh[t % RR][g], w_rh, o);
+              clip_load8_async(rl[t % RR][g], w_rl, o);
             }
           }
         }
@@ -1056,6 +1090,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
           if constexpr (RES == 1) {
             const f32x4 q4 = rr[t % RR][g];
             v4.x += q4[0]; v4.y += q4[1]; v4.z += q4[2]; v4.w += q4[3];
+          } else if constexpr (RES_PLANES && kSplitF16) {
+            // x = hi + lo (RES == 3: minus the row mean, times rstd * gamma; beta rides in the bias vector bb4): the planes are
+            // converted inside the adds (common.h f16_half_plus), the mean leaves before anything is scaled
+            const u32x2 a = rh[t % RR][g], b = rl[t % RR][g];
+            const float c0 = RES == 3 ? -st.x : 0.f;
+            const float d0 = f16_half_plus<0>(b[0], f16_half_plus<0>(a[0], c0));
+            const float d1 = f16_half_plus<1>(b[0], f16_half_plus<1>(a[0], c0));
+            const float d2 = f16_half_plus<0>(b[1], f16_half_plus<0>(a[1], c0));
+            const float d3 = f16_half_plus<1>(b[1], f16_half_plus<1>(a[1], c0));
+            if constexpr (RES == 3) {
+              v4.x = fmaf(d0, st.y * g4.x, v4.x); v4.y = fmaf(d1, st.y * g4.y, v4.y);
+              v4.z = fmaf(d2, st.y * g4.z, v4.z); v4.w = fmaf(d3, st.y * g4.w, v4.w);
+            } else {
+              v4.x += d0; v4.y += d1; v4.z += d2; v4.w += d3;
+            }
           } else if constexpr (RES_PLANES) {
             const u32x2 a = rh[t % RR][g], b = rl[t % RR][g];
             float4 x4 = make_float4(
@@ -1064,8 +1113,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
                 p16_to_f32((p16_t)(a[1] & 0xffffu)) + p16_to_f32((p16_t)(b[1] & 0xffffu)),
                 p16_to_f32((p16_t)(a[1] >> 16)) + p16_to_f32((p16_t)(b[1] >> 16)));
             if constexpr (RES == 3) {   // the residual is LayerNorm(x), rebuilt from x's planes and its row statistics
-              x4.x = (x4.x - st.x) * st.y * g4.x + be4.x; x4.y = (x4.y - st.x) * st.y * g4.y + be4.y;
-              x4.z = (x4.z - st.x) * st.y * g4.z + be4.z; x4.w = (x4.w - st.x) * st.y * g4.w + be4.w;
+              x4.x = (x4.x - st.x) * st.y * g4.x; x4.y = (x4.y - st.x) * st.y * g4.y;   // (+ beta: in bb4)
+              x4.z = (x4.z - st.x) * st.y * g4.z; x4.w = (x4.w - st.x) * st.y * g4.w;
             }
             v4.x += x4.x; v4.y += x4.y; v4.z += x4.z; v4.w += x4.w;
           }
@@ -1078,18 +1127,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
           if ((lane_e & 7) == 0) part[row_in_tile] = make_float2(s1, m2);
         }
         if (!(ABL & 1)) {
-          const int m = m0 + row_in_tile;
-          if (m < m_end && n4 < N) {  // N % 4 == 0
-            if constexpr (EMBED) {
-              const int bb = m / ep.emb_T, tt = m - bb * ep.emb_T;
-              for (int br = 0; br < ep.emb_nbranch; ++br) {
-                const size_t o = ((size_t)(br * ep.emb_B + bb) * (ep.emb_T + 1) + 1 + tt) * ep.ld + n4;
-                split4_store(ep.oh + o, ep.ol + o, v4);
+          if constexpr (CLIP_OUT) split4_store_clip(w_oh, w_ol, voff0 + (uint32_t)(t * 32 + 8 * g) * pitch2, v4);
+          if constexpr (EMBED || OUT_F32) {
+            const int m = m0 + row_in_tile;
+            if (m < m_end && n4 < N) {  // N % 4 == 0
+              if constexpr (EMBED) {
+                const int bb = m / ep.emb_T, tt = m - bb * ep.emb_T;
+                for (int br = 0; br < ep.emb_nbranch; ++br) {
+                  const size_t o = ((size_t)(br * ep.emb_B + bb) * (ep.emb_T + 1) + 1 + tt) * ep.ld + n4;
+                  split4_store(ep.oh + o, ep.ol + o, v4);
+                }
+              } else {
+                st4(ep.out + (size_t)m * ep.ld + n4, v4);
               }
-            } else {
-              const size_t o = (size_t)m * ep.ld + n4;
-              if (OUT_F32) st4(ep.out + o, v4);
-              if (OUT_PLANES) split4_store(ep.oh + o, ep.ol + o, v4);
             }
           }
         }
@@ -1181,6 +1231,7 @@ inline int launch_gemm_x3_w(const X3Operand& A, const X3Weights& W, const X3Epil
   auto kfn = &gemm_x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16, F6, PIPE>;
   if (T16 && rpt > X3_TM - 16) return -2;
   if (PIPE && (K / X3_BK) % 2 != 0) return -2;   // the pipelined k-loop is unrolled over step pairs
+  if (!x3_has_col_scale(ACT, RES) && ep.scale_cols > 0) return -2;   // (this instantiation compiles the column scale out)
 #ifndef MDM_EMU
   if (x3_lds_bytes(WAVES, LN, RINGN) > 65536) {
     static bool configured[kMaxDevices] = {};  // per instantiation and device (the attribute belongs to the device's code object)
