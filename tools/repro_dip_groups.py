@@ -40,3 +40,39 @@ for rep in range(80):
     fails = globals().get("fails", 0) + 1
     globals()["fails"] = fails
 print("FAILS", globals().get("fails", 0), "of 80")
+if os.environ.get("MDM_DEC_DUP_OUT") == "1" or os.environ.get("MDM_DEC_DUP_IN") == "1" or os.environ.get("MDM_DEC_DUP_Q") == "1" or os.environ.get("MDM_PRINT_IDX") == "1":   # Output / InputProcess run twice per pass: elements in which the two results differ
+    import ctypes as C
+    from mdm_amd import _native
+    lib = _native.load_probe()
+    torch.cuda.synchronize()
+    for slot in range(4, 8):
+        d = C.c_double(0.0); lib.mdm_debug_get(100 + slot, C.byref(d)); bad = int(d.value)
+        lib.mdm_debug_get(130 + slot, C.byref(d))
+        print(f"DUP group {slot - 4}: {bad} differing elements in {int(d.value)} doubled launches")
+    d = C.c_double(0.0); lib.mdm_debug_get(200, C.byref(d)); n = min(int(d.value), 256)
+    idx = []
+    for k in range(n):
+        lib.mdm_debug_get(201 + k, C.byref(d)); idx.append(int(d.value))
+    import struct
+    vals = []
+    for k in range(n):
+        lib.mdm_debug_get(1000 + k, C.byref(d)); va = int(d.value)
+        lib.mdm_debug_get(1256 + k, C.byref(d)); vb = int(d.value)
+        f = lambda u: struct.unpack("<f", struct.pack("<I", u))[0]
+        vals.append((idx[k] // 512, idx[k] % 512, f"{va:08x}", f"{vb:08x}", f(va), f(vb)))
+    vals.sort()
+    print("DUP differing elements (row, col, first run bits, second run bits, values):")
+    for v in vals[:96]:
+        print("   ", v)
+if os.environ.get("MDM_DEC_ORD") == "1":   # order probe (mdm_api.hip decoder_pass): LayerNorm rows finished vs OutputProcess's start
+    import ctypes as C
+    from mdm_amd import _native
+    lib = _native.load_probe()
+    torch.cuda.synchronize()
+    for slot in range(4):
+        v = []
+        for what in range(4):
+            d = C.c_double(0.0)
+            lib.mdm_debug_get(100 + 10 * what + slot, C.byref(d))
+            v.append(int(d.value))
+        print(f"ORDER slot {slot}: violations {v[0]} of {v[3]} checks, largest shortfall {v[1]} rows, rows done {v[2]}")

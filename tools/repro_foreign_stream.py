@@ -17,13 +17,16 @@ ref = run()
 side = torch.cuda.Stream()
 bufs = [torch.randn(3840, 512, device=DEV) for _ in range(4)]
 w = torch.randn(512, 512, device=DEV)
-for kind in ("gemm-sized torch ops", "tiny elementwise ops"):
+q = torch.randn(16, 8, 256, 64, device=DEV, dtype=torch.float16)
+for kind in ("gemm-sized torch ops", "tiny elementwise ops", "sdpa (LDS-heavy attention kernels)"):
     fails = 0
     for rep in range(reps):
         with torch.cuda.stream(side):
             for i in range(400):
                 if kind.startswith("gemm"):
                     bufs[(i + 1) % 4] = torch.nn.functional.layer_norm(bufs[i % 4] @ w, (512,))
+                elif kind.startswith("sdpa"):
+                    q = torch.nn.functional.scaled_dot_product_attention(q, q, q)
                 else:
                     bufs[i % 4].mul_(1.0001).add_(0.1)
         fails += int(not torch.equal(run(), ref))
