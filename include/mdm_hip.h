@@ -18,9 +18,15 @@
  *     enqueues kernels takes a per-device lock for the duration of the (asynchronous) enqueue and, when the previous call
  *     on this device used a DIFFERENT stream, makes `stream` wait (hipStreamWaitEvent) for the event recorded behind
  *     that call's kernels.  Two model handles, two streams or two host threads on one GPU therefore run their kernels
- *     back to back, never side by side.  Why: two concurrent chains of the split-precision kernels were measured to
- *     read stale cache lines of rows their own predecessor kernel had just rewritten (profiles/r02e_dip.md; root cause
- *     not established).  Work of OTHER libraries may overlap freely.  Because of the event record, do not call into
+ *     back to back, never side by side.  Why: in the f16x3 mode the DiP path's small eight-wave GEMM returns rare wrong
+ *     values (one 16-lane row of one register reads as zero) when a workgroup of a DIFFERENT kernel that uses LDS is
+ *     resident on the same CU at the same time -- measured with this library's own chains on side streams AND with torch's
+ *     scaled_dot_product_attention kernels on a foreign stream (17 of 60 DiP window loops differed); never on disjoint CUs,
+ *     never in the f32 mode, and not on the encoder path (trans_enc: its kernels own a CU's whole LDS; 0 of 120 forwards
+ *     beside the same foreign stream).  Not cache coherence, not kernel ordering; cause not identified
+ *     (profiles/r03g_dip_groups.md).  THE RULE FOR CALLERS: while mdm_forward_dec / mdm_sample_loop_dec work is in flight
+ *     on a device, do not run other kernels that use LDS on it (GEMM-sized hipBLASLt + layer_norm chains and elementwise
+ *     kernels were measured harmless); the encoder calls need no such care.  Because of the event record, do not call into
  *     this library while `stream` is being captured into a hipGraph together with an earlier call from another stream.
  *   - all tensors are fp32, dense, in the reference's layouts: poses [B, njoints, nfeats, T] (T contiguous).
  */
