@@ -54,15 +54,21 @@ if os.environ.get("MDM_DEC_DUP_OUT") == "1" or os.environ.get("MDM_DEC_DUP_IN") 
     for k in range(n):
         lib.mdm_debug_get(201 + k, C.byref(d)); idx.append(int(d.value))
     import struct
-    vals = []
+    vals, raw = [], []
+    f = lambda u: struct.unpack("<f", struct.pack("<I", u))[0]
     for k in range(n):
         lib.mdm_debug_get(1000 + k, C.byref(d)); va = int(d.value)
         lib.mdm_debug_get(1256 + k, C.byref(d)); vb = int(d.value)
         f = lambda u: struct.unpack("<f", struct.pack("<I", u))[0]
         vals.append((idx[k] // 512, idx[k] % 512, f"{va:08x}", f"{vb:08x}", f(va), f(vb)))
+        raw.append((idx[k], va, vb))
     vals.sort()
+    inker = [(i, va, vb) for (i, va, vb) in raw if i >> 24]     # records of the in-kernel checks (gemm_f32.h MDM_F32_*_CHECK)
+    print(f"records: {n} kept ({len(inker)} from the in-kernel checks)")
+    for (i, va, vb) in inker[:64]:
+        print(f"    in-kernel: lane {i & 255} field {(i >> 8) & 255} wave {(i >> 16) & 255}: {va:08x} ({f(va):.6g}) vs {vb:08x} ({f(vb):.6g})")
     print("DUP differing elements (row, col, first run bits, second run bits, values):")
-    for v in vals[:96]:
+    for v in [v for v in vals if v[0] < 32768][:64]:
         print("   ", v)
 if os.environ.get("MDM_DEC_ORD") == "1":   # order probe (mdm_api.hip decoder_pass): LayerNorm rows finished vs OutputProcess's start
     import ctypes as C
