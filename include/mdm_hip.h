@@ -20,13 +20,15 @@
  *     that call's kernels.  Two model handles, two streams or two host threads on one GPU therefore run their kernels
  *     back to back, never side by side.  Why: in the f16x3 mode the DiP path's small eight-wave GEMM returns rare wrong
  *     values (one 16-lane row of one register reads as zero) when a workgroup of a DIFFERENT kernel that uses LDS is
- *     resident on the same CU at the same time -- measured with this library's own chains on side streams AND with torch's
- *     scaled_dot_product_attention kernels on a foreign stream (17 of 60 DiP window loops differed); never on disjoint CUs,
+ *     resident on the same CU at the same time -- measured with this library's own chains on side streams AND with another
+ *     library's fused attention kernels (scaled-dot-product attention) on a foreign stream (17 of 60 DiP window loops differed); never on disjoint CUs,
  *     never in the f32 mode, and not on the encoder path (trans_enc: its kernels own a CU's whole LDS; 0 of 120 forwards
  *     beside the same foreign stream).  Not cache coherence, not kernel ordering; cause not identified
- *     (profiles/r03g_dip_groups.md).  THE RULE FOR CALLERS: while mdm_forward_dec / mdm_sample_loop_dec work is in flight
- *     on a device, do not run other kernels that use LDS on it (GEMM-sized hipBLASLt + layer_norm chains and elementwise
- *     kernels were measured harmless); the encoder calls need no such care.  Because of the event record, do not call into
+ *     (profiles/r03g_dip_groups.md).  What cures it is building without packed fp32 VALU math (-fno-slp-vectorize, the
+ *     way __graft_entry__.build() builds this library: 0 of 520 window loops in the regimes that corrupted 100 of 520).
+ *     PRECAUTION FOR CALLERS, because the effect is not understood: while mdm_forward_dec / mdm_sample_loop_dec work is in
+ *     flight on a device and the results matter, keep other LDS-using kernels off it; never build the library with SLP
+ *     vectorisation if they cannot be kept off.  The encoder calls need no such care.  Because of the event record, do not call into
  *     this library while `stream` is being captured into a hipGraph together with an earlier call from another stream.
  *   - all tensors are fp32, dense, in the reference's layouts: poses [B, njoints, nfeats, T] (T contiguous).
  */
