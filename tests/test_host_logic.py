@@ -139,3 +139,12 @@ def test_shard_bounds_and_y_slicing():
     s = mdist.shard_y(y, 2, 5)
     assert s["mask"].shape[0] == 3 and s["lengths"].tolist() == [2, 3, 4] and s["text"] == ["c", "d", "e"]
     assert s["text_embed"].shape == (1, 3, 3) and s["text_embed"][0, 0, 0] == 2 and s["uncond"] is False
+
+
+def test_library_is_built_without_slp_vectorisation():
+    """profiles/r03g_dip_groups.md: packed fp32 VALU operations out of hipcc's SLP vectorizer lost their last 16 lanes on the MI355X
+    whenever an LDS-heavy workgroup of another kernel shared the CU (DiP path: 100 of 520 window loops); the flag is the cure
+    (0 of 520) and must not silently disappear from the build recipe."""
+    import __graft_entry__ as ge
+    assert "-fno-slp-vectorize" in ge.HIP_FLAGS
+    assert "--offload-arch=gfx950" in ge.HIP_FLAGS
