@@ -37,3 +37,27 @@ def test_dip_window_loop_is_reproducible_beside_a_foreign_attention_stream():
         torch.cuda.synchronize()
     print(f"[coresidency] DiP window loops differing beside the attention stream: {differing} of 24")
     assert differing == 0
+
+
+def test_encoder_forward_is_reproducible_beside_a_foreign_attention_stream():
+    """The control: the headline path (one CFG denoiser forward, ragged lengths) beside the same stream -- 0 of 120 forwards ever
+    differed, with either build."""
+    from helpers import synth_state_dict, synth_y
+    B, T = 16, 196
+    model, _ = make_pair(synth_state_dict(seed=0), 50, DEV, guided=True, precision="f16x3")
+    y = to_dev(synth_y(B, T, seed=3, lengths=[T - (7 * i) % 150 for i in range(B)]), DEV)
+    x = torch.randn(B, 263, 1, T, generator=torch.Generator().manual_seed(1)).to(DEV)
+    t = torch.full((B,), 25, dtype=torch.long, device=DEV)
+    with torch.no_grad():
+        ref = model(x, t, y=dict(y)).clone()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        q = torch.randn(16, 8, 256, 64, device=DEV, dtype=torch.float16)
+        differing = 0
+        for _ in range(10):
+            q = _hammer(side, q, 300)
+            outs = [model(x, t, y=dict(y)) for _ in range(3)]
+            torch.cuda.synchronize()
+            differing += sum(int(not torch.equal(o, ref)) for o in outs)
+    print(f"[coresidency] encoder forwards differing beside the attention stream: {differing} of 30")
+    assert differing == 0
