@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 
 # algorithmic flops of one MDM forward of one sample (S=197, d=512, ff=1024, L=8, J=263)
 PEAKS_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}      # MI355X_MICROARCH.md: fp32 MFMA / dense fp16 MFMA
-PMC_PROFILE = os.path.join("profiles", "r03_pmc.json")
+PMC_PROFILE = os.path.join("profiles", "r04_pmc.json")
 
 
 def algorithmic_flops_per_forward(T, d=512, ff=1024, L=8, J=263):
@@ -60,6 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the f32_mode, steps1000 and dip sub-records")
     ap.add_argument("--no-steps1000", action="store_true", help="skip the 1000-step (BASELINE.json configs[2]) sub-record")
+    ap.add_argument("--quick", action="store_true", help="the headline line only: no sub-records, no CPU baseline")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the B = 1 / 6 / 10 latency sub-record")
     # test infrastructure (tests/test_round2_cpu.py::test_bench_self_launches_two_ranks_from_a_bare_shell): the same launcher / sharding / gather / JSON code on CPU --
     # gloo ranks, kernels in the CPU emulator, a tiny model.  Never a measurement.
     ap.add_argument("--force-pg", action="store_true",
@@ -67,7 +69,10 @@ def parse_args(argv=None):
     ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--layers", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--latent-dim", type=int, default=512, help=argparse.SUPPRESS)
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.quick:
+        a.no_extras = a.no_cpu_baseline = True
+    return a
 
 
 def _free_port():
@@ -81,7 +86,12 @@ def self_launch(a, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's only working path on this driver
+    # HSA_ENABLE_IPC_MODE_LEGACY=0 selects dmabuf IPC.  It is this image's documented requirement for multi-process GPU work
+    # (the host driver supports dmabuf IPC only; without it RCCL / cross-process tensor sharing fails with
+    # `hipIpcGetMemHandle: invalid argument`) and is already exported on the GPU boxes -- kept here (setdefault: never overrides)
+    # so that a bare `python bench.py --gpus N` builds the same environment for its ranks.  Not measured by this repository:
+    # no N > 1 box has been offered to it.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     return subprocess.call(cmd, env=env)
 
@@ -145,9 +155,11 @@ def cpu_baseline(state, T, dsteps, runs=2):
 
     # torch's default intra-op thread count is every hardware thread of the box; at batch 1 (197-row GEMMs) that
     # over-subscription is SLOWER than a few cores (128 threads: ~17 s per motion on the GPU box, the 8-vCPU build container:
-    # 2.3 s).  Both settings are timed -- all threads once, a moderate count `runs` times -- and the better one is the value.
+    # 2.3 s).  So the thread count is swept and the best setting is the value.
     all_thr = torch.get_num_threads()
-    settings = [(all_thr, 1), (16, runs)] if all_thr > 16 else [(all_thr, runs)]
+    # sweep {8, 16, 32, 64} (those the box has) once each, then `runs` - 1 more passes at the best one; all threads once
+    sweep = sorted({n for n in (8, 16, 32, 64) if n < all_thr} | ({all_thr} if all_thr <= 64 else set()))
+    settings = [(n, 1) for n in sweep]      # (all of a 256-thread box's threads: 0.076 motions/s in round 3, 10x slower than 16)
     results = []
     with torch.no_grad():
         for nthr, n in settings:
@@ -160,6 +172,12 @@ def cpu_baseline(state, T, dsteps, runs=2):
                 ts.append(time.perf_counter() - t0)
                 assert bool(torch.isfinite(out).all())
             results.append((nthr, ts))
+        best_thr = min(results, key=lambda r: sum(r[1]) / len(r[1]))[0]
+        torch.set_num_threads(best_thr)
+        for _ in range(max(runs - 1, 0)):        # the winner again: its value is a mean of `runs` whole loops
+            t0 = time.perf_counter()
+            out = runner()
+            [r for r in results if r[0] == best_thr][0][1].append(time.perf_counter() - t0)
         torch.set_num_threads(all_thr)
     best_thr, best_ts = min(results, key=lambda r: sum(r[1]) / len(r[1]))
     mean = sum(best_ts) / len(best_ts)
@@ -170,7 +188,7 @@ def cpu_baseline(state, T, dsteps, runs=2):
             "runs_s": {str(nthr): [round(t, 3) for t in ts] for nthr, ts in results},
             "sample_steps_per_s": round(B * dsteps / mean, 2),
             "sample": f"BASELINE.json configs[0]: {what}, CFG 2.5, batch={B}, T={T}, all {dsteps} diffusion steps, whole loop "
-                      f"timed after a 2-step warm-up loop at {' and '.join(str(r[0]) for r in results)} intra-op threads "
+                      f"timed after a 2-step warm-up loop at {' / '.join(str(r[0]) for r in results)} intra-op threads "
                       f"({os.cpu_count()} logical host CPUs; keys of runs_*); value = the faster setting ({best_thr} threads, "
                       f"mean of {len(best_ts)}); a reported baseline, not a target"}
 
@@ -181,10 +199,10 @@ def cpu_baseline(state, T, dsteps, runs=2):
 ALGORITHMIC_GEMM_BYTES_PER_LAUNCH = int((458.9e6 + 310.9e6 + 311.9e6 + 415.2e6) / 4)
 
 
-def measure_steps1000(mdm, model, dev, sync, T, layers, latent_dim, B=64, dsteps=1000):
+def measure_steps1000(mdm, model, dev, sync, T, layers, latent_dim, B=64, dsteps=1000, passes=2):
     """BASELINE.json configs[2]: the 1000-step DDPM p_sample_loop at batch = 64 on this GPU (`step-fusion stress`:
     diffusion/gaussian_diffusion.py:708 runs its loop body 1000x): one short warm-up loop (8-step schedule, same kernels
-    and shapes) + ONE timed pass of the whole 1000-step loop, same model / weights / arithmetic as the headline."""
+    and shapes) + `passes` timed passes of the whole 1000-step loop, same model / weights / arithmetic as the headline."""
     import torch
     from mdm_amd import model_util
     diff = model_util.create_gaussian_diffusion(model_util.default_args(diffusion_steps=dsteps, layers=layers,
@@ -195,16 +213,20 @@ def measure_steps1000(mdm, model, dev, sync, T, layers, latent_dim, B=64, dsteps
     shape = (B, 263, 1, T)
     warm.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, seed=1)
     sync()
-    t0 = time.perf_counter()
-    out = diff.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, seed=2)
-    sync()
-    dt = time.perf_counter() - t0
-    assert out.shape[0] == B and bool(torch.isfinite(out).all())
+    dts = []
+    for k in range(passes):
+        t0 = time.perf_counter()
+        out = diff.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, seed=2 + k)
+        sync()
+        dts.append(time.perf_counter() - t0)
+        assert out.shape[0] == B and bool(torch.isfinite(out).all())
+    dt = sum(dts) / len(dts)
     fwd = algorithmic_flops_per_forward(T)
     return {"value": round(B / dt, 3), "unit": "motions/s", "sample_steps_per_s": round(B * dsteps / dt, 1),
-            "ms_per_step": round(dt * 1e3, 2), "steps": 1, "model_tflops": round(B * dsteps / dt * 2 * fwd / 1e12, 2),
+            "ms_per_step": round(dt * 1e3, 2), "steps": passes, "passes_ms": [round(t * 1e3, 1) for t in dts],
+            "model_tflops": round(B * dsteps / dt * 2 * fwd / 1e12, 2),
             "config": {"workload": f"BASELINE.json configs[2]: HumanML3D {dsteps}-step DDPM p_sample_loop with CFG 2.5, "
-                                   f"batch={B}, T={T}, same model and f16x3 arithmetic as the headline; one timed pass",
+                                   f"batch={B}, T={T}, same model and f16x3 arithmetic as the headline; mean of {passes} timed passes",
                        "global_batch": B, "diffusion_steps": dsteps}}
 
 
@@ -217,6 +239,18 @@ def csrc_sha256():
         h.update(os.path.basename(p).encode())
         with open(p, "rb") as f:
             h.update(f.read())
+    # ... AND of how it was built: round 3 changed the binary with a flag (-fno-slp-vectorize) and no source edit
+    import __graft_entry__ as ge
+    h.update(" ".join(ge.HIP_FLAGS).encode())
+    return h.hexdigest()
+
+
+def lib_sha256():
+    """sha256 of the product library itself (the binary the numbers of this line were taken on)."""
+    from mdm_amd import _native
+    h = hashlib.sha256()
+    with open(_native.LIB_PATH, "rb") as f:
+        h.update(f.read())
     return h.hexdigest()
 
 
@@ -235,9 +269,9 @@ def pmc_traffic_per_gemm_launch():
         tot = sum(d["gemm"][k]["hbm_bytes"] * n for k, n in per_layer.items())
         val = int(tot / sum(per_layer.values()))
         if d.get("csrc_sha256") != csrc_sha256():
-            # quoted, but flagged: the kernels were edited after the PMC passes were taken (re-run tools/gpu_prof.sh pmc)
-            return val, True, (f"{PMC_PROFILE}: taken on OTHER kernel sources (csrc_sha256 differs) -- stale, see "
-                               f"roofline.traffic_stale")
+            # the kernels (or their build flags) changed after the PMC passes were taken: NOT quoted (re-run tools/gpu_prof.sh pmc)
+            return None, True, (f"{PMC_PROFILE}: taken on OTHER kernel sources / build flags (csrc_sha256 differs): "
+                                f"{val} bytes/launch there, not quoted here")
         return val, False, f"{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command)"
     except (KeyError, ValueError, OSError) as e:
         return None, False, f"{PMC_PROFILE} unreadable ({type(e).__name__})"
@@ -299,24 +333,46 @@ def main(argv=None):
             dist.barrier()
         sync()
 
-    def timed(passes, warmup, seed0):
+    rank_ms = {}     # label -> per-rank [loop milliseconds] of the last timed() call (a straggler shows as max >> min)
+
+    def timed(passes, warmup, seed0, label="headline"):
         for w in range(warmup):
             one_pass(w)
         fence()
+        # the sampler seam's finite check (one reduction + host sync per loop, gaussian_diffusion.py _check_finite) is moved
+        # OUT of the timed region: switched off here, and the same check is asserted on the last sample behind the clock
+        prev = os.environ.get("MDM_CHECK_FINITE")
+        os.environ["MDM_CHECK_FINITE"] = "0"
         t0 = time.perf_counter()
         out = None
+        t_own = 0.0
         for k in range(passes):
             out = one_pass(seed0 + k)
+        sync()
+        t_own = time.perf_counter() - t0           # this rank's own loops + its part of the gathers, before the rendezvous
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if prev is None:
+            del os.environ["MDM_CHECK_FINITE"]
+        else:
+            os.environ["MDM_CHECK_FINITE"] = prev
+        per_rank = [t_own * 1e3 / passes]
+        if dist.is_initialized():
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+            mine = torch.tensor([t_own * 1e3 / passes], dtype=torch.float64, device=dev)
+            allr = torch.empty(world, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(allr, mine)
+            per_rank = [float(v) for v in allr.tolist()]
+        rank_ms[label] = per_rank
         assert out.shape[0] == GB and bool(torch.isfinite(out).all())
+        rank_ms["gathered_shape"] = list(out.shape)
         return dt
 
     dt = timed(a.steps, a.warmup, 100)
+    rank_ms["headline"] = list(rank_ms["headline"])
+    headline_shape = list(rank_ms["gathered_shape"])
 
     def flush_c_stdio():
         # RCCL printf()s a version banner into C stdio's buffer at communicator creation; flushed only at exit it would land
@@ -340,11 +396,11 @@ def main(argv=None):
     if extras and a.precision != "f32":
         # the same workload on the exact-fp32 MFMA kernels (the on-device parity reference): one warm-up + one timed pass
         mdm.precision = "f32"
-        f32_dt = timed(1, 1, 500)
+        f32_dt = timed(2, 1, 500, label="f32_mode") / 2
         mdm.precision = a.precision
         fwd = algorithmic_flops_per_forward(T)
         f32_tf = GB / f32_dt * DS * 2 * fwd / 1e12
-        f32_mode = {"value": round(GB / f32_dt, 3), "unit": "motions/s", "ms_per_step": round(f32_dt * 1e3, 3), "steps": 1,
+        f32_mode = {"value": round(GB / f32_dt, 3), "unit": "motions/s", "ms_per_step": round(f32_dt * 1e3, 3), "steps": 2,
                     "model_tflops": round(f32_tf, 2), "frac_of_157.3TF": round(f32_tf / 157.3, 4),
                     "dtype": "f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
     steps1000 = None
@@ -375,7 +431,14 @@ def main(argv=None):
             "ranks": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
                       "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""))
                       if dist.is_initialized() else "none (single process)",
-                      "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"},
+                      "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct",
+                      # each rank's own time per loop (its kernels + its side of the all-gather), before the closing barrier:
+                      # the line's `value` uses the MAX over ranks of the barrier-to-barrier time; a straggler shows here
+                      "loop_ms_per_rank": [round(v, 3) for v in rank_ms["headline"]],
+                      "loop_ms_min": round(min(rank_ms["headline"]), 3), "loop_ms_max": round(max(rank_ms["headline"]), 3),
+                      "gathered_shape": headline_shape},
+            "build": {"csrc_sha256": csrc_sha256(), "lib_sha256": lib_sha256(),
+                      "info": eng.lib.lib.mdm_build_info().decode() if hasattr(eng.lib.lib, "mdm_build_info") else None},
             "sample_steps_per_s": round(motions_s * DS, 1),
             "model_tflops": round(motions_s * DS * 2 * fwd / 1e12, 2),
             "roofline": {"bound": "mfma",

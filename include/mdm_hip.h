@@ -28,8 +28,11 @@
  *     way __graft_entry__.build() builds this library: 0 of 520 window loops in the regimes that corrupted 100 of 520).
  *     PRECAUTION FOR CALLERS, because the effect is not understood: while mdm_forward_dec / mdm_sample_loop_dec work is in
  *     flight on a device and the results matter, keep other LDS-using kernels off it; never build the library with SLP
- *     vectorisation if they cannot be kept off.  The encoder calls need no such care.  Because of the event record, do not call into
- *     this library while `stream` is being captured into a hipGraph together with an earlier call from another stream.
+ *     vectorisation if they cannot be kept off (mdm_build_info() says how a binary was built; the loaders check it).  The
+ *     encoder calls need no such care.
+ *   - hipGraph CAPTURE: supported for a loop that stays on ONE stream (since ABI 8 a same-stream call makes no HIP runtime
+ *     call besides its kernel launches and device-to-device copies: the per-device guard is a host mutex).  Not supported: a
+ *     capture that contains calls from two different streams (the guard records an event on the earlier stream).
  *   - all tensors are fp32, dense, in the reference's layouts: poses [B, njoints, nfeats, T] (T contiguous).
  */
 #ifndef MDM_HIP_H
@@ -49,7 +52,7 @@ extern "C" {
 #define MDM_EHIP (-4)     /* a HIP runtime call failed                         */
 #define MDM_EUNSUPPORTED (-5)
 
-#define MDM_ABI_VERSION 7
+#define MDM_ABI_VERSION 8
 
 typedef struct mdm_model mdm_model_t;
 
@@ -74,6 +77,11 @@ typedef struct mdm_config {
 } mdm_config_t;
 
 int mdm_abi_version(void);
+/* How the binary was built, as "key=value;..." -- "slp=off|on;probes=0|1;emu=0|1;planes=f16|bf16".  "slp=off" means the
+ * library was compiled with -fno-slp-vectorize -DMDM_NO_SLP=1 (no packed fp32 VALU math), the only build in which the DiP path
+ * is immune to the co-residency corruption described under CONCURRENCY above; the Python loader (_native.py) and the ctypes
+ * stub of INTEGRATION.md refuse any other product library unless MDM_ALLOW_SLP_BUILD=1 is set (A/B experiments).  ABI 8. */
+const char* mdm_build_info(void);
 const char* mdm_last_error(void);
 
 /* MDM(...) constructor (model/mdm.py:11-135) -- shapes only, no weights yet. */

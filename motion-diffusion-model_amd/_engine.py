@@ -54,14 +54,17 @@ class Engine:
         """'f16x3' (default: split-precision bf16 MFMA for the encoder GEMMs) or 'f32' (exact-fp32 MFMA)."""
         if precision not in nat.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(nat.PRECISIONS)}, got {precision!r}")
+        # refuse BEFORE switching: a caller that catches the error (to fall back) must not be left with a live engine in
+        # f16x3 on weight planes that do not fit it
+        self._check_weight_range(precision)
         self.lib.check(self.lib.mdm_set_precision(self.handle, nat.PRECISIONS[precision]), "mdm_set_precision")
         self.precision = precision
-        self._check_weight_range()
 
-    def _check_weight_range(self):
+    def _check_weight_range(self, precision=None):
         """The f16x3 operand planes hold w * 2^8 as fp16 hi + lo: a weight (or LayerNorm-gamma-folded weight) with
         |w| >= 255.9 does not fit (include/mdm_hip.h mdm_weights_in_range).  Loud at bind / mode switch, not as NaN samples."""
-        if getattr(self, "ready", False) and self.precision != "f32" and not getattr(self, "weights_in_range", True):
+        precision = self.precision if precision is None else precision
+        if getattr(self, "ready", False) and precision != "f32" and not getattr(self, "weights_in_range", True):
             raise nat.MdmError(
                 "this checkpoint does not fit the default precision='f16x3': a weight matrix (possibly scaled by the "
                 "LayerNorm gamma folded into it) has an entry of magnitude >= 255.9, beyond the fp16 operand planes "

@@ -19,7 +19,7 @@ PRECISIONS = {"f32": 0, "f16x3": 1}
 PROF_CLASSES = ("linear", "attention", "layernorm", "embed", "outproj", "elementwise")
 
 EXPORTED_SYMBOLS = [
-    "mdm_abi_version", "mdm_last_error", "mdm_create", "mdm_destroy", "mdm_set_weight", "mdm_const_bytes",
+    "mdm_abi_version", "mdm_build_info", "mdm_last_error", "mdm_create", "mdm_destroy", "mdm_set_weight", "mdm_const_bytes",
     "mdm_prepare", "mdm_workspace_bytes", "mdm_forward", "mdm_sampler_step", "mdm_randn", "mdm_sample_loop",
     "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset",
     "mdm_set_precision", "mdm_linear_x3", "mdm_linear_x3_scratch_bytes", "mdm_attention_x3", "mdm_attention_x3_scratch_bytes",
@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
 ]
 # include/mdm_hip_probe.h: exported by the probe build only
 PROBE_SYMBOLS = ["mdm_debug_set", "mdm_debug_get", "mdm_linear_f16f6", "mdm_linear_f16f6_scratch_bytes", "mdm_probe_in_proj"]
-ABI_VERSION = 7
+ABI_VERSION = 8
 ARCH = {"trans_enc": 0, "trans_dec": 1}
 
 
@@ -79,6 +79,7 @@ class MdmLib:
         sig = {
             "mdm_abi_version": (C.c_int, []),
             "mdm_last_error": (C.c_char_p, []),
+            "mdm_build_info": (C.c_char_p, []),
             "mdm_create": (C.c_int, [P(MdmConfig), P(vp)]),
             "mdm_destroy": (None, [vp]),
             "mdm_set_weight": (C.c_int, [vp, C.c_char_p, vp, i64]),
@@ -123,6 +124,15 @@ class MdmLib:
             fn.argtypes = args
         if lib.mdm_abi_version() != ABI_VERSION:
             raise MdmError(f"{path}: ABI version {lib.mdm_abi_version()} != {ABI_VERSION}")
+        self.build_info = dict(kv.split("=", 1) for kv in lib.mdm_build_info().decode().split(";"))
+        # A GPU library built WITH packed fp32 VALU math (hipcc's SLP vectorizer) returns rare wrong DiP samples whenever another
+        # LDS-using kernel shares a CU with its small GEMM (include/mdm_hip.h CONCURRENCY; profiles/r03g_dip_groups.md): refuse
+        # it at load time instead of trusting whoever built it.  (The CPU emulator of tests/emu has no such hazard.)
+        if self.build_info.get("emu") != "1" and self.build_info.get("slp") != "off" \
+                and os.environ.get("MDM_ALLOW_SLP_BUILD") != "1":
+            raise MdmError(f"{path} was built without -fno-slp-vectorize -DMDM_NO_SLP=1 (mdm_build_info: "
+                           f"{lib.mdm_build_info().decode()}): rebuild with `python __graft_entry__.py`, or set "
+                           f"MDM_ALLOW_SLP_BUILD=1 for an A/B experiment on an otherwise idle device")
 
     def check(self, rc, what):
         if rc != MDM_OK:

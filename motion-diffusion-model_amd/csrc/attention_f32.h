@@ -52,6 +52,10 @@ struct AttnF32Args {
   // local sequence (branch br, sample bl) reads source sequence br * kv_B + kv_b0 + bl; kv_B = 0: the source is local
   int kv_B = 0;
   int kv_b0 = 0;
+  // `lengths` may likewise describe MORE samples than this launch covers: local sample bl is entry len_b0 + bl of an array
+  // laid out for len_B samples (counts [len_B], then -- ABI 7 bitmap form -- eight words per sample); len_B = 0: B samples
+  int len_B = 0;
+  int len_b0 = 0;
 };
 
 // blockDim.x = 64 * ceil(Sq / 32): wave w owns query rows [32w, 32w + 32); NKT = ceil(Sk / 32) key tiles.
@@ -80,9 +84,10 @@ __global__ __launch_bounds__(448) void attention_f32_kernel(AttnF32Args a, float
   int nvalid = S;
   const uint32_t* kbits = nullptr;   // arbitrary frame mask of this sequence (common.h key_valid_bits), else a count
   if (a.lengths != nullptr) {
-    const int cnt = a.lengths[seq % a.B];
+    const int lb = a.len_b0 + seq % a.B, LB = a.len_B > 0 ? a.len_B : a.B;
+    const int cnt = a.lengths[lb];
     if (cnt >= 0) nvalid = min(S, a.lead + cnt);
-    else kbits = reinterpret_cast<const uint32_t*>(a.lengths + a.B + 8 * (seq % a.B));
+    else kbits = reinterpret_cast<const uint32_t*>(a.lengths + LB + 8 * lb);
   }
 
   // ---- Q fragment: query row q = 32w + r, this lane-half's 64 d's

@@ -269,8 +269,10 @@ int launch_attention_args(Profiler* pf, const AttnF32Args& a, float* out, int ns
 
 // self-attention over packed qkv rows [nseq*S][3D]; `lead` tokens in front of the frames are never masked
 int launch_attention(Profiler* pf, const float* qkv, float* out, const int* lengths, int nseq, int B, int S, int D,
-                     int H, p16_t* oh, p16_t* ol, hipStream_t s, int lead = 1) {
-  const AttnF32Args a{qkv, 3 * D, qkv + D, qkv + 2 * D, 3 * D, S, S, lengths, lead, B};
+                     int H, p16_t* oh, p16_t* ol, hipStream_t s, int lead = 1, int len_B = 0, int len_b0 = 0) {
+  AttnF32Args a{qkv, 3 * D, qkv + D, qkv + 2 * D, 3 * D, S, S, lengths, lead, B};
+  a.len_B = len_B;     // `lengths` covers len_B samples, this launch samples len_b0 .. len_b0 + B - 1 of them (0: exactly B)
+  a.len_b0 = len_b0;
   return launch_attention_args(pf, a, out, nseq, D, H, oh, ol, s);
 }
 
@@ -622,13 +624,16 @@ int outproj_x3(mdm_model* m, const Workspace& ws, int nseq, int B, int T, const 
   return rt_launch_status();
 }
 
-// ONE chain of this library's kernels per device.  Two chains of these kernels running concurrently on one GPU (two model
-// handles, two streams, two host threads) intermittently read stale cache lines of rows their own predecessor kernel had
-// rewritten (round 2: profiles/r02e_dip.md, DESIGN.md section 9 -- seen with the f16x3 kernels under two hardware queues,
-// cured by cache-bypassing loads in one loader, root cause not established).  Until it is, the library enforces what its
-// header states: every exported call that enqueues kernels holds this guard, which (i) serialises the host-side enqueue per
-// device and (ii) makes the caller's stream wait for the event recorded behind the previous call's kernels when that call
-// ran on ANOTHER stream.  Same-stream callers (every caller the reference has) pay one hipEventRecord per call.
+// ONE chain of this library's kernels per device (include/mdm_hip.h, "CONCURRENCY").  Why the guard exists: in the f16x3 mode
+// the DiP path's small eight-wave GEMM returned rare wrong values when a workgroup of a DIFFERENT LDS-using kernel was
+// co-resident on its CU -- this library's own chains on side streams, or another library's attention kernels on a foreign
+// stream.  NOT cache coherence and not kernel ordering (round 2's "stale cache lines" reading was disproved in round 3:
+// profiles/r03g_dip_groups.md); cause unknown; what cures it is the build without packed fp32 VALU math (mdm_build_info()).
+// The guard keeps this library's own calls from overlapping each other: every exported call that enqueues kernels (i) takes a
+// per-device lock for the duration of the host-side enqueue and (ii) when the previous call on this device used ANOTHER
+// stream, records an event behind that stream's work and makes the caller's stream wait for it.  Same-stream callers --
+// every caller the reference has -- pay one uncontended mutex and NO HIP call (round 3 recorded an event per call), so a
+// single-stream loop may be captured into a hipGraph.  It cannot, of course, keep FOREIGN kernels off the device.
 #ifdef MDM_EMU
 struct ChainGuard { explicit ChainGuard(void*) {} };
 #else
@@ -644,12 +649,16 @@ struct ChainGuard {
   hipStream_t s;
   explicit ChainGuard(void* stream) : c(g_chain[rt_device_ordinal()]), s(static_cast<hipStream_t>(stream)) {
     c.mu.lock();
-    if (c.has && c.last != s) (void)hipStreamWaitEvent(s, c.ev, 0);
+    if (c.has && c.last != s) {
+      // everything the previous caller's stream holds so far (its call's kernels, and whatever it enqueued since) first
+      if (c.ev == nullptr && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) c.ev = nullptr;
+      if (c.ev != nullptr && hipEventRecord(c.ev, c.last) == hipSuccess) (void)hipStreamWaitEvent(s, c.ev, 0);
+      else (void)hipGetLastError();   // (the other stream no longer exists: its work has drained)
+    }
   }
   ~ChainGuard() {
-    if (c.ev == nullptr && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) c.ev = nullptr;
-    if (c.ev != nullptr && hipEventRecord(c.ev, s) == hipSuccess) { c.last = s; c.has = true; }
-    else c.has = false;
+    c.last = s;
+    c.has = true;
     c.mu.unlock();
   }
   ChainGuard(const ChainGuard&) = delete;
@@ -668,6 +677,35 @@ int check_ready(const mdm_model* m) {
 extern "C" {
 
 int mdm_abi_version(void) { return MDM_ABI_VERSION; }
+
+// How this binary was built (include/mdm_hip.h): the loaders refuse a product library whose string lacks "slp=off".
+const char* mdm_build_info(void) {
+  return "slp="
+#ifdef MDM_NO_SLP
+         "off"
+#else
+         "on"
+#endif
+         ";probes="
+#ifdef MDM_PROBES
+         "1"
+#else
+         "0"
+#endif
+         ";emu="
+#ifdef MDM_EMU
+         "1"
+#else
+         "0"
+#endif
+         ";planes="
+#ifdef MDM_SPLIT_BF16
+         "bf16"
+#else
+         "f16"
+#endif
+      ;
+}
 const char* mdm_last_error(void) { return g_err.c_str(); }
 
 int mdm_create(const mdm_config_t* cfg, mdm_model_t** out) {
@@ -1121,7 +1159,9 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
     if (int rc = launch_linear_lnfold(pf, ws.tok, D, pend, folded ? F.w_in : m->L(l, "self_attn.in_proj_weight"), P.in_proj,
                                       folded ? F.b_in : m->L(l, "self_attn.in_proj_bias"), folded ? F.c_in : nullptr, nullptr,
                                       none, ws.qkv, nullptr, M, 3 * D, D, ACT_NONE, D, qscale, s, x3)) return rc;
-    if (int rc = launch_attention(pf, ws.qkv, ws.att, len, nseq, B, S, D, H, nullptr, nullptr, s, /*lead=*/0)) return rc;
+    // (hoisted: `lengths` is the WHOLE batch's array -- counts, then the ABI-7 bitmaps -- and this pass covers samples kv_b0 ..)
+    if (int rc = launch_attention(pf, ws.qkv, ws.att, len, nseq, B, S, D, H, nullptr, nullptr, s, /*lead=*/0,
+                                  hoisted ? hz.kv_B : 0, hoisted ? hz.kv_b0 : 0)) return rc;
     if (int rc = launch_linear_lnfold(pf, ws.att, D, none, m->L(l, "self_attn.out_proj.weight"), P.out_proj,
                                       m->L(l, "self_attn.out_proj.bias"), nullptr, ws.tok, pend, ws.tok, ws.stat[sp ^ 1], M, D, D,
                                       ACT_NONE, 0, 1.f, s, x3)) return rc;
@@ -1428,7 +1468,7 @@ int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float
       hz.step = k; hz.nsteps = nsteps; hz.kv_text = ws.kv_text; hz.kv_time = ws.kv_time; hz.kv_B = B; hz.kv_b0 = b0;
       const float* prefix_g = pd->prefix_dev != nullptr ? pd->prefix_dev + (size_t)b0 * m->jf * m->cfg.context_len : nullptr;
       rc_loop = decoder_pass(m, wg, x + xo, prefix_g, nullptr, p->text_embed_dev, pd->text_lengths_dev + b0,
-                             p->lengths_dev != nullptr ? p->lengths_dev + b0 : nullptr, Bg, P, ntok, branches, wg.out, gs[g], hz);
+                             p->lengths_dev, Bg, P, ntok, branches, wg.out, gs[g], hz);
       if (rc_loop != MDM_OK) break;
       // CFG combine + posterior / DDIM update, in place on x (each element is read, then written, by the same lane)
       StepCoefs co{p->a_x0[i], p->a_xt[i], p->sigma[i], p->clip_denoised};

@@ -152,7 +152,6 @@ class MDM(nn.Module):
         self.rot2xyz = _IdentityRot2xyz()
         self._engine = None
         self._engine_key = None
-        self._engine_params = self._engine_quick = None
 
     # ---- text encoder (outside the hot path: runs once per prompt batch on the host side) ------------
     @staticmethod
@@ -219,18 +218,14 @@ class MDM(nn.Module):
         return sd
 
     def engine(self):
-        """Native handle bound to the current parameters (rebuilt when they move or change).  The per-call check is one pass
-        over the parameters' in-place version counters (load_state_dict / optimizer steps bump them; .to() / .half() go through
-        _apply, which drops the engine); the full (data_ptr, version) key of ~150 tensors is only rebuilt when that sum, the
-        first parameter's address or the precision changed."""
-        params = self._engine_params
-        if params is None:
-            params = self._engine_params = list(self.parameters_wo_clip())
-        quick = (self.precision, params[0].data_ptr(), sum(q._version for q in params))
-        if self._engine is not None and self._engine_quick == quick:
-            return self._engine
+        """Native handle bound to the current parameters (rebuilt when they move or change).  The key is rebuilt on EVERY call
+        from a fresh walk over the module's parameters -- (data_ptr, in-place version) of each of the ~150 tensors, a few
+        microseconds -- so that nothing that can change a weight slips past it: in-place updates and load_state_dict bump the
+        version, `load_state_dict(assign=True)`, re-assigning any nn.Parameter and `p.data = other` move the address (round 3
+        cached the parameter LIST and compared its first address + the version sum only: all three of those kept serving the
+        old weights, tests/test_host_logic.py::test_engine_key_sees_every_kind_of_weight_change)."""
         p = self.input_process.poseEmbedding.weight
-        params = self._engine_params = list(self.parameters_wo_clip())       # (a parameter may have been re-assigned)
+        params = self.parameters_wo_clip()
         key = (str(p.device), self.precision) + tuple((q.data_ptr(), q._version) for q in params)
         if self._engine is None or self._engine_key != key:
             cfg = dict(njoints=self.njoints, nfeats=self.nfeats, latent_dim=self.latent_dim, ff_size=self.ff_size,
@@ -240,7 +235,6 @@ class MDM(nn.Module):
             eng = Engine(cfg, lib=self._native_lib, precision=self.precision)
             eng.bind(self._native_state(), p.device)
             self._engine, self._engine_key = eng, key
-        self._engine_quick = (self.precision, params[0].data_ptr(), sum(q._version for q in params))
         return self._engine
 
     @staticmethod
@@ -394,6 +388,5 @@ class MDM(nn.Module):
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._engine = None   # parameters moved: rebind lazily
-        self._engine_params = self._engine_quick = None
         self._len_cache = self._dec_cache = None
         return r

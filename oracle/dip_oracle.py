@@ -3,7 +3,8 @@ DistilBERT text memory, prefix completion and the autoregressive sampler.  Only 
 bench.py's cpu_baseline leg may import this module; the product path never does.
 
 Pinned against the upstream reference by oracle/make_golden_dip.py (tests/golden/dip_*.npz, PIN_REPORT.json "dip").
-Scope: emb_policy='add', emb_trans_dec=False, text_encoder_type='bert' -- the configuration DiP ships with.
+Scope: emb_policy='add', emb_trans_dec=False, text_encoder_type='bert' -- the configuration DiP ships with -- and, since
+round 4, text_encoder_type='clip' (one memory token per sample, mdm.py:261-262; pinned by oracle/make_golden_r4.py).
 
 Reference lines restated (paths relative to the upstream tree):
   model/mdm.py:85-93      nn.TransformerDecoder of post-norm nn.TransformerDecoderLayer (gelu)
@@ -71,7 +72,10 @@ def dip_forward(sd, x, timesteps, y, *, context_len, num_heads=4, mask_frames=Fa
         x = torch.cat([y["prefix"].to(dtype), x], dim=-1)
         mask = torch.cat([torch.ones(B, 1, 1, context_len, dtype=mask.dtype), mask], dim=-1)
     S = x.shape[-1]
-    enc, text_pad = y["text_embed"]
+    if isinstance(y["text_embed"], tuple):
+        enc, text_pad = y["text_embed"]
+    else:      # text_encoder_type='clip' (mdm.py:261-262): ONE memory token per sample [1, B, clip_dim], no memory pad mask
+        enc, text_pad = y["text_embed"], torch.zeros(B, y["text_embed"].shape[0], dtype=torch.bool)
     enc = enc.to(dtype)
     if text_pad.shape[0] == 1 and B > 1:                                          # mdm.py:215-216
         text_pad = text_pad.repeat_interleave(B, dim=0)

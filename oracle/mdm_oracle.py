@@ -213,7 +213,7 @@ def ddim_step(tab, x, x0, t, noise, eta=0.0):
 
 def sample_loop(sd, tab, shape, y, x_T, step_noise, *, cfg=True, ddim=False, eta=0.0, clip_denoised=False,
                 skip_timesteps=0, init_image=None, timestep_map=None, num_heads=4, mask_frames=True,
-                dtype=torch.float32, return_all=False, const_noise=False):
+                dtype=torch.float32, return_all=False, const_noise=False, fixed_large=False):
     """p_sample_loop / ddim_sample_loop with an injected noise sequence.
 
     x_T: the torch.randn(*shape) of gaussian_diffusion.py:691; step_noise[k]: the k-th randn_like of
@@ -242,7 +242,7 @@ def sample_loop(sd, tab, shape, y, x_T, step_noise, *, cfg=True, ddim=False, eta
         nz = step_noise[k].to(dtype)
         if const_noise:                                                           # gaussian_diffusion.py:527-528
             nz = nz[[0]].repeat(B, 1, 1, 1)
-        img = ddim_step(tab, img, x0, t, nz, eta) if ddim else ddpm_step(tab, img, x0, t, nz)
+        img = ddim_step(tab, img, x0, t, nz, eta) if ddim else ddpm_step(tab, img, x0, t, nz, fixed_large)
         if return_all:
             traj.append(img.clone())
     return (img, traj) if return_all else img

@@ -323,3 +323,103 @@ def test_emulated_dip_window_loop_sample_groups(lib, monkeypatch, prec):
         tab = orc.Tables(orc.named_betas("cosine", steps))
         want = dip.dip_sample_loop(sd, tab, (B, 263, 1, P), y, seq[0], seq[1:], context_len=C, cfg=True, num_heads=2)
         assert maxabs(many, want) < 5e-5
+
+
+@pytest.mark.parametrize("ddim,clip,fixed_large", [(False, True, False), (True, True, False), (False, False, True)])
+def test_emulated_loop_clip_denoised_and_fixed_large(lib, ddim, clip, fixed_large):
+    """`clip_denoised=True` -- the reference's signature default, gaussian_diffusion.py:591-608, :347-353 -- and FIXED_LARGE
+    variances (:325-333) through the fused loop, on the emulator (the GPU suite holds the same branches against fixtures of the
+    upstream reference: tests/test_gpu_round4.py); the clamp must be live on the case."""
+    steps, B, T = 3, 2, 9
+    sd = small_state_dict(num_layers=1)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, sigma_small=not fixed_large)
+    y = synth_y(B, T, seed=5, lengths=[T, 4])
+    shape = (B, 263, 1, T)
+    x_T, noises = orc.make_noise(shape, steps, 11)
+    fn = diffusion.ddim_sample_loop if ddim else diffusion.p_sample_loop
+    seq = [x_T] + [n.contiguous() for n in noises]
+    got = fn(model, shape, clip_denoised=clip, model_kwargs={"y": dict(y)}, noise_sequence=seq)
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    kw = dict(cfg=True, num_heads=2, ddim=ddim, fixed_large=fixed_large)
+    want = orc.sample_loop(sd, tab, shape, y, x_T, noises, clip_denoised=clip, **kw)
+    assert maxabs(got, want) < 2e-5
+    if clip:
+        assert maxabs(want, orc.sample_loop(sd, tab, shape, y, x_T, noises, clip_denoised=False, **kw)) > 1e-2
+        default = fn(model, shape, model_kwargs={"y": dict(y)}, noise_sequence=seq)       # the signature default IS the clamp
+        assert torch.equal(default, got)
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_emulated_trans_dec_with_clip_memory(lib, prec):
+    """model/mdm.py:85-93, :261-262: the decoder with `text_encoder_type='clip'` -- ONE memory token per sample, no memory pad
+    mask -- forwards (cond / uncond / guided) and a window loop against the oracle."""
+    B, C, P, steps = 2, 5, 12, 2
+    from oracle.synth import synth_dip_state_dict
+    sd = synth_dip_state_dict(seed=1, latent_dim=256, num_layers=1, bert_dim=512)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, precision=prec,
+                                 text_encoder_type="clip")
+    assert model.model.clip_dim == 512
+    g = torch.Generator().manual_seed(3)
+    y = {"mask": torch.ones(B, 1, 1, P, dtype=torch.bool), "lengths": torch.full((B,), P),
+         "text_embed": torch.randn(1, B, 512, generator=g), "prefix": torch.randn(B, 263, 1, C, generator=g),
+         "scale": torch.ones(B) * 2.5}
+    x = torch.randn(B, 263, 1, P, generator=g)
+    t = torch.tensor([1, 0])
+    kw = dict(context_len=C, num_heads=2)
+    assert maxabs(model.model(x, t, y=dict(y)), dip.dip_forward(sd, x, t, y, **kw)) < 2e-5
+    assert maxabs(model.model(x, t, y={**y, "uncond": True}), dip.dip_forward(sd, x, t, {**y, "uncond": True}, **kw)) < 2e-5
+    assert maxabs(model(x, t, y=dict(y)), dip.dip_cfg_forward(sd, x, t, y, **kw)) < 5e-5
+    seq = [torch.randn(B, 263, 1, P, generator=g) for _ in range(1 + steps)]
+    got = diffusion.p_sample_loop(model, (B, 263, 1, P), clip_denoised=False, model_kwargs={"y": dict(y)}, noise_sequence=seq)
+    want = dip.dip_sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), (B, 263, 1, P), y, seq[0], seq[1:],
+                               context_len=C, cfg=True, num_heads=2)
+    assert maxabs(got, want) < 5e-5
+
+
+def test_emulated_dip_sample_groups_with_hole_masks(lib, monkeypatch):
+    """with sample groups (MDM_DIP_GROUPS > 1, probe / emulator builds) the ABI-7 bitmap form of `lengths`
+    ([9B]: counts, then eight words per sample) was sliced as `lengths + b0` with B = the group's size, i.e. a group read the
+    WRONG samples' bitmaps.  The whole-batch array + (len_B, len_b0) now travel to the attention kernel: groups must reproduce
+    the ungrouped loop bit for bit in the exact-fp32 mode on masks with holes."""
+    B, C, P, steps = 4, 5, 12, 2
+    sd = dip_small_state_dict(num_layers=1)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, precision="f32",
+                                 mask_frames=True)
+    y = synth_dip_y(B, P, C, seed=6, text_lengths=[6, 3, 1, 5], lengths=[12, 9, 12, 7], scale=2.5)
+    y["mask"] = y["mask"].clone()
+    y["mask"][1, 0, 0, [0, 4]] = False          # holes: samples 1 and 3 travel as bitmaps, 0 and 2 as counts
+    y["mask"][3, 0, 0, [2, 3, 5]] = False
+    g = torch.Generator().manual_seed(9)
+    seq = [torch.randn(B, 263, 1, P, generator=g) for _ in range(1 + steps)]
+    run = lambda: diffusion.p_sample_loop(model, (B, 263, 1, P), clip_denoised=False, model_kwargs={"y": dict(y)},   # noqa: E731
+                                          noise_sequence=seq)
+    monkeypatch.setenv("MDM_DIP_GROUPS", "1")
+    one = run()
+    monkeypatch.setenv("MDM_DIP_GROUPS", "2")
+    two = run()
+    assert torch.equal(one, two)
+    want = dip.dip_sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), (B, 263, 1, P), y, seq[0], seq[1:],
+                               context_len=C, cfg=True, num_heads=2, mask_frames=True)
+    assert maxabs(one, want) < 5e-5
+
+
+def test_integration_md_snippet_is_a_program_and_its_structs_match_the_binding():
+    """INTEGRATION.md section 2 is executed verbatim on the GPU (tests/test_gpu_round4.py); here: it parses, and the structs it
+    declares by hand have exactly the fields, order and ctypes of the binding the seams use (which tests/test_abi.py ties to
+    include/mdm_hip.h)."""
+    import ast
+    import re
+    from helpers import ROOT
+    from mdm_amd import _native as nat
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"<!-- ctypes-snippet-begin -->\s*```python\n(.*?)```\s*<!-- ctypes-snippet-end -->", text, flags=re.S)
+    assert m
+    tree = ast.parse(m.group(1))
+    ns = {}
+    head = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom, ast.Assign, ast.ClassDef))][:4]
+    # import ctypes ...; the i32/u32/... aliases; the two struct classes
+    exec(compile(ast.Module(body=[n for n in tree.body[:1]] + [n for n in tree.body if isinstance(n, ast.Assign)][:1] +
+                            [n for n in tree.body if isinstance(n, ast.ClassDef)], type_ignores=[]), "snippet", "exec"), ns)
+    for mine, theirs in ((ns["MdmConfig"], nat.MdmConfig), (ns["MdmSampleParams"], nat.MdmSampleParams)):
+        assert [(n, t) for n, t in mine._fields_] == [(n, t) for n, t in theirs._fields_]
+    assert "mdm_abi_version() == %d" % nat.ABI_VERSION in m.group(1)

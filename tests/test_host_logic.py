@@ -148,3 +148,74 @@ def test_library_is_built_without_slp_vectorisation():
     import __graft_entry__ as ge
     assert "-fno-slp-vectorize" in ge.HIP_FLAGS
     assert "--offload-arch=gfx950" in ge.HIP_FLAGS
+    assert "-DMDM_NO_SLP=1" in ge.HIP_FLAGS        # the marker mdm_build_info() reports; the loaders check it
+
+
+def test_loader_refuses_a_gpu_library_built_with_slp(monkeypatch):
+    """nothing at LOAD time checked how the .so was built.  mdm_build_info() (ABI 8) carries the marker and
+    MdmLib refuses a non-emulator library without it (MDM_ALLOW_SLP_BUILD=1 opens it for A/B experiments)."""
+    import ctypes as C
+    from mdm_amd import _native
+    lib = _native.MdmLib(_native.LIB_PATH)
+    assert lib.build_info["slp"] == "off" and lib.build_info["probes"] == "0" and lib.build_info["emu"] == "0"
+    assert _native.MdmLib(_native.PROBE_LIB_PATH).build_info["probes"] == "1"
+
+    real_cdll = C.CDLL
+
+    class Fake:
+        """the real library with a different answer from mdm_build_info"""
+        def __init__(self, path):
+            self._l = real_cdll(path)
+            self.mdm_build_info = lambda: b"slp=on;probes=0;emu=0;planes=f16"
+
+        def __getattr__(self, n):
+            return getattr(self._l, n)
+
+    monkeypatch.setattr(C, "CDLL", Fake)
+    with pytest.raises(_native.MdmError, match="fno-slp-vectorize"):
+        _native.MdmLib(_native.LIB_PATH)
+    monkeypatch.setenv("MDM_ALLOW_SLP_BUILD", "1")
+    assert _native.MdmLib(_native.LIB_PATH).build_info["slp"] == "on"
+
+
+def test_engine_key_sees_every_kind_of_weight_change():
+    """the engine cache key must move after load_state_dict(assign=True), after re-assigning ANY
+    nn.Parameter and after `p.data = other` on a non-first parameter -- round 3's quick key (first address + version sum over a
+    cached parameter list) saw none of the three and kept serving the old weights."""
+    from mdm_amd.mdm import MDM
+
+    class FakeEngine:
+        made = 0
+
+        def __init__(self, cfg, lib=None, precision="f16x3"):
+            FakeEngine.made += 1
+
+        def bind(self, state, device):
+            self.state = {k: v.clone() for k, v in state.items()}
+
+    import mdm_amd.mdm as mm
+    orig = mm.Engine
+    mm.Engine = FakeEngine
+    try:
+        model, _ = model_util.create_model_and_diffusion(model_util.default_args(layers=2))
+        model.eval()
+        e0 = model.engine()
+        assert model.engine() is e0 and FakeEngine.made == 1                         # stable while nothing changes
+        lin2 = model.seqTransEncoder.layers[1].linear2
+        with torch.no_grad():
+            lin2.bias.add_(1.0)                                                      # in-place: version bump
+        e1 = model.engine()
+        assert e1 is not e0 and float(e1.state["seqTransEncoder.layers.1.linear2.bias"][0]) == float(lin2.bias.detach()[0])
+        lin2.bias.data = torch.full_like(lin2.bias, 3.0)                            # p.data = other (non-first parameter)
+        e2 = model.engine()
+        assert e2 is not e1 and float(e2.state["seqTransEncoder.layers.1.linear2.bias"][0]) == 3.0
+        lin2.weight = torch.nn.Parameter(torch.zeros_like(lin2.weight))            # re-assigned nn.Parameter
+        e3 = model.engine()
+        assert e3 is not e2 and float(e3.state["seqTransEncoder.layers.1.linear2.weight"].abs().max()) == 0.0
+        sd = {k: torch.full_like(v, 0.5) for k, v in model.state_dict().items()}
+        model.load_state_dict(sd, assign=True)                                       # fresh tensors, versions reset
+        e4 = model.engine()
+        assert e4 is not e3 and float(e4.state["embed_text.bias"][0]) == 0.5
+        assert model.engine() is e4
+    finally:
+        mm.Engine = orig
