@@ -141,6 +141,7 @@ struct X3Epilogue {
   // res[(1 + t) * ld + n] added and is written, as planes, to token row b*S + 1 + t of every branch (S = emb_T + 1)
   int emb_T, emb_B, emb_nbranch;
   float acc_scale = kX3AccScale;   // accumulators -> value: undoes the 2^8 the weight planes carry (common.h kX3WeightScale)
+  int stat_cols = 256;             // columns each partial of astat / rstat covers: 256 (this kernel's OSTAT), 128 (gemm_x3s.h)
 };
 
 constexpr bool x3_has_col_scale(int act, int res) { return act == 0 && (res == 0 || res == 1); }
@@ -473,10 +474,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         float s1 = 0.f;
         for (int p = 0; p < ep.stat_parts; ++p) s1 += sraw[(tid * ep.stat_parts + p) * 2];
         const float mean = s1 * ep.inv_dim;
+        const float pcols = (float)ep.stat_cols, inv_pcols = 1.0f / pcols;   // columns per partial (256, or 128 from gemm_x3s.h)
         float m2 = 0.f;
         for (int p = 0; p < ep.stat_parts; ++p) {
-          const float dm = sraw[(tid * ep.stat_parts + p) * 2] * (1.0f / X3_TN) - mean;
-          m2 += sraw[(tid * ep.stat_parts + p) * 2 + 1] + (float)X3_TN * dm * dm;
+          const float dm = sraw[(tid * ep.stat_parts + p) * 2] * inv_pcols - mean;
+          m2 += sraw[(tid * ep.stat_parts + p) * 2 + 1] + pcols * dm * dm;
         }
         const float var = m2 * ep.inv_dim;
 #ifdef MDM_EMU

@@ -23,6 +23,7 @@
 #include "elementwise.h"
 #include "gemm_f32.h"
 #include "gemm_x3.h"
+#include "gemm_x3s.h"
 #ifdef MDM_PROBES
 #include "gemm_f16f6.h"
 #endif
@@ -212,7 +213,7 @@ Workspace carve(const mdm_model* m, int nseq, int T, void* base) {
   w.ffnl = w.ffn ? w.ffnh + M * FF : nullptr;
   w.xah = reinterpret_cast<p16_t*>(w.tok);
   w.xal = w.tok ? w.xah + M * D : nullptr;
-  const size_t parts = (D + 255) / 256;
+  const size_t parts = (D + 127) / 128;   // per-row partial statistics: per 256 columns (gemm_x3.h) or per 128 (gemm_x3s.h)
   w.stat1 = take(M * parts * 2);
   w.stat2 = take(M * parts * 2);
   {
@@ -445,7 +446,14 @@ struct LnArgs {
   float* ostat = nullptr;                                                                       // OSTAT
   int parts = 1; float inv_dim = 1.f;
   const float* res_f32 = nullptr; int emb_T = 1, emb_B = 1, emb_nbranch = 1;                     // EMBED (kind 5)
+  bool small = false;      // the small-row-count kernel (gemm_x3s.h): the whole forward runs on one of the two kernels
+  int stat_cols = 256;     // columns per partial of astat / rstat (what the PRODUCER's kernel wrote)
 };
+// The latency regime (gemm_x3s.h): a forward of at most x3s_max_seqs() sequences runs its GEMMs on 32 / 64-row tiles
+inline bool use_small_gemm(const mdm_model* m, int nseq, int S) {
+  return m->precision == MDM_PREC_F16X3 && m->lnfold && nseq <= x3s_max_seqs() && S <= X3_TM &&
+         m->cfg.latent_dim % 128 == 0 && m->cfg.latent_dim % 256 == 0 && m->cfg.ff_size % 256 == 0;
+}
 int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w, const float* bias, const LnArgs& ln,
                  float* out, p16_t* oh, p16_t* ol, const QkvPlanes* qp, int M, int N, int K, int S, int D,
                  int scale_cols, float col_scale, hipStream_t s) {
@@ -455,6 +463,30 @@ int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w,
   X3Epilogue ep{out, bias, ln.res_f32, ln.res.hi, ln.res.lo, oh, ol, N, scale_cols, col_scale, qp ? *qp : QkvPlanes{}, S, D,
                 ln.astat, ln.colsum, ln.rstat, ln.rgamma, ln.rbeta, ln.ostat, ln.parts, ln.inv_dim, ln.emb_T, ln.emb_B,
                 ln.emb_nbranch};
+  ep.stat_cols = ln.stat_cols;
+  bool small = ln.small;
+#ifdef MDM_PROBES   // (bisection of a misbehaving instantiation: bit k = GEMM kind k may run on the small kernel; results are wrong
+                    // when producer and consumer of a row-statistics array disagree about their geometry)
+  if (const char* e = getenv("MDM_X3S_KINDS")) small = small && ((atoi(e) >> kind) & 1);
+#endif
+  if (small) {
+    const int rc = launch_gemm_x3s(kind, a, w, ep, M, N, K, kind == 5 ? ln.emb_T : S, s);
+    if (rc == -1) return fail(MDM_EHIP, "f16x3 linear (small tiles): hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    if (rc == -2) return fail(MDM_EUNSUPPORTED, "f16x3 linear (small tiles): unsupported shape (K must be 288 or a multiple of 256)");
+#if defined(MDM_PROBES) && !defined(MDM_EMU)
+    if (getenv("MDM_X3S_TRACE")) {      // bring-up: which launch faults
+      fprintf(stderr, "[x3s] kind %d M %d N %d K %d launched\n", kind, M, N, K); fflush(stderr);
+      const hipError_t e = hipStreamSynchronize(s);
+      fprintf(stderr, "[x3s] kind %d done: %s\n", kind, hipGetErrorString(e)); fflush(stderr);
+    }
+#endif
+    return rt_launch_status();
+  }
+  if (kind == 6) {   // layer 0's in_proj without a folded LayerNorm on the sequence-tile kernel (only reached by the bisection switch)
+    const int rc6 = launch_gemm_x3_qkv(a, w, ep, M / S, S, D, s);
+    if (rc6 != 0) return fail(MDM_EUNSUPPORTED, "f16x3 in_proj: launch failed");
+    return rt_launch_status();
+  }
   const int rpt = (kind == 0) ? S : x3_rows_per_tile(M, kind == 5 ? ln.emb_T : S);
   const int rc = launch_gemm_x3_ln(kind, a, w, ep, M, N, K, rpt, s);
   if (rc == -1) return fail(MDM_EHIP, "f16x3 linear: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -491,6 +523,7 @@ int embed_frames_x3(mdm_model* m, const Workspace& ws, const float* x, int B, in
   LnArgs a;
   a.res_f32 = m->W("sequence_pos_encoder.pe");
   a.emb_T = T; a.emb_B = B; a.emb_nbranch = nbranch;
+  a.small = use_small_gemm(m, nbranch * B, T + 1) && KP == 288;
   return launch_x3_ln(nullptr, MDM_PROF_EMBED, 5, X3Operand{ph, pl}, m->in_planes, m->W("input_process.poseEmbedding.bias"), a,
                       nullptr, ws.tokh, ws.tokl, nullptr, B * T, D, KP, T + 1, D, 0, 1.f, s);
 }
@@ -533,35 +566,44 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
     // pre-norm sum, each with per-row partial (sum, sum^2) written by its producer; consumers fold the normalisation
     // (gemm_x3.h X3Epilogue).  Layer 0's input (the embedding) is not normalised: plain in_proj, plain residual.
     const X3Operand xb{ws.tokh, ws.tokl}, xa{ws.xah, ws.xal}, attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
-    const int parts = (D + 255) / 256;
+    // few sequences: the latency regime -- every GEMM of the stack on gemm_x3s.h's 32 / 64-row tiles (row statistics per 128
+    // columns); else gemm_x3.h's sequence-sized tiles (per 256)
+    const bool small = use_small_gemm(m, nseq, S);
+    const int scols = small ? X3S_TN : 256;
+    const int parts = (D + scols - 1) / scols;
     const float inv_dim = 1.0f / (float)D;
+    auto LN = [&]() { LnArgs a; a.small = small; a.stat_cols = scols; a.parts = parts; a.inv_dim = inv_dim; return a; };
     // (Running the stack over two half-batches, so that every producer -> consumer hand-over stays inside the 256 MB Infinity
     // Cache, was built and measured: 1.5 % SLOWER on the same box -- profiles/r02_ab.md -- and removed.)
     for (int l = 0; l < m->cfg.num_layers; ++l) {
       const mdm_model::LayerPlanes& P = m->planes[l];
       const mdm_model::LayerFold& F = m->fold[l];
-      if (l == 0) {
+      if (l == 0 && small) {
+        LnArgs a = LN();
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 6, xb, P.in_proj, m->L(l, "self_attn.in_proj_bias"), a, nullptr, nullptr,
+                                  nullptr, &ws.qp, M, 3 * D, D, S, D, D, qscale, s)) return rc;
+      } else if (l == 0) {
         if (int rc = launch_in_proj_x3(pf, xb, P.in_proj, m->L(l, "self_attn.in_proj_bias"), ws.qp, nseq, S, D, qscale, s)) return rc;
       } else {
-        LnArgs a; a.astat = ws.stat2; a.colsum = F.c_qkv; a.parts = parts; a.inv_dim = inv_dim;
+        LnArgs a = LN(); a.astat = ws.stat2; a.colsum = F.c_qkv;
         if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, xb, F.in_proj, F.b_qkv, a, nullptr, nullptr, nullptr, &ws.qp, M,
                                   3 * D, D, S, D, D, qscale, s)) return rc;
       }
       if (int rc = launch_attention_x3(pf, ws.qp, lengths, nseq, B, S, D, nullptr, ws.atth, ws.attl, s)) return rc;
       {  // xa = att.Wo + bo + layer input (normalised on the fly for l >= 1), + row statistics
-        LnArgs a; a.res = xb; a.ostat = ws.stat1; a.parts = parts; a.inv_dim = inv_dim;
+        LnArgs a = LN(); a.res = xb; a.ostat = ws.stat1;
         if (l >= 1) { a.rstat = ws.stat2; a.rgamma = m->L(l - 1, "norm2.weight"); a.rbeta = m->L(l - 1, "norm2.bias"); }
         if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, l == 0 ? 1 : 2, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"),
                                   a, nullptr, ws.xah, ws.xal, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
       }
       {  // ffn = gelu(LN1(xa).W1 + b1), LN1 folded
-        LnArgs a; a.astat = ws.stat1; a.colsum = F.c_1; a.parts = parts; a.inv_dim = inv_dim;
+        LnArgs a = LN(); a.astat = ws.stat1; a.colsum = F.c_1;
         if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 3, xa, F.linear1, F.b_1, a, nullptr, ws.ffnh, ws.ffnl, nullptr, M, FF,
                                   D, S, D, 0, 1.f, s)) return rc;
       }
       {  // xb = ffn.W2 + b2 + LN1(xa), + row statistics
-        LnArgs a; a.res = xa; a.rstat = ws.stat1; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias");
-        a.ostat = ws.stat2; a.parts = parts; a.inv_dim = inv_dim;
+        LnArgs a = LN(); a.res = xa; a.rstat = ws.stat1; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias");
+        a.ostat = ws.stat2;
         if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, ffnp, P.linear2, m->L(l, "linear2.bias"), a, nullptr, ws.tokh,
                                   ws.tokl, nullptr, M, D, FF, S, D, 0, 1.f, s)) return rc;
       }
@@ -613,7 +655,10 @@ int outproj_x3(mdm_model* m, const Workspace& ws, int nseq, int B, int T, const 
   float* out_tok = ws.qkv;
   ProfScope ps(&m->prof, MDM_PROF_OUTPROJ, 2.0 * nseq * T * (double)D * m->jf, s);
   if (m->lnfold && x3_waves_setting() == 8 && S <= X3_TM) {   // the final LayerNorm is folded into this GEMM
-    LnArgs a; a.astat = ws.stat2; a.colsum = m->c_out; a.parts = (D + 255) / 256; a.inv_dim = 1.0f / (float)D;
+    LnArgs a; a.astat = ws.stat2; a.colsum = m->c_out; a.inv_dim = 1.0f / (float)D;
+    a.small = use_small_gemm(m, nseq, S);            // (the same decision the encoder took: who wrote stat2)
+    a.stat_cols = a.small ? X3S_TN : 256;
+    a.parts = (D + a.stat_cols - 1) / a.stat_cols;
     if (int rc = launch_x3_ln(nullptr, MDM_PROF_OUTPROJ, 4, X3Operand{ws.tokh, ws.tokl}, m->out_planes_f, m->b_out, a,
                               out_tok, nullptr, nullptr, nullptr, nseq * S, ldo, D, S, D, 0, 1.f, s)) return rc;
   } else if (int rc = launch_linear_x3(nullptr, X3Operand{ws.tokh, ws.tokl}, m->out_planes, m->out_bias_pad, nullptr, out_tok,

@@ -22,7 +22,7 @@ def lib():
 
 
 @pytest.mark.parametrize("prec,tol", [("f16x3", 2e-5), ("f32", 2e-5)])
-def test_emulated_cfg_loop_matches_oracle(lib, prec, tol):
+def test_emulated_cfg_loop_matches_oracle(lib, gemm_path, prec, tol):
     steps, B, T = 2, 2, 9
     sd = small_state_dict(num_layers=1)
     model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, precision=prec)
@@ -43,7 +43,7 @@ def test_emulated_cfg_loop_matches_oracle(lib, prec, tol):
     ("f16x3", 2e-5, 1, 1, 207, [207]),         # S = 208: the 16-row sub-tile completely used
     ("f16x3", 2e-5, 1, 1, 208, [208]),         # S = 209: does not fit 208 rows -> the 224-row (7 x 32) form
 ])
-def test_emulated_forward_branches(lib, prec, tol, layers, B, T, lengths):
+def test_emulated_forward_branches(lib, gemm_path, prec, tol, layers, B, T, lengths):
     """layers = 2 reaches the GEMM kinds only a second layer uses: in_proj with the previous LayerNorm folded in, and
     out_proj whose residual is a LayerNorm rebuilt from the pre-norm planes + row statistics."""
     sd = small_state_dict(num_layers=layers)
@@ -57,7 +57,7 @@ def test_emulated_forward_branches(lib, prec, tol, layers, B, T, lengths):
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "f32"])
-def test_emulated_frame_masks_with_holes(lib, prec):
+def test_emulated_frame_masks_with_holes(lib, gemm_path, prec):
     """Arbitrary key-padding masks (model/mdm.py:241-247) through the bitmap form of `lengths` (include/mdm_hip.h, ABI 7):
     S = 41 (two key tiles): a prefix-mask sample, a sample with holes at frame 0 / across the tile boundary, a sparse sample."""
     B, T = 3, 40
@@ -423,3 +423,18 @@ def test_integration_md_snippet_is_a_program_and_its_structs_match_the_binding()
     for mine, theirs in ((ns["MdmConfig"], nat.MdmConfig), (ns["MdmSampleParams"], nat.MdmSampleParams)):
         assert [(n, t) for n, t in mine._fields_] == [(n, t) for n, t in theirs._fields_]
     assert "mdm_abi_version() == %d" % nat.ABI_VERSION in m.group(1)
+
+
+@pytest.mark.parametrize("rt", ["1", "2"])
+def test_emulated_small_gemm_at_the_headline_width(lib, monkeypatch, rt):
+    """csrc/gemm_x3s.h at latent_dim = 512 (the emulator cases above run 256: one K-chunk): two chunks for in_proj / out_proj /
+    linear1, four for linear2, the 18-sub-step single chunk of InputProcess (K = 288), N = 264 of OutputProcess (a column tile
+    whose last three waves lie past the packed weight rows), 32- and 64-row tiles, a 5-row last tile (S = 37)."""
+    monkeypatch.setenv("MDM_X3S_RT", rt)
+    B, T = 2, 36
+    sd = small_state_dict(latent_dim=512, num_layers=2)
+    model, _ = make_pair(sd, 50, "cpu", guided=True, native_lib=lib, precision="f16x3")
+    y = synth_y(B, T, seed=2, lengths=[T, 11])
+    g = torch.Generator().manual_seed(0)
+    x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 0])
+    assert maxabs(model(x, t, y=dict(y)), orc.cfg_forward(sd, x, t, y, num_heads=4)) < 5e-5

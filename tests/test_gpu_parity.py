@@ -44,11 +44,19 @@ def _g(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
 
+def _one_path_for_f32(gemm_path, prec):
+    """`gemm_path` (tests/conftest.py) selects between the two split-precision encoder GEMM kernels (gemm_x3s.h's 32-row tiles,
+    the default below 32 sequences, and gemm_x3.h's sequence-sized tiles): it does not exist in the exact-fp32 mode."""
+    if prec == "f32" and gemm_path != "small":
+        pytest.skip("the f32 mode has one GEMM kernel")
+
+
 # ---------------------------------------------------------------------------------------------------
 # MDM.forward / ClassifierFreeSampleModel.forward against the reference's own outputs
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec", PRECISIONS)
-def test_forward_matches_reference_golden(golden_dir, sd, prec):
+def test_forward_matches_reference_golden(gemm_path, golden_dir, sd, prec):
+    _one_path_for_f32(gemm_path, prec)
     g = _g(golden_dir, "fwd_B3_T196")
     B, T = 3, 196
     y = synth_y(B, T, seed=int(g["y_seed"]), lengths=list(g["lengths"]))
@@ -72,7 +80,8 @@ def test_forward_matches_reference_golden(golden_dir, sd, prec):
 @pytest.mark.parametrize("B,T,lengths", [(1, 196, None), (2, 1, None), (5, 31, [31, 1, 7, 30, 16]),
                                          (3, 32, [32, 2, 32]), (2, 223, [223, 100]), (4, 64, None)])
 @pytest.mark.parametrize("prec", PRECISIONS)
-def test_forward_matches_oracle_shapes(sd, B, T, lengths, prec):
+def test_forward_matches_oracle_shapes(gemm_path, sd, B, T, lengths, prec):
+    _one_path_for_f32(gemm_path, prec)
     """Edge shapes: single frame, S on / next to a 32-token tile boundary, the largest supported T, ragged lengths."""
     y = synth_y(B, T, seed=B * 1000 + T, lengths=lengths)
     g = torch.Generator().manual_seed(T)
@@ -91,7 +100,8 @@ def test_forward_matches_oracle_shapes(sd, B, T, lengths, prec):
 @pytest.mark.parametrize("name", ["loop50_nocfg_B2_T64", "ddim50_B2_T64", "ddim50_eta1_B2_T64", "inpaint50_B2_T64",
                                   "skip20_init_B2_T64", "loop1000_B1_T32"])
 @pytest.mark.parametrize("prec", PRECISIONS)
-def test_loop_matches_reference_golden(golden_dir, sd, name, prec):
+def test_loop_matches_reference_golden(gemm_path, golden_dir, sd, name, prec):
+    _one_path_for_f32(gemm_path, prec)
     g = _g(golden_dir, name)
     case = golden_loop_inputs(g)
     out = run_product_loop(sd, case, DEV, precision=prec)
@@ -124,7 +134,8 @@ def test_f16f6_arithmetic_on_the_reference_trajectory(golden_dir, sd):
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
-def test_loop_T196_with_dump_steps(golden_dir, sd, prec):
+def test_loop_T196_with_dump_steps(gemm_path, golden_dir, sd, prec):
+    _one_path_for_f32(gemm_path, prec)
     """BASELINE config shape (T=196, 50 steps, CFG 2.5) at B=2, incl. p_sample_loop(dump_steps=...) (:630-657)."""
     g = _g(golden_dir, "loop50_B2_T196")
     case = golden_loop_inputs(g)
