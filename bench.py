@@ -18,7 +18,8 @@ Prints ONE JSON line on rank 0.  Besides the contract fields it carries
   kernel_ms     per-kernel-class totals of that loop,
   f32_mode      the same workload on the exact-fp32 MFMA kernels (one short extra pass; N = 1 only),
   dip           the DiP configuration (BASELINE.json configs[4] per GPU: trans_dec, 5 windows x 10 steps) -- N = 1 only,
-  steps1000     BASELINE.json configs[2] (1000-step DDPM, batch 64) -- one timed pass, N = 1 only,
+  steps1000     BASELINE.json configs[2] (1000-step DDPM, batch 64) -- two timed passes, N = 1 only,
+  small_batch   the same loop at batch 1 / 6 / 10 (what sample/generate.py runs by default; B1 = configs[0]'s shape), ms per call,
   cpu_baseline  BASELINE.json configs[0]: the whole 50-step CFG loop at batch 1 on this box's host cores, twice -- the
                 reference's own p_sample_loop where the upstream tree is mounted, else the oracle port (N = 1, rank 0),
   ranks         what the process group looked like (backend, world size) -- the evidence that RCCL carried the gather.
@@ -230,6 +231,39 @@ def measure_steps1000(mdm, model, dev, sync, T, layers, latent_dim, B=64, dsteps
                        "global_batch": B, "diffusion_steps": dsteps}}
 
 
+def measure_small_batch(model, dev, sync, T, layers, latent_dim, dsteps, batches=(1, 6, 10), passes=3):
+    """The latency regime the reference's own callers run (sample/generate.py:76,98: `--num_samples` = the batch, default 6;
+    README.md:13 quotes per-call latency): the SAME 50-step CFG p_sample_loop at batch 1 (BASELINE.json configs[0]'s shape, the
+    one `cpu_baseline` times on the host), 6 and 10 -- milliseconds per call, mean of `passes` calls after one warm-up call.
+    Below 40 sequences the encoder GEMMs run on csrc/gemm_x3s.h's 32 / 64-row tiles."""
+    import torch
+    from mdm_amd import model_util
+    diff = model_util.create_gaussian_diffusion(model_util.default_args(diffusion_steps=dsteps, layers=layers, latent_dim=latent_dim))
+    out = {}
+    prev = os.environ.get("MDM_CHECK_FINITE")
+    for B in batches:
+        y = synthetic_y(B, T, dev, seed=3000 + B)
+        shape = (B, 263, 1, T)
+        diff.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, seed=1)
+        sync()
+        os.environ["MDM_CHECK_FINITE"] = "0"          # (the seam's finite check syncs per call: asserted behind the clock instead)
+        t0 = time.perf_counter()
+        for k in range(passes):
+            x = diff.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, seed=2 + k)
+        sync()
+        dt = (time.perf_counter() - t0) / passes
+        if prev is None:
+            del os.environ["MDM_CHECK_FINITE"]
+        else:
+            os.environ["MDM_CHECK_FINITE"] = prev
+        assert bool(torch.isfinite(x).all())
+        out[f"B{B}"] = {"ms_per_call": round(dt * 1e3, 2), "motions_per_s": round(B / dt, 2)}
+    out["config"] = {"workload": f"HumanML3D text2motion, {dsteps}-step p_sample_loop with CFG 2.5, T={T}, batch = 1 / 6 / 10: one "
+                                 f"call = one loop (B1 is BASELINE.json configs[0]'s shape, what cpu_baseline times on the host)",
+                     "passes": passes, "round3_ms_per_call": {"B1": 78.5, "B10": 82.7}}
+    return out
+
+
 def csrc_sha256():
     """Identity of the kernel sources the library was built from (what a committed PMC profile is tied to)."""
     h = hashlib.sha256()
@@ -406,6 +440,9 @@ def main(argv=None):
     steps1000 = None
     if extras and a.precision != "f32" and not a.no_steps1000:
         steps1000 = measure_steps1000(mdm, model, dev, sync, T, a.layers, a.latent_dim)
+    small_batch = None
+    if extras and a.precision != "f32" and not a.no_small_batch:
+        small_batch = measure_small_batch(model, dev, sync, T, a.layers, a.latent_dim, DS)
     if extras:
         import bench_dip
         dip = bench_dip.measure(dev, rank=0, world=1, B=32, steps=3, warmup=1, cpu=False)
@@ -461,6 +498,8 @@ def main(argv=None):
             line["f32_mode"] = f32_mode
         if steps1000 is not None:
             line["steps1000"] = steps1000
+        if small_batch is not None:
+            line["small_batch"] = small_batch
         if dip is not None:
             line["dip"] = dip
         if world == 1 and not a.no_cpu_baseline and not a.emulate:

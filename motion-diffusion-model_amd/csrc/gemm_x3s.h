@@ -4,20 +4,20 @@
 // workgroup per CU): at the batch sizes the reference's own callers use -- sample/generate.py:76,98 defaults to
 // `--num_samples 6`, i.e. 12 sequences under classifier-free guidance; README.md:13 quotes per-call latency -- a launch is one
 // tile deep on 5-30 % of the CUs and its time is that tile's serial k-loop: 33 us per GEMM launch, 73-77 ms per 50-step loop at
-// B = 1 ... 10 (profiles/r04a_small_batch.md).  This kernel cuts the same contraction into 32- or 64-row x 128-column tiles,
-// one NON-persistent 4-wave workgroup each, so that M = 394 rows (B = 1) already give 168 workgroups for in_proj, and keeps
-// everything a tile needs in flight at once:
+// B = 1 ... 10 (profiles/r04a_small_batch.md).  This kernel cuts the same contraction into 32- or 64-row x 128- or 256-column
+// tiles, one NON-persistent 4-wave workgroup each (a wave owns 32 or 64 columns: NCB column blocks sharing every A fragment it
+// reads), so that M = 394 rows (B = 1) already give 168 workgroups for in_proj, and keeps everything a tile needs in flight:
 //   * A (activation planes [rows][K], hi | lo): a K-CHUNK of 16 (18) sub-steps x 16 k of the tile's rows lives in LDS
 //     (32 KB per 32 rows), fetched by global_load_lds_dwordx4 in the 64-byte-row XOR-swizzled image of gemm_x3.h; chunk
 //     c + 1 is requested into the other buffer as soon as the barrier of chunk c has passed: ONE rendezvous per 256 k;
-//   * W (fragment-ordered hi | lo planes, gemm_x3.h header): straight to registers, an eight-sub-step ring of slots
+//   * W (fragment-ordered hi | lo planes, gemm_x3.h header): straight to registers, a ring of sub-step slots
 //     (16 KB per wave in flight) refilled in place behind the MFMAs that consumed them (common.h gload16_refill), retired by
 //     counted vmcnt waits -- the vector-memory queue retires in order across LDS-DMA pieces and register loads
 //     (tools/vmcnt_order);
 //   * fragment reads one sub-step ahead through untracked ds_reads with counted lgkmcnt waits (common.h lds_read16).
 // Same operands, same weight planes, same epilogue algebra (X3Epilogue: folded LayerNorm, Q / K / V^T operand planes,
 // GELU, plane residuals, row statistics, InputProcess / OutputProcess forms) as gemm_x3.h, so a forward may run on either
-// kernel; the row statistics a producer leaves are per 128 columns here (X3Epilogue::stat_cols).
+// kernel; the row statistics a producer leaves are per tile width (128 or 256 columns: X3Epilogue::stat_cols).
 // Replaces the same reference calls as gemm_x3.h (model/mdm.py:77-84 `addmm`s under nn.TransformerEncoderLayer,
 // :343-349 InputProcess, :372-386 OutputProcess) for nseq <= x3s_max_seqs().
 #pragma once
@@ -25,31 +25,36 @@
 
 namespace mdm {
 
-constexpr int X3S_TN = 128;          // columns per tile: 4 waves x 32
 constexpr int X3S_WAVES = 4;
-constexpr int X3S_WDEPTH = 8;        // W sub-steps in flight per wave (hi + lo fragment each: 64 VGPRs)
+constexpr int x3s_tn(int ncb) { return 128 * ncb; }   // columns per tile: 4 waves x NCB blocks of 32
+// W sub-steps in flight per wave (hi + lo fragment per column block, 8 VGPRs each): 16 KB per wave.  Twice the depth for the
+// 32-row / 128-column tiles (a whole 256-k chunk ahead, 64 more VGPRs) measured SLOWER on the same box: 24.1 vs 23.3 ms per
+// 50-step loop at B = 1, 40.4 vs 37.6 at B = 6 (profiles/r04a_small_batch.md) -- the tiles are not waiting for the W stream's depth
+constexpr int x3s_wdepth(int ncb) { return 8 / ncb; }
 constexpr int x3s_buf_bytes(int rt, int nsub) { return nsub * 32 * rt * 64; }        // one K-chunk of A: hi | lo, 64-byte rows per 32 k
 constexpr int x3s_patch_base(int rt, int nsub, bool multi) { return (multi ? 2 : 1) * x3s_buf_bytes(rt, nsub); }
 constexpr int x3s_tab_base(int rt, int nsub, bool multi) { return x3s_patch_base(rt, nsub, multi) + X3S_WAVES * X3_PATCH_BYTES; }
 constexpr int x3s_part_base(int rt, int nsub, bool multi) { return x3s_tab_base(rt, nsub, multi) + 32 * rt * 8; }
-constexpr int x3s_lds_bytes(int rt, int nsub, bool multi) { return x3s_part_base(rt, nsub, multi) + X3S_WAVES * 32 * rt * 8; }
+constexpr int x3s_lds_bytes(int rt, int ncb, int nsub, bool multi) { return x3s_part_base(rt, nsub, multi) + X3S_WAVES * ncb * 32 * rt * 8; }
 
-// RT: 32-row sub-tiles per tile (1 or 2).  NSUB: 16-deep k sub-steps per chunk (even); K = NSUB * 16 * nchunks.
-// MULTI: more than one chunk (double-buffered A).  The other flags are gemm_x3_kernel's.
+// RT: 32-row sub-tiles per tile (1 or 2).  NCB: 32-column blocks per wave (1 or 2).  NSUB: 16-deep k sub-steps per chunk (even);
+// K = NSUB * 16 * nchunks.  MULTI: double-buffered A (more than one chunk).  The other flags are gemm_x3_kernel's.
 // Rows are GROUPED (group_rows = tokens of a sequence; InputProcess: frames of a sample): a tile never straddles two groups, so
 // that the in_proj epilogue's (sequence, token) and the EMBED epilogue's (sample, frame) are tile-uniform / row-affine.
-template <int RT, int NSUB, bool MULTI, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, bool FOLD, bool OSTAT,
+template <int RT, int NCB, int NSUB, bool MULTI, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, bool FOLD, bool OSTAT,
           bool EMBED>
 __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N, int K,
                                                                     int group_rows, int tiles_per_group, int tiles_n,
                                                                     int total) {
   MDM_DYN_SMEM(unsigned char, lds);
-  static_assert(NSUB % 2 == 0 && (RT == 1 || RT == 2), "tile shape");
-  constexpr int TR = 32 * RT, D = X3S_WDEPTH;
+  static_assert(NSUB % 2 == 0 && (RT == 1 || RT == 2) && (NCB == 1 || NCB == 2), "tile shape");
+  constexpr int TR = 32 * RT, TN = x3s_tn(NCB), D = x3s_wdepth(NCB), NBLK = X3S_WAVES * NCB;
   constexpr int BUF = x3s_buf_bytes(RT, NSUB);
   constexpr int PW = NSUB * RT / 2;                      // LDS-DMA pieces (1 KB) per wave and chunk
+  constexpr int LW = 2 * NCB;                            // W loads per wave and sub-step
   static_assert(2 * NSUB * RT % X3S_WAVES == 0, "pieces must divide among the waves");
-  static_assert(2 * (D - 1) + PW <= 63, "vmcnt range");
+  static_assert(LW * (D - 1) + PW <= 63 && (NSUB > D ? LW * D : LW * NSUB) <= 63 && NSUB >= D && (!MULTI || NSUB % D == 0) && (D * NCB) % 4 == 0,
+                "vmcnt range / slot <-> sub-step map across chunks / closing wait");
   constexpr bool LN_TABS = FOLD || RES == 3;
 
   const int tid = threadIdx.x;
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
   const int grp = tile_m / tiles_per_group, tig = tile_m - grp * tiles_per_group;
   const int m0 = grp * group_rows + tig * TR;                       // first row of the tile
   const int rows_valid = min(TR, group_rows - tig * TR);            // rows of the tile inside its group
-  const int n0 = tile_n * X3S_TN;
+  const int n0 = tile_n * TN;
   const int nchunks = K / (NSUB * 16);
 
   // ---- A stream: chunk image = for 32-k block ms, plane p, 16-row group g: 1 KB (16 rows x 64 B); lane -> (row = lane >> 2,
@@ -84,60 +89,77 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
       glds16(src, lds + buf * BUF + ((ms * 2 + p) * 2 * RT + g) * 1024);
     }
   };
-  // ---- W stream: this wave's fragments of 16-deep sub-step `gj` (global index over the whole K): hi and lo, 1 KB each
-  // (a wave whose 32 columns lie past the padded weight rows -- OutputProcess: N = 264 -> 288 packed rows, 384 tile columns --
-  // re-reads the last block: its results are never stored)
-  const uint32_t wbase = (uint32_t)min((n0 >> 5) + wid, (N + 31) / 32 - 1) * (uint32_t)(K / 16) * 512u + (uint32_t)lane * 8u;
+  // ---- W stream: this wave's fragments of 16-deep sub-step `gj` (global index over the whole K): hi and lo of each of its
+  // NCB column blocks, 1 KB each.  (A block whose 32 columns lie past the padded weight rows -- OutputProcess: N = 264 -> 288
+  // packed rows -- re-reads the last block: its results are never stored.)
+  uint32_t wbase[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+    wbase[cb] = (uint32_t)min((n0 >> 5) + wid * NCB + cb, (N + 31) / 32 - 1) * (uint32_t)(K / 16) * 512u + (uint32_t)lane * 8u;
   const int nsub_total = K / 16;
-  p16x8 wsh[D] = {}, wsl[D] = {};     // (zero: the first refill formally reads its slot)
+  p16x8 wsh[D * NCB] = {}, wsl[D * NCB] = {};     // slot d, column block cb: [d * NCB + cb]  (zero: the first refill formally reads its slot)
   auto issue_w = [&](auto slot_tag, int gj) __attribute__((always_inline)) {
-    constexpr int s = decltype(slot_tag)::value;
+    constexpr int sl = decltype(slot_tag)::value;
     const int gg = gj < nsub_total ? gj : gj - nsub_total;          // past the end: a harmless re-fetch keeps the wait counts uniform
-    gload16_refill(wsh[s], W.hi + wbase + (uint32_t)gg * 512u);
-    gload16_refill(wsl[s], W.lo + wbase + (uint32_t)gg * 512u);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      gload16_refill(wsh[sl * NCB + cb], W.hi + wbase[cb] + (uint32_t)gg * 512u);
+      gload16_refill(wsl[sl * NCB + cb], W.lo + wbase[cb] + (uint32_t)gg * 512u);
+    }
   };
 
   issue_chunk(0, 0);
   static_for<D>([&](auto s_tag) __attribute__((always_inline)) { issue_w(s_tag, decltype(s_tag)::value); });
 
   // ---- everything the epilogue needs from memory is requested NOW, under the k-loop: per-column vectors, and the tile's
-  // residual (16 bytes per lane and round) -- fetched where it is used, each of the 4 RT rounds paid an L2 round trip
+  // residual (8 / 16 bytes per lane, round and column block) -- fetched where it is used, each round paid an L2 round trip
   const int prow = lane >> 3, pc4 = (lane & 7) * 4;
-  const int ncol0 = n0 + wid * 32, n4 = ncol0 + pc4;
-  const bool col_ok = n4 < N;                       // N % 4 == 0
-  const float4 b4 = col_ok ? ld4(ep.bias + n4) : zero4();
-  float4 c4 = zero4(), g4 = zero4(), be4 = zero4();
-  if constexpr (FOLD) { if (col_ok) c4 = ld4(ep.colsum + n4); }
-  if constexpr (RES == 3) {
-    if (col_ok) { g4 = ld4(ep.rgamma + n4); be4 = ld4(ep.rbeta + n4); }
-  }
-  float vbias = 0.f, vcsum = 0.f;                   // accumulator layout (lane -> column r of the wave's 32): the V^T path
-  if constexpr (OUT_QKV) {
-    if (ncol0 + r < N) {
-      vbias = ep.bias[ncol0 + r];
-      if constexpr (FOLD) vcsum = ep.colsum[ncol0 + r];
-    }
-  }
-  float4 rres[RES == 1 ? 4 * RT : 1];
-  uint2 rrh[(RES == 2 || RES == 3) ? 4 * RT : 1], rrl[(RES == 2 || RES == 3) ? 4 * RT : 1];
-  if constexpr (RES != 0) {
+  int n4[NCB];
+  bool col_ok[NCB];
+  float4 b4[NCB], c4[NCB], g4[NCB], be4[NCB];
+  float vbias[NCB], vcsum[NCB];                     // accumulator layout (lane -> column r of a 32-column block): the V^T path
 #pragma unroll
-    for (int q = 0; q < 4 * RT; ++q) {
-      const int rit = 8 * q + prow, m = m0 + rit;                    // round q = 4 t + g covers tile rows 8 q .. 8 q + 7
-      const bool ok = rit < rows_valid && m < M && col_ok;
-      if constexpr (RES == 1) {
-        const size_t o = (size_t)(EMBED ? 1 + (m - grp * group_rows) : m) * ep.ld + n4;   // EMBED: the positional row of the frame
-        rres[q] = ok ? ld4(ep.res + o) : zero4();
-      } else {
-        const size_t o = (size_t)m * ep.ld + n4;
-        rrh[q] = ok ? *reinterpret_cast<const uint2*>(ep.resh + o) : make_uint2(0u, 0u);
-        rrl[q] = ok ? *reinterpret_cast<const uint2*>(ep.resl + o) : make_uint2(0u, 0u);
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int nb = n0 + (wid * NCB + cb) * 32;
+    n4[cb] = nb + pc4;
+    col_ok[cb] = n4[cb] < N;                        // N % 4 == 0
+    b4[cb] = col_ok[cb] ? ld4(ep.bias + n4[cb]) : zero4();
+    c4[cb] = g4[cb] = be4[cb] = zero4();
+    if constexpr (FOLD) { if (col_ok[cb]) c4[cb] = ld4(ep.colsum + n4[cb]); }
+    if constexpr (RES == 3) {
+      if (col_ok[cb]) { g4[cb] = ld4(ep.rgamma + n4[cb]); be4[cb] = ld4(ep.rbeta + n4[cb]); }
+    }
+    vbias[cb] = vcsum[cb] = 0.f;
+    if constexpr (OUT_QKV) {
+      if (nb + r < N) {
+        vbias[cb] = ep.bias[nb + r];
+        if constexpr (FOLD) vcsum[cb] = ep.colsum[nb + r];
       }
     }
   }
+  constexpr int NRND = 4 * RT * NCB;                // epilogue rounds: round (cb, t, g) -> index (cb * RT + t) * 4 + g
+  float4 rres[RES == 1 ? NRND : 1];
+  uint2 rrh[(RES == 2 || RES == 3) ? NRND : 1], rrl[(RES == 2 || RES == 3) ? NRND : 1];
+  if constexpr (RES != 0) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4 * RT; ++q) {
+        const int rit = 8 * q + prow, m = m0 + rit;                    // q = 4 t + g covers tile rows 8 q .. 8 q + 7
+        const bool ok = rit < rows_valid && m < M && col_ok[cb];
+        if constexpr (RES == 1) {
+          const size_t o = (size_t)(EMBED ? 1 + (m - grp * group_rows) : m) * ep.ld + n4[cb];   // EMBED: the positional row of the frame
+          rres[cb * 4 * RT + q] = ok ? ld4(ep.res + o) : zero4();
+        } else {
+          const size_t o = (size_t)m * ep.ld + n4[cb];
+          rrh[cb * 4 * RT + q] = ok ? *reinterpret_cast<const uint2*>(ep.resh + o) : make_uint2(0u, 0u);
+          rrl[cb * 4 * RT + q] = ok ? *reinterpret_cast<const uint2*>(ep.resl + o) : make_uint2(0u, 0u);
+        }
+      }
+  }
   // ---- (mean, rstd) of the tile's rows from the producer's per-row partial statistics (FOLD: of the A rows, RES == 3: of
-  // the residual rows; a kernel has one of the two): built BEHIND the prologue's requests: its (compiler-tracked) loads are the youngest of the queue, so what hipcc waits for
-  // in front of the build is what step 0 needs anyway
+  // the residual rows; a kernel has one of the two): built BEHIND the prologue's requests -- its (compiler-tracked) loads are the
+  // youngest of the queue, so what hipcc waits for in front of the build is what step 0 needs anyway
   float2* const stab = reinterpret_cast<float2*>(lds + x3s_tab_base(RT, NSUB, MULTI));
   if constexpr (LN_TABS) {
     if (tid < TR) {
@@ -145,26 +167,30 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
       const int m = m0 + tid;
       float2 v = make_float2(0.f, 0.f);         // pad rows: (0, 0) -> every folded value is the finite constant b' / beta
       if (tid < rows_valid && m < M) {
+        // the row's <= 4 partials (sum, M2) in TWO 16-byte loads issued together: a loop over them was a chain of dependent
+        // round trips (load, wait, add) -- 3-4 us of a tile's 9 at B = 1 (profiles/r04a_small_batch.md)
         const float* q = st + (size_t)m * ep.stat_parts * 2;
-        const float cols = (float)ep.stat_cols;
-        float s1 = 0.f;
-        for (int p = 0; p < ep.stat_parts; ++p) s1 += q[2 * p];
-        const float mean = s1 * ep.inv_dim;
-        float m2 = 0.f;
-        for (int p = 0; p < ep.stat_parts; ++p) {                  // Chan's merge of the centred partials
-          const float dm = q[2 * p] / cols - mean;
-          m2 += q[2 * p + 1] + cols * dm * dm;
-        }
+        float4 p01 = zero4(), p23 = zero4();
+        if (ep.stat_parts == 4) { p01 = ld4(q); p23 = ld4(q + 4); }
+        else if (ep.stat_parts == 2) p01 = ld4(q);
+        else if (ep.stat_parts == 1) { const float2 t = *reinterpret_cast<const float2*>(q); p01.x = t.x; p01.y = t.y; }
+        else { p01 = ld4(q); const float2 t = *reinterpret_cast<const float2*>(q + 4); p23.x = t.x; p23.y = t.y; }   // 3 (D = 768 / 256)
+        const float cols = (float)ep.stat_cols, icols = 1.0f / cols;
+        const float mean = ((p01.x + p01.z) + (p23.x + p23.z)) * ep.inv_dim;
+        // Chan's merge of the centred partials (no E[x^2] - mean^2 cancellation); absent partials contribute nothing
+        const int np = ep.stat_parts;
+        const float d0 = p01.x * icols - mean, d1 = np > 1 ? p01.z * icols - mean : 0.f;
+        const float d2 = np > 2 ? p23.x * icols - mean : 0.f, d3 = np > 3 ? p23.z * icols - mean : 0.f;
+        const float m2 = (p01.y + p01.w) + (p23.y + p23.w) + cols * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
         v = make_float2(mean, 1.0f / sqrtf(m2 * ep.inv_dim + 1e-5f));
       }
       stab[tid] = v;
     }
   }
 
-
-  f32x16 acc[RT];
+  f32x16 acc[NCB * RT];                               // column block cb, row sub-tile t: [cb * RT + t]
 #pragma unroll
-  for (int t = 0; t < RT; ++t)
+  for (int t = 0; t < NCB * RT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
@@ -199,217 +225,246 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
 
   for (int c = 0; c < nchunks; ++c) {
     const int buf = MULTI ? (c & 1) : 0;
-    // chunk c landed (this wave's pieces): c == 0 -- the D W sub-steps of the prologue are younger; c > 0 -- the counted W waits
-    // of chunk c - 1 (sub-steps >= D, all issued behind the pieces) have already retired them
-    if (c == 0) wait_vmem_upto<15>();     // (2 D = 16 younger loads; 15 is the encoding's reach here: one W load more retired)
+    // chunk c landed (this wave's pieces): c == 0 -- the D W sub-steps of the prologue are younger; c > 0, NSUB > D -- the counted
+    // W waits of chunk c - 1 (sub-steps >= D, all issued behind the pieces) have already retired them
+    if constexpr (NSUB > D) {
+      if (c == 0) vmem_wait<LW * D>(wsh[0], wsl[0]);   // (the prologue's W loads are younger than chunk 0's pieces)
+    } else {
+      // short chunks (NSUB == D): no W wait of chunk c - 1 lies behind the pieces of chunk c -- wait for them here: younger
+      // = the LW * NSUB W loads issued since
+      vmem_wait<LW * NSUB>(wsh[0], wsl[0]);
+    }
     wg_barrier_nodrain();                 // every wave's pieces visible; every wave is past chunk c - 1, whose buffer refills now
     if constexpr (MULTI) issue_chunk(min(c + 1, nchunks - 1), buf ^ 1);   // (last chunk: a harmless re-fetch keeps the counts uniform)
     read_frags(std::integral_constant<int, 0>{}, buf);
     static_for<NSUB>([&](auto j_tag) __attribute__((always_inline)) {
-      constexpr int j = decltype(j_tag)::value;
+      constexpr int j = decltype(j_tag)::value, sl = j % D;
       if constexpr (j + 1 < NSUB) read_frags(std::integral_constant<int, j + 1>{}, buf);
       // W(c, j): younger = the D - 1 sub-steps behind it (+ the next chunk's pieces when it was issued in front of them)
-      constexpr int NW = 2 * (D - 1) + ((MULTI && j < D) ? PW : 0);
-      vmem_wait<NW>(wsh[j % D], wsl[j % D]);
+      constexpr int NW = LW * (D - 1) + ((MULTI && j < D) ? PW : 0);
+      if constexpr (NCB == 1) vmem_wait<NW>(wsh[sl], wsl[sl]);
+      else vmem_wait<NW>(wsh[sl * 2], wsl[sl * 2], wsh[sl * 2 + 1], wsl[sl * 2 + 1]);
       wait_frags(j_tag, std::integral_constant<int, (j + 1 < NSUB) ? 2 * RT : 0>{});
 #ifndef MDM_EMU
       __builtin_amdgcn_sched_barrier(0);
 #endif
+      // (accumulators interleaved: consecutive MFMAs on different accumulators; every A fragment feeds NCB column blocks)
 #pragma unroll
-      for (int t = 0; t < RT; ++t) {
-        acc[t] = mfma_p16(fal[j & 1][t], wsh[j % D], acc[t]);
-        acc[t] = mfma_p16(fah[j & 1][t], wsl[j % D], acc[t]);
-        acc[t] = mfma_p16(fah[j & 1][t], wsh[j % D], acc[t]);
-      }
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[cb * RT + t] = mfma_p16(fal[j & 1][t], wsh[sl * NCB + cb], acc[cb * RT + t]);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[cb * RT + t] = mfma_p16(fah[j & 1][t], wsl[sl * NCB + cb], acc[cb * RT + t]);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[cb * RT + t] = mfma_p16(fah[j & 1][t], wsh[sl * NCB + cb], acc[cb * RT + t]);
 #ifndef MDM_EMU
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      issue_w(std::integral_constant<int, j % D>{}, c * NSUB + j + D);
+      issue_w(std::integral_constant<int, sl>{}, c * NSUB + j + D);
     });
   }
-  // The tail's re-fetches land before the registers / LDS they target are reused -- and the wait NAMES the sixteen slot registers:
+  // The tail's re-fetches land before the registers / LDS they target are reused -- and the wait NAMES every slot register:
   // to hipcc an in-place refill writes its slot at the asm statement, so behind a slot's last MFMA the register is free, and a
   // bare s_waitcnt vmcnt(0) here let it hand slots with a load still in flight to the epilogue's lane indices (MI355X: rows of
   // fp16 weight bits as `lane >> 3` in a few lanes, stores into the void -- "Write access to a read-only page"; invisible to
   // the emulator, which executes variables, not registers: the hazard class of profiles/r03b_pipe_determinism.md)
-  static_assert(D == 8, "the closing wait names eight slot pairs");
-  vmem_wait<0>(wsh[0], wsl[0], wsh[1], wsl[1], wsh[2], wsl[2], wsh[3], wsl[3]);
-  vmem_wait<0>(wsh[4], wsl[4], wsh[5], wsl[5], wsh[6], wsl[6], wsh[7], wsl[7]);
+  static_for<D * NCB / 4>([&](auto q_tag) __attribute__((always_inline)) {
+    constexpr int q = 4 * decltype(q_tag)::value;
+    vmem_wait<0>(wsh[q], wsl[q], wsh[q + 1], wsl[q + 1], wsh[q + 2], wsl[q + 2], wsh[q + 3], wsl[q + 3]);
+  });
 
-  // ---- epilogue: each wave turns its RT 32 x 32 accumulators through a private 1 KB LDS patch, 8 rows x 32 columns per round,
-  // into (row = lane >> 3, 4 consecutive columns) per lane -> 16-byte fp32 / 8-byte plane accesses (gemm_x3.h).
+  // ---- epilogue: each wave turns its NCB x RT 32 x 32 accumulators through a private 1 KB LDS patch, 8 rows x 32 columns per
+  // round, into (row = lane >> 3, 4 consecutive columns) per lane -> 16-byte fp32 / 8-byte plane accesses (gemm_x3.h).
   float* patch = reinterpret_cast<float*>(lds + x3s_patch_base(RT, NSUB, MULTI)) + wid * (X3_PATCH_BYTES / 4);
   const float accs = ep.acc_scale;
   constexpr bool COL_SCALE = x3_has_col_scale(ACT, RES);
-  const float mult4 = (COL_SCALE && n4 < ep.scale_cols) ? ep.col_scale : 1.f;
-  auto finish4 = [&](float4 v4, float2 st) __attribute__((always_inline)) {
+  auto finish4 = [&](float4 v4, float2 st, int cb) __attribute__((always_inline)) {
+    const float mult4 = (COL_SCALE && n4[cb] < ep.scale_cols) ? ep.col_scale : 1.f;
+    const float4 bb = b4[cb], cc = c4[cb];
     v4.x *= accs; v4.y *= accs; v4.z *= accs; v4.w *= accs;
     if constexpr (FOLD) {
-      v4.x = st.y * (v4.x - st.x * c4.x) + b4.x; v4.y = st.y * (v4.y - st.x * c4.y) + b4.y;
-      v4.z = st.y * (v4.z - st.x * c4.z) + b4.z; v4.w = st.y * (v4.w - st.x * c4.w) + b4.w;
+      v4.x = st.y * (v4.x - st.x * cc.x) + bb.x; v4.y = st.y * (v4.y - st.x * cc.y) + bb.y;
+      v4.z = st.y * (v4.z - st.x * cc.z) + bb.z; v4.w = st.y * (v4.w - st.x * cc.w) + bb.w;
     } else {
-      v4.x += b4.x; v4.y += b4.y; v4.z += b4.z; v4.w += b4.w;
+      v4.x += bb.x; v4.y += bb.y; v4.z += bb.z; v4.w += bb.w;
     }
     if (ACT == ACT_GELU) { v4.x = gelu_erf_fast(v4.x); v4.y = gelu_erf_fast(v4.y); v4.z = gelu_erf_fast(v4.z); v4.w = gelu_erf_fast(v4.w); }
     else if (ACT == ACT_SILU) { v4.x = silu(v4.x); v4.y = silu(v4.y); v4.z = silu(v4.z); v4.w = silu(v4.w); }
     if constexpr (COL_SCALE) { v4.x *= mult4; v4.y *= mult4; v4.z *= mult4; v4.w *= mult4; }
     return v4;
   };
+  float2* const part_all = reinterpret_cast<float2*>(lds + x3s_part_base(RT, NSUB, MULTI));   // OSTAT: [block][row] partials
 
-  if constexpr (OUT_QKV) {
-    // in_proj -> the attention operand planes of attention_x3.h.  group == sequence, row of the group == token; the tile's 128
-    // columns are ONE head of ONE of Q / K / V (D % 128 == 0).
-    const int Dm = ep.D, SPq = ep.qkv.SP, Hq = ep.qkv.H, nkt = ep.qkv.NKT;
-    const int which = n0 / Dm, hcol = n0 - which * Dm, head = hcol >> 7, d0 = wid * 32;
-    const size_t shq = (size_t)grp * Hq + head;
-    if (n0 < N) {
-      if (which == 2) {
-        // V^T: accumulator registers 8 s2 .. 8 s2 + 7 of a lane ARE positions 8 h .. 8 h + 7 of 16-key group s2 of key tile kt
-        const float bias = vbias, csum = vcsum;
+  static_for<NCB>([&](auto cb_tag) __attribute__((always_inline)) {
+    constexpr int cb = decltype(cb_tag)::value;
+    const int nb = n0 + (wid * NCB + cb) * 32;      // first column of this (wave, block)
+    if constexpr (OUT_QKV) {
+      // in_proj -> the attention operand planes of attention_x3.h.  group == sequence, row of the group == token; a 32-column
+      // block lies inside ONE head of ONE of Q / K / V (D % 128 == 0).
+      const int Dm = ep.D, SPq = ep.qkv.SP, Hq = ep.qkv.H, nkt = ep.qkv.NKT;
+      const int which = nb / Dm, hcol = nb - which * Dm, head = hcol >> 7, d0 = hcol & 127;
+      const size_t shq = (size_t)grp * Hq + head;
+      if (nb < N) {
+        if (which == 2) {
+          // V^T: accumulator registers 8 s2 .. 8 s2 + 7 of a lane ARE positions 8 h .. 8 h + 7 of 16-key group s2 of key tile kt
+          const float bias = vbias[cb], csum = vcsum[cb];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-          const int kt = tig * RT + t;
-          if (kt < nkt) {
-            p16_t* vhp = ep.qkv.vh + ((shq * nkt + kt) * AX_HD + d0 + r) * 32 + 8 * h;
-            p16_t* vlp = ep.qkv.vl + ((shq * nkt + kt) * AX_HD + d0 + r) * 32 + 8 * h;
+          for (int t = 0; t < RT; ++t) {
+            const int kt = tig * RT + t;
+            if (kt < nkt) {
+              p16_t* vhp = ep.qkv.vh + ((shq * nkt + kt) * AX_HD + d0 + r) * 32 + 8 * h;
+              p16_t* vlp = ep.qkv.vl + ((shq * nkt + kt) * AX_HD + d0 + r) * 32 + 8 * h;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-              float vv[8];
+              for (int s2 = 0; s2 < 2; ++s2) {
+                float vv[8];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                if constexpr (FOLD) {
-                  const float2 st = stab[32 * t + mfma_row(8 * s2 + j, h)];
-                  vv[j] = st.y * (acc[t][8 * s2 + j] * accs - st.x * csum) + bias;
-                } else {
-                  vv[j] = acc[t][8 * s2 + j] * accs + bias;
+                for (int j = 0; j < 8; ++j) {
+                  if constexpr (FOLD) {
+                    const float2 st = stab[32 * t + mfma_row(8 * s2 + j, h)];
+                    vv[j] = st.y * (acc[cb * RT + t][8 * s2 + j] * accs - st.x * csum) + bias;
+                  } else {
+                    vv[j] = acc[cb * RT + t][8 * s2 + j] * accs + bias;
+                  }
                 }
+                p16x8 vh8, vl8;
+                split8(vv, vh8, vl8);
+                *reinterpret_cast<p16x8*>(vhp + 16 * s2) = vh8;
+                *reinterpret_cast<p16x8*>(vlp + 16 * s2) = vl8;
               }
-              p16x8 vh8, vl8;
-              split8(vv, vh8, vl8);
-              *reinterpret_cast<p16x8*>(vhp + 16 * s2) = vh8;
-              *reinterpret_cast<p16x8*>(vlp + 16 * s2) = vl8;
             }
           }
+        } else {
+          p16_t* dh = (which == 0 ? ep.qkv.qh : ep.qkv.kh) + shq * SPq * AX_HD + d0 + pc4;
+          p16_t* dl = (which == 0 ? ep.qkv.ql : ep.qkv.kl) + shq * SPq * AX_HD + d0 + pc4;
+#pragma unroll
+          for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = acc[cb * RT + t][4 * g + e];
+              wave_lds_fence();
+              float4 v4 = ld4(&patch[prow * 32 + pc4]);
+              wave_lds_fence();
+              const int rit = t * 32 + 8 * g + prow, tok = tig * TR + rit;
+              float2 st = make_float2(0.f, 1.f);
+              if constexpr (FOLD) st = stab[rit];
+              v4 = finish4(v4, st, cb);
+              if (rit < rows_valid && tok < ep.S) split4_store(dh + (size_t)tok * AX_HD, dl + (size_t)tok * AX_HD, v4);
+            }
         }
-      } else {
-        p16_t* dh = (which == 0 ? ep.qkv.qh : ep.qkv.kh) + shq * SPq * AX_HD + d0 + pc4;
-        p16_t* dl = (which == 0 ? ep.qkv.ql : ep.qkv.kl) + shq * SPq * AX_HD + d0 + pc4;
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = acc[t][4 * g + e];
-            wave_lds_fence();
-            float4 v4 = ld4(&patch[prow * 32 + pc4]);
-            wave_lds_fence();
-            const int rit = t * 32 + 8 * g + prow, tok = tig * TR + rit;
-            float2 st = make_float2(0.f, 1.f);
-            if constexpr (FOLD) st = stab[rit];
-            v4 = finish4(v4, st);
-            if (rit < rows_valid && tok < ep.S) split4_store(dh + (size_t)tok * AX_HD, dl + (size_t)tok * AX_HD, v4);
-          }
       }
-    }
-    return;
-  } else {
-    float2* part = reinterpret_cast<float2*>(lds + x3s_part_base(RT, NSUB, MULTI)) + wid * TR;   // OSTAT: this wave's partials
+    } else {
+      float2* part = part_all + (wid * NCB + cb) * TR;
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+      for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = acc[t][4 * g + e];
-        wave_lds_fence();
-        float4 v4 = ld4(&patch[prow * 32 + pc4]);
-        wave_lds_fence();
-        const int rit = t * 32 + 8 * g + prow, m = m0 + rit;
-        const bool row_ok = rit < rows_valid && m < M;
-        float2 st = make_float2(0.f, 1.f);
-        if constexpr (LN_TABS) st = stab[rit];
-        v4 = finish4(v4, FOLD ? st : make_float2(0.f, 1.f));
-        if constexpr (RES == 1) {
-          v4 = add4(v4, rres[4 * t + g]);
-        } else if constexpr (RES == 2 || RES == 3) {
-          {
-            const uint2 a = rrh[4 * t + g], b = rrl[4 * t + g];
+          for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = acc[cb * RT + t][4 * g + e];
+          wave_lds_fence();
+          float4 v4 = ld4(&patch[prow * 32 + pc4]);
+          wave_lds_fence();
+          const int rit = t * 32 + 8 * g + prow, m = m0 + rit;
+          const bool row_ok = rit < rows_valid && m < M;
+          float2 st = make_float2(0.f, 1.f);
+          if constexpr (LN_TABS) st = stab[rit];
+          v4 = finish4(v4, FOLD ? st : make_float2(0.f, 1.f), cb);
+          if constexpr (RES == 1) {
+            v4 = add4(v4, rres[(cb * RT + t) * 4 + g]);
+          } else if constexpr (RES == 2 || RES == 3) {
+            const uint2 a = rrh[(cb * RT + t) * 4 + g], b = rrl[(cb * RT + t) * 4 + g];
             float4 x4 = make_float4(p16_to_f32((p16_t)(a.x & 0xffffu)) + p16_to_f32((p16_t)(b.x & 0xffffu)),
                                     p16_to_f32((p16_t)(a.x >> 16)) + p16_to_f32((p16_t)(b.x >> 16)),
                                     p16_to_f32((p16_t)(a.y & 0xffffu)) + p16_to_f32((p16_t)(b.y & 0xffffu)),
                                     p16_to_f32((p16_t)(a.y >> 16)) + p16_to_f32((p16_t)(b.y >> 16)));
             if constexpr (RES == 3) {   // the residual is LayerNorm(x), rebuilt from x's planes and its row statistics
-              x4.x = (x4.x - st.x) * st.y * g4.x + be4.x; x4.y = (x4.y - st.x) * st.y * g4.y + be4.y;
-              x4.z = (x4.z - st.x) * st.y * g4.z + be4.z; x4.w = (x4.w - st.x) * st.y * g4.w + be4.w;
+              const float4 gg = g4[cb], be = be4[cb];
+              x4.x = (x4.x - st.x) * st.y * gg.x + be.x; x4.y = (x4.y - st.x) * st.y * gg.y + be.y;
+              x4.z = (x4.z - st.x) * st.y * gg.z + be.z; x4.w = (x4.w - st.x) * st.y * gg.w + be.w;
             }
             v4 = add4(v4, x4);
           }
-        }
-        if constexpr (OSTAT) {   // partial (sum, centred sum of squares) of this row over the wave's 32 columns
-          const float s1 = sum_lanes8((v4.x + v4.y) + (v4.z + v4.w));
-          const float mw = s1 * (1.0f / 32.0f);
-          const float dx = v4.x - mw, dy = v4.y - mw, dz = v4.z - mw, dw = v4.w - mw;
-          const float m2 = sum_lanes8((dx * dx + dy * dy) + (dz * dz + dw * dw));
-          if ((lane & 7) == 0) part[rit] = make_float2(s1, m2);
-        }
-        if (row_ok && col_ok) {
-          if constexpr (EMBED) {
-            const int bb = grp, tt = m - grp * group_rows;      // group == sample, row of the group == frame
-            for (int br = 0; br < ep.emb_nbranch; ++br) {
-              const size_t o = ((size_t)(br * ep.emb_B + bb) * (ep.emb_T + 1) + 1 + tt) * ep.ld + n4;
-              split4_store(ep.oh + o, ep.ol + o, v4);
+          if constexpr (OSTAT) {   // partial (sum, centred sum of squares) of this row over the block's 32 columns
+            const float s1 = sum_lanes8((v4.x + v4.y) + (v4.z + v4.w));
+            const float mw = s1 * (1.0f / 32.0f);
+            const float dx = v4.x - mw, dy = v4.y - mw, dz = v4.z - mw, dw = v4.w - mw;
+            const float m2 = sum_lanes8((dx * dx + dy * dy) + (dz * dz + dw * dw));
+            if ((lane & 7) == 0) part[rit] = make_float2(s1, m2);
+          }
+          if (row_ok && col_ok[cb]) {
+            if constexpr (EMBED) {
+              const int bb = grp, tt = m - grp * group_rows;      // group == sample, row of the group == frame
+              for (int br = 0; br < ep.emb_nbranch; ++br) {
+                const size_t o = ((size_t)(br * ep.emb_B + bb) * (ep.emb_T + 1) + 1 + tt) * ep.ld + n4[cb];
+                split4_store(ep.oh + o, ep.ol + o, v4);
+              }
+            } else {
+              const size_t o = (size_t)m * ep.ld + n4[cb];
+              if constexpr (OUT_PLANES) split4_store(ep.oh + o, ep.ol + o, v4);
+              if constexpr (OUT_F32) st4(ep.out + o, v4);
             }
-          } else {
-            const size_t o = (size_t)m * ep.ld + n4;
-            if constexpr (OUT_PLANES) split4_store(ep.oh + o, ep.ol + o, v4);
-            if constexpr (OUT_F32) st4(ep.out + o, v4);
           }
         }
-      }
-    if constexpr (OSTAT) {   // rows x waves partials -> one (sum, M2) pair per row and 128-column tile (OSTAT launches: N % 128 == 0)
-      wg_barrier();
-      if (tid < rows_valid && m0 + tid < M) {
-        const float2* pp = reinterpret_cast<const float2*>(lds + x3s_part_base(RT, NSUB, MULTI));
-        float s1 = 0.f;
+    }
+  });
+  if constexpr (OSTAT && !OUT_QKV) {   // rows x blocks partials -> one (sum, M2) pair per row and tile (OSTAT launches: N % TN == 0)
+    wg_barrier();
+    if (tid < rows_valid && m0 + tid < M) {
+      float s1 = 0.f;
 #pragma unroll
-        for (int w4 = 0; w4 < X3S_WAVES; ++w4) s1 += pp[w4 * TR + tid].x;
-        const float mt = s1 * (1.0f / X3S_TN);
-        float m2 = 0.f;
+      for (int w4 = 0; w4 < NBLK; ++w4) s1 += part_all[w4 * TR + tid].x;
+      const float mt = s1 * (1.0f / TN);
+      float m2 = 0.f;
 #pragma unroll
-        for (int w4 = 0; w4 < X3S_WAVES; ++w4) {
-          const float2 v = pp[w4 * TR + tid];
-          const float dm = v.x * (1.0f / 32.0f) - mt;
-          m2 += v.y + 32.0f * dm * dm;
-        }
-        *reinterpret_cast<float2*>(ep.ostat + ((size_t)(m0 + tid) * tiles_n + tile_n) * 2) = make_float2(s1, m2);
+      for (int w4 = 0; w4 < NBLK; ++w4) {
+        const float2 v = part_all[w4 * TR + tid];
+        const float dm = v.x * (1.0f / 32.0f) - mt;
+        m2 += v.y + 32.0f * dm * dm;
       }
+      *reinterpret_cast<float2*>(ep.ostat + ((size_t)(m0 + tid) * tiles_n + tile_n) * 2) = make_float2(s1, m2);
     }
   }
 }
 
 #ifndef MDM_X3_KERNEL_ONLY
-// Up to how many token sequences a launch takes this kernel (default 32, i.e. 16 motions under guidance; MDM_X3S_MAX_SEQS=0
-// disables it for same-box A/B runs): measured cross-over with gemm_x3.h's sequence-sized tiles, profiles/r04a_small_batch.md.
+// Up to how many token sequences a forward takes this kernel (default 40, i.e. 20 motions under guidance; MDM_X3S_MAX_SEQS=0
+// disables it for same-box A/B runs): the measured cross-over with gemm_x3.h's sequence-sized tiles lies between 32 sequences
+// (65 vs 80 ms per 50-step loop) and 48 (93 vs ~95), profiles/r04a_small_batch.md.
 inline int x3s_max_seqs() {      // (read per call: the test suites switch kernels inside one process)
   const char* e = getenv("MDM_X3S_MAX_SEQS");
-  return e != nullptr ? atoi(e) : 32;
+  return e != nullptr ? atoi(e) : 40;
 }
-// 32-row tiles while they leave the chip under-filled, 64-row tiles above (MDM_X3S_RT=1|2 pins it for A/B runs)
-inline int x3s_rows_setting(int groups) {
-  const char* e = getenv("MDM_X3S_RT");
-  const int pin = e != nullptr ? atoi(e) : 0;
-  if (pin == 1 || pin == 2) return pin;
-  return groups <= 12 ? 1 : 2;
+// Tile shape of a forward over `nseq` sequences -- ONE shape for all of its GEMMs, because the row statistics a producer leaves
+// (per tile width) are what its consumer merges.  32-row tiles up to 8 sequences (B <= 4 under guidance: 22.2 vs 26.5 ms per
+// 50-step loop at B = 1, 31.1 vs 31.8 at B = 4), 64-row tiles above (37.0 vs 37.6 at B = 6, 66.3 vs 72.5 at B = 16); always
+// 128 columns: the 256-column form (NCB = 2: every A fragment feeds two column blocks, half the LDS reads and half the
+// activation traffic per MFMA) measured no faster anywhere -- 28.7 / 37.0 / 55.7 / 68.1 / 123.7 ms at B = 1 / 6 / 10 / 16 / 32
+// for 32 x 256 against 23.0 / 38.7 / 53.7 / 74.1 / 136.1 for 32 x 128 and 27.3 / 38.4 / 53.2 / 66.5 / 121.6 for 64 x 128 --
+// and is compiled into the probe library only (MDM_X3S_NCB=2).  MDM_X3S_RT=1|2 pins the height for A/B runs.
+struct X3sShape { int rt, ncb; };
+inline X3sShape x3s_shape(int nseq) {
+  X3sShape sh{nseq <= 8 ? 1 : 2, 1};
+  if (const char* e = getenv("MDM_X3S_RT")) { const int v = atoi(e); if (v == 1 || v == 2) sh.rt = v; }
+#ifdef MDM_PROBES
+  if (const char* e = getenv("MDM_X3S_NCB")) { const int v = atoi(e); if (v == 1 || v == 2) sh.ncb = v; }
+#endif
+  return sh;
 }
 
-template <int RT, int NSUB, bool MULTI, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, bool FOLD, bool OSTAT,
+template <int RT, int NCB, int NSUB, bool MULTI, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, bool FOLD, bool OSTAT,
           bool EMBED>
 inline int launch_gemm_x3s_t(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K, int group_rows,
                              hipStream_t stream) {
-  auto kfn = &gemm_x3s_kernel<RT, NSUB, MULTI, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, FOLD, OSTAT, EMBED>;
+  auto kfn = &gemm_x3s_kernel<RT, NCB, NSUB, MULTI, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, FOLD, OSTAT, EMBED>;
   if (K % (NSUB * 16) != 0 || (!MULTI && K != NSUB * 16)) return -2;   // (MULTI with one chunk works: the spare buffer is re-fetched)
   if (M % group_rows != 0) return -2;
   if (!x3_has_col_scale(ACT, RES) && ep.scale_cols > 0) return -2;
-  constexpr int LDS = x3s_lds_bytes(RT, NSUB, MULTI);
+  if (OSTAT && N % x3s_tn(NCB) != 0) return -2;
+  constexpr int LDS = x3s_lds_bytes(RT, NCB, NSUB, MULTI);
 #ifndef MDM_EMU
   if (LDS > 65536) {
     static bool configured[kMaxDevices] = {};
@@ -420,33 +475,39 @@ inline int launch_gemm_x3s_t(const X3Operand& A, const X3Weights& W, const X3Epi
     }
   }
 #endif
-  const int TR = 32 * RT;
-  const int tpg = (group_rows + TR - 1) / TR, tiles_m = (M / group_rows) * tpg, tiles_n = (N + X3S_TN - 1) / X3S_TN;
+  const int TR = 32 * RT, TN = x3s_tn(NCB);
+  const int tpg = (group_rows + TR - 1) / TR, tiles_m = (M / group_rows) * tpg, tiles_n = (N + TN - 1) / TN;
   const int total = tiles_m * tiles_n;
   MDM_LAUNCH(kfn, dim3(total), dim3(64 * X3S_WAVES), LDS, stream, A, W, ep, M, N, K, group_rows, tpg, tiles_n, total);
   return 0;
 }
 
 // the GEMM kinds of launch_gemm_x3_ln (gemm_x3.h), plus kind 6 = layer 0's in_proj (no folded LayerNorm)
-template <int RT>
+template <int RT, int NCB>
 inline int launch_gemm_x3s_rt(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                               int group_rows, hipStream_t s) {
+  // K-chunk: 256 k for 32-row tiles, 128 k for 64-row tiles -- 32 KB per buffer either way, so that two workgroups share a CU
+  constexpr int NS = 16 / RT;
   switch (kind) {
-    case 0: return launch_gemm_x3s_t<RT, 16, true, ACT_NONE, 0, false, false, true, true, false, false>(A, W, ep, M, N, K, group_rows, s);
-    case 6: return launch_gemm_x3s_t<RT, 16, true, ACT_NONE, 0, false, false, true, false, false, false>(A, W, ep, M, N, K, group_rows, s);
-    case 1: return launch_gemm_x3s_t<RT, 16, true, ACT_NONE, 2, false, true, false, false, true, false>(A, W, ep, M, N, K, group_rows, s);
-    case 2: return launch_gemm_x3s_t<RT, 16, true, ACT_NONE, 3, false, true, false, false, true, false>(A, W, ep, M, N, K, group_rows, s);
-    case 3: return launch_gemm_x3s_t<RT, 16, true, ACT_GELU, 0, false, true, false, true, false, false>(A, W, ep, M, N, K, group_rows, s);
-    case 4: return launch_gemm_x3s_t<RT, 16, true, ACT_NONE, 0, true, false, false, true, false, false>(A, W, ep, M, N, K, group_rows, s);
+    case 0: return launch_gemm_x3s_t<RT, NCB, NS, true, ACT_NONE, 0, false, false, true, true, false, false>(A, W, ep, M, N, K, group_rows, s);
+    case 6: return launch_gemm_x3s_t<RT, NCB, NS, true, ACT_NONE, 0, false, false, true, false, false, false>(A, W, ep, M, N, K, group_rows, s);
+    case 1: return launch_gemm_x3s_t<RT, NCB, NS, true, ACT_NONE, 2, false, true, false, false, true, false>(A, W, ep, M, N, K, group_rows, s);
+    case 2: return launch_gemm_x3s_t<RT, NCB, NS, true, ACT_NONE, 3, false, true, false, false, true, false>(A, W, ep, M, N, K, group_rows, s);
+    case 3: return launch_gemm_x3s_t<RT, NCB, NS, true, ACT_GELU, 0, false, true, false, true, false, false>(A, W, ep, M, N, K, group_rows, s);
+    case 4: return launch_gemm_x3s_t<RT, NCB, NS, true, ACT_NONE, 0, true, false, false, true, false, false>(A, W, ep, M, N, K, group_rows, s);
     case 5:   // InputProcess: K = 288 (263 features padded to 9 x 32) is one chunk of 18 sub-steps
-      return launch_gemm_x3s_t<RT, 18, false, ACT_NONE, 1, false, true, false, false, false, true>(A, W, ep, M, N, K, group_rows, s);
+      return launch_gemm_x3s_t<RT, NCB, 18, false, ACT_NONE, 1, false, true, false, false, false, true>(A, W, ep, M, N, K, group_rows, s);
     default: return -2;
   }
 }
-inline int launch_gemm_x3s(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
+inline int launch_gemm_x3s(int kind, X3sShape sh, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                            int group_rows, hipStream_t s) {
-  if (x3s_rows_setting(M / group_rows) == 1) return launch_gemm_x3s_rt<1>(kind, A, W, ep, M, N, K, group_rows, s);
-  return launch_gemm_x3s_rt<2>(kind, A, W, ep, M, N, K, group_rows, s);
+#ifdef MDM_PROBES
+  if (sh.rt == 1 && sh.ncb == 2) return launch_gemm_x3s_rt<1, 2>(kind, A, W, ep, M, N, K, group_rows, s);
+  if (sh.rt == 2 && sh.ncb == 2) return launch_gemm_x3s_rt<2, 2>(kind, A, W, ep, M, N, K, group_rows, s);
+#endif
+  if (sh.rt == 1) return launch_gemm_x3s_rt<1, 1>(kind, A, W, ep, M, N, K, group_rows, s);
+  return launch_gemm_x3s_rt<2, 1>(kind, A, W, ep, M, N, K, group_rows, s);
 }
 #endif  // MDM_X3_KERNEL_ONLY
 

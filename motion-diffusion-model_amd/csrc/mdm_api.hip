@@ -447,6 +447,7 @@ struct LnArgs {
   int parts = 1; float inv_dim = 1.f;
   const float* res_f32 = nullptr; int emb_T = 1, emb_B = 1, emb_nbranch = 1;                     // EMBED (kind 5)
   bool small = false;      // the small-row-count kernel (gemm_x3s.h): the whole forward runs on one of the two kernels
+  X3sShape shape{1, 1};    // ... and on ONE tile shape of it (x3s_shape(nseq))
   int stat_cols = 256;     // columns per partial of astat / rstat (what the PRODUCER's kernel wrote)
 };
 // The latency regime (gemm_x3s.h): a forward of at most x3s_max_seqs() sequences runs its GEMMs on 32 / 64-row tiles
@@ -470,7 +471,7 @@ int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w,
   if (const char* e = getenv("MDM_X3S_KINDS")) small = small && ((atoi(e) >> kind) & 1);
 #endif
   if (small) {
-    const int rc = launch_gemm_x3s(kind, a, w, ep, M, N, K, kind == 5 ? ln.emb_T : S, s);
+    const int rc = launch_gemm_x3s(kind, ln.shape, a, w, ep, M, N, K, kind == 5 ? ln.emb_T : S, s);
     if (rc == -1) return fail(MDM_EHIP, "f16x3 linear (small tiles): hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     if (rc == -2) return fail(MDM_EUNSUPPORTED, "f16x3 linear (small tiles): unsupported shape (K must be 288 or a multiple of 256)");
 #if defined(MDM_PROBES) && !defined(MDM_EMU)
@@ -524,6 +525,7 @@ int embed_frames_x3(mdm_model* m, const Workspace& ws, const float* x, int B, in
   a.res_f32 = m->W("sequence_pos_encoder.pe");
   a.emb_T = T; a.emb_B = B; a.emb_nbranch = nbranch;
   a.small = use_small_gemm(m, nbranch * B, T + 1) && KP == 288;
+  a.shape = x3s_shape(nbranch * B);
   return launch_x3_ln(nullptr, MDM_PROF_EMBED, 5, X3Operand{ph, pl}, m->in_planes, m->W("input_process.poseEmbedding.bias"), a,
                       nullptr, ws.tokh, ws.tokl, nullptr, B * T, D, KP, T + 1, D, 0, 1.f, s);
 }
@@ -569,10 +571,11 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
     // few sequences: the latency regime -- every GEMM of the stack on gemm_x3s.h's 32 / 64-row tiles (row statistics per 128
     // columns); else gemm_x3.h's sequence-sized tiles (per 256)
     const bool small = use_small_gemm(m, nseq, S);
-    const int scols = small ? X3S_TN : 256;
+    const X3sShape shape = x3s_shape(nseq);
+    const int scols = small ? x3s_tn(shape.ncb) : 256;
     const int parts = (D + scols - 1) / scols;
     const float inv_dim = 1.0f / (float)D;
-    auto LN = [&]() { LnArgs a; a.small = small; a.stat_cols = scols; a.parts = parts; a.inv_dim = inv_dim; return a; };
+    auto LN = [&]() { LnArgs a; a.small = small; a.shape = shape; a.stat_cols = scols; a.parts = parts; a.inv_dim = inv_dim; return a; };
     // (Running the stack over two half-batches, so that every producer -> consumer hand-over stays inside the 256 MB Infinity
     // Cache, was built and measured: 1.5 % SLOWER on the same box -- profiles/r02_ab.md -- and removed.)
     for (int l = 0; l < m->cfg.num_layers; ++l) {
@@ -657,7 +660,8 @@ int outproj_x3(mdm_model* m, const Workspace& ws, int nseq, int B, int T, const 
   if (m->lnfold && x3_waves_setting() == 8 && S <= X3_TM) {   // the final LayerNorm is folded into this GEMM
     LnArgs a; a.astat = ws.stat2; a.colsum = m->c_out; a.inv_dim = 1.0f / (float)D;
     a.small = use_small_gemm(m, nseq, S);            // (the same decision the encoder took: who wrote stat2)
-    a.stat_cols = a.small ? X3S_TN : 256;
+    a.shape = x3s_shape(nseq);
+    a.stat_cols = a.small ? x3s_tn(a.shape.ncb) : 256;
     a.parts = (D + a.stat_cols - 1) / a.stat_cols;
     if (int rc = launch_x3_ln(nullptr, MDM_PROF_OUTPROJ, 4, X3Operand{ws.tokh, ws.tokl}, m->out_planes_f, m->b_out, a,
                               out_tok, nullptr, nullptr, nullptr, nseq * S, ldo, D, S, D, 0, 1.f, s)) return rc;

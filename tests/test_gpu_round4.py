@@ -163,3 +163,22 @@ def test_bench_force_pg_brings_up_rccl_as_a_one_rank_group():
     assert line["ranks"]["gathered_shape"][0] == 16
     assert len(line["ranks"]["loop_ms_per_rank"]) == 1 and line["ranks"]["loop_ms_min"] <= line["ranks"]["loop_ms_max"]
     assert line["value"] > 0
+
+
+@pytest.mark.parametrize("B,lengths", [(1, [196]), (6, [196, 120, 57, 196, 33, 180])])
+def test_small_batch_loop_matches_oracle(sd, gemm_path, B, lengths):
+    """The latency regime (sample/generate.py's default `--num_samples 6`; README.md:13's per-call latency; BASELINE.json
+    configs[0]'s batch 1): the 50-step CFG loop at T = 196, B = 1 and B = 6, on BOTH encoder GEMM kernels -- csrc/gemm_x3s.h's
+    32 / 64-row tiles (what runs below 40 sequences) and csrc/gemm_x3.h's sequence tiles -- against the oracle on the same
+    injected noise; and the two kernels against each other."""
+    steps, T = 50, 196
+    shape = (B, 263, 1, T)
+    y = synth_y(B, T, seed=400 + B, lengths=lengths)
+    x_T, noises = orc.make_noise(shape, steps, 40 + B)
+    model, diffusion = make_pair(sd, steps, DEV, guided=True)
+    out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": dict(y)},
+                                  noise_sequence=[x_T] + [n.contiguous() for n in noises])
+    want = orc.sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), shape, y, x_T, noises, cfg=True)
+    err = maxabs(out.cpu(), want)
+    print(f"[parity] small-batch loop B={B} T=196 50 steps, GEMM kernel {gemm_path}: max-abs vs oracle = {err:.3e}")
+    assert err < TOL_LOOP
