@@ -58,6 +58,7 @@ static_assert(AX_SLOT + 4 * 32 * AX_OST * 4 <= AX_RING * AX_SLOT, "output stagin
 
 // ABL (timing experiments only, 0 in production; results are garbage): 1 = no MFMAs, 2 = no LDS fragment reads,
 // 4 = no softmax, 8 = no output staging / stores, 16 = no K / V^T streaming after the prologue, 32 = no per-tile barrier.
+// Results stay CORRECT with: 64 = non-temporal K / V^T LDS-DMA, 128 = non-temporal plane stores (A/B: profiles/r04b_ab.md).
 template <int NKT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const int* __restrict__ lengths,
                                                                     int S, int D, int B, float* __restrict__ out,
@@ -101,11 +102,12 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
         // pad keys (>= S) are fetched from the last real row instead: finite, cache-resident, and no HBM traffic for rows
         // nobody wrote; the swizzle still follows the LDS row
         const int key = 32 * t + 4 * idx + (lv >> 4);
-        glds16((plane ? P.kl : P.kh) + (sh * SP + (size_t)min(key, S - 1)) * AX_HD + (((lv & 15) ^ (key & 15)) * 8), dst);
+        const p16_t* src = (plane ? P.kl : P.kh) + (sh * SP + (size_t)min(key, S - 1)) * AX_HD + (((lv & 15) ^ (key & 15)) * 8);
+        if constexpr ((ABL & 64) != 0) glds16_nt(src, dst); else glds16(src, dst);
       } else {
         const int d = 16 * idx + (lv >> 2);
-        glds16((plane ? P.vl : P.vh) + ((sh * NKT + (size_t)(t - NKT)) * AX_HD + d) * 32 + (((lv & 3) ^ ((d >> 2) & 3)) * 8),
-               dst);
+        const p16_t* src = (plane ? P.vl : P.vh) + ((sh * NKT + (size_t)(t - NKT)) * AX_HD + d) * 32 + (((lv & 3) ^ ((d >> 2) & 3)) * 8);
+        if constexpr ((ABL & 64) != 0) glds16_nt(src, dst); else glds16(src, dst);
       }
     }
   };
@@ -347,7 +349,19 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
           const float4 v = ld4(&so[row * AX_OST + 4 * c4]);
           const size_t oo = obase + (size_t)qq * D + 64 * pass + 4 * c4;
           if (out != nullptr) st4(out + oo, v);
-          if (oh != nullptr) split4_store(oh + oo, ol + oo, v);  // planes for the out_proj f16x3 GEMM
+          if (oh != nullptr) {   // planes for the out_proj f16x3 GEMM
+            if constexpr ((ABL & 128) != 0) {
+#ifndef MDM_EMU
+              uint32_t h01, l01, h23, l23;
+              split2_p16(v.x, v.y, h01, l01);
+              split2_p16(v.z, v.w, h23, l23);
+              __builtin_nontemporal_store(u32x2{h01, h23}, reinterpret_cast<u32x2*>(oh + oo));
+              __builtin_nontemporal_store(u32x2{l01, l23}, reinterpret_cast<u32x2*>(ol + oo));
+#endif
+            } else {
+              split4_store(oh + oo, ol + oo, v);
+            }
+          }
         }
       }
       wave_lds_fence();

@@ -250,11 +250,23 @@ __device__ __forceinline__ void split2_p16(float a, float b, uint32_t& hi2, uint
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (kSplitF16) {
     const f32x2 v = {a, b};
-    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f16x2 h = __builtin_convertvector(v, f16x2);       // v_cvt_pk_f16_f32
+    hi2 = __builtin_bit_cast(uint32_t, h);
+#ifdef MDM_SPLIT_FMAMIX
+    // (A/B build, round 4) lo = fp16(x - float(hi)) in ONE instruction per value: v_fma_mix{lo,hi}_f16 takes the fp16 half of
+    // `hi2` and the fp32 value as mixed-precision sources (hi * -1.0 + x: exact in fp32, then one RNE rounding to fp16 -- bit
+    // for bit the value of the form below, tests/test_gpu_round4.py::test_operand_split_is_bit_exact...).  Per pair 3 instructions
+    // instead of 6 -- and NOT faster: 366.7 / 366.5 vs 366.7 / 367.1 motions/s on the same box (profiles/r04b_ab.md): the epilogues
+    // are not bound by these conversions.  Not the default.
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi2), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi2), "v"(b));
+    lo2 = l;
+#else
     const f32x2 r = v - __builtin_convertvector(h, f32x2);
     const f16x2 l = __builtin_convertvector(r, f16x2);
-    hi2 = __builtin_bit_cast(uint32_t, h);
     lo2 = __builtin_bit_cast(uint32_t, l);
+#endif
     return;
   }
 #endif
@@ -291,6 +303,16 @@ __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_bas
 #else
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+// the same with the non-temporal cache policy (aux = 2): for streams ONE workgroup reads once
+__device__ __forceinline__ void glds16_nt(const void* gsrc_lane, void* lds_wave_base) {
+#ifdef MDM_EMU
+  emu::vm_issue(static_cast<char*>(lds_wave_base) + 16 * emu::lane_id(), gsrc_lane, 16, false);
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
 #endif
 }
 

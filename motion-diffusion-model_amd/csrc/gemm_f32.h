@@ -616,7 +616,14 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int lrow = wm * WT + i * 32 + 8 * p + prow, m = m0 + lrow;
-          const float4 a4 = ld4(&patch[(8 * p + prow) * 36 + pc4]);
+          float4 a4 = ld4(&patch[(8 * p + prow) * 36 + pc4]);
+#if defined(MDM_F32_EPI_NOP) && !defined(MDM_EMU)
+          // (round-4 experiment, profiles/r04c_packed_math.md: the patch values retired by an explicit wait, then MDM_F32_EPI_NOP x 8
+          // idle issue slots in front of their first -- with SLP vectorisation: packed -- consumer)
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a4.x), "+v"(a4.y), "+v"(a4.z), "+v"(a4.w));
+#pragma unroll
+          for (int nn = 0; nn < MDM_F32_EPI_NOP; ++nn) asm volatile("s_nop 7" : "+v"(a4.x), "+v"(a4.y), "+v"(a4.z), "+v"(a4.w));
+#endif
           const bool ok = m < M && nb < N;
           const float4 y = ok ? ep.value4(nb, cv, a4, rv[p], ln_tab[lrow], ln_tab[BT + lrow]) : zero4();
           if (ok) st4(ep.out + (size_t)m * ep.ld + nb, y);

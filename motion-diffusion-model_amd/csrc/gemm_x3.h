@@ -338,6 +338,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
 
   int v = (int)blockIdx.x;
   if (v >= total) return;
+#if defined(MDM_PROBES) && !defined(MDM_EMU)
+  // (probe build, mdm_debug_set(8, d): the SECOND workgroup of every CU -- the upper half of the grid in dispatch order -- starts
+  // d * 64 cycles late, so that the two 4-wave workgroups of a CU run their k-loops and epilogues in anti-phase:
+  // tools/gemm_dephase_probe.py, profiles/r04b_ab.md)
+  if constexpr (WAVES == 4 && !EMBED) {
+    if (ep.emb_B > 1 && (int)blockIdx.x >= gstride / 2) {
+      const unsigned long long t0 = __builtin_readcyclecounter();
+      while (__builtin_readcyclecounter() - t0 < (unsigned long long)ep.emb_B * 64ULL) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+#endif
   Cursor ca{v, 0, {}};
   aim_a(ca);
   int wv = v, wkk = 0;   // the W stream's (tile, k): one step ahead of the MFMAs, like the A stream

@@ -486,8 +486,9 @@ inline int launch_gemm_x3s_t(const X3Operand& A, const X3Weights& W, const X3Epi
 template <int RT, int NCB>
 inline int launch_gemm_x3s_rt(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                               int group_rows, hipStream_t s) {
-  // K-chunk: 256 k for 32-row tiles, 128 k for 64-row tiles -- 32 KB per buffer either way, so that two workgroups share a CU
-  constexpr int NS = 16 / RT;
+  // K-chunks of 128 k (8 sub-steps): 16 / 32 KB per buffer.  (256-k chunks for the 32-row tiles measured 1.5-4 % slower: 22.2 /
+  // 37.3 / 52.7 vs 21.9 / 36.6 / 50.5 ms at B = 1 / 6 / 10; a third resident workgroup per CU changed nothing: r4lat5)
+  constexpr int NS = 8;
   switch (kind) {
     case 0: return launch_gemm_x3s_t<RT, NCB, NS, true, ACT_NONE, 0, false, false, true, true, false, false>(A, W, ep, M, N, K, group_rows, s);
     case 6: return launch_gemm_x3s_t<RT, NCB, NS, true, ACT_NONE, 0, false, false, true, false, false, false>(A, W, ep, M, N, K, group_rows, s);

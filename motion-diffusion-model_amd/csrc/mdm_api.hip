@@ -38,6 +38,7 @@ thread_local std::string g_err;
 int g_x3_ablate = 0;        // gemm_x3.h ABL code
 int g_x3_reuse_planes = 0;  // mdm_linear_x3 skips the operand split and reuses the planes in scratch
 int g_f6_reference = 0;     // mdm_linear_f16f6 on the one-wave-per-tile reference kernel
+int g_x3_delay = 0;         // gemm_x3.h, 4-wave form: start delay (x 64 cycles) of every CU's second workgroup
 #else
 constexpr int g_x3_ablate = 0, g_x3_reuse_planes = 0;
 #endif
@@ -310,7 +311,8 @@ int launch_attention_x3(Profiler* pf, const QkvPlanes& qp, const int* lengths, i
     case 6: return launch_attention_x3_t<6>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
     default:
 #ifdef MDM_PROBES
-      switch (g_ax_ablate) {
+      static const int env_abl = [] { const char* e = getenv("MDM_AX_ABL"); return e != nullptr ? atoi(e) : 0; }();   // whole-bench A/B runs
+      switch (g_ax_ablate != 0 ? g_ax_ablate : env_abl) {
         case 1: return launch_attention_x3_t<7, 1>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
         case 2: return launch_attention_x3_t<7, 2>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
         case 3: return launch_attention_x3_t<7, 3>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
@@ -320,6 +322,9 @@ int launch_attention_x3(Profiler* pf, const QkvPlanes& qp, const int* lengths, i
         case 32: return launch_attention_x3_t<7, 32>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
         case 48: return launch_attention_x3_t<7, 48>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
         case 63: return launch_attention_x3_t<7, 63>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 64: return launch_attention_x3_t<7, 64>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 128: return launch_attention_x3_t<7, 128>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 192: return launch_attention_x3_t<7, 192>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
         default: break;
       }
 #endif
@@ -422,6 +427,9 @@ int launch_linear_x3(Profiler* pf, X3Operand a, X3Weights w, const float* bias, 
   ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)N * K, s);
   X3Epilogue ep{out, bias, res, res_planes.hi, res_planes.lo, oh, ol, N, scale_cols, col_scale, QkvPlanes{}, 0, 0,
                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1};
+#ifdef MDM_PROBES
+  if (g_x3_delay > 1) ep.emb_B = g_x3_delay;
+#endif
   const int rc = launch_gemm_x3(a, w, ep, M, N, K, act, seq_len, s, g_x3_ablate);
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "f16x3 linear: unsupported (activation, residual, output) combination");
   return rt_launch_status();
@@ -1555,6 +1563,7 @@ int mdm_debug_set(int what, int value) {
   if (what == 2 && (value == 4 || value == 8)) x3_waves_setting() = value;
   if (what == 3) g_ax_ablate = value;
   if (what == 4) g_f6_reference = value;
+  if (what == 8) g_x3_delay = value;
   if (what == 5) g_f6_linear = value;
   if (what == 6) x3_pipe_probe() = value;
   return MDM_OK;

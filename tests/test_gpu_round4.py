@@ -182,3 +182,31 @@ def test_small_batch_loop_matches_oracle(sd, gemm_path, B, lengths):
     err = maxabs(out.cpu(), want)
     print(f"[parity] small-batch loop B={B} T=196 50 steps, GEMM kernel {gemm_path}: max-abs vs oracle = {err:.3e}")
     assert err < TOL_LOOP
+
+
+def test_operand_split_is_bit_exact_fp16_hi_plus_lo():
+    """common.h split2_p16 (round 4: lo = fp16(x - float(hi)) in one v_fma_mix{lo,hi}_f16 per value): the planes a kernel writes
+    must be EXACTLY hi = rne16(x), lo = rne16(x - hi) -- checked bit for bit against numpy over normal, tiny (fp16-subnormal
+    hi and lo), large and signed values, through the planes mdm_linear_x3 leaves in its scratch (hi at 0, lo at M*K)."""
+    from mdm_amd import _native
+    lib = _native.load_native()
+    M, N, K = 64, 32, 64
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    x[0] *= 1e-3; x[1] *= 1e-5; x[2] *= 3e-8; x[3] *= 1e3; x[4] *= 6e4 / np.abs(x[4]).max(); x[5] = 0.0
+    x[6, :8] = [65504.0, -65504.0, 6.1e-5, -6.1e-5, 5.96e-8, 1.0, -1.0, 0.33333334]
+    xt = torch.from_numpy(x).to(DEV)
+    w = torch.zeros(N, K, device=DEV); b = torch.zeros(N, device=DEV); out = torch.empty(M, N, device=DEV)
+    nb = lib.mdm_linear_x3_scratch_bytes(M, N, K)
+    scratch = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    lib.check(lib.mdm_linear_x3(xt.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), M, N, K, 0, scratch.data_ptr(), nb,
+                                torch.cuda.current_stream().cuda_stream), "mdm_linear_x3")
+    torch.cuda.synchronize()
+    planes = scratch.cpu().numpy()[: M * K * 4].view(np.uint16)
+    hi, lo = planes[: M * K].reshape(M, K), planes[M * K: 2 * M * K].reshape(M, K)
+    want_hi = x.astype(np.float16)
+    want_lo = (x - want_hi.astype(np.float32)).astype(np.float16)
+    assert np.array_equal(hi, want_hi.view(np.uint16))
+    # (-0.0 vs +0.0 in lo is value-identical: compare values where both are zero, bits elsewhere)
+    z = (want_lo == 0) & (lo.view(np.float16) == 0)
+    assert np.array_equal(lo[~z], want_lo.view(np.uint16)[~z])

@@ -18,7 +18,10 @@ side = torch.cuda.Stream()
 bufs = [torch.randn(3840, 512, device=DEV) for _ in range(4)]
 w = torch.randn(512, 512, device=DEV)
 q = torch.randn(16, 8, 256, 64, device=DEV, dtype=torch.float16)
-for kind in ("gemm-sized torch ops", "tiny elementwise ops", "sdpa (LDS-heavy attention kernels)"):
+kinds = ("gemm-sized torch ops", "tiny elementwise ops", "sdpa (LDS-heavy attention kernels)")
+if len(sys.argv) > 3:     # a substring selects the foreign load(s)
+    kinds = tuple(k for k in kinds if sys.argv[3] in k)
+for kind in kinds:
     fails = 0
     for rep in range(reps):
         with torch.cuda.stream(side):
