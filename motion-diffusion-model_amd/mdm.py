@@ -7,8 +7,9 @@ sub-modules below exist only to hold parameters under the reference's names.
 
 Scope: arch='trans_enc', text conditioning with a cached `y['text_embed']`
 (or no conditioning), inference only; and (DiP) arch='trans_dec' with prefix completion
-and a cached token-level text embedding (DistilBERT) or a single CLIP token as the decoder memory (its GEMMs split their
-fp32 operands on the fly in the default f16x3 mode; attention / LayerNorm fp32).  Everything else raises NotImplementedError loudly.
+and a cached token-level text embedding (DistilBERT) or a single CLIP token as the decoder memory (model/mdm.py:261-262; pinned
+against the reference by tests/golden/dip_clip_*.npz since round 4) -- its GEMMs split their fp32 operands on the fly in the default
+f16x3 mode; attention / LayerNorm fp32.  Everything else raises NotImplementedError loudly.
 """
 import math
 import os

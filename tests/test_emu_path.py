@@ -21,8 +21,18 @@ def lib():
     return emu()
 
 
+def _skip_redundant(gemm_path, prec, T=0):
+    """`gemm_path` (tests/conftest.py) picks one of the two split-precision encoder GEMM kernels: it does not exist in the f32 mode,
+    and the 207 / 208-frame cases are edge shapes of gemm_x3.h's 208- / 224-row tiles only (the CPU suite's time is emulator time)."""
+    if prec == "f32" and gemm_path != "small":
+        pytest.skip("the f32 mode has one GEMM kernel")
+    if T >= 207 and gemm_path == "small":
+        pytest.skip("an edge shape of the sequence-tile kernel")
+
+
 @pytest.mark.parametrize("prec,tol", [("f16x3", 2e-5), ("f32", 2e-5)])
 def test_emulated_cfg_loop_matches_oracle(lib, gemm_path, prec, tol):
+    _skip_redundant(gemm_path, prec)
     steps, B, T = 2, 2, 9
     sd = small_state_dict(num_layers=1)
     model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, precision=prec)
@@ -46,6 +56,7 @@ def test_emulated_cfg_loop_matches_oracle(lib, gemm_path, prec, tol):
 def test_emulated_forward_branches(lib, gemm_path, prec, tol, layers, B, T, lengths):
     """layers = 2 reaches the GEMM kinds only a second layer uses: in_proj with the previous LayerNorm folded in, and
     out_proj whose residual is a LayerNorm rebuilt from the pre-norm planes + row statistics."""
+    _skip_redundant(gemm_path, prec, T)
     sd = small_state_dict(num_layers=layers)
     model, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib, precision=prec)
     y = synth_y(B, T, seed=2, lengths=lengths)
@@ -60,6 +71,7 @@ def test_emulated_forward_branches(lib, gemm_path, prec, tol, layers, B, T, leng
 def test_emulated_frame_masks_with_holes(lib, gemm_path, prec):
     """Arbitrary key-padding masks (model/mdm.py:241-247) through the bitmap form of `lengths` (include/mdm_hip.h, ABI 7):
     S = 41 (two key tiles): a prefix-mask sample, a sample with holes at frame 0 / across the tile boundary, a sparse sample."""
+    _skip_redundant(gemm_path, prec)
     B, T = 3, 40
     sd = small_state_dict(num_layers=1)
     model, _ = make_pair(sd, 50, "cpu", guided=False, native_lib=lib, precision=prec)
@@ -428,13 +440,13 @@ def test_integration_md_snippet_is_a_program_and_its_structs_match_the_binding()
 @pytest.mark.parametrize("rt", ["1", "2"])
 def test_emulated_small_gemm_at_the_headline_width(lib, monkeypatch, rt):
     """csrc/gemm_x3s.h at latent_dim = 512 (the emulator cases above run 256: one K-chunk): two chunks for in_proj / out_proj /
-    linear1, four for linear2, the 18-sub-step single chunk of InputProcess (K = 288), N = 264 of OutputProcess (a column tile
-    whose last three waves lie past the packed weight rows), 32- and 64-row tiles, a 5-row last tile (S = 37)."""
+    linear1 (four 128-k chunks), eight for linear2, the 18-sub-step single chunk of InputProcess (K = 288), N = 264 of OutputProcess
+    (a column tile whose last three waves lie past the packed weight rows), 32- and 64-row tiles, a 5-row last tile (S = 37)."""
     monkeypatch.setenv("MDM_X3S_RT", rt)
-    B, T = 2, 36
+    B, T = 1, 36
     sd = small_state_dict(latent_dim=512, num_layers=2)
     model, _ = make_pair(sd, 50, "cpu", guided=True, native_lib=lib, precision="f16x3")
-    y = synth_y(B, T, seed=2, lengths=[T, 11])
+    y = synth_y(B, T, seed=2, lengths=[23])
     g = torch.Generator().manual_seed(0)
-    x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 0])
+    x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49])
     assert maxabs(model(x, t, y=dict(y)), orc.cfg_forward(sd, x, t, y, num_heads=4)) < 5e-5
