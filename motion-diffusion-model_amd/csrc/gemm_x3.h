@@ -239,14 +239,20 @@ struct X3Cursor {
 // F6: the k-loop runs the "f16f6" arithmetic of gemm_f16f6.h on the same skeleton -- plane 0 holds fp16 values, plane 1 the MX-FP6
 // records, the weight planes come from pack_weight_f16f6_kernel; units are ordered sub-tile-major so that a sub-tile's two
 // 16-byte record reads (k sub-steps 0 and 1) meet in ONE scaled MFMA; 2 + 1 MFMAs per sub-tile and step instead of 6.
+// NCB (round 4, "wide" form): 32-column blocks per wave.  NCB = 2 with WAVES = 4 is the one-wave-per-SIMD arrangement of the SAME
+// 208 x 256 tile: four waves x 64 columns, ONE workgroup per CU, up to 512 registers per lane (accumulators 208, W slots 64), every
+// A fragment read from LDS feeds two column blocks -- half the LDS fragment traffic and half the rendezvous partners of the
+// 8-wave form.  Pipelined loop only.
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
-          bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false, bool PIPE = false>
-__global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N,
+          bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false, bool PIPE = false, int NCB = 1>
+__global__ __launch_bounds__(64 * WAVES, NCB == 2 ? 1 : 2) void gemm_x3_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N,
                                                                      int K, int rows_per_tile, int tiles_n, int total) {
   MDM_DYN_SMEM(unsigned char, lds);
-  static_assert(!PIPE || (T16 && WAVES == 8 && !F6), "the pipelined k-loop exists for 8-wave, 208-row (T16) tiles");
+  static_assert(!PIPE || (T16 && (WAVES == 8 || (WAVES == 4 && NCB == 2)) && !F6), "the pipelined k-loop exists for 208-row (T16), 256-column tiles");
+  static_assert(NCB == 1 || (NCB == 2 && PIPE && WAVES == 4), "two column blocks per wave: the pipelined 4-wave form only");
   constexpr int RINGN = PIPE ? X3_PIPE_RING : X3_A_RING;   // A stages in LDS
-  constexpr int X3_WAVES = WAVES, X3_TN = x3_tn(WAVES), X3_A_PIECES = x3_a_pieces(WAVES);
+  constexpr int NBLK = WAVES * NCB;                        // 32-column blocks of a tile (the LDS layout is per block)
+  constexpr int X3_WAVES = WAVES, X3_TN = 32 * NBLK, X3_A_PIECES = x3_a_pieces(WAVES);
   constexpr int NT32 = T16 ? X3_MSUB - 1 : X3_MSUB;     // 32-row sub-tiles
   constexpr int NROUNDS = 4 * NT32 + (T16 ? 2 : 0);     // epilogue rounds of 8 rows
   using Cursor = X3Cursor<X3_A_PIECES>;
@@ -361,13 +367,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
   auto stats_dma = [&](int m0s, int par) {
     const float* st = FOLD ? ep.astat : ep.rstat;
     const int npieces = (X3_TM * ep.stat_parts * 8 + 1023) / 1024;
-    if (wid < npieces) {
+    for (int pc = wid; pc < npieces; pc += X3_WAVES) {      // (<= 7 pieces; four waves take two)
       // floats in the whole statistics buffer, rounded up to the 16-byte unit of the transfer (M odd with one partial per
       // row ends on an 8-byte boundary; the workspace carves these buffers in 256-byte units, so the tail is addressable)
       const long long total_f = ((long long)M * ep.stat_parts * 2 + 3) / 4 * 4;
-      long long fo = (long long)m0s * ep.stat_parts * 2 + 4LL * (64 * wid + lane);
+      long long fo = (long long)m0s * ep.stat_parts * 2 + 4LL * (64 * pc + lane);
       if (fo > total_f - 4) fo = total_f - 4;                          // rows past the matrix: any valid address
-      glds16(st + fo, lds + x3_raw_base(WAVES, RINGN) + par * X3_RAW_BYTES + wid * 1024);
+      glds16(st + fo, lds + x3_raw_base(NBLK, RINGN) + par * X3_RAW_BYTES + pc * 1024);
     }
   };
   // the epilogue's per-column vectors of the tile starting at column n0c -> LDS buffer `par`: wave 0 bias, wave 1 folded
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     if (wid == 0) src = ep.bias;
     if constexpr (FOLD) { if (wid == 1) src = ep.colsum; }
     if constexpr (RES == 3) { if (wid == 2) src = ep.rgamma; if (wid == 3) src = ep.rbeta; }
-    if (src != nullptr) glds16(src + min(n0c + 4 * lane, N - 4), lds + x3_cvec_base(WAVES, LN_ANY, RINGN) + par * X3_CVEC_BYTES + wid * 1024);
+    if (src != nullptr) glds16(src + min(n0c + 4 * lane, N - 4), lds + x3_cvec_base(NBLK, LN_ANY, RINGN) + par * X3_CVEC_BYTES + wid * 1024);
   };
   {
     int m0f, n0f;
@@ -390,13 +396,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
   p16x8 wh[2], wl[2], wnh[2], wnl[2];
   // PIPE: the W stream lives in four half-step slots (slot 2 * (step parity) + k sub-step; hi and lo plane fragment each),
   // refilled IN PLACE for two steps later as soon as their last MFMA has been issued -- 32 VGPRs, 1.5 steps of cover
-  p16x8 wsh[4] = {}, wsl[4] = {};   // (zero: the first refill formally reads its slot)
+  p16x8 wsh[4 * NCB] = {}, wsl[4 * NCB] = {};   // slot q, column block cb: [q * NCB + cb]  (zero: the first refill formally reads its slot)
   uint32_t wso = 0;           // element offset of the W stream's current step inside the fragment-ordered planes
   uint32_t wtile = 0;         // ... of its tile's first step (wave-uniform): changes only when the stream enters a new tile
   auto aim_w_tile = [&]() {
     int m0w, n0w;
     tile_origin(wv, m0w, n0w);
-    wtile = (uint32_t)((n0w >> 5) + wid) * (uint32_t)wk16 * 512u;
+    wtile = (uint32_t)((n0w >> 5) + wid * NCB) * (uint32_t)wk16 * 512u;   // (column block cb: + cb * wk16 * 512)
   };
   auto aim_w = [&]() { wso = wtile + (uint32_t)wkk * 1024u + (uint32_t)lane * 8u; };
   auto advance_w = [&]() {
@@ -405,14 +411,31 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
       if (wv + gstride < total) { wv += gstride; aim_w_tile(); }
     }
   };
-  auto load_w_half = [&](int ks, p16x8& fh, p16x8& fl) {   // in-place refill of a slot (common.h gload16_refill)
+  auto load_w_half = [&](int ks, auto q_tag) __attribute__((always_inline)) {   // in-place refill of slot q (common.h gload16_refill)
+    constexpr int q = decltype(q_tag)::value;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const uint32_t o = wso + (uint32_t)cb * (uint32_t)wk16 * 512u + 512u * (uint32_t)ks;
 #ifdef MDM_X3_PIPE_NOGUARD
-    gload16_async(fh, W.hi + wso + 512 * ks);
-    gload16_async(fl, W.lo + wso + 512 * ks);
+      gload16_async(wsh[q * NCB + cb], W.hi + o);
+      gload16_async(wsl[q * NCB + cb], W.lo + o);
 #else
-    gload16_refill(fh, W.hi + wso + 512 * ks);
-    gload16_refill(fl, W.lo + wso + 512 * ks);
+      gload16_refill(wsh[q * NCB + cb], W.hi + o);
+      gload16_refill(wsl[q * NCB + cb], W.lo + o);
 #endif
+    }
+  };
+  // counted wait naming slot q's registers (all column blocks); closing wait over every slot
+  auto wait_slot = [&](auto n_tag, auto q_tag) __attribute__((always_inline)) {
+    constexpr int n = decltype(n_tag)::value, q = decltype(q_tag)::value;
+    if constexpr (NCB == 1) vmem_wait<n>(wsh[q], wsl[q]);
+    else vmem_wait<n>(wsh[2 * q], wsl[2 * q], wsh[2 * q + 1], wsl[2 * q + 1]);
+  };
+  auto wait_all_slots = [&]() __attribute__((always_inline)) {
+    static_for<NCB>([&](auto c_tag) __attribute__((always_inline)) {
+      constexpr int c4 = 4 * decltype(c_tag)::value;
+      vmem_wait<0>(wsh[c4], wsl[c4], wsh[c4 + 1], wsl[c4 + 1], wsh[c4 + 2], wsl[c4 + 2], wsh[c4 + 3], wsl[c4 + 3]);
+    });
   };
   int gs = 0;                 // PIPE: global k-step counter of this workgroup (stage of step g = g & 3)
 #if defined(MDM_X3_PIPE_PRIO) && !defined(MDM_EMU)
@@ -430,11 +453,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       aim_w();
-      load_w_half(0, wsh[2 * st], wsl[2 * st]);
-      load_w_half(1, wsh[2 * st + 1], wsl[2 * st + 1]);
+      if (st == 0) { load_w_half(0, std::integral_constant<int, 0>{}); load_w_half(1, std::integral_constant<int, 1>{}); }
+      else { load_w_half(0, std::integral_constant<int, 2>{}); load_w_half(1, std::integral_constant<int, 3>{}); }
       advance_w();
     }
-    vmem_wait<0>(wsh[0], wsl[0], wsh[1], wsl[1], wsh[2], wsl[2], wsh[3], wsl[3]);
+    wait_all_slots();
     wg_barrier();
   } else {
 #pragma unroll
@@ -450,18 +473,25 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
   for (; v < total; v += gstride, tile_parity ^= 1) {
     int m0, n0;
     tile_origin(v, m0, n0);
-    f32x16 acc[NT32];
+    f32x16 accs_[NCB][NT32];     // [column block of the wave][row sub-tile]
+    f32x4 acc16s_[NCB][2];       // T16: rows 192-207 x columns 0-15 / 16-31 of each column block
 #pragma unroll
-    for (int t = 0; t < NT32; ++t)
+    for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // T16: rows 192-207 x columns 0-15 / 16-31 of the wave
-    const int ncol0 = n0 + wid * 32;                     // this wave's first column (wave-uniform)
+      for (int t = 0; t < NT32; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accs_[cb][t][e] = 0.f;
+      acc16s_[cb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc16s_[cb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x16 (&acc)[NT32] = accs_[0];       // the one-block forms (step-synchronous loop) work on block 0
+    f32x4 (&acc16)[2] = acc16s_[0];
+    const int ncol0_w = n0 + wid * NCB * 32;             // this wave's first column (wave-uniform)
     // this tile's per-column epilogue vectors are in LDS buffer `tile_parity` (requested one tile ago / in the prologue: no
     // global-load latency in front of the epilogue); the next tile's are requested in this tile's SECOND k step (below),
     // i.e. behind a workgroup barrier every wave reaches only after its epilogue of the previous tile -- whose vectors
     // live in the buffer being refilled -- and land under the rest of this tile's k-loop
-    const float* const cvec = reinterpret_cast<const float*>(lds + x3_cvec_base(WAVES, LN_ANY, RINGN) + tile_parity * X3_CVEC_BYTES);
+    const float* const cvec = reinterpret_cast<const float*>(lds + x3_cvec_base(NBLK, LN_ANY, RINGN) + tile_parity * X3_CVEC_BYTES);
     const int kt_cvec = nk > 1 ? 1 : 0;
     if (nk == 1) wg_barrier();   // single-step contractions: no k-step barrier in front of the request
     // row statistics (mean, rstd) of this tile's rows, built HERE -- where the accumulators are not live yet -- from the
@@ -469,7 +499,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     // next tile's partials are requested now and land under this tile's k-loop.  Tables and raw buffers alternate with
     // the tile parity: a fast wave may build table j+1 while a slow one still reads table j in its epilogue.
     constexpr bool LN_TABS = FOLD || RES == 3;
-    float2* const stab = reinterpret_cast<float2*>(lds + x3_tab_base(WAVES, RINGN) + tile_parity * X3_TAB_BYTES);
+    float2* const stab = reinterpret_cast<float2*>(lds + x3_tab_base(NBLK, RINGN) + tile_parity * X3_TAB_BYTES);
     if constexpr (LN_TABS) {
       if (tid < X3_TM) {
         // rows of the tile past the matrix (the last sequence's pad rows) have no statistics: their raw slots hold whatever the
@@ -479,7 +509,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         int m0t, n0t;
         tile_origin(v, m0t, n0t);
         const bool pad_row = m0t + tid >= M;
-        const float* sraw = reinterpret_cast<const float*>(lds + x3_raw_base(WAVES, RINGN) + tile_parity * X3_RAW_BYTES);
+        const float* sraw = reinterpret_cast<const float*>(lds + x3_raw_base(NBLK, RINGN) + tile_parity * X3_RAW_BYTES);
         // partials are (sum, CENTRED sum of squares about the partial's own mean) of X3_TN columns each; merged by Chan's
         // formula -- no E[x^2] - mean^2 cancellation when a row's mean is large against its spread
         float s1 = 0.f;
@@ -536,6 +566,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
 #define MDM_X3_PIPE_DEPTH 2
 #endif
       constexpr int NU = 2 * NT32, NE = NU + 1, XP = NT32, DEPTH = MDM_X3_PIPE_DEPTH, RING = DEPTH + 1;
+      // counted waits, generalised: a half-step slot is LWH = 2 NCB loads, a wave issues at least NA_MIN = 26 / WAVES pieces per step
+      //   step start, slot W0(g): younger = A(g+1) + W1(g) + W0(g+1) + A(g+2) + W1(g+1) = 2 NA_MIN + 3 LWH   (8 waves: 12)
+      //   middle, A(g+1) and W1(g): younger = W0(g+1) + A(g+2) + W1(g+1) = NA_MIN + 2 LWH                  (8 waves: 7)
+      constexpr int LWH = 2 * NCB, NA_MIN = 26 / X3_WAVES;
+      constexpr int WAIT_WS = (NCB == 1 && X3_WAVES == 8) ? X3P_WAIT_WS : 2 * NA_MIN + 3 * LWH;
+      constexpr int WAIT_MID = (NCB == 1 && X3_WAVES == 8) ? X3P_WAIT_MID : NA_MIN + 2 * LWH;
+      static_assert((NCB == 1 && X3_WAVES == 8) || (WAIT_WS == 24 && WAIT_MID == 14), "wide form: 4 waves x 2 column blocks");
       static_assert(NU % RING == 0, "fragment ring slots must line up across steps");
       p16x8 ah[RING], al[RING], a16h, a16l;
 #ifndef MDM_EMU
@@ -568,12 +605,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
       auto pipe_step = [&](auto par_tag) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         const uint32_t cur = (uint32_t)gs & 3u, nxt = (uint32_t)(gs + 1) & 3u, fill = (uint32_t)(gs + 3) & 3u;
-        p16x8 w16h[2], w16l[2];
+        p16x8 w16h[NCB][2], w16l[NCB][2];
 #ifdef MDM_X3_PIPE_NOLOOK
         static_for<DEPTH>([&](auto d_tag) __attribute__((always_inline)) { issue_reads(d_tag, cur); });
 #endif
         // slot W0(g) landed?  (issued in the middle of step g-2)
-        vmem_wait<X3P_WAIT_WS>(wsh[2 * PAR], wsl[2 * PAR]);
+        wait_slot(std::integral_constant<int, WAIT_WS>{}, std::integral_constant<int, 2 * PAR>{});
         static_for<NE>([&](auto e_tag) __attribute__((always_inline)) {
           constexpr int e = decltype(e_tag)::value;
           // ---- 1. reads of the element DEPTH ahead (past the step: units 0, 1 of step g+1, from the next stage)
@@ -584,19 +621,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
           // ---- 2. the middle of the step sits in front of the 16-row sub-tile
           if constexpr (e == XP) {
             // own pieces of A(g+1) and slot W1(g) (both issued during step g-2) landed
-            vmem_wait<X3P_WAIT_MID + X3P_MID_SLACK>(wsh[2 * PAR + 1], wsl[2 * PAR + 1]);
+            wait_slot(std::integral_constant<int, WAIT_MID + X3P_MID_SLACK>{}, std::integral_constant<int, 2 * PAR + 1>{});
 #if (defined(MDM_X3_PIPE_SNOP) || defined(MDM_X3_PIPE_SNOP2)) && !defined(MDM_EMU)   // (bisection build: the matrix pipe drains before slot W0 is rewritten)
             asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
 #endif
-            w16h[0] = wsh[2 * PAR]; w16h[1] = wsh[2 * PAR + 1];
-            w16l[0] = wsl[2 * PAR]; w16l[1] = wsl[2 * PAR + 1];
-            frag32_to_frag16(w16h[0], w16h[1]);
-            frag32_to_frag16(w16l[0], w16l[1]);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+              w16h[cb][0] = wsh[(2 * PAR) * NCB + cb]; w16h[cb][1] = wsh[(2 * PAR + 1) * NCB + cb];
+              w16l[cb][0] = wsl[(2 * PAR) * NCB + cb]; w16l[cb][1] = wsl[(2 * PAR + 1) * NCB + cb];
+              frag32_to_frag16(w16h[cb][0], w16h[cb][1]);
+              frag32_to_frag16(w16l[cb][0], w16l[cb][1]);
+            }
 #ifndef MDM_EMU
             __builtin_amdgcn_sched_barrier(0);
 #endif
             // slot W0 is free (its last 32-row MFMA was issued with unit NT32-1, its lane-swapped copy is taken): refill for g+2
-            if constexpr (!(ABL & 2)) { aim_w(); load_w_half(0, wsh[2 * PAR], wsl[2 * PAR]); }
+            if constexpr (!(ABL & 2)) { aim_w(); load_w_half(0, std::integral_constant<int, 2 * PAR>{}); }
 #ifdef MDM_X3_PIPE_DRAINBAR   // (bisection build: lgkmcnt(0) in front of the rendezvous)
             lds_wait<0>(a16h, a16l);
             wg_barrier();
@@ -626,26 +666,32 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
           if constexpr (e == XP) {
             if constexpr ((ABL & 4) != 0) {
 #ifndef MDM_EMU
-              asm volatile("" ::"v"(a16h), "v"(a16l), "v"(w16h[0]), "v"(w16h[1]), "v"(w16l[0]), "v"(w16l[1]));
+              asm volatile("" ::"v"(a16h), "v"(a16l), "v"(w16h[0][0]), "v"(w16h[0][1]), "v"(w16l[0][0]), "v"(w16l[0][1]));
 #endif
             } else {
 #pragma unroll
-              for (int cb = 0; cb < 2; ++cb) {
-                acc16[cb] = mfma16_p16(a16l, w16h[cb], acc16[cb]);
-                acc16[cb] = mfma16_p16(a16h, w16l[cb], acc16[cb]);
-                acc16[cb] = mfma16_p16(a16h, w16h[cb], acc16[cb]);
-              }
+              for (int wb = 0; wb < NCB; ++wb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                  acc16s_[wb][cb] = mfma16_p16(a16l, w16h[wb][cb], acc16s_[wb][cb]);
+                  acc16s_[wb][cb] = mfma16_p16(a16h, w16l[wb][cb], acc16s_[wb][cb]);
+                  acc16s_[wb][cb] = mfma16_p16(a16h, w16h[wb][cb], acc16s_[wb][cb]);
+                }
             }
           } else {
             constexpr int u = e < XP ? e : e - 1, ks = u / NT32, t = u - ks * NT32;
             if constexpr ((ABL & 4) != 0) {
 #ifndef MDM_EMU
-              asm volatile("" ::"v"(al[u % RING]), "v"(ah[u % RING]), "v"(wsh[2 * PAR + ks]), "v"(wsl[2 * PAR + ks]));
+              asm volatile("" ::"v"(al[u % RING]), "v"(ah[u % RING]), "v"(wsh[(2 * PAR + ks) * NCB]), "v"(wsl[(2 * PAR + ks) * NCB]));
 #endif
             } else {
-              acc[t] = mfma_p16(al[u % RING], wsh[2 * PAR + ks], acc[t]);
-              acc[t] = mfma_p16(ah[u % RING], wsl[2 * PAR + ks], acc[t]);
-              acc[t] = mfma_p16(ah[u % RING], wsh[2 * PAR + ks], acc[t]);
+              // (the wave's column blocks interleaved: consecutive MFMAs on different accumulators, one A fragment pair for all)
+#pragma unroll
+              for (int wb = 0; wb < NCB; ++wb) accs_[wb][t] = mfma_p16(al[u % RING], wsh[(2 * PAR + ks) * NCB + wb], accs_[wb][t]);
+#pragma unroll
+              for (int wb = 0; wb < NCB; ++wb) accs_[wb][t] = mfma_p16(ah[u % RING], wsl[(2 * PAR + ks) * NCB + wb], accs_[wb][t]);
+#pragma unroll
+              for (int wb = 0; wb < NCB; ++wb) accs_[wb][t] = mfma_p16(ah[u % RING], wsh[(2 * PAR + ks) * NCB + wb], accs_[wb][t]);
             }
           }
 #ifndef MDM_EMU
@@ -661,7 +707,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
 #if defined(MDM_X3_PIPE_SNOP2) && !defined(MDM_EMU)   // (bisection build: the matrix pipe drains before slot W1 is rewritten)
         asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
 #endif
-        if constexpr (!(ABL & 2)) load_w_half(1, wsh[2 * PAR + 1], wsl[2 * PAR + 1]);
+        if constexpr (!(ABL & 2)) load_w_half(1, std::integral_constant<int, 2 * PAR + 1>{});
         advance_w();
         advance_a(ca);
         ++gs;
@@ -694,7 +740,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
 #endif
       // the epilogue must not meet a W slot whose load is still in flight (a spill would save the stale register); hipcc
       // drains the queue in front of the epilogue's first LDS read anyway (LDS-DMA pending)
-      vmem_wait<0>(wsh[0], wsl[0], wsh[1], wsl[1], wsh[2], wsl[2], wsh[3], wsl[3]);
+      wait_all_slots();
     } else {
     for (int kt = 0; kt < nk; ++kt) {
       if (kt == kt_cvec && v + gstride < total) {
@@ -850,6 +896,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     unsigned long long dbg_t1 = 0;
     if constexpr ((ABL & 128) != 0) dbg_t1 = x3_now();
 #endif
+    static_for<NCB>([&](auto cbk_tag) __attribute__((always_inline)) {   // the wave's column blocks, one after the other
+    constexpr int cbk = decltype(cbk_tag)::value;
+    f32x16 (&acc)[NT32] = accs_[cbk];
+    f32x4 (&acc16)[2] = acc16s_[cbk];
+    const int wblk = wid * NCB + cbk;               // this pass's 32-column block inside the tile (wave-uniform)
+    const int ncol0 = ncol0_w + cbk * 32;           // ... and its first column
     {   // epilogue scope: every lane-derived index below is rebuilt from an OPAQUE copy of the lane id, so that hipcc cannot
         // compute the epilogue's per-round offsets once, in front of the tile loop, and carry them (24 VGPRs of hoisted
         // store offsets, spilled in the in_proj instantiation) through every k-loop
@@ -863,7 +915,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
     const int prow = lane_e >> 3, pc4 = (lane_e & 7) * 4;
     const int n4 = ncol0 + pc4;                          // first of this lane's 4 columns in the row layout
     // per-lane column vectors of the row-major side: bias (or folded bias), Q scale, folded column sums, residual gamma/beta
-    const int cl4 = wid * 32 + pc4;                      // this lane's first column inside the tile
+    const int cl4 = wblk * 32 + pc4;                      // this lane's first column inside the tile
     const float4 b4 = ld4(cvec + cl4);
     // column scale (in_proj's Q columns; scale_cols is a multiple of the tile width): only the instantiations without an
     // activation and without a plane residual carry one (the launcher refuses it elsewhere) -- two packed multiplies per round
@@ -876,9 +928,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
       be4 = ld4(cvec + 768 + cl4);
     }
     // the same in the accumulator layout (lane -> column r of the wave's 32): V^T path
-    const float bias = cvec[wid * 32 + r];
+    const float bias = cvec[wblk * 32 + r];
     float csum = 0.f;
-    if constexpr (FOLD) csum = cvec[256 + wid * 32 + r];
+    if constexpr (FOLD) csum = cvec[256 + wblk * 32 + r];
     // accumulator values of one round, row-major, -> the GEMM's value:  fold / bias, activation, Q scale
     const float accs = ep.acc_scale;
     // RES == 3: the rebuilt LayerNorm residual's beta is a per-column constant like the bias -- added with it
@@ -1079,7 +1131,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
         res_issue(std::integral_constant<int, 0>{});
         if constexpr (RR == 3) res_issue(std::integral_constant<int, 1>{});
       }
-      float2* part = reinterpret_cast<float2*>(lds + x3_part_base(WAVES, RINGN)) + wid * X3_TM;   // OSTAT: this wave's partials
+      float2* part = reinterpret_cast<float2*>(lds + x3_part_base(NBLK, RINGN)) + wblk * X3_TM;   // OSTAT: this column block's partials
       patch_write(std::integral_constant<int, 0>{});
       float2 st_cur = row_stats(std::integral_constant<int, 0>{});
       static_for<NROUNDS>([&](auto j_tag) __attribute__((always_inline)) {
@@ -1157,17 +1209,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
           }
         }
       });
-      if constexpr (OSTAT) {   // rows x waves partials -> one (sum, sum^2) pair per row and column tile
+    }
+    }   // epilogue scope
+    });
+    if constexpr (OSTAT && !OUT_QKV) {   // rows x column blocks partials -> one (sum, M2) pair per row and column tile
+        const int m_end = min(M, m0 + rows_per_tile);
         wg_barrier();
         if (tid < X3_TM && m0 + tid < m_end) {
-          const float2* pp = reinterpret_cast<const float2*>(lds + x3_part_base(WAVES, RINGN));
+          const float2* pp = reinterpret_cast<const float2*>(lds + x3_part_base(NBLK, RINGN));
           float s1 = 0.f;
 #pragma unroll
-          for (int w8 = 0; w8 < X3_WAVES; ++w8) s1 += pp[w8 * X3_TM + tid].x;
-          const float mt = s1 * (1.0f / X3_TN);     // OSTAT launches have N % X3_TN == 0: every wave contributes 32 columns
+          for (int w8 = 0; w8 < NBLK; ++w8) s1 += pp[w8 * X3_TM + tid].x;
+          const float mt = s1 * (1.0f / X3_TN);     // OSTAT launches have N % X3_TN == 0: every block contributes 32 columns
           float m2 = 0.f;
 #pragma unroll
-          for (int w8 = 0; w8 < X3_WAVES; ++w8) {
+          for (int w8 = 0; w8 < NBLK; ++w8) {
             const float2 v = pp[w8 * X3_TM + tid];
             const float dm = v.x * (1.0f / 32.0f) - mt;
             m2 += v.y + 32.0f * dm * dm;
@@ -1175,8 +1231,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_x3_kernel(X3Operand A, X3W
           *reinterpret_cast<float2*>(ep.ostat + ((size_t)(m0 + tid) * tiles_n + n0 / X3_TN) * 2) = make_float2(s1, m2);
         }
       }
-    }
-    }   // epilogue scope
 #ifdef MDM_X3_DBG
     if constexpr ((ABL & 128) != 0) {
       const unsigned long long t2 = x3_now();
@@ -1232,34 +1286,46 @@ inline int x3_waves_setting() { return 8; }   // the 4-wave form is compiled int
 #endif
 
 template <int WAVES, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, int ABL, bool FOLD = false,
-          bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false, bool PIPE = false>
+          bool OSTAT = false, bool EMBED = false, bool T16 = false, bool F6 = false, bool PIPE = false, int NCB = 1>
 inline int launch_gemm_x3_w(const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N, int K,
                                 int rpt, hipStream_t stream) {
-  constexpr int TN = x3_tn(WAVES);
+  constexpr int NBLK = WAVES * NCB;          // 32-column blocks per tile: the LDS layout is per block
+  constexpr int TN = 32 * NBLK;
   constexpr bool LN = FOLD || OSTAT || RES == 3;
   constexpr int RINGN = PIPE ? X3_PIPE_RING : X3_A_RING;
   const int tiles_m = (M + rpt - 1) / rpt, tiles_n = (N + TN - 1) / TN;
   const int total = tiles_m * tiles_n;
   static_assert(!(F6 && T16), "the f16f6 k-loop has no 16-row sub-tile yet");
-  auto kfn = &gemm_x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16, F6, PIPE>;
+  auto kfn = &gemm_x3_kernel<WAVES, ACT, RES, OUT_F32, OUT_PLANES, OUT_QKV, ABL, FOLD, OSTAT, EMBED, T16, F6, PIPE, NCB>;
   if (T16 && rpt > X3_TM - 16) return -2;
   if (PIPE && (K / X3_BK) % 2 != 0) return -2;   // the pipelined k-loop is unrolled over step pairs
   if (!x3_has_col_scale(ACT, RES) && ep.scale_cols > 0) return -2;   // (this instantiation compiles the column scale out)
 #ifndef MDM_EMU
-  if (x3_lds_bytes(WAVES, LN, RINGN) > 65536) {
+  if (x3_lds_bytes(NBLK, LN, RINGN) > 65536) {
     static bool configured[kMaxDevices] = {};  // per instantiation and device (the attribute belongs to the device's code object)
     bool& done = configured[rt_device_ordinal()];
     if (!done) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              x3_lds_bytes(WAVES, LN, RINGN)) != hipSuccess)
+                              x3_lds_bytes(NBLK, LN, RINGN)) != hipSuccess)
         return -1;
       done = true;
     }
   }
 #endif
-  const int grid = std::min(total, x3_grid_limit(WAVES == 4 ? 2 : 1));
-  MDM_LAUNCH(kfn, dim3(grid), dim3(64 * WAVES), x3_lds_bytes(WAVES, LN, RINGN), stream, A, W, ep, M, N, K, rpt, tiles_n, total);
+  const int grid = std::min(total, x3_grid_limit((WAVES == 4 && NCB == 1) ? 2 : 1));
+  MDM_LAUNCH(kfn, dim3(grid), dim3(64 * WAVES), x3_lds_bytes(NBLK, LN, RINGN), stream, A, W, ep, M, N, K, rpt, tiles_n, total);
   return 0;
+}
+
+// MDM_X3_WIDE=1 (probe library only; read per launch) selects the four-wave, 64-columns-per-wave form of the pipelined loop --
+// built, parity-green on the MI355X and 12 % slower over the whole loop (323 vs 367 motions/s): profiles/r04d_wide.md
+inline bool x3_wide_setting() {
+#ifdef MDM_PROBES
+  const char* e = getenv("MDM_X3_WIDE");
+  return e != nullptr && e[0] == '1';
+#else
+  return false;
+#endif
 }
 
 // The pipelined k-loop (PIPE) is the default wherever it exists (208-row tiles, an even number of 32-deep k steps);
@@ -1285,9 +1351,22 @@ inline bool x3_pipe_setting(int kind = 0) {
 //   kind 3  linear1                             FOLD + GELU -> planes
 //   kind 4  OutputProcess                       FOLD -> fp32
 //   kind 5  InputProcess                        + positional rows, planes to the token rows of every branch (EMBED)
-template <bool T16, bool PIPE = false>
+// WIDE (round 4): the pipelined loop as four waves x 64 columns, one wave per SIMD (kernel header, NCB = 2)
+template <bool T16, bool PIPE = false, bool WIDE = false>
 inline int launch_gemm_x3_ln_t(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
                                    int K, int rpt, hipStream_t s) {
+#ifdef MDM_PROBES   // (measured 12-18 % slower per launch, profiles/r04d_wide.md: instantiated in the probe library only)
+  if constexpr (WIDE) {
+    switch (kind) {
+      case 0: return launch_gemm_x3_w<4, ACT_NONE, 0, false, false, true, 0, true, false, false, T16, false, PIPE, 2>(A, W, ep, M, N, K, rpt, s);
+      case 1: return launch_gemm_x3_w<4, ACT_NONE, 2, false, true, false, 0, false, true, false, T16, false, PIPE, 2>(A, W, ep, M, N, K, rpt, s);
+      case 2: return launch_gemm_x3_w<4, ACT_NONE, 3, false, true, false, 0, false, true, false, T16, false, PIPE, 2>(A, W, ep, M, N, K, rpt, s);
+      case 3: return launch_gemm_x3_w<4, ACT_GELU, 0, false, true, false, 0, true, false, false, T16, false, PIPE, 2>(A, W, ep, M, N, K, rpt, s);
+      case 4: return launch_gemm_x3_w<4, ACT_NONE, 0, true, false, false, 0, true, false, false, T16, false, PIPE, 2>(A, W, ep, M, N, K, rpt, s);
+      default: return -2;
+    }
+  }
+#endif
   switch (kind) {
     case 0: return launch_gemm_x3_w<8, ACT_NONE, 0, false, false, true, 0, true, false, false, T16, false, PIPE>(A, W, ep, M, N, K, rpt, s);
     case 1: return launch_gemm_x3_w<8, ACT_NONE, 2, false, true, false, 0, false, true, false, T16, false, PIPE>(A, W, ep, M, N, K, rpt, s);
@@ -1314,7 +1393,10 @@ inline bool x3_t16_setting() {
 inline int launch_gemm_x3_ln(int kind, const X3Operand& A, const X3Weights& W, const X3Epilogue& ep, int M, int N,
                                  int K, int rpt, hipStream_t s) {
   if (rpt <= X3_TM - 16 && x3_t16_setting()) {
-    if (kind != 5 && (K / X3_BK) % 2 == 0 && x3_pipe_setting(kind)) return launch_gemm_x3_ln_t<true, true>(kind, A, W, ep, M, N, K, rpt, s);
+    if (kind != 5 && (K / X3_BK) % 2 == 0 && x3_pipe_setting(kind)) {
+      if (x3_wide_setting()) return launch_gemm_x3_ln_t<true, true, true>(kind, A, W, ep, M, N, K, rpt, s);
+      return launch_gemm_x3_ln_t<true, true>(kind, A, W, ep, M, N, K, rpt, s);
+    }
     return launch_gemm_x3_ln_t<true>(kind, A, W, ep, M, N, K, rpt, s);
   }
   return launch_gemm_x3_ln_t<false>(kind, A, W, ep, M, N, K, rpt, s);
@@ -1415,9 +1497,15 @@ inline int launch_gemm_x3_qkv(const X3Operand& A, const X3Weights& W, const X3Ep
                                   hipStream_t s) {
   if (S > X3_TM) return -2;
   if (x3_waves_setting() == 8 && S <= X3_TM - 16 && x3_t16_setting()) {
-    if ((D / X3_BK) % 2 == 0 && x3_pipe_setting(5))
+    if ((D / X3_BK) % 2 == 0 && x3_pipe_setting(5)) {
+#ifdef MDM_PROBES
+      if (x3_wide_setting())
+        return launch_gemm_x3_w<4, ACT_NONE, 0, false, false, true, 0, false, false, false, true, false, true, 2>(A, W, ep, nseq * S,
+                                                                                                                   3 * D, D, S, s);
+#endif
       return launch_gemm_x3_w<8, ACT_NONE, 0, false, false, true, 0, false, false, false, true, false, true>(A, W, ep, nseq * S,
                                                                                                               3 * D, D, S, s);
+    }
     return launch_gemm_x3_w<8, ACT_NONE, 0, false, false, true, 0, false, false, false, true>(A, W, ep, nseq * S, 3 * D, D,
                                                                                                  S, s);
   }

@@ -450,3 +450,18 @@ def test_emulated_small_gemm_at_the_headline_width(lib, monkeypatch, rt):
     g = torch.Generator().manual_seed(0)
     x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49])
     assert maxabs(model(x, t, y=dict(y)), orc.cfg_forward(sd, x, t, y, num_heads=4)) < 5e-5
+
+
+def test_emulated_wide_form_of_the_pipelined_gemm(lib, monkeypatch):
+    """gemm_x3.h NCB = 2 (round 4, probe / emulator builds: MDM_X3_WIDE=1): the pipelined k-loop as four waves x 64 columns -- W slots,
+    counted waits, 16-row sub-tile and every epilogue over two column blocks per wave.  Measured slower on the MI355X and not a
+    product path (profiles/r04d_wide.md); kept correct."""
+    monkeypatch.setenv("MDM_X3_WIDE", "1")
+    monkeypatch.setenv("MDM_X3S_MAX_SEQS", "0")
+    B, T = 2, 33
+    sd = small_state_dict(num_layers=2)
+    model, _ = make_pair(sd, 50, "cpu", guided=True, native_lib=lib, precision="f16x3")
+    y = synth_y(B, T, seed=2, lengths=[33, 5])
+    g = torch.Generator().manual_seed(0)
+    x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 0])
+    assert maxabs(model(x, t, y=dict(y)), orc.cfg_forward(sd, x, t, y, num_heads=2)) < 5e-5
