@@ -94,3 +94,14 @@ def to_dev(y, device):
         else:
             out[k] = v
     return out
+
+
+_MEMO = {}
+
+
+def memo(key, fn):
+    """Oracle results are pure functions of their seeded inputs: tests that run once per GEMM kernel / arithmetic mode
+    (tests/conftest.py gemm_path) compute the CPU oracle once (the GPU suite's time is mostly oracle time)."""
+    if key not in _MEMO:
+        _MEMO[key] = fn()
+    return _MEMO[key]

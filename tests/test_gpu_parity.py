@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (ClassifierFreeSampleModel, dip, golden_loop_inputs, make_pair, maxabs, orc, run_product_loop,
+from helpers import (ClassifierFreeSampleModel, dip, golden_loop_inputs, make_pair, maxabs, memo, orc, run_product_loop,
                      synth_dip_state_dict, synth_dip_y, synth_state_dict, synth_y, to_dev)
 
 pytestmark = pytest.mark.gpu
@@ -89,7 +89,7 @@ def test_forward_matches_oracle_shapes(gemm_path, sd, B, T, lengths, prec):
     t = torch.randint(0, 50, (B,), generator=g)
     model, _ = make_pair(sd, 50, DEV, guided=True, precision=prec)
     got = model(x.to(DEV), t.to(DEV), y=dict(y)).cpu()
-    want = orc.cfg_forward(sd, x, t, y)
+    want = memo(("shapes", B, T), lambda: orc.cfg_forward(sd, x, t, y))
     assert maxabs(got, want) < 4 * TOL_FWD[prec]
     assert torch.isfinite(got).all()
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import make_pair, maxabs, orc, synth_state_dict, synth_y
+from helpers import make_pair, maxabs, memo, orc, synth_state_dict, synth_y
 from oracle.synth import synth_state_dict_hostile, synth_y_hostile
 
 pytestmark = pytest.mark.gpu
@@ -102,9 +102,7 @@ def _respaced_pair(sd, spacing, precision):
 
 @pytest.mark.parametrize("name", ["respaced_ddim50of1000_B2_T64", "respaced_p50of1000_B2_T64"])
 @pytest.mark.parametrize("prec", PRECISIONS)
-def test_respaced_timestep_map_matches_reference(gemm_path, golden_dir, sd, name, prec):
-    if prec == "f32" and gemm_path != "small":
-        pytest.skip("the f32 mode has one GEMM kernel")
+def test_respaced_timestep_map_matches_reference(golden_dir, sd, name, prec):
     """A non-identity `timestep_map` (respace.py:125-130) handed to the native loop: 50 of 1000 steps, DDIM and DDPM."""
     g = _g(golden_dir, name)
     B, T, seed = int(g["B"]), int(g["T"]), int(g["seed"])
@@ -169,14 +167,14 @@ def test_const_noise_matches_reference_and_broadcasts_sample_zero(golden_dir, sd
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_hostile_weights_forward_and_loop(gemm_path, golden_dir, prec):
-    if prec == "f32" and gemm_path != "small":
-        pytest.skip("the f32 mode has one GEMM kernel")
     """Outlier channels (|beta|, bias 50-300x), LayerNorm gamma in [0.05, 8], 10x weight rows, 20x text embedding
     (oracle/synth.py synth_state_dict_hostile).  These weights amplify rounding noise, so the fixtures record the reference
     arithmetic's OWN noise `floor` = |reference fp32 - fp64 oracle|; the bars are the unchanged tolerances or a multiple of
     that floor, whichever is larger -- measured against fp64 truth for the loop: 3 floors for the exact-fp32 mode, 6 for the
     split mode (22-bit products against fp32's 24: a factor 4 by construction).  The round-1 bf16 split is ~100 floors here
     (tools/precision_probe.py --hostile); the folded LayerNorm's statistics are merged Chan-style (gemm_x3.h)."""
+    if prec == "f32" and gemm_path != "small":
+        pytest.skip("the f32 mode has one GEMM kernel")
     K = {"f32": 3.0, "f16x3": 6.0}[prec]
     sdh = synth_state_dict_hostile(0)
     g = _g(golden_dir, "hostile_fwd_B2_T196")
@@ -200,7 +198,8 @@ def test_hostile_weights_forward_and_loop(gemm_path, golden_dir, prec):
     model, diffusion = make_pair(sdh, steps, DEV, guided=True, precision=prec)
     out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": dict(y)},
                                   noise_sequence=[x_T] + [n.contiguous() for n in noises]).cpu()
-    truth = orc.sample_loop(sdh, orc.Tables(orc.named_betas("cosine", steps)), shape, y, x_T, noises, cfg=True, dtype=torch.float64)
+    truth = memo("hostile_truth", lambda: orc.sample_loop(sdh, orc.Tables(orc.named_betas("cosine", steps)), shape, y, x_T, noises,
+                                                          cfg=True, dtype=torch.float64))
     floor = float(g["floor"])
     e_ref, e_64 = maxabs(out, g["final"]), maxabs(out, truth)
     print(f"[parity] hostile loop50 {prec}: vs reference {e_ref:.3e}, vs fp64 {e_64:.3e} (reference's own {floor:.1e}; |x0| max "
@@ -260,11 +259,11 @@ def test_fp16_planes_keep_subnormals_and_fail_loudly_out_of_range(sd):
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec", PRECISIONS)
 def test_frame_masks_with_holes_are_honoured(gemm_path, sd, prec):
-    if prec == "f32" and gemm_path != "small":
-        pytest.skip("the f32 mode has one GEMM kernel")
     """model/mdm.py:241-247 hands ANY `~y['mask']` to src_key_padding_mask; masks that are not prefix masks reach the attention
     kernels as per-sample bitmaps (include/mdm_hip.h lengths_dev, ABI 7).  T = 196 (seven key tiles), three samples: a prefix
     mask, a mask with holes incl. frame 0 and a tile boundary, a mask with only scattered frames; cond, uncond and guided."""
+    if prec == "f32" and gemm_path != "small":
+        pytest.skip("the f32 mode has one GEMM kernel")
     B, T = 3, 196
     y = synth_y(B, T, seed=2, lengths=[196, 150, 196])
     y["mask"] = y["mask"].clone()
@@ -275,8 +274,8 @@ def test_frame_masks_with_holes_are_honoured(gemm_path, sd, prec):
     g = torch.Generator().manual_seed(4)
     x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 7, 0])
     yd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in y.items()}
-    want_c = orc.mdm_forward(sd, x, t, y)
-    want_u = orc.mdm_forward(sd, x, t, {**y, "uncond": True})
+    want_c = memo("holes_c", lambda: orc.mdm_forward(sd, x, t, y))
+    want_u = memo("holes_u", lambda: orc.mdm_forward(sd, x, t, {**y, "uncond": True}))
     assert maxabs(model.model(x.to(DEV), t.to(DEV), y=dict(yd)).cpu(), want_c) < TOL_FWD[prec]
     assert maxabs(model.model(x.to(DEV), t.to(DEV), y={**yd, "uncond": True}).cpu(), want_u) < TOL_FWD[prec]
     want_g = want_u + y["scale"].view(-1, 1, 1, 1) * (want_c - want_u)
@@ -331,9 +330,7 @@ def test_dip_dump_steps_are_loop_indices():
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
-def test_kit_shape_251_features(gemm_path, prec):
-    if prec == "f32" and gemm_path != "small":
-        pytest.skip("the f32 mode has one GEMM kernel")
+def test_kit_shape_251_features(prec):
     """dataset='kit' (utils/model_util.py:47-49): 251 pose features instead of 263 -- other K / N paddings of the 263-wide
     projections, other tail tiles in the transposing kernels.  Forward and a short guided loop against the oracle."""
     sdk = synth_state_dict(seed=0, input_feats=251)
@@ -343,10 +340,10 @@ def test_kit_shape_251_features(gemm_path, prec):
     y = synth_y(B, T, seed=8, lengths=[50, 17, 33])
     x = torch.randn(B, 251, 1, T, generator=torch.Generator().manual_seed(2))
     t = torch.tensor([5, 0, 3])
-    assert maxabs(model(x.to(DEV), t.to(DEV), y=dict(y)).cpu(), orc.cfg_forward(sdk, x, t, y)) < 4 * TOL_FWD[prec]
+    assert maxabs(model(x.to(DEV), t.to(DEV), y=dict(y)).cpu(), memo("kit_fwd", lambda: orc.cfg_forward(sdk, x, t, y))) < 4 * TOL_FWD[prec]
     shape = (B, 251, 1, T)
     g = torch.Generator().manual_seed(4)
     seq = [torch.randn(shape, generator=g) for _ in range(steps + 1)]
     out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": dict(y)}, noise_sequence=seq)
-    want = orc.sample_loop(sdk, orc.Tables(orc.named_betas("cosine", steps)), shape, y, seq[0], seq[1:], cfg=True)
+    want = memo("kit_loop", lambda: orc.sample_loop(sdk, orc.Tables(orc.named_betas("cosine", steps)), shape, y, seq[0], seq[1:], cfg=True))
     assert maxabs(out.cpu(), want) < TOL_LOOP[prec]

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (ROOT, dip, make_pair, maxabs, orc, synth_dip_state_dict, synth_state_dict, synth_y, to_dev)
+from helpers import (ROOT, dip, make_pair, maxabs, memo, orc, synth_dip_state_dict, synth_state_dict, synth_y, to_dev)
 
 pytestmark = pytest.mark.gpu
 
@@ -178,7 +178,7 @@ def test_small_batch_loop_matches_oracle(sd, gemm_path, B, lengths):
     model, diffusion = make_pair(sd, steps, DEV, guided=True)
     out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": dict(y)},
                                   noise_sequence=[x_T] + [n.contiguous() for n in noises])
-    want = orc.sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), shape, y, x_T, noises, cfg=True)
+    want = memo(("small_batch", B), lambda: orc.sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), shape, y, x_T, noises, cfg=True))
     err = maxabs(out.cpu(), want)
     print(f"[parity] small-batch loop B={B} T=196 50 steps, GEMM kernel {gemm_path}: max-abs vs oracle = {err:.3e}")
     assert err < TOL_LOOP

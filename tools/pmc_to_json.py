@@ -30,6 +30,9 @@ def classify(name):
             full = name[name.rfind("<") + 1:name.rfind(">")].split(",") if "<" in name else []
             has_pipe = len(full) == 13 or ("<" not in name and os.environ.get("PMC_PIPE_ARG", "1") == "1")
             tail = args[::-1][1:12] if has_pipe else args[::-1][:11]
+            # round 4 appended a 14th argument (NCB, an integer): the last argument is then a number, PIPE the one before it
+            if args[-1].strip().isdigit() and len(args) >= 13 and args[-2].strip() in ("true", "false"):
+                tail = args[::-1][2:13]
             f6, t16, embed, ostat, fold, abl, qkv, planes, f32, res, act = tail
             b = lambda v: v == "true"   # noqa: E731
             if b(embed):
