@@ -439,15 +439,16 @@ inline int x3s_max_seqs() {      // (read per call: the test suites switch kerne
   return e != nullptr ? atoi(e) : 40;
 }
 // Tile shape of a forward over `nseq` sequences -- ONE shape for all of its GEMMs, because the row statistics a producer leaves
-// (per tile width) are what its consumer merges.  32-row tiles up to 8 sequences (B <= 4 under guidance: 22.2 vs 26.5 ms per
-// 50-step loop at B = 1, 31.1 vs 31.8 at B = 4), 64-row tiles above (37.0 vs 37.6 at B = 6, 66.3 vs 72.5 at B = 16); always
+// (per tile width) are what its consumer merges.  32-row tiles up to 12 sequences (B <= 6 under guidance: 22.0 vs 26.5 ms per
+// 50-step loop at B = 1, 30.7 vs 32.4 at B = 5, 36.2 vs 37.4 at B = 6), 64-row tiles above (39.2 vs 42.1 at B = 8, 61.9 vs 72.5
+// at B = 16; r4lat8); always
 // 128 columns: the 256-column form (NCB = 2: every A fragment feeds two column blocks, half the LDS reads and half the
 // activation traffic per MFMA) measured no faster anywhere -- 28.7 / 37.0 / 55.7 / 68.1 / 123.7 ms at B = 1 / 6 / 10 / 16 / 32
 // for 32 x 256 against 23.0 / 38.7 / 53.7 / 74.1 / 136.1 for 32 x 128 and 27.3 / 38.4 / 53.2 / 66.5 / 121.6 for 64 x 128 --
 // and is compiled into the probe library only (MDM_X3S_NCB=2).  MDM_X3S_RT=1|2 pins the height for A/B runs.
 struct X3sShape { int rt, ncb; };
 inline X3sShape x3s_shape(int nseq) {
-  X3sShape sh{nseq <= 8 ? 1 : 2, 1};
+  X3sShape sh{nseq <= 12 ? 1 : 2, 1};
   if (const char* e = getenv("MDM_X3S_RT")) { const int v = atoi(e); if (v == 1 || v == 2) sh.rt = v; }
 #ifdef MDM_PROBES
   if (const char* e = getenv("MDM_X3S_NCB")) { const int v = atoi(e); if (v == 1 || v == 2) sh.ncb = v; }

@@ -479,7 +479,11 @@ int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w,
   if (const char* e = getenv("MDM_X3S_KINDS")) small = small && ((atoi(e) >> kind) & 1);
 #endif
   if (small) {
-    const int rc = launch_gemm_x3s(kind, ln.shape, a, w, ep, M, N, K, kind == 5 ? ln.emb_T : S, s);
+    // rows are grouped by sequence only where the epilogue needs (sequence, token) -- in_proj's Q / K / V^T planes, InputProcess's
+    // (sample, frame); every other GEMM tiles its M rows CONTIGUOUSLY: 197 tokens are three 64-row tiles plus one of 5 rows, i.e.
+    // a quarter of the workgroups of a sequence-aligned launch would do 8 % of a tile's work (B = 6: 37 row tiles instead of 48)
+    const int group_rows = (kind == 0 || kind == 6) ? S : (kind == 5 ? ln.emb_T : M);
+    const int rc = launch_gemm_x3s(kind, ln.shape, a, w, ep, M, N, K, group_rows, s);
     if (rc == -1) return fail(MDM_EHIP, "f16x3 linear (small tiles): hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     if (rc == -2) return fail(MDM_EUNSUPPORTED, "f16x3 linear (small tiles): unsupported shape (K must be 288 or a multiple of 256)");
 #if defined(MDM_PROBES) && !defined(MDM_EMU)
