@@ -6,7 +6,7 @@ OUT=gpurun_out/${1:-r4final}
 mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "import bench; print(bench.csrc_sha256()); print(bench.lib_sha256())" > $OUT/csrc_sha256.txt
-timeout 2400 python -m pytest tests -m gpu -x -q -s > $OUT/pytest_gpu.log 2>&1
+timeout 2400 python -m pytest tests -m gpu -x -q -s --durations=25 > $OUT/pytest_gpu.log 2>&1
 echo "pytest: $(tail -1 $OUT/pytest_gpu.log)"
 grep "parity\]" $OUT/pytest_gpu.log > $OUT/parity_lines.txt; wc -l $OUT/parity_lines.txt
 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
