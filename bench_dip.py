@@ -123,7 +123,7 @@ def measure(dev, rank, world, B, steps, warmup, cpu=True):
                                    f"frames, {NTOK}-token DistilBERT memory (cached), {DSTEPS} DDPM steps per window, "
                                    f"CFG 7.5, batch={B} per GPU, random-init weights", "global_batch": GB,
                        "parallelism": f"dp{world}: batch shards, all_gather of final samples"},
-            "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3_kernel") + ")",
+            "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3s_kernel on operand planes; K / V of the text memory: gemm_f32_kernel<X3>") + ")",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": None, "launches": lin["launches"],
                          "avg_launch_us": round(lin["ms"] * 1e3 / max(lin["launches"], 1), 2)},

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, con
 }
 
 // Tail of the split-precision OutputProcess: the f16x3 GEMM leaves every token's 263 output features as a fp32 ROW
-// (out_tok [nseq*S][ldo]); this kernel drops token 0 (mdm.py:253), transposes 32x32 tiles through LDS into the
+// (out_tok [nseq*S][ldo]); this kernel drops the S - T leading tokens (the condition token, mdm.py:253; the DiP
+// decoder's context_len prefix tokens, mdm.py:278-282), transposes 32x32 tiles through LDS into the
 // reference's [.., JF, T] pose layout (mdm.py:385) and fuses, per element, what OutProjEpilogue fuses in the fp32 path:
 // mode 0 plain model output for every sequence; mode 1 classifier-free-guidance combine of the two branches
 // (utils/sampler_util.py:34 -- here AFTER the projection, which is linear), inpainting blend, clamp, posterior /
@@ -166,9 +167,9 @@ __global__ __launch_bounds__(256) void outproj_finish_kernel(const float* __rest
     const int t = t0 + ty + 8 * i, j = j0 + tx;
     float v = 0.f;
     if (t < T && j < JF) {
-      v = out_tok[((size_t)b * S + 1 + t) * ldo + j];
+      v = out_tok[((size_t)b * S + (S - T) + t) * ldo + j];
       if (mode == 1 && scale != nullptr) {
-        const float u = out_tok[((size_t)(B + b) * S + 1 + t) * ldo + j];
+        const float u = out_tok[((size_t)(B + b) * S + (S - T) + t) * ldo + j];
         v = u + scale[b] * (v - u);
       }
     }

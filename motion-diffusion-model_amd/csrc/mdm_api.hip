@@ -854,8 +854,11 @@ size_t mdm_const_bytes(const mdm_model_t* m) {
     const size_t fold = align_up(3 * D * D * 4, 256) + align_up(D * D * 4, 256) + align_up(FF * D * 4, 256) +
                         2 * (align_up(3 * D * 4, 256) + align_up(D * 4, 256) + align_up(FF * 4, 256));
     const size_t planes = align_up(3 * D * D * 4, 256) + 3 * align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
+    // OutputProcess with the last norm3 folded in (the plane path of decoder_pass): fp32 copy, 2 vectors, planes
+    const size_t outp = align_up((size_t)m->jf * D * 4, 256) + 2 * align_up((size_t)32 * ((m->jf_out + 31) / 32) * 4, 256) +
+                        align_up(x3_packed_weight_elems(m->jf_out, (int)D) * 4, 256);
     return 256 /* range flag */ + align_up(D * m->jf_pad * sizeof(float), 256) +
-           2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) + (size_t)m->cfg.num_layers * (fold + planes);
+           2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) + (size_t)m->cfg.num_layers * (fold + planes) + outp;
   }
   const size_t per_layer = align_up(3 * D * D * 4, 256) + align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
   return 256 /* range flag */ + align_up(D * m->jf_pad * sizeof(float), 256) +
@@ -943,6 +946,17 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
       if (int rc = make_planes(m->L(l, "multihead_attn.out_proj.weight"), D, D, P.out_proj2)) return rc;
       if (int rc = make_planes(F.w_1, FFd, D, P.linear1)) return rc;
       if (int rc = make_planes(m->L(l, "linear2.weight"), D, FFd, P.linear2)) return rc;
+    }
+    {  // OutputProcess <- norm3(L-1) (decoder_pass on operand planes: no LayerNorm kernel in front of poseFinal)
+      const int jf32 = (m->jf_out + 31) / 32 * 32;
+      float* wf = take((size_t)m->jf * D);
+      m->c_out = take(jf32);
+      m->b_out = take(jf32);
+      MDM_LAUNCH(fold_layernorm_kernel, dim3((jf32 + 3) / 4), dim3(256), 0, s, m->W("output_process.poseFinal.weight"),
+                 m->L(L - 1, "norm3.weight"), m->L(L - 1, "norm3.bias"), m->W("output_process.poseFinal.bias"), wf, m->c_out,
+                 m->b_out, m->jf, D, jf32);
+      if (int rc = rt_launch_status()) return rc;
+      if (int rc = make_planes(wf, m->jf, D, m->out_planes_f)) return rc;
     }
     if ((size_t)(base - static_cast<char*>(const_ws)) > const_ws_bytes) return fail(MDM_ENOSPC, "mdm_prepare: const workspace too small");
     m->prepared = true;
@@ -1094,6 +1108,11 @@ namespace {
 struct DecWorkspace {
   float *tok, *qkv, *att, *ffn, *mem, *kv, *proj;
   float *stat[2];    // [M][D/32][2] partial LayerNorm statistics of the residual stream (gemm_f32.h LnFold), ping-pong
+  // the plane path (decoder_pass_planes): the residual stream as two ping-pong pairs of hi | lo operand planes; the attention
+  // outputs and the GELU output as planes over att / ffn; Q / K / V^T planes over qkv
+  p16_t *xh[2], *xl[2];
+  p16_t *atth, *attl, *ffnh, *ffnl;
+  QkvPlanes qp;
   // window loop only (nsteps > 0): what is constant over the steps of one p_sample_loop
   float *out;        // [nseq][J*F*pred_len] model output of the current step
   float *kv_text;    // [L][nseq*ntok][2D]   Wkv_l . (text part of the memory)            (no bias)
@@ -1111,9 +1130,26 @@ DecWorkspace carve_dec(const mdm_model* m, int nseq, int S, int ntok, int B, voi
   };
   DecWorkspace w;
   w.tok = take(M * D);
-  w.qkv = take(M * 3 * D);        // self-attention: packed q|k|v rows; cross-attention: the projected queries [M][D]
+  const size_t NKT = ((size_t)S + 31) / 32, SP = 32 * NKT;
+  w.qkv = take((size_t)nseq * SP * 3 * D);   // self-attention: packed q|k|v rows [M][3D] (or six 16-bit planes of nseq*SP*D: the
+                                             // plane path); cross-attention: the projected queries [M][D]
   w.att = take(M * D);
   w.ffn = take(M * FF);
+  for (int i = 0; i < 2; ++i) {   // two 16-bit planes = one fp32 array's worth of bytes
+    float* tp = take(M * D);
+    w.xh[i] = reinterpret_cast<p16_t*>(tp);
+    w.xl[i] = tp ? w.xh[i] + M * D : nullptr;
+  }
+  w.atth = reinterpret_cast<p16_t*>(w.att);
+  w.attl = w.att ? w.atth + M * D : nullptr;
+  w.ffnh = reinterpret_cast<p16_t*>(w.ffn);
+  w.ffnl = w.ffn ? w.ffnh + M * FF : nullptr;
+  {
+    const size_t plane = (size_t)nseq * SP * D;
+    p16_t* q = reinterpret_cast<p16_t*>(w.qkv);
+    w.qp = QkvPlanes{q, q ? q + plane : nullptr, q ? q + 2 * plane : nullptr, q ? q + 3 * plane : nullptr,
+                     q ? q + 4 * plane : nullptr, q ? q + 5 * plane : nullptr, (int)SP, (int)NKT, m->cfg.num_heads};
+  }
   w.mem = take(Mm * D);           // text memory [nseq][ntok][D]
   w.kv = take(Mm * 2 * D);        // its key | value projections of the current layer
   w.proj = take((size_t)ntok * B * D);   // embed_text(enc_text), token-major
@@ -1164,6 +1200,123 @@ struct DecHoist {         // step k of a window loop: where the hoisted projecti
   const float* kv_time = nullptr;   // [L][nsteps][2D]
   int kv_B = 0, kv_b0 = 0;          // this pass covers samples kv_b0 .. kv_b0 + B - 1 of kv_B
 };
+// The decoder stack on 16-bit operand planes: the f16x3 mode at the sizes the reference's DiP callers run (model/mdm.py:255-270
+// under sample/generate.py's autoregressive windows: 2 x 32 sequences of 20 + 40 tokens = 3,840 token rows).  That is the row
+// count of the encoder's latency regime, so the six GEMMs of a layer run on gemm_x3s.h's 32 / 64-row tiles straight from planes
+// (the fp32 skeleton of gemm_f32.h splits its operands inside the k-loop: 28 us per GEMM at this size), the self-attention on
+// attention_x3.h's Q / K / V^T planes, and only the cross-attention -- 24 memory tokens whose keys / values are hoisted fp32 --
+// stays on attention_f32.h (fp32 queries in, planes out).  All three LayerNorms of a layer are folded exactly as in the encoder
+// (row statistics per 128 columns from the producer, merged by the consumer); the residual stream ping-pongs between two plane
+// pairs because a GEMM cannot write the array its residual's statistics are read from.
+// Not taken (the fp32 skeleton below stays): f32 mode, frame masks (attention_x3.h's mask has the encoder's lead token), more
+// token rows than x3s_max_seqs() sequences of 197, sample groups of the probe build.
+inline bool dec_on_planes(const mdm_model* m, int M, int S, const int* len, const DecHoist& hz, int B) {
+  return m->precision == MDM_PREC_F16X3 && len == nullptr && S <= X3_TM && (long long)M <= 197LL * x3s_max_seqs() &&
+         m->cfg.latent_dim % 256 == 0 && m->cfg.ff_size % 256 == 0 && m->out_planes_f.hi != nullptr &&
+         (hz.step < 0 || (hz.kv_b0 == 0 && hz.kv_B == B));
+}
+
+int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x, const float* prefix, const int32_t* text_lengths,
+                          int B, int pred_len, int ntok, int nbranch, float* out, hipStream_t s, const DecHoist& hz) {
+  const int C = m->cfg.context_len, S = C + pred_len, D = m->cfg.latent_dim, H = m->cfg.num_heads, FF = m->cfg.ff_size;
+  const int nseq = nbranch * B, M = nseq * S, Mm = nseq * ntok;
+  Profiler* pf = &m->prof;
+  const float qscale = 1.0f / sqrtf((float)ATT_HD);
+  const bool hoisted = hz.step >= 0;
+  int cur = 0;   // which plane pair holds the layer input
+  {  // tgt tokens: InputProcess over cat(prefix, x) + positional rows, written as planes (the fp32 copy in ws.tok is not read)
+    PoseGatherLoader al{x, S, m->jf, B * S, prefix, C};
+    RowMajorLoader bl{m->w_in_pad, m->jf_pad, D, m->jf_pad};
+    EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, S, S, D, nbranch,
+                     ws.xh[cur], ws.xl[cur], 0};
+    ProfScope ps(pf, MDM_PROF_EMBED, 2.0 * B * S * (double)D * m->jf, s);
+    launch_gemm_f32(al, bl, ep, B * S, D, m->jf_pad, s, true);
+    if (int rc = rt_launch_status()) return rc;
+  }
+  const X3sShape shape = x3s_shape((M + 196) / 197);   // the encoder's 32- / 64-row threshold, in its token rows
+  const int scols = x3s_tn(shape.ncb), parts = (D + scols - 1) / scols;
+  const float inv_dim = 1.0f / (float)D;
+  auto LN = [&]() { LnArgs a; a.small = true; a.shape = shape; a.stat_cols = scols; a.parts = parts; a.inv_dim = inv_dim; return a; };
+  const X3Operand attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
+  float* q32 = ws.tok;   // the projected cross-attention queries [M][D]
+  for (int l = 0; l < m->cfg.num_layers; ++l) {
+    const mdm_model::DecFold& F = m->dec_fold[l];
+    const mdm_model::DecPlanes& P = m->dec_planes[l];
+    p16_t *Xh = ws.xh[cur], *Xl = ws.xl[cur], *Yh = ws.xh[cur ^ 1], *Yl = ws.xl[cur ^ 1];
+    const X3Operand X{Xh, Xl}, Y{Yh, Yl};
+    float *sX = ws.stat[cur], *sY = ws.stat[cur ^ 1];
+    // ---- Y = X' + self_attn(X'), X' = norm3(l-1)(X) (the embedded tokens for l = 0)
+    if (l == 0) {
+      LnArgs a = LN();
+      if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 6, X, P.in_proj, m->L(l, "self_attn.in_proj_bias"), a, nullptr, nullptr,
+                                nullptr, &ws.qp, M, 3 * D, D, S, D, D, qscale, s)) return rc;
+    } else {
+      LnArgs a = LN(); a.astat = sX; a.colsum = F.c_in;
+      if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, X, P.in_proj, F.b_in, a, nullptr, nullptr, nullptr, &ws.qp, M, 3 * D, D,
+                                S, D, D, qscale, s)) return rc;
+    }
+    if (int rc = launch_attention_x3(pf, ws.qp, nullptr, nseq, B, S, D, nullptr, ws.atth, ws.attl, s)) return rc;
+    {
+      LnArgs a = LN(); a.res = X; a.ostat = sY;
+      if (l >= 1) { a.rstat = sX; a.rgamma = m->L(l - 1, "norm3.weight"); a.rbeta = m->L(l - 1, "norm3.bias"); }
+      if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, l == 0 ? 1 : 2, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"), a,
+                                nullptr, Yh, Yl, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
+    }
+    // ---- X = norm1(Y) + multihead_attn(norm1(Y), memory, memory): fp32 queries (pre-scaled), k | v from the memory
+    {
+      LnArgs a = LN(); a.astat = sY; a.colsum = F.c_q;
+      if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 4, Y, P.q, F.b_q, a, q32, nullptr, nullptr, nullptr, M, D, D, S, D, D, qscale,
+                                s)) return rc;
+    }
+    if (!hoisted) {
+      const float* wc = m->L(l, "multihead_attn.in_proj_weight");
+      const float* bc = m->L(l, "multihead_attn.in_proj_bias");
+      if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s, true)) return rc;
+      const AttnF32Args a{q32, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
+      if (int rc = launch_attention_args(pf, a, nullptr, nseq, D, H, ws.atth, ws.attl, s)) return rc;
+    } else {
+      const float* kvt = hz.kv_text + (size_t)l * ((size_t)nbranch * hz.kv_B * ntok) * 2 * D;
+      const float* row = hz.kv_time + ((size_t)l * hz.nsteps + hz.step) * 2 * D;
+      AttnF32Args a{q32, D, kvt, kvt + D, 2 * D, S, ntok, text_lengths, 0, B};
+      a.kadd = row;
+      a.vadd = row + D;
+      a.kv_B = hz.kv_B;
+      a.kv_b0 = hz.kv_b0;
+      if (int rc = launch_attention_args(pf, a, nullptr, nseq, D, H, ws.atth, ws.attl, s)) return rc;
+    }
+    {
+      LnArgs a = LN(); a.res = Y; a.rstat = sY; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias"); a.ostat = sX;
+      if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, attp, P.out_proj2, m->L(l, "multihead_attn.out_proj.bias"), a, nullptr,
+                                Xh, Xl, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
+    }
+    // ---- Y = norm2(X) + linear2(gelu(linear1(norm2(X))))
+    {
+      LnArgs a = LN(); a.astat = sX; a.colsum = F.c_1;
+      if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 3, X, P.linear1, F.b_1, a, nullptr, ws.ffnh, ws.ffnl, nullptr, M, FF, D, S, D,
+                                0, 1.f, s)) return rc;
+    }
+    {
+      LnArgs a = LN(); a.res = X; a.rstat = sX; a.rgamma = m->L(l, "norm2.weight"); a.rbeta = m->L(l, "norm2.bias"); a.ostat = sY;
+      if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, ffnp, P.linear2, m->L(l, "linear2.bias"), a, nullptr, Yh, Yl, nullptr, M, D, FF, S, D, 0, 1.f, s)) return rc;
+    }
+    cur ^= 1;   // the layer's output (pre-norm3) is the next layer's X
+  }
+  // ---- OutputProcess over the completed suffix (mdm.py:278-282) with the last norm3 folded in: every token's features as an
+  // fp32 row (in the dead qkv region), then the transposing tail over token rows context_len .. S-1
+  float* out_tok = ws.qkv;
+  const int ldo = m->jf_out;
+  ProfScope ps(pf, MDM_PROF_OUTPROJ, 2.0 * nseq * pred_len * (double)D * m->jf, s);
+  {
+    LnArgs a = LN(); a.astat = ws.stat[cur]; a.colsum = m->c_out;
+    if (int rc = launch_x3_ln(nullptr, MDM_PROF_OUTPROJ, 4, X3Operand{ws.xh[cur], ws.xl[cur]}, m->out_planes_f, m->b_out, a, out_tok,
+                              nullptr, nullptr, nullptr, M, ldo, D, S, D, 0, 1.f, s)) return rc;
+  }
+  MDM_LAUNCH(outproj_finish_kernel, dim3((pred_len + 31) / 32, (m->jf + 31) / 32, nseq), dim3(256), 0, s, (const float*)out_tok,
+             ldo, S, pred_len, m->jf, B, (const float*)nullptr, 0, out, (float*)nullptr, (const float*)nullptr, NoiseSource{},
+             (const unsigned char*)nullptr, (const float*)nullptr, StepCoefs{});
+  return rt_launch_status();
+}
+
 int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const float* prefix, const int64_t* timesteps,
                  const float* text_tokens, const int32_t* text_lengths, const int32_t* lengths, int B, int pred_len,
                  int ntok, int branches, float* out, hipStream_t s, const DecHoist& hz) {
@@ -1187,6 +1340,8 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
                (branches == MDM_BRANCH_UNCOND) ? 0 : 1, (int)m->cfg.max_len);
     if (int rc = rt_launch_status()) return rc;
   }
+  if (dec_on_planes(m, M, S, len, hz, B))
+    return decoder_layers_planes(m, ws, x, prefix, text_lengths, B, pred_len, ntok, nbranch, out, s, hz);
   // ---- tgt tokens: InputProcess over cat(prefix, x) + positional rows (mdm.py:203-206, :239, :259-260); both branches
   {
     PoseGatherLoader al{x, S, m->jf, B * S, prefix, C};

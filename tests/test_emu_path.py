@@ -286,6 +286,30 @@ def test_emulated_dip_decoder_forward(lib, masked, prec):
     assert maxabs(model(x, t, y=dict(y)), dip.dip_cfg_forward(sd, x, t, y, **kw)) < 5e-5
 
 
+def test_emulated_dip_decoder_planes_and_fp32_skeleton(lib, monkeypatch):
+    """The f16x3 trans_dec stack has two routes (csrc/mdm_api.hip dec_on_planes): operand planes through gemm_x3s.h /
+    attention_x3.h (unmasked, up to 40 x 197 token rows: what DiP's callers run) and the fp32 skeleton of gemm_f32.h (frame
+    masks, larger batches; MDM_X3S_MAX_SEQS=0 forces it).  Both against the oracle, on 32- and 64-row tiles; the two are different
+    arithmetic, so agreeing bit for bit would mean the switch did nothing."""
+    B, C, P = 3, 5, 12
+    sd = dip_small_state_dict(num_layers=2)
+    y = synth_dip_y(B, P, C, seed=3, text_lengths=[6, 3, 2], lengths=None, scale=2.5)
+    x = torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([9, 0, 4])
+    want = dip.dip_cfg_forward(sd, x, t, y, context_len=C, num_heads=2, mask_frames=False)
+    outs = {}
+    for tag, env in (("planes32", {"MDM_X3S_RT": "1"}), ("planes64", {"MDM_X3S_RT": "2"}), ("skeleton", {"MDM_X3S_MAX_SEQS": "0"})):
+        monkeypatch.delenv("MDM_X3S_RT", raising=False)
+        monkeypatch.delenv("MDM_X3S_MAX_SEQS", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model, _ = make_pair(sd, 10, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, precision="f16x3")
+        outs[tag] = model(x, t, y=dict(y))
+        assert maxabs(outs[tag], want) < 5e-5, tag
+    assert not torch.equal(outs["planes32"], outs["skeleton"])
+    assert maxabs(outs["planes32"], outs["planes64"]) < 1e-5
+
+
 @pytest.mark.parametrize("guided,prec", [(True, "f16x3"), (False, "f32")])
 def test_emulated_dip_window_loop(lib, monkeypatch, guided, prec):
     """mdm_sample_loop_dec (one p_sample_loop over a DiP prediction window: text projections hoisted out of the steps, the

@@ -135,6 +135,48 @@ def test_trans_dec_with_a_clip_memory_token_matches_reference(golden_dir, prec):
     assert err < 2e-4
 
 
+@pytest.mark.parametrize("route", ["planes32", "planes64", "skeleton"])
+def test_dip_decoder_routes_match_reference_goldens(golden_dir, monkeypatch, route):
+    """The f16x3 trans_dec stack on its two routes (csrc/mdm_api.hip dec_on_planes): operand planes through gemm_x3s.h +
+    attention_x3.h -- what the DiP callers' sizes take; 32- and 64-row tiles -- and the fp32 skeleton of gemm_f32.h that frame
+    masks and large batches take (forced here by MDM_X3S_MAX_SEQS=0).  Each against the UPSTREAM reference's own outputs: the
+    B = 3 forward (both branches, guided) and the 100-frame autoregressive generation (3 windows x 10 steps, CFG 7.5)."""
+    from types import SimpleNamespace
+    from helpers import synth_dip_y
+    from mdm_amd.sampler_util import AutoRegressiveSampler
+    for k in ("MDM_X3S_RT", "MDM_X3S_MAX_SEQS"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv(*{"planes32": ("MDM_X3S_RT", "1"), "planes64": ("MDM_X3S_RT", "2"), "skeleton": ("MDM_X3S_MAX_SEQS", "0")}[route])
+    sd_dip = memo("sd_dip0", lambda: synth_dip_state_dict(seed=0))
+    g = _g(golden_dir, "dip_fwd_B3")
+    model, _ = make_pair(sd_dip, 10, DEV, guided=True, context_len=20, pred_len=40, mask_frames=False)
+    y = to_dev(synth_dip_y(3, 40, 20, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]), lengths=None), DEV)
+    x = torch.randn(3, 263, 1, 40, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV)
+    t = torch.from_numpy(g["t"]).to(DEV)
+    e_c = maxabs(model.model(x, t, y=dict(y)).cpu(), g["out_cond"])
+    e_u = maxabs(model.model(x, t, y={**y, "uncond": True}).cpu(), g["out_uncond"])
+    e_g = maxabs(model(x, t, y=dict(y)).cpu(), g["out_cfg"])
+    print(f"[parity] DiP forward B=3 ({route}) f16x3: max-abs vs reference = {e_c:.3e} / {e_u:.3e} / {e_g:.3e} (cond / uncond / guided)")
+    assert e_c < 2e-5 and e_u < 2e-5 and e_g < 5e-5
+    g = _g(golden_dir, "dip_ar10_B2_F100")
+    steps, B, frames, seed = int(g["steps"]), int(g["B"]), int(g["frames"]), int(g["seed"])
+    model, diffusion = make_pair(sd_dip, steps, DEV, guided=True, context_len=20, pred_len=40)
+    y = to_dev(synth_dip_y(B, 40, 20, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]), scale=float(g["scale"])), DEV)
+    chunks = iter(dip.make_noise_chunks((B, 263, 1, 40), steps, seed, 3))
+
+    def sample_fn(mdl, shape, **kw):
+        x_T, eps = next(chunks)
+        return diffusion.p_sample_loop(mdl, shape, noise_sequence=[x_T] + [e.contiguous() for e in eps], **kw)
+
+    args = SimpleNamespace(pred_len=40, context_len=20, autoregressive_include_prefix=False)
+    out = AutoRegressiveSampler(args, sample_fn, frames).sample(
+        model, (B, 263, 1, frames), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, init_image=None,
+        progress=False, dump_steps=None, noise=None, const_noise=False)
+    err = maxabs(out.cpu(), g["final"])
+    print(f"[parity] dip_ar10_B2_F100 ({route}) f16x3: max-abs vs reference = {err:.3e}")
+    assert err < 2e-4
+
+
 def test_integration_md_ctypes_snippet_runs_as_written(tmp_path):
     """the stand-alone ctypes binding of `mdm_sample_loop` -- the fenced python block is extracted and
     executed verbatim in a fresh interpreter (only torch for device memory); it must print its own `max-abs vs oracle` line."""
