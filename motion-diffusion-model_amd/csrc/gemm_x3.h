@@ -368,11 +368,15 @@ __global__ __launch_bounds__(64 * WAVES, NCB == 2 ? 1 : 2) void gemm_x3_kernel(X
     const float* st = FOLD ? ep.astat : ep.rstat;
     const int npieces = (X3_TM * ep.stat_parts * 8 + 1023) / 1024;
     for (int pc = wid; pc < npieces; pc += X3_WAVES) {      // (<= 7 pieces; four waves take two)
-      // floats in the whole statistics buffer, rounded up to the 16-byte unit of the transfer (M odd with one partial per
-      // row ends on an 8-byte boundary; the workspace carves these buffers in 256-byte units, so the tail is addressable)
-      const long long total_f = ((long long)M * ep.stat_parts * 2 + 3) / 4 * 4;
+      // A 16-byte unit keeps its place in the table (unit u of the tile = floats 4u .. 4u+3 behind the tile's first row) as long
+      // as it holds any float of the matrix; units entirely past it read a valid address instead.  With an odd number of
+      // partials per row (D = 256, 768) a tile that starts on an odd row is only 8-byte aligned and its last unit may straddle
+      // the end of the array by up to 12 bytes: the workspace carves every statistics array with 16 spare bytes for this
+      // (mdm_api.hip carve).  (Round 3 clamped straddling units to the last 16 bytes of the array, which moved the last row's
+      // partials to the wrong table slot: wrong last token row for D = 256 when the last tile starts on an odd row.)
+      const long long total_f = (long long)M * ep.stat_parts * 2;
       long long fo = (long long)m0s * ep.stat_parts * 2 + 4LL * (64 * pc + lane);
-      if (fo > total_f - 4) fo = total_f - 4;                          // rows past the matrix: any valid address
+      if (fo >= total_f) fo = 0;                                       // rows past the matrix: any valid address
       glds16(st + fo, lds + x3_raw_base(NBLK, RINGN) + par * X3_RAW_BYTES + pc * 1024);
     }
   };

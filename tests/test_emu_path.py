@@ -50,6 +50,8 @@ def test_emulated_cfg_loop_matches_oracle(lib, gemm_path, prec, tol):
     ("f32", 1e-5, 1, 2, 33, [33, 5]),
     ("f16x3", 2e-5, 2, 2, 33, [33, 5]),        # S = 34: two key tiles, ragged tail; six sequences per 208-row GEMM tile
     ("f16x3", 2e-5, 2, 1, 196, [150]),         # S = 197 (headline): one sequence per 208-row tile, 16-row last sub-tile
+    ("f16x3", 2e-5, 2, 2, 100, [100, 100]),    # S = 101, D = 256: in_proj's second tile starts on an odd row, i.e. 8-byte aligned in
+                                               # the one-partial-per-row statistics array (round 4: its last row read row M-2's)
     ("f16x3", 2e-5, 1, 1, 207, [207]),         # S = 208: the 16-row sub-tile completely used
     ("f16x3", 2e-5, 1, 1, 208, [208]),         # S = 209: does not fit 208 rows -> the 224-row (7 x 32) form
 ])
