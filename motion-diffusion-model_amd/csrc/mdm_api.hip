@@ -570,12 +570,6 @@ int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long l
   return rt_launch_status();
 }
 
-// MDM_ENC_HALVES (read per call): which producer -> consumer pairs of the encoder run one guidance branch at a time
-inline int enc_halves_setting() {
-  const char* e = getenv("MDM_ENC_HALVES");
-  return e != nullptr ? (atoi(e) & 3) : 0;
-}
-
 // seqTransEncoder: num_layers post-norm layers over ws.tok [nseq*S, D] (in place).
 int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int* lengths, hipStream_t s) {
   Profiler* pf = &m->prof;
@@ -596,63 +590,41 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
     auto LN = [&]() { LnArgs a; a.small = small; a.shape = shape; a.stat_cols = scols; a.parts = parts; a.inv_dim = inv_dim; return a; };
     // (Running the stack over two half-batches, so that every producer -> consumer hand-over stays inside the 256 MB Infinity
     // Cache, was built and measured: 1.5 % SLOWER on the same box -- profiles/r02_ab.md -- and removed.)
-    // Producer -> consumer pairs whose hand-over is larger than the 256 MB Infinity Cache run branch by branch on the sequence
-    // tiles (guided batches: nseq = 2 B): in_proj -> attention hands over six Q / K / V^T planes (352 MB at B = 128, T = 196: the
-    // attention kernel would read every byte from HBM), linear1 -> linear2 the GELU planes (207 MB).  MDM_ENC_HALVES = bit 0 the
-    // first pair, bit 1 the second (same-box A/B: profiles/r04i_halves.md).
-    const int halves = (!small && nseq == 2 * B) ? enc_halves_setting() : 0;
-    const size_t Mh = (size_t)B * S;
-    auto rows = [&](X3Operand o, size_t r, int ld) { return X3Operand{o.hi + r * ld, o.lo + r * ld}; };
-    auto qp_from = [&](int seq0) {
-      QkvPlanes q = ws.qp;
-      const size_t o = (size_t)seq0 * q.SP * D;
-      q.qh += o; q.ql += o; q.kh += o; q.kl += o; q.vh += o; q.vl += o;
-      return q;
-    };
+    // (Running in_proj -> attention and / or linear1 -> linear2 one guidance branch at a time, so that the 352 MB of Q / K / V^T
+    // planes or the 207 MB of GELU planes stay inside the 256 MB Infinity Cache between producer and consumer, was built and
+    // measured in round 4: attention 2 x 59.4 us against 111.5, in_proj 2 x 132.1 against 257.3, whole loop 1.0-1.5 % SLOWER on the
+    // same box -- profiles/r04i_halves.md -- and removed.)
     for (int l = 0; l < m->cfg.num_layers; ++l) {
       const mdm_model::LayerPlanes& P = m->planes[l];
       const mdm_model::LayerFold& F = m->fold[l];
-      const int nh1 = (halves & 1) ? 2 : 1;
-      for (int h = 0; h < nh1; ++h) {   // in_proj -> attention, per branch or over the whole batch
-        const int ns = nseq / nh1, Ms = M / nh1;
-        const size_t r0 = (size_t)h * Mh;
-        const QkvPlanes qp = qp_from(h * B);
-        const X3Operand xin = rows(xb, r0, D);
-        if (l == 0 && small) {
-          LnArgs a = LN();
-          if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 6, xin, P.in_proj, m->L(l, "self_attn.in_proj_bias"), a, nullptr, nullptr,
-                                    nullptr, &qp, Ms, 3 * D, D, S, D, D, qscale, s)) return rc;
-        } else if (l == 0) {
-          if (int rc = launch_in_proj_x3(pf, xin, P.in_proj, m->L(l, "self_attn.in_proj_bias"), qp, ns, S, D, qscale, s)) return rc;
-        } else {
-          LnArgs a = LN(); a.astat = ws.stat2 + r0 * parts * 2; a.colsum = F.c_qkv;
-          if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, xin, F.in_proj, F.b_qkv, a, nullptr, nullptr, nullptr, &qp, Ms,
-                                    3 * D, D, S, D, D, qscale, s)) return rc;
-        }
-        if (int rc = launch_attention_x3(pf, qp, lengths, ns, B, S, D, nullptr, ws.atth + r0 * D, ws.attl + r0 * D, s)) return rc;
+      if (l == 0 && small) {
+        LnArgs a = LN();
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 6, xb, P.in_proj, m->L(l, "self_attn.in_proj_bias"), a, nullptr, nullptr,
+                                  nullptr, &ws.qp, M, 3 * D, D, S, D, D, qscale, s)) return rc;
+      } else if (l == 0) {
+        if (int rc = launch_in_proj_x3(pf, xb, P.in_proj, m->L(l, "self_attn.in_proj_bias"), ws.qp, nseq, S, D, qscale, s)) return rc;
+      } else {
+        LnArgs a = LN(); a.astat = ws.stat2; a.colsum = F.c_qkv;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, xb, F.in_proj, F.b_qkv, a, nullptr, nullptr, nullptr, &ws.qp, M,
+                                  3 * D, D, S, D, D, qscale, s)) return rc;
       }
+      if (int rc = launch_attention_x3(pf, ws.qp, lengths, nseq, B, S, D, nullptr, ws.atth, ws.attl, s)) return rc;
       {  // xa = att.Wo + bo + layer input (normalised on the fly for l >= 1), + row statistics
         LnArgs a = LN(); a.res = xb; a.ostat = ws.stat1;
         if (l >= 1) { a.rstat = ws.stat2; a.rgamma = m->L(l - 1, "norm2.weight"); a.rbeta = m->L(l - 1, "norm2.bias"); }
         if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, l == 0 ? 1 : 2, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"),
                                   a, nullptr, ws.xah, ws.xal, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
       }
-      const int nh2 = (halves & 2) ? 2 : 1;
-      for (int h = 0; h < nh2; ++h) {   // linear1 -> linear2
-        const int Ms = M / nh2;
-        const size_t r0 = (size_t)h * Mh;
-        {  // ffn = gelu(LN1(xa).W1 + b1), LN1 folded
-          LnArgs a = LN(); a.astat = ws.stat1 + r0 * parts * 2; a.colsum = F.c_1;
-          if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 3, rows(xa, r0, D), F.linear1, F.b_1, a, nullptr, ws.ffnh + r0 * FF,
-                                    ws.ffnl + r0 * FF, nullptr, Ms, FF, D, S, D, 0, 1.f, s)) return rc;
-        }
-        {  // xb = ffn.W2 + b2 + LN1(xa), + row statistics
-          LnArgs a = LN(); a.res = rows(xa, r0, D); a.rstat = ws.stat1 + r0 * parts * 2; a.rgamma = m->L(l, "norm1.weight");
-          a.rbeta = m->L(l, "norm1.bias");
-          a.ostat = ws.stat2 + r0 * parts * 2;
-          if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, rows(ffnp, r0, FF), P.linear2, m->L(l, "linear2.bias"), a, nullptr,
-                                    ws.tokh + r0 * D, ws.tokl + r0 * D, nullptr, Ms, D, FF, S, D, 0, 1.f, s)) return rc;
-        }
+      {  // ffn = gelu(LN1(xa).W1 + b1), LN1 folded
+        LnArgs a = LN(); a.astat = ws.stat1; a.colsum = F.c_1;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 3, xa, F.linear1, F.b_1, a, nullptr, ws.ffnh, ws.ffnl, nullptr, M, FF,
+                                  D, S, D, 0, 1.f, s)) return rc;
+      }
+      {  // xb = ffn.W2 + b2 + LN1(xa), + row statistics
+        LnArgs a = LN(); a.res = xa; a.rstat = ws.stat1; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias");
+        a.ostat = ws.stat2;
+        if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, ffnp, P.linear2, m->L(l, "linear2.bias"), a, nullptr, ws.tokh,
+                                  ws.tokl, nullptr, M, D, FF, S, D, 0, 1.f, s)) return rc;
       }
     }
     return 0;   // the encoder's output is LN2(L-1)(xb): folded into OutputProcess (outproj_x3)
