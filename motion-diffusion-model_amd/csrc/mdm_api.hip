@@ -1212,10 +1212,13 @@ struct DecHoist {         // step k of a window loop: where the hoisted projecti
 // stays on attention_f32.h (fp32 queries in, planes out).  All three LayerNorms of a layer are folded exactly as in the encoder
 // (row statistics per 128 columns from the producer, merged by the consumer); the residual stream ping-pongs between two plane
 // pairs because a GEMM cannot write the array its residual's statistics are read from.
-// Not taken (the fp32 skeleton below stays): f32 mode, frame masks (attention_x3.h's mask has the encoder's lead token), more
-// token rows than x3s_max_seqs() sequences of 197, sample groups of the probe build.
+// Not taken (the fp32 skeleton below stays): f32 mode, frame masks (attention_x3.h's mask has the encoder's lead token), sample
+// groups of the probe build; MDM_X3S_MAX_SEQS=0 forces the skeleton for A/B runs.  There is no upper row count: the alternative
+// is not gemm_x3.h's sequence tiles (a 60-token sequence fills a quarter of one) but the skeleton, and the planes win at every
+// size measured (B = 32: 544 vs 391 motions/s, B = 64: 660 vs 448; profiles/r04h_dip_planes.md).
 inline bool dec_on_planes(const mdm_model* m, int M, int S, const int* len, const DecHoist& hz, int B) {
-  return m->precision == MDM_PREC_F16X3 && len == nullptr && S <= X3_TM && (long long)M <= 197LL * x3s_max_seqs() &&
+  (void)M;
+  return m->precision == MDM_PREC_F16X3 && len == nullptr && S <= X3_TM && x3s_max_seqs() > 0 &&
          m->cfg.latent_dim % 256 == 0 && m->cfg.ff_size % 256 == 0 && m->out_planes_f.hi != nullptr &&
          (hz.step < 0 || (hz.kv_b0 == 0 && hz.kv_B == B));
 }

@@ -290,8 +290,8 @@ def test_emulated_dip_decoder_forward(lib, masked, prec):
 
 def test_emulated_dip_decoder_planes_and_fp32_skeleton(lib, monkeypatch):
     """The f16x3 trans_dec stack has two routes (csrc/mdm_api.hip dec_on_planes): operand planes through gemm_x3s.h /
-    attention_x3.h (unmasked, up to 40 x 197 token rows: what DiP's callers run) and the fp32 skeleton of gemm_f32.h (frame
-    masks, larger batches; MDM_X3S_MAX_SEQS=0 forces it).  Both against the oracle, on 32- and 64-row tiles; the two are different
+    attention_x3.h (unmasked: what DiP's callers run) and the fp32 skeleton of gemm_f32.h (frame
+    masks; MDM_X3S_MAX_SEQS=0 forces it).  Both against the oracle, on 32- and 64-row tiles; the two are different
     arithmetic, so agreeing bit for bit would mean the switch did nothing."""
     B, C, P = 3, 5, 12
     sd = dip_small_state_dict(num_layers=2)
