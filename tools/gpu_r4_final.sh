@@ -12,6 +12,11 @@ grep "parity\]" $OUT/pytest_gpu.log > $OUT/parity_lines.txt; wc -l $OUT/parity_l
 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 bash tools/gpu_prof.sh ${1:-r4final}/prof pmc > $OUT/prof.log 2>&1
 head -14 $OUT/prof/kernel_stats.md | cut -c1-170
+for B in 32 128; do for R in planes skeleton; do
+  E=A=1; [ $R = skeleton ] && E=MDM_X3S_MAX_SEQS=0
+  env $E timeout 300 python bench_dip.py --steps 3 --warmup 1 --no-cpu-baseline --batch $B > $OUT/dip_${R}_B$B.json 2> $OUT/dip_${R}_B$B.err
+  python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1], d['value'], d['ms_per_step'], d['kernel_ms'])" $OUT/dip_${R}_B$B.json
+done; done
 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
 python - $OUT/bench_full.json <<'PY'
 import json, sys
