@@ -41,6 +41,21 @@ constexpr int x3s_lds_bytes(int rt, int ncb, int nsub, bool multi) { return x3s_
 // K = NSUB * 16 * nchunks.  MULTI: double-buffered A (more than one chunk).  The other flags are gemm_x3_kernel's.
 // Rows are GROUPED (group_rows = tokens of a sequence; InputProcess: frames of a sample): a tile never straddles two groups, so
 // that the in_proj epilogue's (sequence, token) and the EMBED epilogue's (sample, frame) are tile-uniform / row-affine.
+#if defined(MDM_PROBES) && !defined(MDM_EMU)
+// PROBE BUILD ONLY: wave 0's shader-clock stamps of ONE selected launch (mdm_debug_set(9, n): the n-th gemm_x3s launch after the
+// call; mdm_debug_get(100 + 4 * workgroup + i)): i = 0 kernel entry, 1 chunk 0 visible to the workgroup (first barrier passed),
+// 2 k-loop and its trailing re-fetches retired, 3 last store issued.  tools/x3s_timeline.py
+constexpr int X3S_TL_WGS = 4096;
+__device__ unsigned long long g_x3s_tl[4 * X3S_TL_WGS];
+__device__ int g_x3s_tl_on;
+#define X3S_STAMP(i)                                                                                     \
+  do {                                                                                                   \
+    if (tl_on && tid == 0 && blockIdx.x < X3S_TL_WGS) g_x3s_tl[4 * blockIdx.x + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define X3S_STAMP(i) do { } while (0)
+#endif
+
 template <int RT, int NCB, int NSUB, bool MULTI, int ACT, int RES, bool OUT_F32, bool OUT_PLANES, bool OUT_QKV, bool FOLD, bool OSTAT,
           bool EMBED>
 __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A, X3Weights W, X3Epilogue ep, int M, int N, int K,
@@ -52,12 +67,22 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
   constexpr int BUF = x3s_buf_bytes(RT, NSUB);
   constexpr int PW = NSUB * RT / 2;                      // LDS-DMA pieces (1 KB) per wave and chunk
   constexpr int LW = 2 * NCB;                            // W loads per wave and sub-step
+  // RES_LDS: the plane residual of the tile (TR rows x 128 columns x hi | lo = exactly one chunk buffer) arrives by LDS-DMA in the
+  // buffer that is spare during the LAST chunk -- the slot of the harmless re-fetch, same piece count, same counted waits --
+  // instead of 16 RT row-divergent 8-byte register loads per lane in the prologue (each touches 8 cache lines; the table build's
+  // compiler-tracked wait drained them in front of the first barrier: 8.3 k cycles from kernel entry to the first chunk against
+  // 5.4 k for a kind without residual, profiles/r04j_x3s_timeline.md) and 32 VGPRs held across the k-loop
+  constexpr bool RES_LDS = (RES == 2 || RES == 3) && MULTI && NCB == 1;
   static_assert(2 * NSUB * RT % X3S_WAVES == 0, "pieces must divide among the waves");
   static_assert(LW * (D - 1) + PW <= 63 && (NSUB > D ? LW * D : LW * NSUB) <= 63 && NSUB >= D && (!MULTI || NSUB % D == 0) && (D * NCB) % 4 == 0,
                 "vmcnt range / slot <-> sub-step map across chunks / closing wait");
   constexpr bool LN_TABS = FOLD || RES == 3;
 
   const int tid = threadIdx.x;
+#if defined(MDM_PROBES) && !defined(MDM_EMU)
+  const bool tl_on = g_x3s_tl_on != 0;
+#endif
+  X3S_STAMP(0);
   const int lane = tid & 63;
 #ifdef MDM_EMU
   const int wid = tid >> 6;
@@ -87,6 +112,22 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
       const int arow = min(m0 + g * 16 + (lane >> 2), M - 1);
       const p16_t* src = (p ? A.lo : A.hi) + (size_t)arow * K + (size_t)c * (NSUB * 16) + ms * 32 + schunk * 8;
       glds16(src, lds + buf * BUF + ((ms * 2 + p) * 2 * RT + g) * 1024);
+    }
+  };
+  // residual tile -> LDS image [plane][row][256 B]: piece q = 4 rows of one plane (1 KB); lane -> (row of the piece = lane >> 4,
+  // stored 16-byte slot = lane & 15) fetches the logical chunk slot ^ 4 (row & 3), so that the epilogue's 8-byte reads of 8 rows x
+  // 64 B spread over all banks (two passes for 512 B: the minimum)
+  auto issue_res = [&](int buf) {
+    if constexpr (RES_LDS) {
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        const int q = wid + X3S_WAVES * i;
+        const int p = q / (TR / 4), ig = q % (TR / 4);
+        const int rl = lane >> 4, cch = (lane & 15) ^ (4 * rl);
+        const int rrow = min(m0 + ig * 4 + rl, M - 1);
+        const p16_t* src = (p ? ep.resl : ep.resh) + (size_t)rrow * ep.ld + n0 + cch * 8;
+        glds16(src, lds + buf * BUF + p * (TR * 256) + ig * 1024);
+      }
     }
   };
   // ---- W stream: this wave's fragments of 16-deep sub-step `gj` (global index over the whole K): hi and lo of each of its
@@ -139,8 +180,8 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
   }
   constexpr int NRND = 4 * RT * NCB;                // epilogue rounds: round (cb, t, g) -> index (cb * RT + t) * 4 + g
   float4 rres[RES == 1 ? NRND : 1];
-  uint2 rrh[(RES == 2 || RES == 3) ? NRND : 1], rrl[(RES == 2 || RES == 3) ? NRND : 1];
-  if constexpr (RES != 0) {
+  uint2 rrh[((RES == 2 || RES == 3) && !RES_LDS) ? NRND : 1], rrl[((RES == 2 || RES == 3) && !RES_LDS) ? NRND : 1];
+  if constexpr (RES != 0 && !RES_LDS) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -235,7 +276,13 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
       vmem_wait<LW * NSUB>(wsh[0], wsl[0]);
     }
     wg_barrier_nodrain();                 // every wave's pieces visible; every wave is past chunk c - 1, whose buffer refills now
-    if constexpr (MULTI) issue_chunk(min(c + 1, nchunks - 1), buf ^ 1);   // (last chunk: a harmless re-fetch keeps the counts uniform)
+    if (c == 0) X3S_STAMP(1);
+    if constexpr (RES_LDS) {            // (last chunk: the residual tile takes the spare buffer -- PW pieces like a chunk)
+      if (c == nchunks - 1) issue_res(buf ^ 1);
+      else issue_chunk(c + 1, buf ^ 1);
+    } else if constexpr (MULTI) {
+      issue_chunk(min(c + 1, nchunks - 1), buf ^ 1);   // (last chunk: a harmless re-fetch keeps the counts uniform)
+    }
     read_frags(std::integral_constant<int, 0>{}, buf);
     static_for<NSUB>([&](auto j_tag) __attribute__((always_inline)) {
       constexpr int j = decltype(j_tag)::value, sl = j % D;
@@ -277,6 +324,8 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
     vmem_wait<0>(wsh[q], wsl[q], wsh[q + 1], wsl[q + 1], wsh[q + 2], wsl[q + 2], wsh[q + 3], wsl[q + 3]);
   });
 
+  if constexpr (RES_LDS) wg_barrier_nodrain();   // every wave's residual pieces have landed (its own closing wait) -> visible to all
+  X3S_STAMP(2);
   // ---- epilogue: each wave turns its NCB x RT 32 x 32 accumulators through a private 1 KB LDS patch, 8 rows x 32 columns per
   // round, into (row = lane >> 3, 4 consecutive columns) per lane -> 16-byte fp32 / 8-byte plane accesses (gemm_x3.h).
   float* patch = reinterpret_cast<float*>(lds + x3s_patch_base(RT, NSUB, MULTI)) + wid * (X3_PATCH_BYTES / 4);
@@ -376,7 +425,17 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
           if constexpr (RES == 1) {
             v4 = add4(v4, rres[(cb * RT + t) * 4 + g]);
           } else if constexpr (RES == 2 || RES == 3) {
-            const uint2 a = rrh[(cb * RT + t) * 4 + g], b = rrl[(cb * RT + t) * 4 + g];
+            uint2 a, b;
+            if constexpr (RES_LDS) {
+              const int cch = (wid * NCB + cb) * 4 + ((lane & 7) >> 1);
+              const uint32_t ro = (uint32_t)(((nchunks - 1) & 1) ^ 1) * BUF + (uint32_t)rit * 256u +
+                                  (uint32_t)((cch ^ (4 * (rit & 3))) * 16 + (lane & 1) * 8);
+              a = *reinterpret_cast<const uint2*>(lds + ro);
+              b = *reinterpret_cast<const uint2*>(lds + ro + TR * 256);
+            } else {
+              a = rrh[(cb * RT + t) * 4 + g];
+              b = rrl[(cb * RT + t) * 4 + g];
+            }
             float4 x4 = make_float4(p16_to_f32((p16_t)(a.x & 0xffffu)) + p16_to_f32((p16_t)(b.x & 0xffffu)),
                                     p16_to_f32((p16_t)(a.x >> 16)) + p16_to_f32((p16_t)(b.x >> 16)),
                                     p16_to_f32((p16_t)(a.y & 0xffffu)) + p16_to_f32((p16_t)(b.y & 0xffffu)),
@@ -428,6 +487,7 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
       *reinterpret_cast<float2*>(ep.ostat + ((size_t)(m0 + tid) * tiles_n + tile_n) * 2) = make_float2(s1, m2);
     }
   }
+  X3S_STAMP(3);
 }
 
 #ifndef MDM_X3_KERNEL_ONLY
@@ -446,6 +506,10 @@ inline int x3s_max_seqs() {      // (read per call: the test suites switch kerne
 // activation traffic per MFMA) measured no faster anywhere -- 28.7 / 37.0 / 55.7 / 68.1 / 123.7 ms at B = 1 / 6 / 10 / 16 / 32
 // for 32 x 256 against 23.0 / 38.7 / 53.7 / 74.1 / 136.1 for 32 x 128 and 27.3 / 38.4 / 53.2 / 66.5 / 121.6 for 64 x 128 --
 // and is compiled into the probe library only (MDM_X3S_NCB=2).  MDM_X3S_RT=1|2 pins the height for A/B runs.
+#if defined(MDM_PROBES) && !defined(MDM_EMU)
+inline int& x3s_tl_target() { static int v = -1; return v; }   // mdm_debug_set(9, n); < 0: off
+inline int& x3s_tl_count() { static int v = 0; return v; }
+#endif
 struct X3sShape { int rt, ncb; };
 inline X3sShape x3s_shape(int nseq) {
   X3sShape sh{nseq <= 12 ? 1 : 2, 1};
@@ -479,6 +543,15 @@ inline int launch_gemm_x3s_t(const X3Operand& A, const X3Weights& W, const X3Epi
   const int TR = 32 * RT, TN = x3s_tn(NCB);
   const int tpg = (group_rows + TR - 1) / TR, tiles_m = (M / group_rows) * tpg, tiles_n = (N + TN - 1) / TN;
   const int total = tiles_m * tiles_n;
+#if defined(MDM_PROBES) && !defined(MDM_EMU)
+  if (x3s_tl_target() >= 0) {   // timeline probe: stamps on for exactly the selected launch (stream-ordered switch)
+    static int on_v[2] = {0, 1};
+    const int on = (x3s_tl_count()++ == x3s_tl_target()) ? 1 : 0;
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_x3s_tl_on), &on_v[on], sizeof(int), 0, hipMemcpyHostToDevice, stream) != hipSuccess) return -1;
+    if (on) fprintf(stderr, "[x3s timeline] launch: RT %d NSUB %d ACT %d RES %d F32 %d PLANES %d QKV %d FOLD %d OSTAT %d | M %d N %d K %d group_rows %d workgroups %d\n",
+                    RT, NSUB, ACT, RES, (int)OUT_F32, (int)OUT_PLANES, (int)OUT_QKV, (int)FOLD, (int)OSTAT, M, N, K, group_rows, total);
+  }
+#endif
   MDM_LAUNCH(kfn, dim3(total), dim3(64 * X3S_WAVES), LDS, stream, A, W, ep, M, N, K, group_rows, tpg, tiles_n, total);
   return 0;
 }

@@ -1732,11 +1732,23 @@ int mdm_debug_set(int what, int value) {
   if (what == 8) g_x3_delay = value;
   if (what == 5) g_f6_linear = value;
   if (what == 6) x3_pipe_probe() = value;
+#ifndef MDM_EMU
+  if (what == 9) { x3s_tl_target() = value; x3s_tl_count() = 0; }   // gemm_x3s.h timeline probe: stamp the value-th launch from now
+#endif
   return MDM_OK;
 }
 
 int mdm_debug_get(int idx, double* out) {   // ABL & 128 cycle counters of gemm_x3.h; idx < 0 resets them
 #ifndef MDM_EMU
+  if (idx >= 100) {   // gemm_x3s.h timeline stamps (read once at idx == 100, then served from the host copy)
+    static std::vector<unsigned long long> tl(4 * X3S_TL_WGS);
+    if (idx - 100 >= 4 * X3S_TL_WGS || out == nullptr) return fail(MDM_EINVAL, "mdm_debug_get: bad timeline index");
+    if (idx == 100 && (hipDeviceSynchronize() != hipSuccess ||
+                       hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_x3s_tl), tl.size() * sizeof(unsigned long long)) != hipSuccess))
+      return fail(MDM_EHIP, "mdm_debug_get: reading the timeline failed");
+    *out = (double)tl[idx - 100];
+    return MDM_OK;
+  }
   unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (idx < 0) return hipMemcpyToSymbol(HIP_SYMBOL(g_x3_dbg), v, sizeof(v)) == hipSuccess ? MDM_OK : fail(MDM_EHIP, "mdm_debug_get: reset failed");
   if (idx >= 8 || out == nullptr) return fail(MDM_EINVAL, "mdm_debug_get: bad argument");
