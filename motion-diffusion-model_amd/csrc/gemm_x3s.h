@@ -67,12 +67,6 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
   constexpr int BUF = x3s_buf_bytes(RT, NSUB);
   constexpr int PW = NSUB * RT / 2;                      // LDS-DMA pieces (1 KB) per wave and chunk
   constexpr int LW = 2 * NCB;                            // W loads per wave and sub-step
-  // RES_LDS: the plane residual of the tile (TR rows x 128 columns x hi | lo = exactly one chunk buffer) arrives by LDS-DMA in the
-  // buffer that is spare during the LAST chunk -- the slot of the harmless re-fetch, same piece count, same counted waits --
-  // instead of 16 RT row-divergent 8-byte register loads per lane in the prologue (each touches 8 cache lines; the table build's
-  // compiler-tracked wait drained them in front of the first barrier: 8.3 k cycles from kernel entry to the first chunk against
-  // 5.4 k for a kind without residual, profiles/r04j_x3s_timeline.md) and 32 VGPRs held across the k-loop
-  constexpr bool RES_LDS = (RES == 2 || RES == 3) && MULTI && NCB == 1;
   static_assert(2 * NSUB * RT % X3S_WAVES == 0, "pieces must divide among the waves");
   static_assert(LW * (D - 1) + PW <= 63 && (NSUB > D ? LW * D : LW * NSUB) <= 63 && NSUB >= D && (!MULTI || NSUB % D == 0) && (D * NCB) % 4 == 0,
                 "vmcnt range / slot <-> sub-step map across chunks / closing wait");
@@ -112,22 +106,6 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
       const int arow = min(m0 + g * 16 + (lane >> 2), M - 1);
       const p16_t* src = (p ? A.lo : A.hi) + (size_t)arow * K + (size_t)c * (NSUB * 16) + ms * 32 + schunk * 8;
       glds16(src, lds + buf * BUF + ((ms * 2 + p) * 2 * RT + g) * 1024);
-    }
-  };
-  // residual tile -> LDS image [plane][row][256 B]: piece q = 4 rows of one plane (1 KB); lane -> (row of the piece = lane >> 4,
-  // stored 16-byte slot = lane & 15) fetches the logical chunk slot ^ 4 (row & 3), so that the epilogue's 8-byte reads of 8 rows x
-  // 64 B spread over all banks (two passes for 512 B: the minimum)
-  auto issue_res = [&](int buf) {
-    if constexpr (RES_LDS) {
-#pragma unroll
-      for (int i = 0; i < PW; ++i) {
-        const int q = wid + X3S_WAVES * i;
-        const int p = q / (TR / 4), ig = q % (TR / 4);
-        const int rl = lane >> 4, cch = (lane & 15) ^ (4 * rl);
-        const int rrow = min(m0 + ig * 4 + rl, M - 1);
-        const p16_t* src = (p ? ep.resl : ep.resh) + (size_t)rrow * ep.ld + n0 + cch * 8;
-        glds16(src, lds + buf * BUF + p * (TR * 256) + ig * 1024);
-      }
     }
   };
   // ---- W stream: this wave's fragments of 16-deep sub-step `gj` (global index over the whole K): hi and lo of each of its
@@ -180,8 +158,12 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
   }
   constexpr int NRND = 4 * RT * NCB;                // epilogue rounds: round (cb, t, g) -> index (cb * RT + t) * 4 + g
   float4 rres[RES == 1 ? NRND : 1];
-  uint2 rrh[((RES == 2 || RES == 3) && !RES_LDS) ? NRND : 1], rrl[((RES == 2 || RES == 3) && !RES_LDS) ? NRND : 1];
-  if constexpr (RES != 0 && !RES_LDS) {
+  uint2 rrh[(RES == 2 || RES == 3) ? NRND : 1], rrl[(RES == 2 || RES == 3) ? NRND : 1];
+  // (Round 4 also built the plane residual as an LDS-DMA of the tile into the buffer that is spare during the last chunk -- same
+  // piece count as the re-fetch it replaces, 32 VGPRs fewer: kernel entry -> first chunk visible 8.3 k -> 5.6 k cycles as
+  // predicted, but the k-loop and the epilogue took the time back (10.4 k -> 11.2 k, 4.4 k -> 5.1 k): +-0.5 % on every bench,
+  // tools/x3s_res_lds.patch, profiles/r04j_x3s_timeline.md; not kept.)
+  if constexpr (RES != 0) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -277,12 +259,7 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
     }
     wg_barrier_nodrain();                 // every wave's pieces visible; every wave is past chunk c - 1, whose buffer refills now
     if (c == 0) X3S_STAMP(1);
-    if constexpr (RES_LDS) {            // (last chunk: the residual tile takes the spare buffer -- PW pieces like a chunk)
-      if (c == nchunks - 1) issue_res(buf ^ 1);
-      else issue_chunk(c + 1, buf ^ 1);
-    } else if constexpr (MULTI) {
-      issue_chunk(min(c + 1, nchunks - 1), buf ^ 1);   // (last chunk: a harmless re-fetch keeps the counts uniform)
-    }
+    if constexpr (MULTI) issue_chunk(min(c + 1, nchunks - 1), buf ^ 1);   // (last chunk: a harmless re-fetch keeps the counts uniform)
     read_frags(std::integral_constant<int, 0>{}, buf);
     static_for<NSUB>([&](auto j_tag) __attribute__((always_inline)) {
       constexpr int j = decltype(j_tag)::value, sl = j % D;
@@ -324,7 +301,6 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
     vmem_wait<0>(wsh[q], wsl[q], wsh[q + 1], wsl[q + 1], wsh[q + 2], wsl[q + 2], wsh[q + 3], wsl[q + 3]);
   });
 
-  if constexpr (RES_LDS) wg_barrier_nodrain();   // every wave's residual pieces have landed (its own closing wait) -> visible to all
   X3S_STAMP(2);
   // ---- epilogue: each wave turns its NCB x RT 32 x 32 accumulators through a private 1 KB LDS patch, 8 rows x 32 columns per
   // round, into (row = lane >> 3, 4 consecutive columns) per lane -> 16-byte fp32 / 8-byte plane accesses (gemm_x3.h).
@@ -425,17 +401,7 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
           if constexpr (RES == 1) {
             v4 = add4(v4, rres[(cb * RT + t) * 4 + g]);
           } else if constexpr (RES == 2 || RES == 3) {
-            uint2 a, b;
-            if constexpr (RES_LDS) {
-              const int cch = (wid * NCB + cb) * 4 + ((lane & 7) >> 1);
-              const uint32_t ro = (uint32_t)(((nchunks - 1) & 1) ^ 1) * BUF + (uint32_t)rit * 256u +
-                                  (uint32_t)((cch ^ (4 * (rit & 3))) * 16 + (lane & 1) * 8);
-              a = *reinterpret_cast<const uint2*>(lds + ro);
-              b = *reinterpret_cast<const uint2*>(lds + ro + TR * 256);
-            } else {
-              a = rrh[(cb * RT + t) * 4 + g];
-              b = rrl[(cb * RT + t) * 4 + g];
-            }
+            const uint2 a = rrh[(cb * RT + t) * 4 + g], b = rrl[(cb * RT + t) * 4 + g];
             float4 x4 = make_float4(p16_to_f32((p16_t)(a.x & 0xffffu)) + p16_to_f32((p16_t)(b.x & 0xffffu)),
                                     p16_to_f32((p16_t)(a.x >> 16)) + p16_to_f32((p16_t)(b.x >> 16)),
                                     p16_to_f32((p16_t)(a.y & 0xffffu)) + p16_to_f32((p16_t)(b.y & 0xffffu)),
