@@ -10,6 +10,43 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _cpu_workers(config):
+    """The CPU suite is ~12 minutes of single-threaded work (the lock-step emulator of the HIP kernels, the torch-CPU oracle): when it
+    is run as the whole `-m "not gpu"` selection, pytest-xdist is installed and nobody asked for a worker count, spread it over the
+    host's cores.  Never for GPU runs (one device), never inside a worker; MDM_TEST_SERIAL=1 switches it off."""
+    try:
+        if os.environ.get("MDM_TEST_SERIAL") or os.environ.get("PYTEST_XDIST_WORKER"):
+            return 0
+        if not config.pluginmanager.hasplugin("xdist") or getattr(config.option, "numprocesses", None):
+            return 0
+        if (getattr(config.option, "markexpr", "") or "").strip() != "not gpu":
+            return 0
+        if getattr(config.option, "collectonly", False) or getattr(config.option, "usepdb", False):
+            return 0
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        return min(8, n - 2) if n >= 4 else 0
+    except Exception:       # whatever goes wrong here must not keep the suite from running serially
+        return 0
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    n = _cpu_workers(config)
+    if n >= 2:
+        config.option.numprocesses = n      # (registered after the xdist plugin, so this runs before its own cmdline hook reads it)
+    return None
+
+
+if os.environ.get("PYTEST_XDIST_WORKER"):     # one of several workers: the oracle's torch-CPU ops must not spin up a thread pool each
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    os.environ.setdefault("MKL_NUM_THREADS", "1")
+    try:
+        import torch
+        torch.set_num_threads(1)
+    except Exception:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test")

@@ -1,4 +1,5 @@
 """TEST INFRASTRUCTURE: build + load the CPU emulation of libmdm_hip (see hip_emu.h)."""
+import fcntl
 import os
 import subprocess
 
@@ -23,8 +24,11 @@ def _stale():
 def emu():
     global _lib
     if _lib is None:
-        if _stale():
-            subprocess.check_call([os.path.join(HERE, "build_emu.sh")], stdout=subprocess.DEVNULL)
+        os.makedirs(os.path.dirname(SO), exist_ok=True)
+        with open(SO + ".lock", "w") as lk:      # several pytest-xdist workers may arrive here at once: one builds, the rest wait
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if _stale():
+                subprocess.check_call([os.path.join(HERE, "build_emu.sh")], stdout=subprocess.DEVNULL)
         import mdm_amd._native as nat
         _lib = nat.MdmLib(SO)
     return _lib
