@@ -312,6 +312,25 @@ def test_emulated_dip_decoder_planes_and_fp32_skeleton(lib, monkeypatch):
     assert maxabs(outs["planes32"], outs["planes64"]) < 1e-5
 
 
+@pytest.mark.parametrize("B,C,P,text_lengths,rt", [(2, 3, 70, [40, 3], "2"), (3, 0, 33, [5, 9, 1], "1")])
+def test_emulated_dip_decoder_planes_other_windows(lib, monkeypatch, B, C, P, text_lengths, rt):
+    """The plane route of the trans_dec stack at other window shapes than 20 + 40: S = 73 tokens (a 64-row tile + 9 rows per sequence
+    for in_proj, contiguous tiles elsewhere), a 40-token memory (two key tiles in the cross-attention), no prefix at all."""
+    monkeypatch.setenv("MDM_X3S_RT", rt)
+    monkeypatch.delenv("MDM_X3S_MAX_SEQS", raising=False)
+    sd = dip_small_state_dict(num_layers=2)
+    y = synth_dip_y(B, P, max(C, 1), seed=3, text_lengths=text_lengths, lengths=None, scale=2.5)
+    if C == 0:
+        y.pop("prefix")
+    else:
+        y["prefix"] = y["prefix"][..., :C].contiguous()
+    x = torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(1))
+    t = torch.arange(B) % 10
+    model, _ = make_pair(sd, 10, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, precision="f16x3")
+    want = dip.dip_cfg_forward(sd, x, t, y, context_len=C, num_heads=2, mask_frames=False)
+    assert maxabs(model(x, t, y=dict(y)), want) < 5e-5
+
+
 @pytest.mark.parametrize("guided,prec", [(True, "f16x3"), (False, "f32")])
 def test_emulated_dip_window_loop(lib, monkeypatch, guided, prec):
     """mdm_sample_loop_dec (one p_sample_loop over a DiP prediction window: text projections hoisted out of the steps, the
