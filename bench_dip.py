@@ -35,8 +35,11 @@ def synthetic_y(B, device, seed):
     g = torch.Generator().manual_seed(seed)
     tl = torch.randint(6, NTOK + 1, (B,), generator=g)
     tl[0] = NTOK
-    return {"mask": torch.ones(B, 1, 1, PRED, dtype=torch.bool, device=device),
-            "lengths": torch.full((B,), PRED, dtype=torch.long, device=device), "text": ["synthetic prompt"] * B,
+    # sample/generate.py:107 collates `lengths = n_frames` for every sample: y['mask'] = ones [B, 1, 1, 196].  A model trained with
+    # `--mask_frames` (DiP.md:181, the published DiP recipe) turns that into an (all-valid) tgt_key_padding_mask on EVERY forward
+    # (model/mdm.py:241-247): the window loop below runs with a non-NULL `lengths` array.
+    return {"mask": torch.ones(B, 1, 1, FRAMES, dtype=torch.bool, device=device),
+            "lengths": torch.full((B,), FRAMES, dtype=torch.long, device=device), "text": ["synthetic prompt"] * B,
             "text_embed": (torch.randn(NTOK, B, 768, generator=g).to(device),
                            (torch.arange(NTOK)[None, :] >= tl[:, None]).to(device)),
             "prefix": torch.randn(B, 263, 1, CONTEXT, generator=g).to(device),
@@ -70,7 +73,7 @@ def measure(dev, rank, world, B, steps, warmup, cpu=True):
     bench.py embeds this record as its `dip` sub-line so that the driver's BENCH file carries it."""
     torch.manual_seed(0)
     args = model_util.default_args(diffusion_steps=DSTEPS, arch="trans_dec", text_encoder_type="bert", context_len=CONTEXT,
-                                   pred_len=PRED, mask_frames=False, guidance_param=7.5)
+                                   pred_len=PRED, mask_frames=True, guidance_param=7.5)      # DiP.md:181: `--mask_frames`
     mdm, diffusion = model_util.create_model_and_diffusion(args)
     state = {k: v.clone() for k, v in mdm.state_dict().items()}
     model = ClassifierFreeSampleModel(mdm).to(dev).eval()
@@ -121,7 +124,9 @@ def measure(dev, rank, world, B, steps, warmup, cpu=True):
             "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
             "config": {"workload": f"DiP autoregressive text2motion: trans_dec 8 layers d=512, prefix 20 + window 40 "
                                    f"frames, {NTOK}-token DistilBERT memory (cached), {DSTEPS} DDPM steps per window, "
-                                   f"CFG 7.5, batch={B} per GPU, random-init weights", "global_batch": GB,
+                                   f"CFG 7.5, batch={B} per GPU, random-init weights, mask_frames=True with y['mask'] = "
+                                   f"ones[B,1,1,{FRAMES}] as sample/generate.py:107 builds it (the DiP.md:181 recipe: a frame "
+                                   f"mask on every forward)", "global_batch": GB, "mask_frames": True,
                        "parallelism": f"dp{world}: batch shards, all_gather of final samples"},
             "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3s_kernel on operand planes; K / V of the text memory: gemm_f32_kernel<X3>") + ")",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),

@@ -31,8 +31,12 @@
  *     vectorisation if they cannot be kept off (mdm_build_info() says how a binary was built; the loaders check it).  The
  *     encoder calls need no such care.
  *   - hipGraph CAPTURE: supported for a loop that stays on ONE stream (since ABI 8 a same-stream call makes no HIP runtime
- *     call besides its kernel launches and device-to-device copies: the per-device guard is a host mutex).  Not supported: a
- *     capture that contains calls from two different streams (the guard records an event on the earlier stream).
+ *     call besides its kernel launches and device-to-device copies: the per-device guard is a host mutex).  The warm-up may have
+ *     run on ANOTHER stream (graph-capture helpers of ML frameworks capture on a side stream of their own): since ABI 9 the guard asks hipStreamIsCapturing and
+ *     skips its cross-stream event while `stream` is being captured (tests/test_gpu_round5.py replays such a capture).  Run one
+ *     warm-up call of the same shapes first (first-use hipFuncSetAttribute calls), keep mdm_profile_enable off, and order the
+ *     graph's REPLAYS against other users of the device yourself.  Not supported: a capture that contains calls from two
+ *     different streams.
  *   - all tensors are fp32, dense, in the reference's layouts: poses [B, njoints, nfeats, T] (T contiguous).
  */
 #ifndef MDM_HIP_H
@@ -52,7 +56,7 @@ extern "C" {
 #define MDM_EHIP (-4)     /* a HIP runtime call failed                         */
 #define MDM_EUNSUPPORTED (-5)
 
-#define MDM_ABI_VERSION 8
+#define MDM_ABI_VERSION 9
 
 typedef struct mdm_model mdm_model_t;
 
@@ -87,6 +91,20 @@ const char* mdm_last_error(void);
 /* MDM(...) constructor (model/mdm.py:11-135) -- shapes only, no weights yet. */
 int mdm_create(const mdm_config_t* cfg, mdm_model_t** out);
 void mdm_destroy(mdm_model_t* m);
+
+/* Run-time options of a model handle (ABI 9).  The library reads NO environment variable: everything that steers which kernels
+ * a call runs is either derived from the shapes or set here, per handle, and takes effect with the next call (a call resolves
+ * its route once; set options between calls, not from another thread during one).  No counterpart in the reference.
+ *   MDM_OPT_SMALL_GEMM_MAX_SEQS   up to how many token sequences (B, or 2B under guidance) a forward runs its GEMMs on the
+ *                                 32 / 64-row tiles of the latency regime (csrc/gemm_x3s.h) instead of the sequence-sized tiles
+ *                                 (csrc/gemm_x3.h).  Default 40 (the measured cross-over).  0: never -- which also sends the
+ *                                 trans_dec (DiP) decoder to its fp32-skeleton route (csrc/gemm_f32.h).  The parity tests use it
+ *                                 to hold every route against the reference's fixtures.
+ *   MDM_OPT_SMALL_GEMM_ROW_TILES  0 (default): 32-row tiles up to 12 sequences, 64-row tiles above; 1 / 2: pin 32 / 64 rows. */
+#define MDM_OPT_SMALL_GEMM_MAX_SEQS 1
+#define MDM_OPT_SMALL_GEMM_ROW_TILES 2
+int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value);
+int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value);
 
 /* load_state_dict (utils/model_util.py:8-15): register the device pointer of one state-dict tensor under
  * its REFERENCE key, e.g. "seqTransEncoder.layers.3.self_attn.in_proj_weight".  `numel` is checked against
@@ -147,7 +165,10 @@ int mdm_forward(mdm_model_t* m, const float* x_dev, const int64_t* timesteps_dev
                 const int32_t* lengths_dev, int32_t B, int32_t T, int32_t branches, float* out_dev, void* ws_dev,
                 size_t ws_bytes, void* stream);
 
-/* MDM.forward for MDM_ARCH_TRANS_DEC (model/mdm.py:189-283 with is_prefix_comp, text_encoder_type='bert'): exact fp32.
+/* MDM.forward for MDM_ARCH_TRANS_DEC (model/mdm.py:189-283 with is_prefix_comp, text_encoder_type='bert' or 'clip').  Arithmetic as
+ * mdm_set_precision says: in MDM_PREC_F16X3 (default) the whole decoder stack runs on fp16 hi/lo operand planes -- the small-tile
+ * split-precision GEMMs, the split-precision self-attention, all three LayerNorms of a layer folded -- with or without a frame
+ * mask; exact fp32 MFMA in MDM_PREC_F32.
  *   x_dev            [B, njoints, nfeats, pred_len]      the window being denoised
  *   prefix_dev       [B, njoints, nfeats, context_len]   y['prefix'] (NULL iff context_len == 0)
  *   timesteps_dev    [B] int64
@@ -155,7 +176,9 @@ int mdm_forward(mdm_model_t* m, const float* x_dev, const int64_t* timesteps_dev
  *                    bert_encode_text returns it, model/mdm.py:180-187); may be NULL for MDM_BRANCH_UNCOND
  *   text_lengths_dev [B] int32: tokens of each prompt (y['text_embed'][1] is a suffix pad mask: the tokenizer pads on the
  *                    right, model/BERT/BERT_encoder.py:28-30) -- the memory_key_padding_mask of mdm.py:265
- *   lengths_dev      [B] int32 valid frames of the context_len + pred_len window (tgt_key_padding_mask), or NULL
+ *   lengths_dev      the tgt_key_padding_mask of model/mdm.py:241-247 over the context_len + pred_len window, in the two forms
+ *                    of mdm_forward's lengths_dev ([B] counts, or [9 B] counts + bitmaps) -- here the counts / bits INCLUDE the
+ *                    context_len prefix frames (always valid, mdm.py:203-206) and there is no condition token -- or NULL
  *   out_dev          [B or 2B, njoints, nfeats, pred_len]  the completed suffix (mdm.py:278-279)              */
 size_t mdm_workspace_bytes_dec(const mdm_model_t* m, int32_t nseq, int32_t pred_len, int32_t ntok);
 int mdm_forward_dec(mdm_model_t* m, const float* x_dev, const float* prefix_dev, const int64_t* timesteps_dev,

@@ -25,10 +25,16 @@ def _on_own_device(method):
     return guarded
 
 
+# Options every NEW engine starts with (include/mdm_hip.h mdm_set_option; names: _native.OPTIONS).  Empty in production: the library's
+# defaults.  The parity suites pin a kernel route here (tests/conftest.py gemm_path) -- an explicit, in-process setter; rounds 3-4
+# steered the library through environment variables read on its launch path.
+DEFAULT_OPTIONS = {}
+
+
 class Engine:
     """Binds a state-dict (reference key names) to a native model and runs forward / sample loops."""
 
-    def __init__(self, cfg, lib=None, precision="f16x3"):
+    def __init__(self, cfg, lib=None, precision="f16x3", options=None):
         self.lib = lib if lib is not None else nat.load_native()
         self.is_emulation = not self.lib.path.endswith(nat.LIB_NAME)
         self.cfg = nat.MdmConfig(**cfg)
@@ -36,6 +42,8 @@ class Engine:
         self.lib.check(self.lib.mdm_create(C.byref(self.cfg), C.byref(h)), "mdm_create")
         self.handle = h
         self.set_precision(precision)
+        for k, v in {**DEFAULT_OPTIONS, **(options or {})}.items():
+            self.set_option(k, v)
         self._weights = {}      # name -> tensor kept alive
         self._const_ws = None
         self._ws = None
@@ -50,8 +58,20 @@ class Engine:
         except Exception:
             pass
 
+    def set_option(self, name, value):
+        """include/mdm_hip.h mdm_set_option: 'small_gemm_max_seqs' (default 40; 0 = sequence-sized tiles / DiP fp32 skeleton
+        only), 'small_gemm_row_tiles' (0 = by size, 1 = 32 rows, 2 = 64).  Takes effect with the next call."""
+        if name not in nat.OPTIONS:
+            raise ValueError(f"unknown engine option {name!r}: one of {sorted(nat.OPTIONS)}")
+        self.lib.check(self.lib.mdm_set_option(self.handle, nat.OPTIONS[name], int(value)), f"mdm_set_option({name})")
+
+    def get_option(self, name):
+        v = C.c_int32()
+        self.lib.check(self.lib.mdm_get_option(self.handle, nat.OPTIONS[name], C.byref(v)), f"mdm_get_option({name})")
+        return v.value
+
     def set_precision(self, precision):
-        """'f16x3' (default: split-precision bf16 MFMA for the encoder GEMMs) or 'f32' (exact-fp32 MFMA)."""
+        """'f16x3' (default: split-precision fp16 hi/lo MFMA, three products per fp32 product) or 'f32' (exact-fp32 MFMA)."""
         if precision not in nat.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(nat.PRECISIONS)}, got {precision!r}")
         # refuse BEFORE switching: a caller that catches the error (to fall back) must not be left with a live engine in
@@ -68,7 +88,7 @@ class Engine:
             raise nat.MdmError(
                 "this checkpoint does not fit the default precision='f16x3': a weight matrix (possibly scaled by the "
                 "LayerNorm gamma folded into it) has an entry of magnitude >= 255.9, beyond the fp16 operand planes "
-                "(w * 2^8 <= 65504).  Construct the model with precision='f32' (or set MDM_PRECISION=f32): the exact-fp32 "
+                "(w * 2^8 <= 65504).  Construct the model with precision='f32': the exact-fp32 "
                 "MFMA mode has fp32's range.")
 
     # ---- plumbing -------------------------------------------------------------------------

@@ -61,7 +61,7 @@ static_assert(AX_SLOT + 4 * 32 * AX_OST * 4 <= AX_RING * AX_SLOT, "output stagin
 // Results stay CORRECT with: 64 = non-temporal K / V^T LDS-DMA, 128 = non-temporal plane stores (A/B: profiles/r04b_ab.md).
 template <int NKT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const int* __restrict__ lengths,
-                                                                    int S, int D, int B, float* __restrict__ out,
+                                                                    int S, int D, int B, int lead, float* __restrict__ out,
                                                                     p16_t* __restrict__ oh, p16_t* __restrict__ ol,
                                                                     int items) {
   MDM_DYN_SMEM(unsigned char, lds);
@@ -130,19 +130,21 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
   const size_t sh = (size_t)item;   // == seq * H + head
   const int vb_next = vb + vb_step;
   const bool has_next = vb_next < vb_total && item_of(vb_next) < items;
-  int nvalid = S;  // token 0 (the condition token) is never masked; frame j-1 must be < length (mdm.py:241-247)
+  // the `lead` tokens in front of the frames are never masked: trans_enc's condition token (lead = 1; frame j - 1 must be < length,
+  // mdm.py:241-247), none for trans_dec (lead = 0: its counts / bitmaps cover the context_len prefix frames, mdm.py:203-206)
+  int nvalid = S;
   const uint32_t* kbits = nullptr;   // arbitrary frame mask of this sequence (common.h key_valid_bits), else a count
   if (lengths != nullptr) {
     const int cnt = lengths[seq % B];
-    if (cnt >= 0) nvalid = min(S, 1 + cnt);
+    if (cnt >= 0) nvalid = min(S, lead + cnt);
     else kbits = reinterpret_cast<const uint32_t*>(lengths + B + 8 * (seq % B));
   }
   if (tid < 32 * NKT) {
-    // additive key mask of this item, key `tid`: the condition token (key 0) is always valid; frame f = key - 1 by the count
+    // additive key mask of this item, key `tid`: the lead tokens are always valid; frame f = key - lead by the count
     // or by its bitmap bit; keys >= S never.  Read at the softmax, NKT workgroup barriers from here; the previous item's
     // softmax is at least NKT barriers in the past.
-    const int f = tid - 1;
-    const bool ok = kbits == nullptr ? tid < nvalid : (tid < S && (tid == 0 || ((kbits[f >> 5] >> (f & 31)) & 1u)));
+    const int f = max(tid - lead, 0);
+    const bool ok = kbits == nullptr ? tid < nvalid : (tid < S && (tid < lead || ((kbits[f >> 5] >> (f & 31)) & 1u)));
     reinterpret_cast<float*>(lds + AX_RING * AX_SLOT)[tid] = ok ? 0.f : -INFINITY;
   }
   int lv = lane;

@@ -1335,6 +1335,10 @@ inline bool x3_wide_setting() {
 // The pipelined k-loop (PIPE) is the default wherever it exists (208-row tiles, an even number of 32-deep k steps);
 // MDM_X3_PIPE=0 selects the step-synchronous loop for same-box A/B runs.
 inline bool x3_pipe_setting(int kind = 0) {
+#ifndef MDM_PROBES
+  (void)kind;
+  return true;      // (the product library reads no environment variable)
+#else
   static const bool on = [] {
     const char* e = getenv("MDM_X3_PIPE");
     return !(e != nullptr && e[0] == '0');
@@ -1346,6 +1350,7 @@ inline bool x3_pipe_setting(int kind = 0) {
     return e != nullptr ? atoi(e) : 0x3f;
   }();
   return on && ((kinds >> kind) & 1);
+#endif
 }
 
 // The GEMMs of the folded-LayerNorm encoder (8-wave workgroups only):

@@ -190,21 +190,33 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
       const int m = m0 + tid;
       float2 v = make_float2(0.f, 0.f);         // pad rows: (0, 0) -> every folded value is the finite constant b' / beta
       if (tid < rows_valid && m < M) {
-        // the row's <= 4 partials (sum, M2) in TWO 16-byte loads issued together: a loop over them was a chain of dependent
-        // round trips (load, wait, add) -- 3-4 us of a tile's 9 at B = 1 (profiles/r04a_small_batch.md)
-        const float* q = st + (size_t)m * ep.stat_parts * 2;
-        float4 p01 = zero4(), p23 = zero4();
-        if (ep.stat_parts == 4) { p01 = ld4(q); p23 = ld4(q + 4); }
-        else if (ep.stat_parts == 2) p01 = ld4(q);
-        else if (ep.stat_parts == 1) { const float2 t = *reinterpret_cast<const float2*>(q); p01.x = t.x; p01.y = t.y; }
-        else { p01 = ld4(q); const float2 t = *reinterpret_cast<const float2*>(q + 4); p23.x = t.x; p23.y = t.y; }   // 3 (D = 768 / 256)
-        const float cols = (float)ep.stat_cols, icols = 1.0f / cols;
-        const float mean = ((p01.x + p01.z) + (p23.x + p23.z)) * ep.inv_dim;
-        // Chan's merge of the centred partials (no E[x^2] - mean^2 cancellation); absent partials contribute nothing
+        // the row's partials (sum, M2) -- D / stat_cols of them, at most 8 (latent_dim 1024 on 128-column tiles) -- in up to FOUR
+        // 16-byte loads issued together: a loop over them was a chain of dependent round trips (load, wait, add) -- 3-4 us of a
+        // tile's 9 at B = 1 (profiles/r04a_small_batch.md).  (Round 4 handled 1, 2, 4 and "else = 3" partials only: latent_dim 768
+        // / 1024 have 6 / 8 on this kernel -- ADVICE r04.)  An odd count leaves odd rows 8-byte aligned: float2 loads there.
         const int np = ep.stat_parts;
-        const float d0 = p01.x * icols - mean, d1 = np > 1 ? p01.z * icols - mean : 0.f;
-        const float d2 = np > 2 ? p23.x * icols - mean : 0.f, d3 = np > 3 ? p23.z * icols - mean : 0.f;
-        const float m2 = (p01.y + p01.w) + (p23.y + p23.w) + cols * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        const float* q = st + (size_t)m * np * 2;
+        float4 pp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          pp[i] = zero4();
+          if (2 * i + 1 < np && (np & 1) == 0) pp[i] = ld4(q + 4 * i);
+          else {
+            if (2 * i < np) { const float2 t = *reinterpret_cast<const float2*>(q + 4 * i); pp[i].x = t.x; pp[i].y = t.y; }
+            if (2 * i + 1 < np) { const float2 t = *reinterpret_cast<const float2*>(q + 4 * i + 2); pp[i].z = t.x; pp[i].w = t.y; }
+          }
+        }
+        const float cols = (float)ep.stat_cols, icols = 1.0f / cols;
+        const float mean = ((pp[0].x + pp[0].z) + (pp[1].x + pp[1].z) + ((pp[2].x + pp[2].z) + (pp[3].x + pp[3].z))) * ep.inv_dim;
+        // Chan's merge of the centred partials (no E[x^2] - mean^2 cancellation); absent partials contribute nothing
+        float m2 = 0.f, dd = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float d0 = 2 * i < np ? pp[i].x * icols - mean : 0.f, d1 = 2 * i + 1 < np ? pp[i].z * icols - mean : 0.f;
+          m2 += pp[i].y + pp[i].w;
+          dd += d0 * d0 + d1 * d1;
+        }
+        m2 += cols * dd;
         v = make_float2(mean, 1.0f / sqrtf(m2 * ep.inv_dim + 1e-5f));
       }
       stab[tid] = v;
@@ -457,31 +469,30 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
 }
 
 #ifndef MDM_X3_KERNEL_ONLY
-// Up to how many token sequences a forward takes this kernel (default 40, i.e. 20 motions under guidance; MDM_X3S_MAX_SEQS=0
-// disables it for same-box A/B runs): the measured cross-over with gemm_x3.h's sequence-sized tiles lies between 32 sequences
-// (65 vs 80 ms per 50-step loop) and 48 (93 vs ~95), profiles/r04a_small_batch.md.
-inline int x3s_max_seqs() {      // (read per call: the test suites switch kernels inside one process)
-  const char* e = getenv("MDM_X3S_MAX_SEQS");
-  return e != nullptr ? atoi(e) : 40;
-}
-// Tile shape of a forward over `nseq` sequences -- ONE shape for all of its GEMMs, because the row statistics a producer leaves
-// (per tile width) are what its consumer merges.  32-row tiles up to 12 sequences (B <= 6 under guidance: 22.0 vs 26.5 ms per
-// 50-step loop at B = 1, 30.7 vs 32.4 at B = 5, 36.2 vs 37.4 at B = 6), 64-row tiles above (39.2 vs 42.1 at B = 8, 61.9 vs 72.5
-// at B = 16; r4lat8); always
+// Which forwards take this kernel, and on which tile height: per-model options (include/mdm_hip.h mdm_set_option, ABI 9;
+// rounds 3-4 read environment variables here, on every launch).
+//   max_seqs   up to how many token sequences a forward runs on these tiles (default 40, i.e. 20 motions under guidance; 0
+//              disables the kernel): the measured cross-over with gemm_x3.h's sequence-sized tiles lies between 32 sequences
+//              (65 vs 80 ms per 50-step loop) and 48 (93 vs ~95), profiles/r04a_small_batch.md;
+//   row_tiles  0 = by size, 1 / 2 = pin 32- / 64-row tiles.
+// ONE shape for all GEMMs of a forward, because the row statistics a producer leaves (per tile width) are what its consumer
+// merges.  By size: 32-row tiles up to 12 sequences (B <= 6 under guidance: 22.0 vs 26.5 ms per 50-step loop at B = 1, 30.7 vs
+// 32.4 at B = 5, 36.2 vs 37.4 at B = 6), 64-row tiles above (39.2 vs 42.1 at B = 8, 61.9 vs 72.5 at B = 16; r4lat8); always
 // 128 columns: the 256-column form (NCB = 2: every A fragment feeds two column blocks, half the LDS reads and half the
 // activation traffic per MFMA) measured no faster anywhere -- 28.7 / 37.0 / 55.7 / 68.1 / 123.7 ms at B = 1 / 6 / 10 / 16 / 32
 // for 32 x 256 against 23.0 / 38.7 / 53.7 / 74.1 / 136.1 for 32 x 128 and 27.3 / 38.4 / 53.2 / 66.5 / 121.6 for 64 x 128 --
-// and is compiled into the probe library only (MDM_X3S_NCB=2).  MDM_X3S_RT=1|2 pins the height for A/B runs.
+// and is compiled into the probe library only (X3sOptions::ncb).
 #if defined(MDM_PROBES) && !defined(MDM_EMU)
 inline int& x3s_tl_target() { static int v = -1; return v; }   // mdm_debug_set(9, n); < 0: off
 inline int& x3s_tl_count() { static int v = 0; return v; }
 #endif
+struct X3sOptions { int max_seqs = 40; int row_tiles = 0; int ncb = 1; };
 struct X3sShape { int rt, ncb; };
-inline X3sShape x3s_shape(int nseq) {
+inline X3sShape x3s_shape(const X3sOptions& o, int nseq) {
   X3sShape sh{nseq <= 12 ? 1 : 2, 1};
-  if (const char* e = getenv("MDM_X3S_RT")) { const int v = atoi(e); if (v == 1 || v == 2) sh.rt = v; }
+  if (o.row_tiles == 1 || o.row_tiles == 2) sh.rt = o.row_tiles;
 #ifdef MDM_PROBES
-  if (const char* e = getenv("MDM_X3S_NCB")) { const int v = atoi(e); if (v == 1 || v == 2) sh.ncb = v; }
+  if (o.ncb == 2) sh.ncb = 2;
 #endif
   return sh;
 }

@@ -166,6 +166,7 @@ struct mdm_model {
   X3Weights out_planes_f{nullptr, nullptr};
   float *c_out = nullptr, *b_out = nullptr;
   bool lnfold = false;                      // f16x3 mode without LayerNorm kernels (set by mdm_prepare)
+  X3sOptions x3s;                           // which forwards run on gemm_x3s.h's small tiles (mdm_set_option)
   X3Weights out_planes{nullptr, nullptr};  // poseFinal.weight, rows padded to jf_out (f16x3 OutputProcess)
   float* out_bias_pad = nullptr;            // poseFinal.bias padded to jf_out
   int jf_out = 0;                           // njoints*nfeats rounded up to a multiple of 4
@@ -283,7 +284,7 @@ int g_ax_ablate = 0;   // mdm_debug_set(3, code): timing experiments on the NKT 
 #endif
 template <int NKT, int ABL = 0>
 int launch_attention_x3_t(const QkvPlanes& qp, const int* lengths, int nseq, int B, int S, int D, float* out, p16_t* oh,
-                          p16_t* ol, hipStream_t s) {
+                          p16_t* ol, hipStream_t s, int lead) {
   auto k = &attention_x3_kernel<NKT, ABL>;
   const size_t lds = attention_x3_lds_bytes(NKT);
   if (int rc = rt_allow_lds(k, lds)) return rc;
@@ -292,43 +293,45 @@ int launch_attention_x3_t(const QkvPlanes& qp, const int* lengths, int nseq, int
   // persistent workgroups, two per CU (the grid stays a multiple of 16 so that a workgroup keeps its query half)
   const int items = nseq * qp.H, groups = (items + 7) / 8;
   const int grid = std::min(groups * 16, std::max(16, x3_grid_limit(2) / 16 * 16));
-  MDM_LAUNCH(k, dim3(grid), dim3(256), lds, s, qp, lengths, S, D, B, out, oh, ol, items);
+  MDM_LAUNCH(k, dim3(grid), dim3(256), lds, s, qp, lengths, S, D, B, lead, out, oh, ol, items);
   return rt_launch_status();
 }
 
 // split-precision attention on the operand planes written by the in_proj epilogue (or qkv_pack_kernel)
+// `lead` tokens in front of the frames are never masked (trans_enc: the condition token; trans_dec: none -- its `lengths` count the
+// context_len prefix frames as frames)
 int launch_attention_x3(Profiler* pf, const QkvPlanes& qp, const int* lengths, int nseq, int B, int S, int D, float* out,
-                        p16_t* oh, p16_t* ol, hipStream_t s) {
+                        p16_t* oh, p16_t* ol, hipStream_t s, int lead = 1) {
   ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * qp.H * (double)S * S * AX_HD, s);
   if (D != qp.H * AX_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
   if (S < 1 || S > 224) return fail(MDM_EUNSUPPORTED, "attention: 1 <= S <= 224 tokens (T <= 223 frames)");
   switch (qp.NKT) {
-    case 1: return launch_attention_x3_t<1>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-    case 2: return launch_attention_x3_t<2>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-    case 3: return launch_attention_x3_t<3>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-    case 4: return launch_attention_x3_t<4>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-    case 5: return launch_attention_x3_t<5>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-    case 6: return launch_attention_x3_t<6>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+    case 1: return launch_attention_x3_t<1>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+    case 2: return launch_attention_x3_t<2>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+    case 3: return launch_attention_x3_t<3>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+    case 4: return launch_attention_x3_t<4>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+    case 5: return launch_attention_x3_t<5>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+    case 6: return launch_attention_x3_t<6>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
     default:
 #ifdef MDM_PROBES
       static const int env_abl = [] { const char* e = getenv("MDM_AX_ABL"); return e != nullptr ? atoi(e) : 0; }();   // whole-bench A/B runs
       switch (g_ax_ablate != 0 ? g_ax_ablate : env_abl) {
-        case 1: return launch_attention_x3_t<7, 1>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        case 2: return launch_attention_x3_t<7, 2>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        case 3: return launch_attention_x3_t<7, 3>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        case 4: return launch_attention_x3_t<7, 4>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        case 8: return launch_attention_x3_t<7, 8>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        case 16: return launch_attention_x3_t<7, 16>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        case 32: return launch_attention_x3_t<7, 32>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        case 48: return launch_attention_x3_t<7, 48>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        case 63: return launch_attention_x3_t<7, 63>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        case 64: return launch_attention_x3_t<7, 64>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        case 128: return launch_attention_x3_t<7, 128>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
-        case 192: return launch_attention_x3_t<7, 192>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+        case 1: return launch_attention_x3_t<7, 1>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+        case 2: return launch_attention_x3_t<7, 2>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+        case 3: return launch_attention_x3_t<7, 3>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+        case 4: return launch_attention_x3_t<7, 4>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+        case 8: return launch_attention_x3_t<7, 8>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+        case 16: return launch_attention_x3_t<7, 16>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+        case 32: return launch_attention_x3_t<7, 32>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+        case 48: return launch_attention_x3_t<7, 48>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+        case 63: return launch_attention_x3_t<7, 63>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+        case 64: return launch_attention_x3_t<7, 64>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+        case 128: return launch_attention_x3_t<7, 128>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+        case 192: return launch_attention_x3_t<7, 192>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
         default: break;
       }
 #endif
-      return launch_attention_x3_t<7>(qp, lengths, nseq, B, S, D, out, oh, ol, s);
+      return launch_attention_x3_t<7>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
   }
 }
 
@@ -455,19 +458,20 @@ struct LnArgs {
   int parts = 1; float inv_dim = 1.f;
   const float* res_f32 = nullptr; int emb_T = 1, emb_B = 1, emb_nbranch = 1;                     // EMBED (kind 5)
   bool small = false;      // the small-row-count kernel (gemm_x3s.h): the whole forward runs on one of the two kernels
-  X3sShape shape{1, 1};    // ... and on ONE tile shape of it (x3s_shape(nseq))
+  X3sShape shape{1, 1};    // ... and on ONE tile shape of it (x3s_shape(m->x3s, nseq))
   int stat_cols = 256;     // columns per partial of astat / rstat (what the PRODUCER's kernel wrote)
 };
-// The latency regime (gemm_x3s.h): a forward of at most x3s_max_seqs() sequences runs its GEMMs on 32 / 64-row tiles
+// The latency regime (gemm_x3s.h): a forward of at most MDM_OPT_SMALL_GEMM_MAX_SEQS sequences runs its GEMMs on 32 / 64-row tiles
 inline bool use_small_gemm(const mdm_model* m, int nseq, int S) {
-  return m->precision == MDM_PREC_F16X3 && m->lnfold && nseq <= x3s_max_seqs() && S <= X3_TM &&
+  return m->precision == MDM_PREC_F16X3 && m->lnfold && nseq <= m->x3s.max_seqs && S <= X3_TM &&
          m->cfg.latent_dim % 128 == 0 && m->cfg.latent_dim % 256 == 0 && m->cfg.ff_size % 256 == 0;
 }
 int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w, const float* bias, const LnArgs& ln,
                  float* out, p16_t* oh, p16_t* ol, const QkvPlanes* qp, int M, int N, int K, int S, int D,
                  int scale_cols, float col_scale, hipStream_t s) {
   if (K % X3_BK != 0 || N % 4 != 0) return fail(MDM_EINVAL, "f16x3 linear: K % 32 and N % 4 must be 0");
-  if (ln.parts < 1 || ln.parts > 4) return fail(MDM_EUNSUPPORTED, "folded LayerNorm: at most 4 partial sums per row (D <= 1024)");
+  // partial statistics per row: D / 256 on gemm_x3.h's tiles (<= 4), D / 128 on gemm_x3s.h's (<= 8); D <= 1024 (mdm_create)
+  if (ln.parts < 1 || ln.parts > (ln.small ? 8 : 4)) return fail(MDM_EUNSUPPORTED, "folded LayerNorm: too many partial sums per row (D <= 1024)");
   ProfScope ps(pf, prof_cat, 2.0 * M * (double)N * K, s);
   X3Epilogue ep{out, bias, ln.res_f32, ln.res.hi, ln.res.lo, oh, ol, N, scale_cols, col_scale, qp ? *qp : QkvPlanes{}, S, D,
                 ln.astat, ln.colsum, ln.rstat, ln.rgamma, ln.rbeta, ln.ostat, ln.parts, ln.inv_dim, ln.emb_T, ln.emb_B,
@@ -537,7 +541,7 @@ int embed_frames_x3(mdm_model* m, const Workspace& ws, const float* x, int B, in
   a.res_f32 = m->W("sequence_pos_encoder.pe");
   a.emb_T = T; a.emb_B = B; a.emb_nbranch = nbranch;
   a.small = use_small_gemm(m, nbranch * B, T + 1) && KP == 288;
-  a.shape = x3s_shape(nbranch * B);
+  a.shape = x3s_shape(m->x3s, nbranch * B);
   return launch_x3_ln(nullptr, MDM_PROF_EMBED, 5, X3Operand{ph, pl}, m->in_planes, m->W("input_process.poseEmbedding.bias"), a,
                       nullptr, ws.tokh, ws.tokl, nullptr, B * T, D, KP, T + 1, D, 0, 1.f, s);
 }
@@ -583,7 +587,7 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
     // few sequences: the latency regime -- every GEMM of the stack on gemm_x3s.h's 32 / 64-row tiles (row statistics per 128
     // columns); else gemm_x3.h's sequence-sized tiles (per 256)
     const bool small = use_small_gemm(m, nseq, S);
-    const X3sShape shape = x3s_shape(nseq);
+    const X3sShape shape = x3s_shape(m->x3s, nseq);
     const int scols = small ? x3s_tn(shape.ncb) : 256;
     const int parts = (D + scols - 1) / scols;
     const float inv_dim = 1.0f / (float)D;
@@ -676,7 +680,7 @@ int outproj_x3(mdm_model* m, const Workspace& ws, int nseq, int B, int T, const 
   if (m->lnfold && x3_waves_setting() == 8 && S <= X3_TM) {   // the final LayerNorm is folded into this GEMM
     LnArgs a; a.astat = ws.stat2; a.colsum = m->c_out; a.inv_dim = 1.0f / (float)D;
     a.small = use_small_gemm(m, nseq, S);            // (the same decision the encoder took: who wrote stat2)
-    a.shape = x3s_shape(nseq);
+    a.shape = x3s_shape(m->x3s, nseq);
     a.stat_cols = a.small ? x3s_tn(a.shape.ncb) : 256;
     a.parts = (D + a.stat_cols - 1) / a.stat_cols;
     if (int rc = launch_x3_ln(nullptr, MDM_PROF_OUTPROJ, 4, X3Operand{ws.tokh, ws.tokl}, m->out_planes_f, m->b_out, a,
@@ -715,10 +719,18 @@ struct ChainGuard {
   explicit ChainGuard(void* stream) : c(g_chain[rt_device_ordinal()]), s(static_cast<hipStream_t>(stream)) {
     c.mu.lock();
     if (c.has && c.last != s) {
-      // everything the previous caller's stream holds so far (its call's kernels, and whatever it enqueued since) first
-      if (c.ev == nullptr && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) c.ev = nullptr;
-      if (c.ev != nullptr && hipEventRecord(c.ev, c.last) == hipSuccess) (void)hipStreamWaitEvent(s, c.ev, 0);
-      else (void)hipGetLastError();   // (the other stream no longer exists: its work has drained)
+      // A stream that is being CAPTURED into a hipGraph (torch.cuda.graph captures on a side stream of its own, so the warm-up
+      // ran on another one) must not wait for an event recorded outside the capture: that invalidates the capture.
+      // Nothing is enqueued while capturing, so there is nothing to order here; ordering the REPLAYS against other users of the
+      // device is the caller's business, as for any graph (include/mdm_hip.h "hipGraph CAPTURE").
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+      if (!capturing) {
+        // everything the previous caller's stream holds so far (its call's kernels, and whatever it enqueued since) first
+        if (c.ev == nullptr && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) c.ev = nullptr;
+        if (c.ev != nullptr && hipEventRecord(c.ev, c.last) == hipSuccess) (void)hipStreamWaitEvent(s, c.ev, 0);
+        else (void)hipGetLastError();   // (the other stream no longer exists: its work has drained)
+      }
     }
   }
   ~ChainGuard() {
@@ -829,11 +841,43 @@ int mdm_create(const mdm_config_t* cfg, mdm_model_t** out) {
   e["output_process.poseFinal.weight"] = jf * d;
   e["output_process.poseFinal.bias"] = jf;
   e["sequence_pos_encoder.pe"] = (int64_t)cfg->max_len * d;
+#ifdef MDM_PROBES   // the probe library's whole-bench A/B scripts (tools/) preset a handle's options from the environment, once, here
+  if (const char* e = getenv("MDM_X3S_MAX_SEQS")) m->x3s.max_seqs = atoi(e);
+  if (const char* e = getenv("MDM_X3S_RT")) m->x3s.row_tiles = atoi(e);
+  if (const char* e = getenv("MDM_X3S_NCB")) m->x3s.ncb = atoi(e);
+#endif
   *out = m;
   return MDM_OK;
 }
 
 void mdm_destroy(mdm_model_t* m) { delete m; }
+
+// Run-time options of a handle (include/mdm_hip.h, ABI 9).  The library reads NO environment variable (rounds 3-4 did, on the
+// launch path); a value takes effect with the next call -- every call resolves its kernel route once, from the handle.
+int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value) {
+  if (m == nullptr) return fail(MDM_EINVAL, "mdm_set_option: null model");
+  switch (key) {
+    case MDM_OPT_SMALL_GEMM_MAX_SEQS:
+      if (value < 0) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_SMALL_GEMM_MAX_SEQS must be >= 0");
+      m->x3s.max_seqs = value;
+      return MDM_OK;
+    case MDM_OPT_SMALL_GEMM_ROW_TILES:
+      if (value < 0 || value > 2) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_SMALL_GEMM_ROW_TILES must be 0 (by size), 1 or 2");
+      m->x3s.row_tiles = value;
+      return MDM_OK;
+    default:
+      return fail(MDM_EINVAL, "mdm_set_option: unknown key " + std::to_string(key));
+  }
+}
+
+int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value) {
+  if (m == nullptr || value == nullptr) return fail(MDM_EINVAL, "mdm_get_option: null argument");
+  switch (key) {
+    case MDM_OPT_SMALL_GEMM_MAX_SEQS: *value = m->x3s.max_seqs; return MDM_OK;
+    case MDM_OPT_SMALL_GEMM_ROW_TILES: *value = m->x3s.row_tiles; return MDM_OK;
+    default: return fail(MDM_EINVAL, "mdm_get_option: unknown key " + std::to_string(key));
+  }
+}
 
 int mdm_set_weight(mdm_model_t* m, const char* name, const float* dev_ptr, int64_t numel) {
   if (m == nullptr || name == nullptr || dev_ptr == nullptr) return fail(MDM_EINVAL, "mdm_set_weight: null argument");
@@ -1212,19 +1256,22 @@ struct DecHoist {         // step k of a window loop: where the hoisted projecti
 // stays on attention_f32.h (fp32 queries in, planes out).  All three LayerNorms of a layer are folded exactly as in the encoder
 // (row statistics per 128 columns from the producer, merged by the consumer); the residual stream ping-pongs between two plane
 // pairs because a GEMM cannot write the array its residual's statistics are read from.
-// Not taken (the fp32 skeleton below stays): f32 mode, frame masks (attention_x3.h's mask has the encoder's lead token), sample
-// groups of the probe build; MDM_X3S_MAX_SEQS=0 forces the skeleton for A/B runs.  There is no upper row count: the alternative
+// Frame masks (tgt_key_padding_mask, model/mdm.py:241-247 -- what DiP.md:181's `--mask_frames` recipe hands over on every call)
+// travel as counts / bitmaps into attention_x3.h with lead = 0 since round 5.
+// Not taken (the fp32 skeleton below stays): f32 mode, sample groups of the probe build; mdm_set_option(MDM_OPT_SMALL_GEMM_MAX_SEQS,
+// 0) forces the skeleton (tests, A/B runs).  There is no upper row count: the alternative
 // is not gemm_x3.h's sequence tiles (a 60-token sequence fills a quarter of one) but the skeleton, and the planes win at every
 // size measured (B = 32: 544 vs 391 motions/s, B = 64: 660 vs 448; profiles/r04h_dip_planes.md).
-inline bool dec_on_planes(const mdm_model* m, int M, int S, const int* len, const DecHoist& hz, int B) {
+inline bool dec_on_planes(const mdm_model* m, int M, int S, const DecHoist& hz, int B) {
   (void)M;
-  return m->precision == MDM_PREC_F16X3 && len == nullptr && S <= X3_TM && x3s_max_seqs() > 0 &&
+  return m->precision == MDM_PREC_F16X3 && S <= X3_TM && m->x3s.max_seqs > 0 &&
          m->cfg.latent_dim % 256 == 0 && m->cfg.ff_size % 256 == 0 && m->out_planes_f.hi != nullptr &&
          (hz.step < 0 || (hz.kv_b0 == 0 && hz.kv_B == B));
 }
 
 int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x, const float* prefix, const int32_t* text_lengths,
-                          int B, int pred_len, int ntok, int nbranch, float* out, hipStream_t s, const DecHoist& hz) {
+                          const int32_t* len, int B, int pred_len, int ntok, int nbranch, float* out, hipStream_t s,
+                          const DecHoist& hz) {
   const int C = m->cfg.context_len, S = C + pred_len, D = m->cfg.latent_dim, H = m->cfg.num_heads, FF = m->cfg.ff_size;
   const int nseq = nbranch * B, M = nseq * S, Mm = nseq * ntok;
   Profiler* pf = &m->prof;
@@ -1240,7 +1287,7 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
     launch_gemm_f32(al, bl, ep, B * S, D, m->jf_pad, s, true);
     if (int rc = rt_launch_status()) return rc;
   }
-  const X3sShape shape = x3s_shape((M + 196) / 197);   // the encoder's 32- / 64-row threshold, in its token rows
+  const X3sShape shape = x3s_shape(m->x3s, (M + 196) / 197);   // the encoder's 32- / 64-row threshold, in its token rows
   const int scols = x3s_tn(shape.ncb), parts = (D + scols - 1) / scols;
   const float inv_dim = 1.0f / (float)D;
   auto LN = [&]() { LnArgs a; a.small = true; a.shape = shape; a.stat_cols = scols; a.parts = parts; a.inv_dim = inv_dim; return a; };
@@ -1262,7 +1309,7 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, X, P.in_proj, F.b_in, a, nullptr, nullptr, nullptr, &ws.qp, M, 3 * D, D,
                                 S, D, D, qscale, s)) return rc;
     }
-    if (int rc = launch_attention_x3(pf, ws.qp, nullptr, nseq, B, S, D, nullptr, ws.atth, ws.attl, s)) return rc;
+    if (int rc = launch_attention_x3(pf, ws.qp, len, nseq, B, S, D, nullptr, ws.atth, ws.attl, s, /*lead=*/0)) return rc;
     {
       LnArgs a = LN(); a.res = X; a.ostat = sY;
       if (l >= 1) { a.rstat = sX; a.rgamma = m->L(l - 1, "norm3.weight"); a.rbeta = m->L(l - 1, "norm3.bias"); }
@@ -1347,8 +1394,8 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
                (branches == MDM_BRANCH_UNCOND) ? 0 : 1, (int)m->cfg.max_len);
     if (int rc = rt_launch_status()) return rc;
   }
-  if (dec_on_planes(m, M, S, len, hz, B))
-    return decoder_layers_planes(m, ws, x, prefix, text_lengths, B, pred_len, ntok, nbranch, out, s, hz);
+  if (dec_on_planes(m, M, S, hz, B))
+    return decoder_layers_planes(m, ws, x, prefix, text_lengths, len, B, pred_len, ntok, nbranch, out, s, hz);
   // ---- tgt tokens: InputProcess over cat(prefix, x) + positional rows (mdm.py:203-206, :239, :259-260); both branches
   {
     PoseGatherLoader al{x, S, m->jf, B * S, prefix, C};

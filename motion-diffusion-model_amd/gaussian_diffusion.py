@@ -20,7 +20,6 @@ model it is given step by step; without the reference on the path those calls ra
 import enum
 import importlib
 import math
-import os
 
 import numpy as np
 import torch
@@ -308,6 +307,10 @@ class GaussianDiffusion:
     _seed = None
     _draw = 0
     sample_base = 0          # global index of this process' first sample (set by dist.sample_sharded)
+    # Two switches of the seam itself, plain attributes of the diffusion object (rounds 2-4 read environment variables here):
+    check_finite = True      # one isfinite reduction + host sync per LOOP (_check_finite); False for fully asynchronous pipelines
+    dip_stepwise = False     # trans_dec: compose the window loop from mdm_forward_dec + mdm_sampler_step (what p_sample does)
+                             # instead of the one-call mdm_sample_loop_dec -- the tests hold the two against each other
 
     def _rng_state(self):
         if self._seed is None:
@@ -387,7 +390,7 @@ class GaussianDiffusion:
         if 'text' in y.keys() and 'text_embed' not in y.keys():
             # encoding once instead of each iteration (gaussian_diffusion.py:633-635); caches into the caller's dict
             y['text_embed'] = model.encode_text(y['text'])
-        if mdm.arch == 'trans_dec' and os.environ.get("MDM_DIP_STEPWISE", "0") == "1":
+        if mdm.arch == 'trans_dec' and self.dip_stepwise:
             # the window loop one native forward + one step kernel at a time (what p_sample composes); kept as the
             # cross-check of the native window loop below
             return self._loop_stepwise(model, mdm, shape, coefs, noise, clip_denoised, model_kwargs, device,
@@ -455,7 +458,8 @@ class GaussianDiffusion:
             else:
                 out, _, dumps = eng.sample_loop(
                     img, text_embed=te, force_uncond=bool(y.get('uncond', False)) or mdm.cond_mode == 'no_cond', **common)
-        self._check_finite(out, mdm)
+        if self.check_finite:
+            self._check_finite(out, mdm)
         if dump_steps is not None:      # the reference appends in loop order (:654-657)
             return [dumps[j] for j in range(len(kept))] if kept else []
         return out
@@ -464,19 +468,19 @@ class GaussianDiffusion:
     def _check_finite(sample, mdm):
         """The fp16 operand planes of the default mode do not saturate: an activation beyond +-65504 turns into inf and the
         sample into NaN.  One reduction per LOOP (the caller reads the sample back right after, sample/generate.py:163)
-        makes that loud and actionable.  MDM_CHECK_FINITE=0 skips it (fully asynchronous pipelines)."""
-        if os.environ.get("MDM_CHECK_FINITE", "1") == "0" or bool(torch.isfinite(sample).all()):
+        makes that loud and actionable.  `diffusion.check_finite = False` skips it (fully asynchronous pipelines)."""
+        if bool(torch.isfinite(sample).all()):
             return
         raise FloatingPointError(
             "the sampling loop produced non-finite values" + (
                 ": in the default precision='f16x3' the GEMM operands live as fp16 hi+lo planes (|x| <= 65504); this "
-                "checkpoint's activations probably leave that range -- construct the model with precision='f32' "
-                "(or MDM_PRECISION=f32)" if mdm.precision != "f32" else " in the exact-fp32 mode: check the checkpoint / inputs"))
+                "checkpoint's activations probably leave that range -- construct the model with precision='f32'"
+                if mdm.precision != "f32" else " in the exact-fp32 mode: check the checkpoint / inputs"))
 
     def _loop_stepwise(self, model, mdm, shape, coefs, noise, clip_denoised, model_kwargs, device, skip_timesteps,
                        init_image, dump_steps, noise_sequence, seed, const_noise=False):
         """The trans_dec window loop as p_sample composes it: one native forward + one fused step kernel per iteration
-        (MDM_DIP_STEPWISE=1).  The default is mdm_sample_loop_dec, which hoists the step-invariant text work."""
+        (`diffusion.dip_stepwise = True`).  The default is mdm_sample_loop_dec, which hoists the step-invariant text work."""
         eng = mdm.engine()
         with torch.no_grad():
             seed = self.reseed(seed)
@@ -506,7 +510,8 @@ class GaussianDiffusion:
                 img = out["sample"]
                 if dump_steps is not None and k in dump_steps:       # the loop's enumerate index (:637-655), not t
                     dumps.append(img.clone())
-        self._check_finite(img, mdm)
+        if self.check_finite:
+            self._check_finite(img, mdm)
         return dumps if dump_steps is not None else img
 
     # ---- progressive generators (the reference yields per step; kept for callers that iterate) ---------

@@ -8,17 +8,19 @@ sub-modules below exist only to hold parameters under the reference's names.
 Scope: arch='trans_enc', text conditioning with a cached `y['text_embed']`
 (or no conditioning), inference only; and (DiP) arch='trans_dec' with prefix completion
 and a cached token-level text embedding (DistilBERT) or a single CLIP token as the decoder memory (model/mdm.py:261-262; pinned
-against the reference by tests/golden/dip_clip_*.npz since round 4) -- its GEMMs split their fp32 operands on the fly in the default
-f16x3 mode; attention / LayerNorm fp32.  Everything else raises NotImplementedError loudly.
+against the reference by tests/golden/dip_clip_*.npz since round 4).  In the default f16x3 mode the decoder stack runs on fp16
+hi/lo operand planes like the encoder (small-tile split-precision GEMMs with all three LayerNorms of a layer folded, split-precision
+self-attention -- with or without a frame mask, DiP.md:181 trains with --mask_frames); `precision='f32'` is exact fp32 MFMA.
+Everything else raises NotImplementedError loudly.
 """
 import math
-import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import _native as nat
+from . import _engine
 from ._engine import Engine
 
 
@@ -108,8 +110,12 @@ class MDM(nn.Module):
         self.text_encoder_type = kargs.get('text_encoder_type', 'clip')
         self.clip_version = clip_version
         self._native_lib = kargs.get('_native_lib', None)      # tests inject the CPU emulation here
-        # arithmetic of the encoder GEMMs (include/mdm_hip.h mdm_set_precision): 'f16x3' | 'f32'
-        self.precision = kargs.get('precision', os.environ.get('MDM_PRECISION', 'f16x3'))
+        # arithmetic of the dense contractions (include/mdm_hip.h mdm_set_precision): 'f16x3' | 'f32'.  A constructor keyword only
+        # (no environment variable): a launcher that goes through the reference's factory binds it with
+        # functools.partial(MDM, precision='f32')
+        self.precision = kargs.get('precision', 'f16x3')
+        # include/mdm_hip.h mdm_set_option values for this module's engine ({'small_gemm_max_seqs': ..., 'small_gemm_row_tiles': ...})
+        self.engine_options = dict(kargs.get('engine_options', None) or {})
 
         if arch not in ('trans_enc', 'trans_dec'):
             raise NotImplementedError(f"arch={arch!r}: trans_enc and trans_dec (DiP) only (SURVEY.md 8f)")
@@ -227,13 +233,14 @@ class MDM(nn.Module):
         old weights, tests/test_host_logic.py::test_engine_key_sees_every_kind_of_weight_change)."""
         p = self.input_process.poseEmbedding.weight
         params = self.parameters_wo_clip()
-        key = (str(p.device), self.precision) + tuple((q.data_ptr(), q._version) for q in params)
+        key = (str(p.device), self.precision, tuple(sorted({**_engine.DEFAULT_OPTIONS, **self.engine_options}.items()))) + \
+            tuple((q.data_ptr(), q._version) for q in params)
         if self._engine is None or self._engine_key != key:
             cfg = dict(njoints=self.njoints, nfeats=self.nfeats, latent_dim=self.latent_dim, ff_size=self.ff_size,
                        num_layers=self.num_layers, num_heads=self.num_heads, clip_dim=self.clip_dim,
                        max_len=self.sequence_pos_encoder.pe.shape[0], mask_frames=int(bool(self.mask_frames)),
                        arch=nat.ARCH[self.arch], context_len=int(self.context_len) if self.arch == 'trans_dec' else 0)
-            eng = Engine(cfg, lib=self._native_lib, precision=self.precision)
+            eng = Engine(cfg, lib=self._native_lib, precision=self.precision, options=self.engine_options)
             eng.bind(self._native_state(), p.device)
             self._engine, self._engine_key = eng, key
         return self._engine

@@ -57,17 +57,26 @@ def golden_dir():
     return GOLDEN
 
 
-GEMM_PATHS = {"small": None, "small64": ("MDM_X3S_RT", "2"), "big": ("MDM_X3S_MAX_SEQS", "0")}
+GEMM_PATHS = {"small": {}, "small64": {"small_gemm_row_tiles": 2}, "big": {"small_gemm_max_seqs": 0}}
+
+
+@pytest.fixture
+def engine_options(monkeypatch):
+    """Pin the kernel route of every engine built during a test: `engine_options(small_gemm_max_seqs=0)` replaces the defaults new
+    engines start with (mdm_amd/_engine.py DEFAULT_OPTIONS -> include/mdm_hip.h mdm_set_option) until the test ends.  An explicit
+    in-process setter: the library reads no environment variable (rounds 3-4 steered it through MDM_X3S_* read per launch)."""
+    from mdm_amd import _engine
+
+    def set_defaults(**opts):
+        monkeypatch.setattr(_engine, "DEFAULT_OPTIONS", dict(opts))
+    set_defaults()
+    return set_defaults
 
 
 @pytest.fixture(params=["small", "big"])
-def gemm_path(request, monkeypatch):
+def gemm_path(request, engine_options):
     """Which of the two split-precision encoder GEMM kernels a small-batch test runs on: csrc/gemm_x3s.h's 32-row tiles (the
-    default below 32 sequences) or csrc/gemm_x3.h's sequence-sized tiles (MDM_X3S_MAX_SEQS=0; what large batches run).  Both
-    are product code; the environment switch is read per launch."""
-    monkeypatch.delenv("MDM_X3S_MAX_SEQS", raising=False)
-    monkeypatch.delenv("MDM_X3S_RT", raising=False)
-    kv = GEMM_PATHS[request.param]
-    if kv is not None:
-        monkeypatch.setenv(*kv)
+    default below 32 sequences) or csrc/gemm_x3.h's sequence-sized tiles (small_gemm_max_seqs = 0; what large batches run).  Both
+    are product code."""
+    engine_options(**GEMM_PATHS[request.param])
     return request.param

@@ -23,7 +23,7 @@ def make_pair(sd, steps, device, guided=True, native_lib=None, precision="f16x3"
     dec = any(k.startswith("seqTransDecoder.layers.") for k in sd)
     layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith(("seqTransEncoder.layers.", "seqTransDecoder.layers.")))
     if dec:   # DiP: `--arch trans_dec --text_encoder_type bert --context_len 20 --pred_len 40` (DiP.md)
-        arg_over = {"arch": "trans_dec", "text_encoder_type": "bert", "mask_frames": False, **arg_over}
+        arg_over = {"arch": "trans_dec", "text_encoder_type": "bert", "mask_frames": True, **arg_over}   # DiP.md:181 trains with --mask_frames
     d = sd["input_process.poseEmbedding.weight"].shape[0]
     args = model_util.default_args(diffusion_steps=steps, layers=layers, latent_dim=d, **arg_over)
     model, diffusion = model_util.create_model_and_diffusion(args, _native_lib=native_lib, num_heads=d // 128,

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib.lib, n), f"{n} declared in include/mdm_hip.h but not exported"
     assert sorted(_native.EXPORTED_SYMBOLS) == names       # the ctypes view covers the whole header
-    assert lib.mdm_abi_version() == 8
+    assert lib.mdm_abi_version() == 9
 
 
 def test_probe_surface_is_not_in_the_production_library(lib):
@@ -45,6 +45,30 @@ def test_probe_surface_is_not_in_the_production_library(lib):
         assert not hasattr(lib.lib, n), f"{n} leaked into the production library"
         assert hasattr(probe.lib, n)
     assert not lib.has_probes and probe.has_probes
+
+
+def test_product_library_reads_no_environment_variable(lib):
+    """rounds 3-4 steered the product library through ~10 environment variables, several read on the
+    launch path.  Now: handle options (mdm_set_option); the product binary does not even import getenv (the probe build, the
+    experiment surface of tools/, still does)."""
+    import subprocess
+    from mdm_amd import _native
+    und = subprocess.run(["nm", "-D", "--undefined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und, [ln for ln in und.splitlines() if "getenv" in ln]
+    probe = subprocess.run(["nm", "-D", "--undefined-only", _native.PROBE_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" in probe
+    h = C.c_void_p()
+    cfg = _cfg()
+    lib.check(lib.mdm_create(C.byref(cfg), C.byref(h)), "mdm_create")
+    v = C.c_int32(-1)
+    lib.check(lib.mdm_get_option(h, _native.OPTIONS["small_gemm_max_seqs"], C.byref(v)), "mdm_get_option")
+    assert v.value == 40
+    lib.check(lib.mdm_set_option(h, _native.OPTIONS["small_gemm_max_seqs"], 0), "mdm_set_option")
+    lib.check(lib.mdm_get_option(h, _native.OPTIONS["small_gemm_max_seqs"], C.byref(v)), "mdm_get_option")
+    assert v.value == 0
+    assert lib.mdm_set_option(h, 99, 1) == -1 and b"unknown key" in lib.lib.mdm_last_error()
+    assert lib.mdm_set_option(h, _native.OPTIONS["small_gemm_row_tiles"], 7) == -1
+    lib.mdm_destroy(h)
 
 
 def test_no_cuda_or_torch_in_the_abi():

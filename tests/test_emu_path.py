@@ -288,11 +288,11 @@ def test_emulated_dip_decoder_forward(lib, masked, prec):
     assert maxabs(model(x, t, y=dict(y)), dip.dip_cfg_forward(sd, x, t, y, **kw)) < 5e-5
 
 
-def test_emulated_dip_decoder_planes_and_fp32_skeleton(lib, monkeypatch):
+def test_emulated_dip_decoder_planes_and_fp32_skeleton(lib, engine_options):
     """The f16x3 trans_dec stack has two routes (csrc/mdm_api.hip dec_on_planes): operand planes through gemm_x3s.h /
-    attention_x3.h (unmasked: what DiP's callers run) and the fp32 skeleton of gemm_f32.h (frame
-    masks; MDM_X3S_MAX_SEQS=0 forces it).  Both against the oracle, on 32- and 64-row tiles; the two are different
-    arithmetic, so agreeing bit for bit would mean the switch did nothing."""
+    attention_x3.h (what DiP's callers run) and the fp32 skeleton of gemm_f32.h (small_gemm_max_seqs = 0 forces it).  Both
+    against the oracle, on 32- and 64-row tiles; the two are different arithmetic, so agreeing bit for bit would mean the switch
+    did nothing."""
     B, C, P = 3, 5, 12
     sd = dip_small_state_dict(num_layers=2)
     y = synth_dip_y(B, P, C, seed=3, text_lengths=[6, 3, 2], lengths=None, scale=2.5)
@@ -300,11 +300,9 @@ def test_emulated_dip_decoder_planes_and_fp32_skeleton(lib, monkeypatch):
     t = torch.tensor([9, 0, 4])
     want = dip.dip_cfg_forward(sd, x, t, y, context_len=C, num_heads=2, mask_frames=False)
     outs = {}
-    for tag, env in (("planes32", {"MDM_X3S_RT": "1"}), ("planes64", {"MDM_X3S_RT": "2"}), ("skeleton", {"MDM_X3S_MAX_SEQS": "0"})):
-        monkeypatch.delenv("MDM_X3S_RT", raising=False)
-        monkeypatch.delenv("MDM_X3S_MAX_SEQS", raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for tag, opts in (("planes32", {"small_gemm_row_tiles": 1}), ("planes64", {"small_gemm_row_tiles": 2}),
+                      ("skeleton", {"small_gemm_max_seqs": 0})):
+        engine_options(**opts)
         model, _ = make_pair(sd, 10, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, precision="f16x3")
         outs[tag] = model(x, t, y=dict(y))
         assert maxabs(outs[tag], want) < 5e-5, tag
@@ -312,12 +310,11 @@ def test_emulated_dip_decoder_planes_and_fp32_skeleton(lib, monkeypatch):
     assert maxabs(outs["planes32"], outs["planes64"]) < 1e-5
 
 
-@pytest.mark.parametrize("B,C,P,text_lengths,rt", [(2, 3, 70, [40, 3], "2"), (3, 0, 33, [5, 9, 1], "1")])
-def test_emulated_dip_decoder_planes_other_windows(lib, monkeypatch, B, C, P, text_lengths, rt):
+@pytest.mark.parametrize("B,C,P,text_lengths,rt", [(2, 3, 70, [40, 3], 2), (3, 0, 33, [5, 9, 1], 1)])
+def test_emulated_dip_decoder_planes_other_windows(lib, engine_options, B, C, P, text_lengths, rt):
     """The plane route of the trans_dec stack at other window shapes than 20 + 40: S = 73 tokens (a 64-row tile + 9 rows per sequence
     for in_proj, contiguous tiles elsewhere), a 40-token memory (two key tiles in the cross-attention), no prefix at all."""
-    monkeypatch.setenv("MDM_X3S_RT", rt)
-    monkeypatch.delenv("MDM_X3S_MAX_SEQS", raising=False)
+    engine_options(small_gemm_row_tiles=rt)
     sd = dip_small_state_dict(num_layers=2)
     y = synth_dip_y(B, P, max(C, 1), seed=3, text_lengths=text_lengths, lengths=None, scale=2.5)
     if C == 0:
@@ -332,10 +329,10 @@ def test_emulated_dip_decoder_planes_other_windows(lib, monkeypatch, B, C, P, te
 
 
 @pytest.mark.parametrize("guided,prec", [(True, "f16x3"), (False, "f32")])
-def test_emulated_dip_window_loop(lib, monkeypatch, guided, prec):
+def test_emulated_dip_window_loop(lib, guided, prec):
     """mdm_sample_loop_dec (one p_sample_loop over a DiP prediction window: text projections hoisted out of the steps, the
     step's projected time row added while the attention kernel stages K / V) against the oracle's loop, and against the
-    same loop composed step by step from mdm_forward_dec + mdm_sampler_step (MDM_DIP_STEPWISE=1); dump_steps included."""
+    same loop composed step by step from mdm_forward_dec + mdm_sampler_step (diffusion.dip_stepwise); dump_steps included."""
     B, C, P, steps = 2, 5, 12, 2
     sd = dip_small_state_dict(num_layers=1)
     model, diffusion = make_pair(sd, steps, "cpu", guided=guided, native_lib=lib, context_len=C, pred_len=P, precision=prec)
@@ -350,7 +347,7 @@ def test_emulated_dip_window_loop(lib, monkeypatch, guided, prec):
     assert maxabs(got, want) < 5e-5
     dumps = run(dump_steps=[0, 1])
     assert len(dumps) == 2 and torch.equal(dumps[1], got)
-    monkeypatch.setenv("MDM_DIP_STEPWISE", "1")
+    diffusion.dip_stepwise = True
     step = run(dump_steps=[0, 1])
     assert maxabs(got, step[1]) < 2e-5 and maxabs(step[0], dumps[0]) < 2e-5
 
@@ -482,12 +479,12 @@ def test_integration_md_snippet_is_a_program_and_its_structs_match_the_binding()
     assert "mdm_abi_version() == %d" % nat.ABI_VERSION in m.group(1)
 
 
-@pytest.mark.parametrize("rt", ["1", "2"])
-def test_emulated_small_gemm_at_the_headline_width(lib, monkeypatch, rt):
+@pytest.mark.parametrize("rt", [1, 2])
+def test_emulated_small_gemm_at_the_headline_width(lib, engine_options, rt):
     """csrc/gemm_x3s.h at latent_dim = 512 (the emulator cases above run 256: one K-chunk): two chunks for in_proj / out_proj /
     linear1 (four 128-k chunks), eight for linear2, the 18-sub-step single chunk of InputProcess (K = 288), N = 264 of OutputProcess
     (a column tile whose last three waves lie past the packed weight rows), 32- and 64-row tiles, a 5-row last tile (S = 37)."""
-    monkeypatch.setenv("MDM_X3S_RT", rt)
+    engine_options(small_gemm_row_tiles=rt)
     B, T = 1, 36
     sd = small_state_dict(latent_dim=512, num_layers=2)
     model, _ = make_pair(sd, 50, "cpu", guided=True, native_lib=lib, precision="f16x3")
@@ -497,12 +494,12 @@ def test_emulated_small_gemm_at_the_headline_width(lib, monkeypatch, rt):
     assert maxabs(model(x, t, y=dict(y)), orc.cfg_forward(sd, x, t, y, num_heads=4)) < 5e-5
 
 
-def test_emulated_wide_form_of_the_pipelined_gemm(lib, monkeypatch):
+def test_emulated_wide_form_of_the_pipelined_gemm(lib, monkeypatch, engine_options):
     """gemm_x3.h NCB = 2 (round 4, probe / emulator builds: MDM_X3_WIDE=1): the pipelined k-loop as four waves x 64 columns -- W slots,
     counted waits, 16-row sub-tile and every epilogue over two column blocks per wave.  Measured slower on the MI355X and not a
     product path (profiles/r04d_wide.md); kept correct."""
-    monkeypatch.setenv("MDM_X3_WIDE", "1")
-    monkeypatch.setenv("MDM_X3S_MAX_SEQS", "0")
+    monkeypatch.setenv("MDM_X3_WIDE", "1")       # (an experiment switch of the probe / emulator builds; not in the product library)
+    engine_options(small_gemm_max_seqs=0)
     B, T = 2, 33
     sd = small_state_dict(num_layers=2)
     model, _ = make_pair(sd, 50, "cpu", guided=True, native_lib=lib, precision="f16x3")
@@ -510,3 +507,95 @@ def test_emulated_wide_form_of_the_pipelined_gemm(lib, monkeypatch):
     g = torch.Generator().manual_seed(0)
     x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 0])
     assert maxabs(model(x, t, y=dict(y)), orc.cfg_forward(sd, x, t, y, num_heads=2)) < 5e-5
+
+
+# ---- round 5 ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("route", ["planes32", "planes64"])
+def test_emulated_dip_plane_route_takes_frame_masks(lib, engine_options, route):
+    """VERDICT r04, What's missing 1: DiP's recipe trains with --mask_frames (DiP.md:181), so every forward of a real checkpoint
+    carries a tgt_key_padding_mask (model/mdm.py:241-247, :263-265) -- and round 4's operand-plane route refused any.  Now the
+    counts / bitmaps reach attention_x3.h with lead = 0 (no condition token; the context_len prefix frames are counted as frames):
+    prefix masks (counts), masks with holes (bitmaps) and the all-valid mask of sample/generate.py:107, forward and window loop,
+    against the oracle -- and the route really is the plane route (differs from the fp32 skeleton in the last bits)."""
+    B, C, P, steps = 4, 5, 12, 2
+    engine_options(small_gemm_row_tiles=1 if route == "planes32" else 2)
+    sd = dip_small_state_dict(num_layers=2)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, mask_frames=True)
+    y = synth_dip_y(B, P, C, seed=6, text_lengths=[6, 3, 1, 5], lengths=[12, 9, 12, 7], scale=2.5)
+    x = torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([1, 0, 1, 0])
+    kw = dict(context_len=C, num_heads=2, mask_frames=True)
+    got = model(x, t, y=dict(y))
+    assert maxabs(got, dip.dip_cfg_forward(sd, x, t, y, **kw)) < 5e-5
+    assert maxabs(got, dip.dip_cfg_forward(sd, x, t, y, context_len=C, num_heads=2, mask_frames=False)) > 1e-3   # the mask matters
+    yh = dict(y)
+    yh["mask"] = y["mask"].clone()
+    yh["mask"][1, 0, 0, [0, 4]] = False          # holes: samples 1 and 3 travel as bitmaps, 0 and 2 as counts
+    yh["mask"][3, 0, 0, [2, 3, 5]] = False
+    got_h = model(x, t, y=dict(yh))
+    assert maxabs(got_h, dip.dip_cfg_forward(sd, x, t, yh, **kw)) < 5e-5
+    assert maxabs(got_h, got) > 1e-4
+    g = torch.Generator().manual_seed(9)
+    seq = [torch.randn(B, 263, 1, P, generator=g) for _ in range(1 + steps)]
+    loop = diffusion.p_sample_loop(model, (B, 263, 1, P), clip_denoised=False, model_kwargs={"y": dict(yh)}, noise_sequence=seq)
+    want = dip.dip_sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), (B, 263, 1, P), yh, seq[0], seq[1:],
+                               context_len=C, cfg=True, num_heads=2, mask_frames=True)
+    assert maxabs(loop, want) < 5e-5
+    # generate.py's mask: ones, wider than the window -> all valid, equal to the unmasked model's output on this route bit for bit
+    ya = dict(y)
+    ya["mask"] = torch.ones(B, 1, 1, 196, dtype=torch.bool)
+    plain, _ = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, mask_frames=False)
+    assert torch.equal(model(x, t, y=dict(ya)), plain(x, t, y=dict(ya)))
+    engine_options(small_gemm_max_seqs=0)
+    skel, _ = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, mask_frames=True)
+    got_s = skel(x, t, y=dict(yh))
+    assert maxabs(got_s, got_h) < 5e-5 and not torch.equal(got_s, got_h)
+
+
+@pytest.mark.parametrize("latent_dim", [768, 1024])
+def test_emulated_wide_latent_dims_on_both_gemm_kernels(lib, gemm_path, latent_dim):
+    """ADVICE r04 (high): mdm_create accepts latent_dim 768 and 1024, the small-tile kernel leaves D / 128 = 6 / 8 partial
+    statistics per row, and its consumer only knew 1, 2, 4 and "else = 3" (round 4: launch refused with parts > 4 -- no small batch
+    ran at those widths at all).  Both GEMM kernels, two layers (every folded-LayerNorm kind), against the oracle."""
+    B, T = 1, 21
+    sd = small_state_dict(latent_dim=latent_dim, num_layers=2)
+    model, _ = make_pair(sd, 50, "cpu", guided=True, native_lib=lib, precision="f16x3")
+    y = synth_y(B, T, seed=2, lengths=[17])
+    g = torch.Generator().manual_seed(0)
+    x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([31])
+    assert maxabs(model(x, t, y=dict(y)), orc.cfg_forward(sd, x, t, y, num_heads=latent_dim // 128)) < 5e-5
+
+
+def test_emulated_dip_plane_route_at_latent_dim_768(lib, engine_options):
+    """The same six-partial statistics on the trans_dec stack (three folded LayerNorms per layer), with a frame mask."""
+    B, C, P = 2, 5, 12
+    engine_options(small_gemm_row_tiles=1)
+    sd = dip_small_state_dict(latent_dim=768, num_layers=2)
+    model, _ = make_pair(sd, 10, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, mask_frames=True)
+    y = synth_dip_y(B, P, C, seed=3, text_lengths=[6, 3], lengths=[12, 7], scale=2.5)
+    x = torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([9, 0])
+    assert maxabs(model(x, t, y=dict(y)), dip.dip_cfg_forward(sd, x, t, y, context_len=C, num_heads=6, mask_frames=True)) < 5e-5
+
+
+def test_engine_options_are_set_through_the_abi_not_the_environment(lib, monkeypatch):
+    """VERDICT r04 item 6: the kernel route of a handle is an option of the handle (include/mdm_hip.h mdm_set_option, ABI 9); the
+    environment variables rounds 3-4 read on the launch path do nothing any more."""
+    from mdm_amd._engine import Engine
+    cfg = dict(njoints=263, nfeats=1, latent_dim=256, ff_size=1024, num_layers=1, num_heads=2, clip_dim=512, max_len=64,
+               mask_frames=1, arch=0, context_len=0)
+    monkeypatch.setenv("MDM_X3S_MAX_SEQS", "0")
+    monkeypatch.setenv("MDM_X3S_RT", "2")
+    if not lib.has_probes:      # (the probe / emulator builds preset new handles from these two variables for tools/' A/B scripts)
+        e = Engine(cfg, lib=lib)
+        assert e.get_option("small_gemm_max_seqs") == 40 and e.get_option("small_gemm_row_tiles") == 0
+    monkeypatch.delenv("MDM_X3S_MAX_SEQS")
+    monkeypatch.delenv("MDM_X3S_RT")
+    e = Engine(cfg, lib=lib, options={"small_gemm_row_tiles": 2})
+    assert e.get_option("small_gemm_max_seqs") == 40 and e.get_option("small_gemm_row_tiles") == 2
+    e.set_option("small_gemm_max_seqs", 0)
+    assert e.get_option("small_gemm_max_seqs") == 0
+    with pytest.raises(Exception, match="ROW_TILES"):
+        e.set_option("small_gemm_row_tiles", 3)
+    with pytest.raises(ValueError):
+        e.set_option("no_such_option", 1)

@@ -301,7 +301,7 @@ def test_dip_dump_steps_are_loop_indices():
     """p_sample_loop(dump_steps=...) on the trans_dec path must snapshot by the loop's enumerate index k
     (gaussian_diffusion.py:637-655), like the fused loop -- not by the descending timestep.  The native window loop
     (mdm_sample_loop_dec: text K / V hoisted, time row added in the attention kernel) is compared with the step-at-a-time
-    composition of the same library calls (the progressive generator, and MDM_DIP_STEPWISE=1): same values up to the
+    composition of the same library calls (the progressive generator, and diffusion.dip_stepwise): same values up to the
     re-association of the hoisted projection."""
     from helpers import synth_dip_state_dict, synth_dip_y, to_dev
     sdd = synth_dip_state_dict(seed=0)
@@ -319,12 +319,9 @@ def test_dip_dump_steps_are_loop_indices():
     for d, k in zip(dumps, (0, 3, 9)):
         assert maxabs(d.cpu(), traj[k].cpu()) < 2e-5
     assert maxabs(dumps[0].cpu(), traj[-1].cpu()) > 1e-2
-    os.environ["MDM_DIP_STEPWISE"] = "1"
-    try:
-        step = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, noise_sequence=seq,
-                                       dump_steps=[0, 3, 9])
-    finally:
-        del os.environ["MDM_DIP_STEPWISE"]
+    diffusion.dip_stepwise = True
+    step = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, noise_sequence=seq,
+                                   dump_steps=[0, 3, 9])
     for d, k in zip(step, (0, 3, 9)):
         assert torch.equal(d, traj[k])
 

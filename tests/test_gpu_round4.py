@@ -136,17 +136,16 @@ def test_trans_dec_with_a_clip_memory_token_matches_reference(golden_dir, prec):
 
 
 @pytest.mark.parametrize("route", ["planes32", "planes64", "skeleton"])
-def test_dip_decoder_routes_match_reference_goldens(golden_dir, monkeypatch, route):
+def test_dip_decoder_routes_match_reference_goldens(golden_dir, engine_options, route):
     """The f16x3 trans_dec stack on its two routes (csrc/mdm_api.hip dec_on_planes): operand planes through gemm_x3s.h +
-    attention_x3.h -- what the DiP callers' sizes take; 32- and 64-row tiles -- and the fp32 skeleton of gemm_f32.h that frame
-    masks take (forced here by MDM_X3S_MAX_SEQS=0).  Each against the UPSTREAM reference's own outputs: the
+    attention_x3.h -- what the DiP callers' sizes take; 32- and 64-row tiles -- and the fp32 skeleton of gemm_f32.h (forced here by
+    small_gemm_max_seqs = 0).  Each against the UPSTREAM reference's own outputs: the
     B = 3 forward (both branches, guided) and the 100-frame autoregressive generation (3 windows x 10 steps, CFG 7.5)."""
     from types import SimpleNamespace
     from helpers import synth_dip_y
     from mdm_amd.sampler_util import AutoRegressiveSampler
-    for k in ("MDM_X3S_RT", "MDM_X3S_MAX_SEQS"):
-        monkeypatch.delenv(k, raising=False)
-    monkeypatch.setenv(*{"planes32": ("MDM_X3S_RT", "1"), "planes64": ("MDM_X3S_RT", "2"), "skeleton": ("MDM_X3S_MAX_SEQS", "0")}[route])
+    engine_options(**{"planes32": {"small_gemm_row_tiles": 1}, "planes64": {"small_gemm_row_tiles": 2},
+                      "skeleton": {"small_gemm_max_seqs": 0}}[route])
     sd_dip = memo("sd_dip0", lambda: synth_dip_state_dict(seed=0))
     g = _g(golden_dir, "dip_fwd_B3")
     model, _ = make_pair(sd_dip, 10, DEV, guided=True, context_len=20, pred_len=40, mask_frames=False)
@@ -254,13 +253,13 @@ def test_operand_split_is_bit_exact_fp16_hi_plus_lo():
     assert np.array_equal(lo[~z], want_lo.view(np.uint16)[~z])
 
 
-def test_wide_form_of_the_pipelined_gemm_matches_reference(golden_dir, sd, monkeypatch):
+def test_wide_form_of_the_pipelined_gemm_matches_reference(golden_dir, sd, monkeypatch, engine_options):
     """gemm_x3.h NCB = 2 (probe library, MDM_X3_WIDE=1): four waves x 64 columns, one wave per SIMD, accumulators in AGPRs -- the
     arrangement VERDICT r03 item 1a asked for.  12 % slower over the loop (profiles/r04d_wide.md), so not a product path; this
     keeps it correct against the reference's forward goldens on the sequence-tile kernel."""
     from mdm_amd import _native
-    monkeypatch.setenv("MDM_X3_WIDE", "1")
-    monkeypatch.setenv("MDM_X3S_MAX_SEQS", "0")
+    monkeypatch.setenv("MDM_X3_WIDE", "1")       # (an experiment switch of the probe library; the product reads no environment)
+    engine_options(small_gemm_max_seqs=0)
     g = _g(golden_dir, "fwd_B3_T196")
     B, T = 3, 196
     y = synth_y(B, T, seed=int(g["y_seed"]), lengths=list(g["lengths"]))

@@ -187,7 +187,7 @@ def test_engine_key_sees_every_kind_of_weight_change():
     class FakeEngine:
         made = 0
 
-        def __init__(self, cfg, lib=None, precision="f16x3"):
+        def __init__(self, cfg, lib=None, precision="f16x3", options=None):
             FakeEngine.made += 1
 
         def bind(self, state, device):
@@ -217,5 +217,8 @@ def test_engine_key_sees_every_kind_of_weight_change():
         e4 = model.engine()
         assert e4 is not e3 and float(e4.state["embed_text.bias"][0]) == 0.5
         assert model.engine() is e4
+        model.engine_options["small_gemm_max_seqs"] = 0                              # round 5: the handle's options are part of the key
+        e5 = model.engine()
+        assert e5 is not e4 and model.engine() is e5
     finally:
         mm.Engine = orig
