@@ -68,12 +68,12 @@ def cpu_baseline(state, budget_s=12.0):
                       f"{DSTEPS} steps per motion ({per_step * 1e3:.0f} ms per batch-step)"}
 
 
-def measure(dev, rank, world, B, steps, warmup, cpu=True):
+def measure(dev, rank, world, B, steps, warmup, cpu=True, mask_frames=True):
     """Time `steps` whole 196-frame generations of B motions per rank on `dev`; returns the JSON record (rank 0) or None.
     bench.py embeds this record as its `dip` sub-line so that the driver's BENCH file carries it."""
     torch.manual_seed(0)
     args = model_util.default_args(diffusion_steps=DSTEPS, arch="trans_dec", text_encoder_type="bert", context_len=CONTEXT,
-                                   pred_len=PRED, mask_frames=True, guidance_param=7.5)      # DiP.md:181: `--mask_frames`
+                                   pred_len=PRED, mask_frames=mask_frames, guidance_param=7.5)      # DiP.md:181: `--mask_frames`
     mdm, diffusion = model_util.create_model_and_diffusion(args)
     state = {k: v.clone() for k, v in mdm.state_dict().items()}
     model = ClassifierFreeSampleModel(mdm).to(dev).eval()
@@ -124,9 +124,10 @@ def measure(dev, rank, world, B, steps, warmup, cpu=True):
             "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
             "config": {"workload": f"DiP autoregressive text2motion: trans_dec 8 layers d=512, prefix 20 + window 40 "
                                    f"frames, {NTOK}-token DistilBERT memory (cached), {DSTEPS} DDPM steps per window, "
-                                   f"CFG 7.5, batch={B} per GPU, random-init weights, mask_frames=True with y['mask'] = "
-                                   f"ones[B,1,1,{FRAMES}] as sample/generate.py:107 builds it (the DiP.md:181 recipe: a frame "
-                                   f"mask on every forward)", "global_batch": GB, "mask_frames": True,
+                                   f"CFG 7.5, batch={B} per GPU, random-init weights, mask_frames={mask_frames} with y['mask'] = "
+                                   f"ones[B,1,1,{FRAMES}] as sample/generate.py:107 builds it" +
+                                   (" (the DiP.md:181 recipe: a frame mask on every forward)" if mask_frames else " (no frame mask reaches the kernels: A/B only)"),
+                       "global_batch": GB, "mask_frames": bool(mask_frames),
                        "parallelism": f"dp{world}: batch shards, all_gather of final samples"},
             "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3s_kernel on operand planes; K / V of the text memory: gemm_f32_kernel<X3>") + ")",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -146,12 +147,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="motions per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mask-frames", action="store_true", help="A/B: a model built without --mask_frames (NULL lengths)")
     a = ap.parse_args()
     rank, world, local = mdist.init_from_env("nccl")
     assert world == a.gpus and torch.cuda.is_available()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    line = measure(dev, rank, world, a.batch, a.steps, a.warmup, cpu=not a.no_cpu_baseline)
+    line = measure(dev, rank, world, a.batch, a.steps, a.warmup, cpu=not a.no_cpu_baseline, mask_frames=not a.no_mask_frames)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -1248,6 +1248,20 @@ struct DecHoist {         // step k of a window loop: where the hoisted projecti
   const float* kv_time = nullptr;   // [L][nsteps][2D]
   int kv_B = 0, kv_b0 = 0;          // this pass covers samples kv_b0 .. kv_b0 + B - 1 of kv_B
 };
+// The sampler update of a window-loop step, handed DOWN to the plane route: its transposing tail kernel (outproj_finish_kernel
+// mode 1) then performs guidance combine + inpainting blend + clamp + posterior / DDIM update + inline Philox in place on x, exactly
+// as the encoder loop's tail does -- one launch and one [nseq, J, P] round trip through memory fewer per step than
+// OutputProcess -> sampler_step_kernel (same arithmetic, element for element).  `done` says whether the route applied it.
+struct DecTail {
+  const float* scale = nullptr;      // [B] or null (single branch)
+  float* x = nullptr;                // [B, J, F, P]: x_t in, x_{t-1} out
+  float* x0_out = nullptr;
+  NoiseSource ns{};
+  const unsigned char* inpaint_mask = nullptr;
+  const float* inpaint_motion = nullptr;
+  StepCoefs co{};
+  bool done = false;
+};
 // The decoder stack on 16-bit operand planes: the f16x3 mode at the sizes the reference's DiP callers run (model/mdm.py:255-270
 // under sample/generate.py's autoregressive windows: 2 x 32 sequences of 20 + 40 tokens = 3,840 token rows).  That is the row
 // count of the encoder's latency regime, so the six GEMMs of a layer run on gemm_x3s.h's 32 / 64-row tiles straight from planes
@@ -1271,7 +1285,7 @@ inline bool dec_on_planes(const mdm_model* m, int M, int S, const DecHoist& hz, 
 
 int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x, const float* prefix, const int32_t* text_lengths,
                           const int32_t* len, int B, int pred_len, int ntok, int nbranch, float* out, hipStream_t s,
-                          const DecHoist& hz) {
+                          const DecHoist& hz, DecTail* tail) {
   const int C = m->cfg.context_len, S = C + pred_len, D = m->cfg.latent_dim, H = m->cfg.num_heads, FF = m->cfg.ff_size;
   const int nseq = nbranch * B, M = nseq * S, Mm = nseq * ntok;
   Profiler* pf = &m->prof;
@@ -1365,6 +1379,13 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
     if (int rc = launch_x3_ln(nullptr, MDM_PROF_OUTPROJ, 4, X3Operand{ws.xh[cur], ws.xl[cur]}, m->out_planes_f, m->b_out, a, out_tok,
                               nullptr, nullptr, nullptr, M, ldo, D, S, D, 0, 1.f, s)) return rc;
   }
+  if (tail != nullptr) {   // window loop: the step's sampler update in the tail kernel (the guidance branches are rows b and B + b)
+    MDM_LAUNCH(outproj_finish_kernel, dim3((pred_len + 31) / 32, (m->jf + 31) / 32, B), dim3(256), 0, s, (const float*)out_tok,
+               ldo, S, pred_len, m->jf, B, tail->scale, 1, tail->x, tail->x0_out, (const float*)tail->x, tail->ns,
+               tail->inpaint_mask, tail->inpaint_motion, tail->co);
+    tail->done = true;
+    return rt_launch_status();
+  }
   MDM_LAUNCH(outproj_finish_kernel, dim3((pred_len + 31) / 32, (m->jf + 31) / 32, nseq), dim3(256), 0, s, (const float*)out_tok,
              ldo, S, pred_len, m->jf, B, (const float*)nullptr, 0, out, (float*)nullptr, (const float*)nullptr, NoiseSource{},
              (const unsigned char*)nullptr, (const float*)nullptr, StepCoefs{});
@@ -1373,7 +1394,7 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
 
 int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const float* prefix, const int64_t* timesteps,
                  const float* text_tokens, const int32_t* text_lengths, const int32_t* lengths, int B, int pred_len,
-                 int ntok, int branches, float* out, hipStream_t s, const DecHoist& hz) {
+                 int ntok, int branches, float* out, hipStream_t s, const DecHoist& hz, DecTail* tail = nullptr) {
   const int C = m->cfg.context_len, S = C + pred_len, D = m->cfg.latent_dim, H = m->cfg.num_heads, FF = m->cfg.ff_size;
   const int nbranch = (branches == MDM_BRANCH_BOTH) ? 2 : 1;
   const int nseq = nbranch * B, M = nseq * S, Mm = nseq * ntok;
@@ -1395,7 +1416,8 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
     if (int rc = rt_launch_status()) return rc;
   }
   if (dec_on_planes(m, M, S, hz, B))
-    return decoder_layers_planes(m, ws, x, prefix, text_lengths, len, B, pred_len, ntok, nbranch, out, s, hz);
+    return decoder_layers_planes(m, ws, x, prefix, text_lengths, len, B, pred_len, ntok, nbranch, out, s, hz,
+                                 (tail != nullptr && (nbranch == 1) == (tail->scale == nullptr)) ? tail : nullptr);
   // ---- tgt tokens: InputProcess over cat(prefix, x) + positional rows (mdm.py:203-206, :239, :259-260); both branches
   {
     PoseGatherLoader al{x, S, m->jf, B * S, prefix, C};
@@ -1737,16 +1759,25 @@ int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float
       DecHoist hz;
       hz.step = k; hz.nsteps = nsteps; hz.kv_text = ws.kv_text; hz.kv_time = ws.kv_time; hz.kv_B = B; hz.kv_b0 = b0;
       const float* prefix_g = pd->prefix_dev != nullptr ? pd->prefix_dev + (size_t)b0 * m->jf * m->cfg.context_len : nullptr;
-      rc_loop = decoder_pass(m, wg, x + xo, prefix_g, nullptr, p->text_embed_dev, pd->text_lengths_dev + b0,
-                             p->lengths_dev, Bg, P, ntok, branches, wg.out, gs[g], hz);
-      if (rc_loop != MDM_OK) break;
-      // CFG combine + posterior / DDIM update, in place on x (each element is read, then written, by the same lane)
+      // CFG combine + posterior / DDIM update, in place on x (each element is read, then written, by the same lane): inside the
+      // plane route's tail kernel (DecTail), else as a kernel of its own behind the denoiser
       StepCoefs co{p->a_x0[i], p->a_xt[i], p->sigma[i], p->clip_denoised};
       const float* step_noise = (p->noise_dev != nullptr && p->sigma[i] != 0.f) ? p->noise_dev + (size_t)k * B * per_sample + xo : nullptr;
       NoiseSource ns{step_noise, p->seed, p->sample_base + (uint32_t)b0, (uint32_t)(1 + k), (uint32_t)(p->const_noise != 0)};
+      DecTail tail;
+      tail.scale = cfg ? p->scale_dev + b0 : nullptr;
+      tail.x = x + xo;
+      tail.x0_out = (i == 0 && p->x0_dev != nullptr) ? p->x0_dev + xo : nullptr;
+      tail.ns = ns;
+      tail.inpaint_mask = p->inpaint_mask_dev != nullptr ? p->inpaint_mask_dev + xo : nullptr;
+      tail.inpaint_motion = p->inpaint_motion_dev != nullptr ? p->inpaint_motion_dev + xo : nullptr;
+      tail.co = co;
+      rc_loop = decoder_pass(m, wg, x + xo, prefix_g, nullptr, p->text_embed_dev, pd->text_lengths_dev + b0,
+                             p->lengths_dev, Bg, P, ntok, branches, wg.out, gs[g], hz, G == 1 ? &tail : nullptr);
+      if (rc_loop != MDM_OK) break;
       const size_t total = (size_t)Bg * per_sample;
       const int grid = (int)std::min<size_t>((total + 255) / 256, 2048);
-      {
+      if (!tail.done) {
         ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, gs[g]);
         MDM_LAUNCH(sampler_step_kernel, dim3(grid), dim3(256), 0, gs[g], (const float*)(x + xo), (const float*)wg.out,
                    cfg ? (const float*)(wg.out + (size_t)Bg * per_sample) : (const float*)nullptr,
