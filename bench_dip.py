@@ -68,13 +68,13 @@ def cpu_baseline(state, budget_s=12.0):
                       f"{DSTEPS} steps per motion ({per_step * 1e3:.0f} ms per batch-step)"}
 
 
-def measure(dev, rank, world, B, steps, warmup, cpu=True, mask_frames=True):
+def measure(dev, rank, world, B, steps, warmup, cpu=True, mask_frames=True, engine_options=None):
     """Time `steps` whole 196-frame generations of B motions per rank on `dev`; returns the JSON record (rank 0) or None.
     bench.py embeds this record as its `dip` sub-line so that the driver's BENCH file carries it."""
     torch.manual_seed(0)
     args = model_util.default_args(diffusion_steps=DSTEPS, arch="trans_dec", text_encoder_type="bert", context_len=CONTEXT,
                                    pred_len=PRED, mask_frames=mask_frames, guidance_param=7.5)      # DiP.md:181: `--mask_frames`
-    mdm, diffusion = model_util.create_model_and_diffusion(args)
+    mdm, diffusion = model_util.create_model_and_diffusion(args, engine_options=engine_options)
     state = {k: v.clone() for k, v in mdm.state_dict().items()}
     model = ClassifierFreeSampleModel(mdm).to(dev).eval()
     y = synthetic_y(B, dev, 1000 + rank)
@@ -129,7 +129,7 @@ def measure(dev, rank, world, B, steps, warmup, cpu=True, mask_frames=True):
                                    (" (the DiP.md:181 recipe: a frame mask on every forward)" if mask_frames else " (no frame mask reaches the kernels: A/B only)"),
                        "global_batch": GB, "mask_frames": bool(mask_frames),
                        "parallelism": f"dp{world}: batch shards, all_gather of final samples"},
-            "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3s_kernel on operand planes; K / V of the text memory: gemm_f32_kernel<X3>") + ")",
+            "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3s_kernel on operand planes + xattn_block_kernel (q projection, memory attention and out_proj of the cross-attention block in one launch); K / V of the text memory: gemm_f32_kernel<X3>") + ")",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": None, "launches": lin["launches"],
                          "avg_launch_us": round(lin["ms"] * 1e3 / max(lin["launches"], 1), 2)},
@@ -148,12 +148,14 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="motions per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mask-frames", action="store_true", help="A/B: a model built without --mask_frames (NULL lengths)")
+    ap.add_argument("--no-fused-xattn", action="store_true", help="A/B: the cross-attention block as three launches (round 4's form)")
     a = ap.parse_args()
     rank, world, local = mdist.init_from_env("nccl")
     assert world == a.gpus and torch.cuda.is_available()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    line = measure(dev, rank, world, a.batch, a.steps, a.warmup, cpu=not a.no_cpu_baseline, mask_frames=not a.no_mask_frames)
+    line = measure(dev, rank, world, a.batch, a.steps, a.warmup, cpu=not a.no_cpu_baseline, mask_frames=not a.no_mask_frames,
+                   engine_options={"dec_fused_xattn": 0} if a.no_fused_xattn else None)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

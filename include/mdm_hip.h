@@ -100,9 +100,14 @@ void mdm_destroy(mdm_model_t* m);
  *                                 (csrc/gemm_x3.h).  Default 40 (the measured cross-over).  0: never -- which also sends the
  *                                 trans_dec (DiP) decoder to its fp32-skeleton route (csrc/gemm_f32.h).  The parity tests use it
  *                                 to hold every route against the reference's fixtures.
- *   MDM_OPT_SMALL_GEMM_ROW_TILES  0 (default): 32-row tiles up to 12 sequences, 64-row tiles above; 1 / 2: pin 32 / 64 rows. */
+ *   MDM_OPT_SMALL_GEMM_ROW_TILES  0 (default): 32-row tiles up to 12 sequences, 64-row tiles above; 1 / 2: pin 32 / 64 rows.
+ *   MDM_OPT_DEC_FUSED_XATTN       1 (default): the cross-attention block of a trans_dec layer on the operand-plane route -- query
+ *                                 projection with norm1 folded, attention over the text memory, out_proj + residual + row statistics
+ *                                 (model/mdm.py:85-93, :263-265) -- runs as ONE kernel (csrc/xattn_block.h) where its shapes are covered
+ *                                 (latent_dim 256 / 512, <= 96 memory tokens); 0: as three launches (round 4's form; A/B and tests). */
 #define MDM_OPT_SMALL_GEMM_MAX_SEQS 1
 #define MDM_OPT_SMALL_GEMM_ROW_TILES 2
+#define MDM_OPT_DEC_FUSED_XATTN 3
 int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value);
 int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value);
 

@@ -24,6 +24,7 @@
 #include "gemm_f32.h"
 #include "gemm_x3.h"
 #include "gemm_x3s.h"
+#include "xattn_block.h"
 #ifdef MDM_PROBES
 #include "gemm_f16f6.h"
 #endif
@@ -167,6 +168,7 @@ struct mdm_model {
   float *c_out = nullptr, *b_out = nullptr;
   bool lnfold = false;                      // f16x3 mode without LayerNorm kernels (set by mdm_prepare)
   X3sOptions x3s;                           // which forwards run on gemm_x3s.h's small tiles (mdm_set_option)
+  bool fused_xattn = true;                  // trans_dec plane route: the cross-attention block as one kernel (xattn_block.h)
   X3Weights out_planes{nullptr, nullptr};  // poseFinal.weight, rows padded to jf_out (f16x3 OutputProcess)
   float* out_bias_pad = nullptr;            // poseFinal.bias padded to jf_out
   int jf_out = 0;                           // njoints*nfeats rounded up to a multiple of 4
@@ -865,6 +867,10 @@ int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value) {
       if (value < 0 || value > 2) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_SMALL_GEMM_ROW_TILES must be 0 (by size), 1 or 2");
       m->x3s.row_tiles = value;
       return MDM_OK;
+    case MDM_OPT_DEC_FUSED_XATTN:
+      if (value != 0 && value != 1) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_DEC_FUSED_XATTN must be 0 or 1");
+      m->fused_xattn = value != 0;
+      return MDM_OK;
     default:
       return fail(MDM_EINVAL, "mdm_set_option: unknown key " + std::to_string(key));
   }
@@ -875,6 +881,7 @@ int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value) {
   switch (key) {
     case MDM_OPT_SMALL_GEMM_MAX_SEQS: *value = m->x3s.max_seqs; return MDM_OK;
     case MDM_OPT_SMALL_GEMM_ROW_TILES: *value = m->x3s.row_tiles; return MDM_OK;
+    case MDM_OPT_DEC_FUSED_XATTN: *value = m->fused_xattn ? 1 : 0; return MDM_OK;
     default: return fail(MDM_EINVAL, "mdm_get_option: unknown key " + std::to_string(key));
   }
 }
@@ -1330,16 +1337,42 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, l == 0 ? 1 : 2, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"), a,
                                 nullptr, Yh, Yl, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
     }
-    // ---- X = norm1(Y) + multihead_attn(norm1(Y), memory, memory): fp32 queries (pre-scaled), k | v from the memory
+    // ---- X = norm1(Y) + multihead_attn(norm1(Y), memory, memory).  One kernel (xattn_block.h: q projection with norm1 folded ->
+    // attention over the memory -> out_proj + norm1 residual + row statistics) where its shapes are covered; else three launches:
+    // fp32 queries (pre-scaled) from the small GEMM, the exact-fp32 attention kernel over k | v of the memory, the small GEMM again
+    const bool fused = m->fused_xattn && xattn_block_supported(D, ntok) && scols == 128;
+    if (!hoisted) {
+      const float* wc = m->L(l, "multihead_attn.in_proj_weight");
+      const float* bc = m->L(l, "multihead_attn.in_proj_bias");
+      if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s, true)) return rc;
+    }
+    if (fused) {
+      XattnArgs xa{};
+      xa.y = Y; xa.ystat = sY; xa.wq = P.q; xa.cq = F.c_q; xa.bq = F.b_q; xa.qscale = qscale;
+      if (!hoisted) {
+        xa.k = ws.kv; xa.v = ws.kv + D; xa.kadd = xa.vadd = nullptr; xa.kv_B = 0; xa.kv_b0 = 0;
+      } else {
+        const float* kvt = hz.kv_text + (size_t)l * ((size_t)nbranch * hz.kv_B * ntok) * 2 * D;
+        const float* row = hz.kv_time + ((size_t)l * hz.nsteps + hz.step) * 2 * D;
+        xa.k = kvt; xa.v = kvt + D; xa.kadd = row; xa.vadd = row + D; xa.kv_B = hz.kv_B; xa.kv_b0 = hz.kv_b0;
+      }
+      xa.ldkv = 2 * D; xa.text_lengths = text_lengths; xa.ntok = ntok; xa.B = B;
+      xa.wo = P.out_proj2; xa.bo = m->L(l, "multihead_attn.out_proj.bias");
+      xa.gamma = m->L(l, "norm1.weight"); xa.beta = m->L(l, "norm1.bias");
+      xa.oh = Xh; xa.ol = Xl; xa.ostat = sX; xa.M = M; xa.S = S; xa.inv_dim = inv_dim; xa.acc_scale = kX3AccScale;
+      // (profiled as ONE launch of the GEMM class: 2 D^2 per row twice + the attention contractions)
+      ProfScope ps(pf, MDM_PROF_LINEAR, 4.0 * M * (double)D * D + 4.0 * M * (double)ntok * D, s);
+      const int rc = launch_xattn_block(xa, D, s);
+      if (rc == -1) return fail(MDM_EHIP, "cross-attention block: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      if (rc != 0) return fail(MDM_EUNSUPPORTED, "cross-attention block: unsupported shape");
+      if (int rc2 = rt_launch_status()) return rc2;
+    } else {
     {
       LnArgs a = LN(); a.astat = sY; a.colsum = F.c_q;
       if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 4, Y, P.q, F.b_q, a, q32, nullptr, nullptr, nullptr, M, D, D, S, D, D, qscale,
                                 s)) return rc;
     }
     if (!hoisted) {
-      const float* wc = m->L(l, "multihead_attn.in_proj_weight");
-      const float* bc = m->L(l, "multihead_attn.in_proj_bias");
-      if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s, true)) return rc;
       const AttnF32Args a{q32, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
       if (int rc = launch_attention_args(pf, a, nullptr, nseq, D, H, ws.atth, ws.attl, s)) return rc;
     } else {
@@ -1357,6 +1390,7 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, attp, P.out_proj2, m->L(l, "multihead_attn.out_proj.bias"), a, nullptr,
                                 Xh, Xl, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
     }
+    }   // !fused
     // ---- Y = norm2(X) + linear2(gelu(linear1(norm2(X))))
     {
       LnArgs a = LN(); a.astat = sX; a.colsum = F.c_1;
@@ -1812,12 +1846,22 @@ int mdm_debug_set(int what, int value) {
   if (what == 6) x3_pipe_probe() = value;
 #ifndef MDM_EMU
   if (what == 9) { x3s_tl_target() = value; x3s_tl_count() = 0; }   // gemm_x3s.h timeline probe: stamp the value-th launch from now
+  if (what == 10) { xb_tl_target() = value; xb_tl_count() = 0; }    // xattn_block.h timeline probe
 #endif
   return MDM_OK;
 }
 
 int mdm_debug_get(int idx, double* out) {   // ABL & 128 cycle counters of gemm_x3.h; idx < 0 resets them
 #ifndef MDM_EMU
+  if (idx >= 200000) {   // xattn_block.h timeline stamps (read once at idx == 200000, then served from the host copy)
+    static std::vector<unsigned long long> tl(8 * XB_TL_WGS);
+    if (idx - 200000 >= 8 * XB_TL_WGS || out == nullptr) return fail(MDM_EINVAL, "mdm_debug_get: bad timeline index");
+    if (idx == 200000 && (hipDeviceSynchronize() != hipSuccess ||
+                          hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_xb_tl), tl.size() * sizeof(unsigned long long)) != hipSuccess))
+      return fail(MDM_EHIP, "mdm_debug_get: reading the timeline failed");
+    *out = (double)tl[idx - 200000];
+    return MDM_OK;
+  }
   if (idx >= 100) {   // gemm_x3s.h timeline stamps (read once at idx == 100, then served from the host copy)
     static std::vector<unsigned long long> tl(4 * X3S_TL_WGS);
     if (idx - 100 >= 4 * X3S_TL_WGS || out == nullptr) return fail(MDM_EINVAL, "mdm_debug_get: bad timeline index");

@@ -11,7 +11,7 @@ import os
 import torch
 import torch.distributed as dist
 
-_SHARDED_KEYS = ("mask", "lengths", "scale", "inpainting_mask", "inpainted_motion")
+_SHARDED_KEYS = ("mask", "lengths", "scale", "inpainting_mask", "inpainted_motion", "prefix")
 
 
 def init_from_env(backend=None, force=False):
@@ -49,6 +49,9 @@ def shard_y(y, lo, hi):
     for k, v in y.items():
         if k == "text_embed" and torch.is_tensor(v):
             out[k] = v[:, lo:hi]                         # [1, B, clip_dim]
+        elif k == "text_embed" and isinstance(v, tuple):  # DiP: (tokens [Ntok, B, 768], pad mask [B or 1, Ntok]) (model/mdm.py:180-187)
+            tok, pad = v
+            out[k] = (tok[:, lo:hi], pad if pad.shape[0] == 1 else pad[lo:hi])
         elif k == "text" and isinstance(v, (list, tuple)):
             out[k] = list(v[lo:hi])
         elif k in _SHARDED_KEYS and torch.is_tensor(v) and v.dim() >= 1:
@@ -94,6 +97,29 @@ def sample_sharded(diffusion, model, shape, model_kwargs, *, seed, ddim=False, g
     try:
         fn = diffusion.ddim_sample_loop if ddim else diffusion.p_sample_loop
         local = fn(model, (hi - lo,) + tuple(shape[1:]), model_kwargs=kw, seed=seed, **loop_kw)
+    finally:
+        diffusion.sample_base = prev
+    return all_gather_samples(local, B, world) if gather else local
+
+
+def autoregressive_sharded(sampler, diffusion, model, shape, model_kwargs, *, gather=True, **sample_kw):
+    """DiP across ranks (BASELINE.json configs[4]: 256 motions over 8 GPUs): `sampler.sample(model, shape, ...)` -- an
+    `AutoRegressiveSampler` whose `sample_fn` draws its per-window seeds identically on every rank -- for the GLOBAL batch
+    `shape[0]`, one contiguous shard per rank.  As in `sample_sharded` the data path has no collective: `diffusion.sample_base`
+    carries the shard's first global sample index into every window's Philox streams, so that the gathered `[B, J, F, frames]`
+    batch is bit-identical to the one-rank run; one all-gather at the end."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    B = int(shape[0])
+    lo, hi = shard_bounds(B, rank, world)
+    if hi == lo:
+        raise ValueError(f"batch {B} is smaller than the world size {world}")
+    kw = dict(model_kwargs or {})
+    kw["y"] = shard_y(kw.get("y", {}), lo, hi)
+    prev = diffusion.sample_base
+    diffusion.sample_base = lo
+    try:
+        local = sampler.sample(model, (hi - lo,) + tuple(shape[1:]), model_kwargs=kw, **sample_kw)
     finally:
         diffusion.sample_base = prev
     return all_gather_samples(local, B, world) if gather else local

@@ -48,3 +48,54 @@ def test_two_rank_sharded_sampling_equals_unsharded(tmp_path):
     r = torch.load(out)
     assert torch.equal(r["full"], r["ref"])
     assert torch.isfinite(r["full"]).all()
+
+
+def _worker_dip(rank, world, port, out_path):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from types import SimpleNamespace
+    from emu_lib import emu
+    from helpers import dip_small_state_dict, make_pair, synth_dip_y
+    from mdm_amd import dist as mdist
+    from mdm_amd.sampler_util import AutoRegressiveSampler
+    mdist.init_from_env("gloo")
+    steps, B, C, P, frames = 2, 3, 5, 12, 30           # ragged shards (2 + 1), 3 windows (12 + 12 + 6 frames)
+    sd = dip_small_state_dict(num_layers=1)
+    y = synth_dip_y(B, P, C, seed=3, text_lengths=[6, 2, 5], lengths=[12, 12, 9], scale=2.5)
+    args = SimpleNamespace(pred_len=P, context_len=C, autoregressive_include_prefix=False)
+    res = {}
+    for prec in ("f32", "f16x3"):
+        model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=emu(), context_len=C, pred_len=P, mask_frames=True,
+                                     precision=prec)
+
+        def sampler():                                 # per-window seeds: the same sequence on every rank
+            it = iter(range(500, 510))
+            return AutoRegressiveSampler(args, lambda m, shp, **kw: diffusion.p_sample_loop(m, shp, seed=next(it), **kw), frames)
+
+        full = mdist.autoregressive_sharded(sampler(), diffusion, model, (B, 263, 1, frames), {"y": y}, clip_denoised=False)
+        assert full.shape == (B, 263, 1, frames) and diffusion.sample_base == 0
+        if rank == 0:
+            res[prec] = (full, sampler().sample(model, (B, 263, 1, frames), clip_denoised=False, model_kwargs={"y": dict(y)}))
+    if rank == 0:
+        torch.save(res, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_autoregressive_dip_equals_unsharded(tmp_path):
+    """VERDICT r04 item 7 / SURVEY 8e for BASELINE.json configs[4]: the DiP window loops of a batch sharded over two `gloo` ranks
+    (mdm_amd.dist.autoregressive_sharded: per-window seeds + `sample_base`, sharded prefix / token embeddings / masks) gather to
+    the one-rank result: bit for bit in the exact-fp32 mode; in f16x3 up to the re-association of the hoisted memory projection, a
+    GEMM whose tile shape follows its row count (csrc/gemm_f32.h; cf. test_emulated_dip_window_loop_sample_groups)."""
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    from emu_lib import emu
+    emu()
+    out = str(tmp_path / "out_dip.pt")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_dip, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert torch.equal(*r["f32"]) and torch.isfinite(r["f32"][0]).all()
+    assert float((r["f16x3"][0] - r["f16x3"][1]).abs().max()) < 2e-5 and torch.isfinite(r["f16x3"][0]).all()

@@ -599,3 +599,40 @@ def test_engine_options_are_set_through_the_abi_not_the_environment(lib, monkeyp
         e.set_option("small_gemm_row_tiles", 3)
     with pytest.raises(ValueError):
         e.set_option("no_such_option", 1)
+
+
+@pytest.mark.parametrize("B,C,P,text_lengths,lengths", [(3, 5, 12, [6, 3, 2], [12, 7, 12]),      # S = 17: one 17-row tile per sequence
+                                                         (2, 3, 70, [70, 3], None),              # S = 73: 32 + 32 + 9 rows; 3 key tiles
+                                                         (2, 0, 33, [40, 9], [33, 20])])         # no prefix; S = 33: 32 + 1; 2 key tiles
+def test_emulated_dip_fused_cross_attention_block(lib, engine_options, B, C, P, text_lengths, lengths):
+    """csrc/xattn_block.h (round 5): query projection with norm1 folded -> attention over the text memory -> out_proj + norm1
+    residual + row statistics as ONE kernel per decoder layer, against the oracle and against the three-launch form it replaces
+    (dec_fused_xattn = 0: the small GEMM twice around the exact-fp32 attention kernel): same values to the last few bits, not the
+    same bits (the attention contractions are split-precision here, exact fp32 there).  Forward (memory projected per call) and
+    window loop (text K / V hoisted, the step's time row added while the fragments are built)."""
+    steps = 2
+    sd = dip_small_state_dict(num_layers=2)
+    masked = lengths is not None
+    y = synth_dip_y(B, P, max(C, 1), seed=3, text_lengths=text_lengths, lengths=lengths, scale=2.5)
+    if C == 0:
+        y.pop("prefix")
+    else:
+        y["prefix"] = y["prefix"][..., :C].contiguous()
+    x = torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(1))
+    t = torch.arange(B) % steps
+    g = torch.Generator().manual_seed(9)
+    seq = [torch.randn(B, 263, 1, P, generator=g) for _ in range(1 + steps)]
+    kw = dict(context_len=C, num_heads=2, mask_frames=masked)
+    want_f = dip.dip_cfg_forward(sd, x, t, y, **kw)
+    want_l = dip.dip_sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), (B, 263, 1, P), y, seq[0], seq[1:],
+                                 context_len=C, cfg=True, num_heads=2, mask_frames=masked)
+    outs = {}
+    for fused in (1, 0):
+        engine_options(dec_fused_xattn=fused, small_gemm_row_tiles=1)
+        model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, mask_frames=masked)
+        assert model.model.engine().get_option("dec_fused_xattn") == fused
+        f = model(x, t, y=dict(y))
+        lo = diffusion.p_sample_loop(model, (B, 263, 1, P), clip_denoised=False, model_kwargs={"y": dict(y)}, noise_sequence=seq)
+        assert maxabs(f, want_f) < 5e-5 and maxabs(lo, want_l) < 5e-5, fused
+        outs[fused] = (f, lo)
+    assert not torch.equal(outs[0][0], outs[1][0]) and maxabs(outs[0][0], outs[1][0]) < 2e-5

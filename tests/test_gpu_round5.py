@@ -164,3 +164,70 @@ def test_sample_loop_is_captured_into_a_hip_graph_on_a_side_stream(arch):
     # and the eager path still works afterwards (the guard's "previous stream" is the capture stream, which may be gone)
     again = diffusion.p_sample_loop(model, shape, noise=xs[1], clip_denoised=False, model_kwargs={"y": dict(y)}, seed=77)
     assert torch.equal(again, eager[1])
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_dip_fused_cross_attention_block_matches_reference_goldens(golden_dir, engine_options, fused):
+    """csrc/xattn_block.h (the cross-attention block of a decoder layer as one kernel) against the UPSTREAM reference's own outputs:
+    the B = 3 forwards (plain and frame-masked), the 100-frame autoregressive generation (3 windows x 10 steps, CFG 7.5) -- and the
+    three-launch form it replaces (dec_fused_xattn = 0) on the same fixtures."""
+    from types import SimpleNamespace
+    from mdm_amd.sampler_util import AutoRegressiveSampler
+    engine_options(dec_fused_xattn=fused)
+    sd_dip = memo("sd_dip0", lambda: synth_dip_state_dict(seed=0))
+    errs = []
+    for name, masked in (("dip_fwd_B3", False), ("dip_fwd_masked_B3", True)):
+        g = _g(golden_dir, name)
+        model, _ = make_pair(sd_dip, 10, DEV, guided=True, context_len=20, pred_len=40, mask_frames=masked)
+        assert model.model.engine().get_option("dec_fused_xattn") == fused
+        y = to_dev(synth_dip_y(3, 40, 20, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]),
+                               lengths=list(g["lengths"]) if masked else None), DEV)
+        x = torch.randn(3, 263, 1, 40, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV)
+        t = torch.from_numpy(g["t"]).to(DEV)
+        errs.append(maxabs(model.model(x, t, y=dict(y)).cpu(), g["out_cond"]))
+        if not masked:
+            errs.append(maxabs(model.model(x, t, y={**y, "uncond": True}).cpu(), g["out_uncond"]))
+            e_g = maxabs(model(x, t, y=dict(y)).cpu(), g["out_cfg"])
+    g = _g(golden_dir, "dip_ar10_B2_F100")
+    steps, B, frames, seed = int(g["steps"]), int(g["B"]), int(g["frames"]), int(g["seed"])
+    model, diffusion = make_pair(sd_dip, steps, DEV, guided=True, context_len=20, pred_len=40)
+    y = to_dev(synth_dip_y(B, 40, 20, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]), scale=float(g["scale"])), DEV)
+    chunks = iter(dip.make_noise_chunks((B, 263, 1, 40), steps, seed, 3))
+
+    def sample_fn(mdl, shape, **kw):
+        x_T, eps = next(chunks)
+        return diffusion.p_sample_loop(mdl, shape, noise_sequence=[x_T] + [e.contiguous() for e in eps], **kw)
+
+    args = SimpleNamespace(pred_len=40, context_len=20, autoregressive_include_prefix=False)
+    out = AutoRegressiveSampler(args, sample_fn, frames).sample(
+        model, (B, 263, 1, frames), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, init_image=None,
+        progress=False, dump_steps=None, noise=None, const_noise=False)
+    e_ar = maxabs(out.cpu(), g["final"])
+    print(f"[parity] DiP cross-attention block {'fused (xattn_block_kernel)' if fused else 'as three launches'}: forwards vs reference "
+          f"{errs[0]:.3e} / {errs[1]:.3e} / masked {errs[2]:.3e}, guided {e_g:.3e}; dip_ar10_B2_F100 {e_ar:.3e}")
+    assert max(errs) < TOL_DIP_FWD and e_g < 5e-5 and e_ar < TOL_DIP_AR
+
+
+@pytest.mark.parametrize("B,C,P,text_lengths,lengths", [(2, 0, 64, [70, 3], [64, 31]), (3, 8, 100, [5, 5, 12], [100, 2, 57]),
+                                                         (4, 20, 40, [33, 40, 1, 17], None)])
+def test_dip_fused_cross_attention_block_other_shapes(engine_options, B, C, P, text_lengths, lengths):
+    """The fused block at other shapes than DiP's 20 + 40 / 24 tokens: 70 and 40 memory tokens (3 / 2 key tiles), a 108-token window
+    (32 + 32 + 32 + 12 rows), no prefix, against the oracle and against the three-launch form."""
+    sd_dip = memo("sd_dip0", lambda: synth_dip_state_dict(seed=0))
+    masked = lengths is not None
+    y = synth_dip_y(B, P, max(C, 1), seed=B, text_lengths=text_lengths, lengths=lengths)
+    if C == 0:
+        y.pop("prefix")
+    else:
+        y["prefix"] = y["prefix"][..., :C].contiguous()
+    x = torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(P))
+    t = torch.arange(B) % 10
+    want = dip.dip_forward(sd_dip, x, t, y, context_len=C, mask_frames=masked)
+    outs = []
+    for fused in (1, 0):
+        engine_options(dec_fused_xattn=fused)
+        model, _ = make_pair(sd_dip, 10, DEV, guided=False, context_len=C, pred_len=P, mask_frames=masked)
+        outs.append(model(x.to(DEV), t.to(DEV), y=to_dev(y, DEV)).cpu())
+    e1, e0 = maxabs(outs[0], want), maxabs(outs[1], want)
+    print(f"[parity] DiP forward B={B} C={C} P={P} ntok={max(text_lengths)}: fused block {e1:.3e}, three launches {e0:.3e} (max-abs vs oracle)")
+    assert e1 < TOL_DIP_FWD and e0 < TOL_DIP_FWD and not torch.equal(outs[0], outs[1])
