@@ -104,10 +104,14 @@ void mdm_destroy(mdm_model_t* m);
  *   MDM_OPT_DEC_FUSED_XATTN       1 (default): the cross-attention block of a trans_dec layer on the operand-plane route -- query
  *                                 projection with norm1 folded, attention over the text memory, out_proj + residual + row statistics
  *                                 (model/mdm.py:85-93, :263-265) -- runs as ONE kernel (csrc/xattn_block.h) where its shapes are covered
- *                                 (latent_dim 256 / 512, <= 96 memory tokens); 0: as three launches (round 4's form; A/B and tests). */
+ *                                 (latent_dim 256 / 512, <= 96 memory tokens); 0: as three launches (round 4's form; A/B and tests).
+ *   MDM_OPT_DEC_FUSED_SELFATTN    1 (default): in_proj + self-attention of a trans_dec layer on the operand-plane route run as ONE
+ *                                 kernel per (sequence, head) for sequences of at most 64 tokens (csrc/selfattn_block.h: DiP's 20 + 40);
+ *                                 0: in_proj into Q / K / V^T planes + the attention kernel (two launches; A/B and tests). */
 #define MDM_OPT_SMALL_GEMM_MAX_SEQS 1
 #define MDM_OPT_SMALL_GEMM_ROW_TILES 2
 #define MDM_OPT_DEC_FUSED_XATTN 3
+#define MDM_OPT_DEC_FUSED_SELFATTN 4
 int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value);
 int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value);
 

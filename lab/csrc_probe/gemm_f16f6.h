@@ -22,8 +22,8 @@
 // row (column) r; scaled MFMA (K = 64 = both cross terms of the block): A lane (r, h) holds the block's 32 codes of hi (h = 0) /
 // lo (h = 1) and that part's scale in byte 0; B lane (c, h) holds the codes of lo (h = 0) / hi (h = 1) of column c.
 #pragma once
-#include "common.h"
-#include "gemm_f32.h"  // ACT_* enums
+#include "../../motion-diffusion-model_amd/csrc/common.h"
+#include "../../motion-diffusion-model_amd/csrc/gemm_f32.h"  // ACT_* enums
 
 namespace mdm {
 

@@ -380,6 +380,7 @@ __device__ __forceinline__ void gload16_async(p16x8& dst, const p16_t* p) { emu:
 __device__ __forceinline__ void gload16_refill(p16x8& slot, const p16_t* p) { emu::vm_issue(&slot, p, 16, true); }
 template <int N> __device__ __forceinline__ void vmem_wait(p16x8&, p16x8&) { emu::vm_wait(N); }
 template <int N> __device__ __forceinline__ void vmem_wait(p16x8&, p16x8&, p16x8&, p16x8&) { emu::vm_wait(N); }
+template <int N> __device__ __forceinline__ void vmem_wait(p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&) { emu::vm_wait(N); }
 template <int N>
 __device__ __forceinline__ void vmem_wait(p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&, p16x8&) { emu::vm_wait(N); }
 #else
@@ -408,6 +409,9 @@ template <int N> __device__ __forceinline__ void vmem_wait(p16x8& a, p16x8& b) {
 }
 template <int N> __device__ __forceinline__ void vmem_wait(p16x8& a, p16x8& b, p16x8& c, p16x8& d) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void vmem_wait(p16x8& a, p16x8& b, p16x8& c, p16x8& d, p16x8& e, p16x8& f) {
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "i"(N) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void vmem_wait(p16x8& a, p16x8& b, p16x8& c, p16x8& d, p16x8& e, p16x8& f, p16x8& g, p16x8& h) {

@@ -25,8 +25,9 @@
 #include "gemm_x3.h"
 #include "gemm_x3s.h"
 #include "xattn_block.h"
-#ifdef MDM_PROBES
-#include "gemm_f16f6.h"
+#include "selfattn_block.h"
+#ifdef MDM_PROBES   // the rejected fp16 + MX-FP6 GEMM arithmetic of round 1: an experiment of the probe library, kept under lab/
+#include "../../lab/csrc_probe/gemm_f16f6.h"
 #endif
 #include "motion_recover.h"
 
@@ -169,6 +170,7 @@ struct mdm_model {
   bool lnfold = false;                      // f16x3 mode without LayerNorm kernels (set by mdm_prepare)
   X3sOptions x3s;                           // which forwards run on gemm_x3s.h's small tiles (mdm_set_option)
   bool fused_xattn = true;                  // trans_dec plane route: the cross-attention block as one kernel (xattn_block.h)
+  bool fused_selfattn = true;               // ... and in_proj + self-attention of a (sequence, head) as one kernel (selfattn_block.h)
   X3Weights out_planes{nullptr, nullptr};  // poseFinal.weight, rows padded to jf_out (f16x3 OutputProcess)
   float* out_bias_pad = nullptr;            // poseFinal.bias padded to jf_out
   int jf_out = 0;                           // njoints*nfeats rounded up to a multiple of 4
@@ -871,6 +873,10 @@ int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value) {
       if (value != 0 && value != 1) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_DEC_FUSED_XATTN must be 0 or 1");
       m->fused_xattn = value != 0;
       return MDM_OK;
+    case MDM_OPT_DEC_FUSED_SELFATTN:
+      if (value != 0 && value != 1) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_DEC_FUSED_SELFATTN must be 0 or 1");
+      m->fused_selfattn = value != 0;
+      return MDM_OK;
     default:
       return fail(MDM_EINVAL, "mdm_set_option: unknown key " + std::to_string(key));
   }
@@ -882,6 +888,7 @@ int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value) {
     case MDM_OPT_SMALL_GEMM_MAX_SEQS: *value = m->x3s.max_seqs; return MDM_OK;
     case MDM_OPT_SMALL_GEMM_ROW_TILES: *value = m->x3s.row_tiles; return MDM_OK;
     case MDM_OPT_DEC_FUSED_XATTN: *value = m->fused_xattn ? 1 : 0; return MDM_OK;
+    case MDM_OPT_DEC_FUSED_SELFATTN: *value = m->fused_selfattn ? 1 : 0; return MDM_OK;
     default: return fail(MDM_EINVAL, "mdm_get_option: unknown key " + std::to_string(key));
   }
 }
@@ -1320,7 +1327,21 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
     p16_t *Xh = ws.xh[cur], *Xl = ws.xl[cur], *Yh = ws.xh[cur ^ 1], *Yl = ws.xl[cur ^ 1];
     const X3Operand X{Xh, Xl}, Y{Yh, Yl};
     float *sX = ws.stat[cur], *sY = ws.stat[cur ^ 1];
-    // ---- Y = X' + self_attn(X'), X' = norm3(l-1)(X) (the embedded tokens for l = 0)
+    // ---- Y = X' + self_attn(X'), X' = norm3(l-1)(X) (the embedded tokens for l = 0).  Sequences of at most 64 tokens (DiP: 20 + 40):
+    // in_proj + attention of a (sequence, head) in one kernel (selfattn_block.h: Q / K / V^T never leave the CU); else in_proj into
+    // operand planes + attention_x3.h
+    if (m->fused_selfattn && selfattn_block_supported(D, S)) {
+      SelfAttnArgs sa{};
+      sa.x = X; sa.xstat = l == 0 ? nullptr : sX; sa.w = P.in_proj;
+      sa.bias = l == 0 ? m->L(l, "self_attn.in_proj_bias") : F.b_in; sa.colsum = l == 0 ? nullptr : F.c_in;
+      sa.qscale = qscale; sa.lengths = len; sa.lead = 0; sa.B = B; sa.oh = ws.atth; sa.ol = ws.attl;
+      sa.M = M; sa.S = S; sa.D = D; sa.H = H; sa.stat_parts = parts; sa.stat_cols = scols; sa.inv_dim = inv_dim; sa.acc_scale = kX3AccScale;
+      ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * 3.0 * D * (double)D + 4.0 * nseq * H * (double)S * S * ATT_HD, s);
+      const int rc = launch_selfattn_block(sa, l != 0, s);
+      if (rc == -1) return fail(MDM_EHIP, "self-attention block: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      if (rc != 0) return fail(MDM_EUNSUPPORTED, "self-attention block: unsupported shape");
+      if (int rc2 = rt_launch_status()) return rc2;
+    } else {
     if (l == 0) {
       LnArgs a = LN();
       if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 6, X, P.in_proj, m->L(l, "self_attn.in_proj_bias"), a, nullptr, nullptr,
@@ -1331,6 +1352,7 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
                                 S, D, D, qscale, s)) return rc;
     }
     if (int rc = launch_attention_x3(pf, ws.qp, len, nseq, B, S, D, nullptr, ws.atth, ws.attl, s, /*lead=*/0)) return rc;
+    }   // !fused self-attention
     {
       LnArgs a = LN(); a.res = X; a.ostat = sY;
       if (l >= 1) { a.rstat = sX; a.rgamma = m->L(l - 1, "norm3.weight"); a.rbeta = m->L(l - 1, "norm3.bias"); }

@@ -17,7 +17,8 @@ def _stale():
         return True
     t = os.path.getmtime(SO)
     srcs = [os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR) if f.endswith((".h", ".hip"))]
-    srcs += [os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "mdm_hip.h")]
+    srcs += [os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "mdm_hip.h"),
+             os.path.join(ROOT, "lab", "csrc_probe", "gemm_f16f6.h")]
     return any(os.path.getmtime(s) > t for s in srcs)
 
 

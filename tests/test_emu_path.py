@@ -173,7 +173,7 @@ def test_emulated_linear_f16x3(lib, M, N, K, act, res):
 
 
 def _f16f6_reference(a, w):
-    """numpy restatement of csrc/gemm_f16f6.h's operand decomposition: fp16 hi + MX-FP6 (E2M3, power-of-two scale per 32 k)
+    """numpy restatement of lab/csrc_probe/gemm_f16f6.h's operand decomposition: fp16 hi + MX-FP6 (E2M3, power-of-two scale per 32 k)
     of hi and lo; returns sum_k ah*wh + q6(ah)*q6(wl) + q6(al)*q6(wh) in float64."""
     def q6(x):
         R, K = x.shape
@@ -636,3 +636,35 @@ def test_emulated_dip_fused_cross_attention_block(lib, engine_options, B, C, P, 
         assert maxabs(f, want_f) < 5e-5 and maxabs(lo, want_l) < 5e-5, fused
         outs[fused] = (f, lo)
     assert not torch.equal(outs[0][0], outs[1][0]) and maxabs(outs[0][0], outs[1][0]) < 2e-5
+
+
+@pytest.mark.parametrize("B,C,P,text_lengths,holes", [(3, 5, 12, [6, 3, 2], True),       # S = 17: one sub-tile, 47 pad rows
+                                                       (2, 20, 40, [9, 24], False),      # S = 60: DiP's window
+                                                       (2, 0, 64, [5, 9], True)])        # S = 64: the full tile, no prefix
+def test_emulated_dip_fused_self_attention_block(lib, engine_options, B, C, P, text_lengths, holes):
+    """csrc/selfattn_block.h (round 5): in_proj (norm3 of the previous layer folded for l >= 1) + self-attention of a (sequence, head)
+    as ONE kernel for sequences of at most 64 tokens -- Q, K, V^T live in LDS fragment images instead of 35 MB of planes per layer.
+    Against the oracle and against the two-launch form (dec_fused_selfattn = 0: gemm_x3s kind 0 / 6 + attention_x3_kernel), with
+    frame masks as counts and as bitmaps (lead = 0), two layers (plain and folded in_proj)."""
+    sd = dip_small_state_dict(num_layers=2)
+    lengths = [P - 3 * i for i in range(B)]
+    y = synth_dip_y(B, P, max(C, 1), seed=3, text_lengths=text_lengths, lengths=lengths, scale=2.5)
+    if C == 0:
+        y.pop("prefix")
+    else:
+        y["prefix"] = y["prefix"][..., :C].contiguous()
+    if holes:
+        y["mask"] = y["mask"].clone()
+        y["mask"][0, 0, 0, [1, 4]] = False
+        y["mask"][B - 1, 0, 0, [0, 2, 3]] = False
+    x = torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(1))
+    t = torch.arange(B) % 10
+    want = dip.dip_cfg_forward(sd, x, t, y, context_len=C, num_heads=2, mask_frames=True)
+    outs = {}
+    for fused in (1, 0):
+        engine_options(dec_fused_selfattn=fused, small_gemm_row_tiles=1)
+        model, _ = make_pair(sd, 10, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, mask_frames=True)
+        assert model.model.engine().get_option("dec_fused_selfattn") == fused
+        outs[fused] = model(x, t, y=dict(y))
+        assert maxabs(outs[fused], want) < 5e-5, fused
+    assert maxabs(outs[0], outs[1]) < 2e-5

@@ -112,7 +112,7 @@ def test_loop_matches_reference_golden(gemm_path, golden_dir, sd, name, prec):
 
 
 def test_f16f6_arithmetic_on_the_reference_trajectory(golden_dir, sd):
-    """The NEXT GEMM arithmetic (fp16 pass + one scaled MX-FP6 MFMA per 32-k block, csrc/gemm_f16f6.h on the production GEMM
+    """The NEXT GEMM arithmetic (fp16 pass + one scaled MX-FP6 MFMA per 32-k block, lab/csrc_probe/gemm_f16f6.h on the production GEMM
     skeleton) held against the reference's 50-step guided trajectory through the product seams: `f32` mode with its encoder
     GEMMs routed, unfused, to the f16f6 kernel (mdm_debug_set(5, 1), a test-only switch).  tools/precision_probe.py predicts
     ~1e-4 from a CPU emulation of the same decomposition; the bar of the shipped f16x3 mode is 5e-4, BASELINE's 1e-3."""
@@ -307,7 +307,7 @@ def test_mdm_linear_x3(M, N, K, act, res):
                                                       (197 * 256, 1536, 512, 0, False, False), (197 * 256, 512, 512, 0, True, False),
                                                       (197 * 64, 1024, 512, 1, False, False), (197 * 64 + 5, 512, 1024, 0, True, False)])
 def test_mdm_linear_f16f6(M, N, K, act, res, ref_kernel):
-    """Seed of the next GEMM (csrc/gemm_f16f6.h) on the real instructions: one v_mfma_f32_32x32x16_f16 pass + two
+    """Seed of the next GEMM (lab/csrc_probe/gemm_f16f6.h) on the real instructions: one v_mfma_f32_32x32x16_f16 pass + two
     v_mfma_scale_f32_32x32x64_f8f6f4 (MX-FP6) cross terms against fp64; the error budget is ~3x the bf16 split's (1.2e-5 of rms)."""
     lib = _probe()
     g = torch.Generator().manual_seed(M + N)

@@ -166,14 +166,15 @@ def test_sample_loop_is_captured_into_a_hip_graph_on_a_side_stream(arch):
     assert torch.equal(again, eager[1])
 
 
-@pytest.mark.parametrize("fused", [1, 0])
-def test_dip_fused_cross_attention_block_matches_reference_goldens(golden_dir, engine_options, fused):
-    """csrc/xattn_block.h (the cross-attention block of a decoder layer as one kernel) against the UPSTREAM reference's own outputs:
-    the B = 3 forwards (plain and frame-masked), the 100-frame autoregressive generation (3 windows x 10 steps, CFG 7.5) -- and the
-    three-launch form it replaces (dec_fused_xattn = 0) on the same fixtures."""
+@pytest.mark.parametrize("fused,fused_sa", [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_dip_fused_cross_attention_block_matches_reference_goldens(golden_dir, engine_options, fused, fused_sa):
+    """csrc/xattn_block.h (the cross-attention block of a decoder layer as one kernel) and csrc/selfattn_block.h (in_proj +
+    self-attention of a (sequence, head) as one kernel) against the UPSTREAM reference's own outputs: the B = 3 forwards (plain and
+    frame-masked), the 100-frame autoregressive generation (3 windows x 10 steps, CFG 7.5) -- and the multi-launch forms they replace
+    (dec_fused_xattn = 0 / dec_fused_selfattn = 0) on the same fixtures."""
     from types import SimpleNamespace
     from mdm_amd.sampler_util import AutoRegressiveSampler
-    engine_options(dec_fused_xattn=fused)
+    engine_options(dec_fused_xattn=fused, dec_fused_selfattn=fused_sa)
     sd_dip = memo("sd_dip0", lambda: synth_dip_state_dict(seed=0))
     errs = []
     for name, masked in (("dip_fwd_B3", False), ("dip_fwd_masked_B3", True)):
@@ -203,7 +204,8 @@ def test_dip_fused_cross_attention_block_matches_reference_goldens(golden_dir, e
         model, (B, 263, 1, frames), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, init_image=None,
         progress=False, dump_steps=None, noise=None, const_noise=False)
     e_ar = maxabs(out.cpu(), g["final"])
-    print(f"[parity] DiP cross-attention block {'fused (xattn_block_kernel)' if fused else 'as three launches'}: forwards vs reference "
+    print(f"[parity] DiP cross-attention block {'fused (xattn_block_kernel)' if fused else 'as three launches'}, self-attention "
+          f"{'fused (selfattn_block_kernel)' if fused_sa else 'as two launches'}: forwards vs reference "
           f"{errs[0]:.3e} / {errs[1]:.3e} / masked {errs[2]:.3e}, guided {e_g:.3e}; dip_ar10_B2_F100 {e_ar:.3e}")
     assert max(errs) < TOL_DIP_FWD and e_g < 5e-5 and e_ar < TOL_DIP_AR
 
@@ -231,3 +233,31 @@ def test_dip_fused_cross_attention_block_other_shapes(engine_options, B, C, P, t
     e1, e0 = maxabs(outs[0], want), maxabs(outs[1], want)
     print(f"[parity] DiP forward B={B} C={C} P={P} ntok={max(text_lengths)}: fused block {e1:.3e}, three launches {e0:.3e} (max-abs vs oracle)")
     assert e1 < TOL_DIP_FWD and e0 < TOL_DIP_FWD and not torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("B,C,P,text_lengths,holes", [(5, 20, 40, [1, 9, 24, 17, 12], True), (3, 0, 64, [5, 9, 70], True), (4, 5, 12, [6, 3, 2, 9], False)])
+def test_dip_fused_self_attention_block_other_shapes(engine_options, B, C, P, text_lengths, holes):
+    """selfattn_block_kernel at DiP's window with ragged / holed frame masks, at the full 64-token tile without a prefix, at a 17-token
+    window, against the oracle and against the two-launch form."""
+    sd_dip = memo("sd_dip0", lambda: synth_dip_state_dict(seed=0))
+    lengths = [max(P - 7 * i, 1) for i in range(B)]
+    y = synth_dip_y(B, P, max(C, 1), seed=B, text_lengths=text_lengths, lengths=lengths)
+    if C == 0:
+        y.pop("prefix")
+    else:
+        y["prefix"] = y["prefix"][..., :C].contiguous()
+    if holes:
+        y["mask"] = y["mask"].clone()
+        y["mask"][0, 0, 0, [1, 4, 9]] = False
+        y["mask"][B - 1, 0, 0, [0]] = False
+    x = torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(P))
+    t = torch.arange(B) % 10
+    want = dip.dip_forward(sd_dip, x, t, y, context_len=C, mask_frames=True)
+    outs = []
+    for fused in (1, 0):
+        engine_options(dec_fused_selfattn=fused)
+        model, _ = make_pair(sd_dip, 10, DEV, guided=False, context_len=C, pred_len=P, mask_frames=True)
+        outs.append(model(x.to(DEV), t.to(DEV), y=to_dev(y, DEV)).cpu())
+    e1, e0 = maxabs(outs[0], want), maxabs(outs[1], want)
+    print(f"[parity] DiP forward B={B} C={C} P={P} masked{' + holes' if holes else ''}: fused self-attention {e1:.3e}, two launches {e0:.3e} (max-abs vs oracle)")
+    assert e1 < TOL_DIP_FWD and e0 < TOL_DIP_FWD
