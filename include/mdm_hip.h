@@ -101,10 +101,13 @@ void mdm_destroy(mdm_model_t* m);
  *                                 trans_dec (DiP) decoder to its fp32-skeleton route (csrc/gemm_f32.h).  The parity tests use it
  *                                 to hold every route against the reference's fixtures.
  *   MDM_OPT_SMALL_GEMM_ROW_TILES  0 (default): 32-row tiles up to 12 sequences, 64-row tiles above; 1 / 2: pin 32 / 64 rows.
- *   MDM_OPT_DEC_FUSED_XATTN       1 (default): the cross-attention block of a trans_dec layer on the operand-plane route -- query
- *                                 projection with norm1 folded, attention over the text memory, out_proj + residual + row statistics
- *                                 (model/mdm.py:85-93, :263-265) -- runs as ONE kernel (csrc/xattn_block.h) where its shapes are covered
- *                                 (latent_dim 256 / 512, <= 96 memory tokens); 0: as three launches (round 4's form; A/B and tests).
+ *   MDM_OPT_DEC_FUSED_XATTN       the cross-attention block of a trans_dec layer on the operand-plane route -- query projection with
+ *                                 norm1 folded, attention over the text memory, out_proj + residual + row statistics (model/mdm.py:
+ *                                 85-93, :263-265).  2 (default): projection + attention of a (sequence, head) in one kernel
+ *                                 (csrc/selfattn_block.h, CROSS mode: windows and memories of at most 64 tokens), then the out_proj
+ *                                 GEMM; 1: the whole block as ONE kernel (csrc/xattn_block.h: latent_dim 256 / 512, <= 96 memory
+ *                                 tokens); 0: as three launches around the exact-fp32 attention kernel (round 4's form).  A value
+ *                                 whose shapes are not covered falls through to the next lower one.
  *   MDM_OPT_DEC_FUSED_SELFATTN    1 (default): in_proj + self-attention of a trans_dec layer on the operand-plane route run as ONE
  *                                 kernel per (sequence, head) for sequences of at most 64 tokens (csrc/selfattn_block.h: DiP's 20 + 40);
  *                                 0: in_proj into Q / K / V^T planes + the attention kernel (two launches; A/B and tests). */

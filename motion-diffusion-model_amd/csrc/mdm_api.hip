@@ -169,7 +169,9 @@ struct mdm_model {
   float *c_out = nullptr, *b_out = nullptr;
   bool lnfold = false;                      // f16x3 mode without LayerNorm kernels (set by mdm_prepare)
   X3sOptions x3s;                           // which forwards run on gemm_x3s.h's small tiles (mdm_set_option)
-  bool fused_xattn = true;                  // trans_dec plane route: the cross-attention block as one kernel (xattn_block.h)
+  int fused_xattn = 2;                      // trans_dec plane route, the cross-attention block: 2 = q projection + memory attention per
+                                            // (sequence, head) (selfattn_block.h CROSS) + out_proj GEMM; 1 = one kernel (xattn_block.h);
+                                            // 0 = q projection, exact-fp32 attention kernel, out_proj: three launches
   bool fused_selfattn = true;               // ... and in_proj + self-attention of a (sequence, head) as one kernel (selfattn_block.h)
   X3Weights out_planes{nullptr, nullptr};  // poseFinal.weight, rows padded to jf_out (f16x3 OutputProcess)
   float* out_bias_pad = nullptr;            // poseFinal.bias padded to jf_out
@@ -870,8 +872,8 @@ int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value) {
       m->x3s.row_tiles = value;
       return MDM_OK;
     case MDM_OPT_DEC_FUSED_XATTN:
-      if (value != 0 && value != 1) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_DEC_FUSED_XATTN must be 0 or 1");
-      m->fused_xattn = value != 0;
+      if (value < 0 || value > 2) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_DEC_FUSED_XATTN must be 0, 1 or 2");
+      m->fused_xattn = value;
       return MDM_OK;
     case MDM_OPT_DEC_FUSED_SELFATTN:
       if (value != 0 && value != 1) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_DEC_FUSED_SELFATTN must be 0 or 1");
@@ -887,7 +889,7 @@ int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value) {
   switch (key) {
     case MDM_OPT_SMALL_GEMM_MAX_SEQS: *value = m->x3s.max_seqs; return MDM_OK;
     case MDM_OPT_SMALL_GEMM_ROW_TILES: *value = m->x3s.row_tiles; return MDM_OK;
-    case MDM_OPT_DEC_FUSED_XATTN: *value = m->fused_xattn ? 1 : 0; return MDM_OK;
+    case MDM_OPT_DEC_FUSED_XATTN: *value = m->fused_xattn; return MDM_OK;
     case MDM_OPT_DEC_FUSED_SELFATTN: *value = m->fused_selfattn ? 1 : 0; return MDM_OK;
     default: return fail(MDM_EINVAL, "mdm_get_option: unknown key " + std::to_string(key));
   }
@@ -1337,7 +1339,7 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       sa.qscale = qscale; sa.lengths = len; sa.lead = 0; sa.B = B; sa.oh = ws.atth; sa.ol = ws.attl;
       sa.M = M; sa.S = S; sa.D = D; sa.H = H; sa.stat_parts = parts; sa.stat_cols = scols; sa.inv_dim = inv_dim; sa.acc_scale = kX3AccScale;
       ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * 3.0 * D * (double)D + 4.0 * nseq * H * (double)S * S * ATT_HD, s);
-      const int rc = launch_selfattn_block(sa, l != 0, s);
+      const int rc = launch_seqhead_block(sa, l != 0 ? 1 : 0, s);
       if (rc == -1) return fail(MDM_EHIP, "self-attention block: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
       if (rc != 0) return fail(MDM_EUNSUPPORTED, "self-attention block: unsupported shape");
       if (int rc2 = rt_launch_status()) return rc2;
@@ -1362,13 +1364,37 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
     // ---- X = norm1(Y) + multihead_attn(norm1(Y), memory, memory).  One kernel (xattn_block.h: q projection with norm1 folded ->
     // attention over the memory -> out_proj + norm1 residual + row statistics) where its shapes are covered; else three launches:
     // fp32 queries (pre-scaled) from the small GEMM, the exact-fp32 attention kernel over k | v of the memory, the small GEMM again
-    const bool fused = m->fused_xattn && xattn_block_supported(D, ntok) && scols == 128;
+    const bool seqhead = m->fused_xattn == 2 && crossattn_block_supported(D, S, ntok);
+    const bool fused = !seqhead && m->fused_xattn != 0 && xattn_block_supported(D, ntok) && scols == 128;
     if (!hoisted) {
       const float* wc = m->L(l, "multihead_attn.in_proj_weight");
       const float* bc = m->L(l, "multihead_attn.in_proj_bias");
       if (int rc = launch_linear(pf, ws.mem, D, wc + (size_t)D * D, bc + D, nullptr, ws.kv, Mm, 2 * D, D, ACT_NONE, 0, 1.f, s, true)) return rc;
     }
-    if (fused) {
+    if (seqhead) {
+      SelfAttnArgs ca{};
+      ca.x = Y; ca.xstat = sY; ca.w = P.q; ca.bias = F.b_q; ca.colsum = F.c_q; ca.qscale = qscale;
+      ca.lengths = nullptr; ca.lead = 0; ca.B = B; ca.oh = ws.atth; ca.ol = ws.attl;
+      ca.M = M; ca.S = S; ca.D = D; ca.H = H; ca.stat_parts = parts; ca.stat_cols = scols; ca.inv_dim = inv_dim; ca.acc_scale = kX3AccScale;
+      if (!hoisted) {
+        ca.mk = ws.kv; ca.mv = ws.kv + D; ca.kadd = ca.vadd = nullptr; ca.kv_B = 0; ca.kv_b0 = 0;
+      } else {
+        const float* kvt = hz.kv_text + (size_t)l * ((size_t)nbranch * hz.kv_B * ntok) * 2 * D;
+        const float* row = hz.kv_time + ((size_t)l * hz.nsteps + hz.step) * 2 * D;
+        ca.mk = kvt; ca.mv = kvt + D; ca.kadd = row; ca.vadd = row + D; ca.kv_B = hz.kv_B; ca.kv_b0 = hz.kv_b0;
+      }
+      ca.ldkv = 2 * D; ca.text_lengths = text_lengths; ca.ntok = ntok;
+      {
+        ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)D * D + 4.0 * M * (double)ntok * D, s);
+        const int rc = launch_seqhead_block(ca, 2, s);
+        if (rc == -1) return fail(MDM_EHIP, "cross-attention (sequence, head) kernel: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        if (rc != 0) return fail(MDM_EUNSUPPORTED, "cross-attention (sequence, head) kernel: unsupported shape");
+        if (int rc2 = rt_launch_status()) return rc2;
+      }
+      LnArgs a = LN(); a.res = Y; a.rstat = sY; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias"); a.ostat = sX;
+      if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, attp, P.out_proj2, m->L(l, "multihead_attn.out_proj.bias"), a, nullptr,
+                                Xh, Xl, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
+    } else if (fused) {
       XattnArgs xa{};
       xa.y = Y; xa.ystat = sY; xa.wq = P.q; xa.cq = F.c_q; xa.bq = F.b_q; xa.qscale = qscale;
       if (!hoisted) {
@@ -1869,12 +1895,22 @@ int mdm_debug_set(int what, int value) {
 #ifndef MDM_EMU
   if (what == 9) { x3s_tl_target() = value; x3s_tl_count() = 0; }   // gemm_x3s.h timeline probe: stamp the value-th launch from now
   if (what == 10) { xb_tl_target() = value; xb_tl_count() = 0; }    // xattn_block.h timeline probe
+  if (what == 11) { sb_tl_target() = value; sb_tl_count() = 0; }    // selfattn_block.h timeline probe (self and cross launches)
 #endif
   return MDM_OK;
 }
 
 int mdm_debug_get(int idx, double* out) {   // ABL & 128 cycle counters of gemm_x3.h; idx < 0 resets them
 #ifndef MDM_EMU
+  if (idx >= 300000) {   // selfattn_block.h timeline stamps (read once at idx == 300000, then served from the host copy)
+    static std::vector<unsigned long long> tl(8 * SB_TL_WGS);
+    if (idx - 300000 >= 8 * SB_TL_WGS || out == nullptr) return fail(MDM_EINVAL, "mdm_debug_get: bad timeline index");
+    if (idx == 300000 && (hipDeviceSynchronize() != hipSuccess ||
+                          hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_sb_tl), tl.size() * sizeof(unsigned long long)) != hipSuccess))
+      return fail(MDM_EHIP, "mdm_debug_get: reading the timeline failed");
+    *out = (double)tl[idx - 300000];
+    return MDM_OK;
+  }
   if (idx >= 200000) {   // xattn_block.h timeline stamps (read once at idx == 200000, then served from the host copy)
     static std::vector<unsigned long long> tl(8 * XB_TL_WGS);
     if (idx - 200000 >= 8 * XB_TL_WGS || out == nullptr) return fail(MDM_EINVAL, "mdm_debug_get: bad timeline index");

@@ -21,6 +21,13 @@
 //     takes query tile w & 1 and the d half w >> 1 of the output (both waves of a query tile compute its 64 x 32 scores: 48 MFMAs);
 //     the output goes to the attention planes [M][D] that out_proj reads, 8 bytes per lane.
 // Sequences of more than 64 tokens keep the two-launch form (mdm_api.hip).
+//
+// CROSS mode (MODE 2) -- the same decomposition for the cross-attention of the layer (model/mdm.py:263-265: multihead_attn(x, memory,
+// memory) with x = norm1(y)): the workgroup of (sequence, head) projects ONLY the head's 128 query columns (norm1 folded; one W block
+// per wave), fills the K and V^T images from the hoisted fp32 memory projections (+ the step's projected time row) of its sequence --
+// at most 64 text tokens, masked by the prompt's token count -- and attends as above; the attention planes then feed the out_proj GEMM
+// (gemm_x3s.h kind 2).  Measured against xattn_block.h's whole-block kernel (every workgroup re-reads all of Wq | Wo for 32 rows:
+// W-delivery-bound on half the CUs, 35 us): profiles/r05c_seqhead_blocks.md.
 #pragma once
 #include "gemm_x3s.h"
 
@@ -40,6 +47,14 @@ struct SelfAttnArgs {
   int M, S, D, H;          // rows, tokens per sequence (<= 64), width, heads
   int stat_parts, stat_cols;
   float inv_dim, acc_scale;
+  // CROSS mode: the projected text memory of the layer (xattn_block.h XattnArgs: rows (kseq * ntok + tok) * ldkv, head h at + 128 h)
+  const float* mk;
+  const float* mv;
+  int ldkv;
+  const float* kadd;       // [D] added to every key / value row (the step's projected time embedding) or null
+  const float* vadd;
+  const int* text_lengths; // [B] valid memory tokens
+  int ntok, kv_B, kv_b0;
 };
 
 constexpr int SB_WAVES = 4, SB_TR = 64;
@@ -51,16 +66,37 @@ constexpr int SB_VEC = SB_V + SB_IMG;                        // bias[384] | cols
 constexpr int SB_TAB = SB_VEC + 2 * 384 * 4;                 // (mean, rstd) of the 64 rows
 constexpr int SB_MASK = SB_TAB + SB_TR * 8;                  // additive key mask (0 / -inf) of the 64 keys
 constexpr int SB_LDS = SB_MASK + SB_TR * 4;
+#if defined(MDM_PROBES) && !defined(MDM_EMU)
+// PROBE BUILD ONLY: wave 0's shader-clock stamps of ONE selected launch (mdm_debug_set(11, n): the n-th launch of this kernel after the
+// call; mdm_debug_get(300000 + 8 * workgroup + i)): i = 0 kernel entry, 1 chunk 0 / vectors / mask visible (first barrier passed),
+// 2 contraction retired, 3 fragment images complete, 4 attention arithmetic done, 5 last plane store issued.
+constexpr int SB_TL_WGS = 1024;
+__device__ unsigned long long g_sb_tl[8 * SB_TL_WGS];
+__device__ int g_sb_tl_on;
+#define SB_STAMP(i)                                                                                    \
+  do {                                                                                                 \
+    if (tl_on && tid == 0 && blockIdx.x < SB_TL_WGS) g_sb_tl[8 * blockIdx.x + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define SB_STAMP(i) do { } while (0)
+#endif
 
-template <bool FOLD>
+// MODE 0: self-attention, plain in_proj (layer 0); 1: self-attention, norm3 of the previous layer folded; 2: CROSS (norm1 folded)
+template <int MODE>
 __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAttnArgs a, int total) {
   MDM_DYN_SMEM(unsigned char, lds);
-  constexpr int WD = 4;                        // W ring: four sub-step slots per wave (hi + lo fragment of its Q, K and V block)
-  constexpr int LW = 6;                        // W loads per wave and sub-step
+  constexpr bool FOLD = MODE != 0, CROSS = MODE == 2;
+  constexpr int NWB = CROSS ? 1 : 3;           // W blocks per wave: Q (and K, V of the same 32 d)
+  constexpr int WD = 4;                        // W ring: four sub-step slots per wave (hi + lo fragment of each of its blocks)
+  constexpr int LW = 2 * NWB;                  // W loads per wave and sub-step
   constexpr int PW = SB_NSUB * 2 / 2;          // LDS-DMA pieces (1 KB) per wave and chunk: 16 pieces over 4 waves
   static_assert(SB_NSUB == WD && LW * (WD - 1) + PW <= 63, "slot <-> sub-step map across chunks (gemm_x3s.h: NSUB == D); vmcnt range");
 
   const int tid = threadIdx.x, lane = tid & 63;
+#if defined(MDM_PROBES) && !defined(MDM_EMU)
+  const bool tl_on = g_sb_tl_on != 0;
+#endif
+  SB_STAMP(0);
 #ifdef MDM_EMU
   const int wid = tid >> 6;
 #else
@@ -91,28 +127,33 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     }
   };
   // ---- W stream: this wave's block of Q (which = 0), K (1), V (2): packed rows which * D + head * 128 + 32 wid .. + 31
-  uint32_t wbase[3];
+  uint32_t wbase[NWB];
 #pragma unroll
-  for (int wh = 0; wh < 3; ++wh)
+  for (int wh = 0; wh < NWB; ++wh)
     wbase[wh] = (uint32_t)((wh * D + head * 128) / 32 + wid) * (uint32_t)nsub_total * 512u + (uint32_t)lane * 8u;
-  p16x8 wsh[WD * 3] = {}, wsl[WD * 3] = {};       // slot d, block wh: [d * 3 + wh]
+  p16x8 wsh[WD * NWB] = {}, wsl[WD * NWB] = {};       // slot d, block wh: [d * NWB + wh]
   auto issue_w = [&](auto slot_tag, int gj) __attribute__((always_inline)) {
     constexpr int sl = decltype(slot_tag)::value;
     const int gg = gj < nsub_total ? gj : gj - nsub_total;          // past the end: a harmless re-fetch keeps the wait counts uniform
 #pragma unroll
-    for (int wh = 0; wh < 3; ++wh) {
-      gload16_refill(wsh[sl * 3 + wh], a.w.hi + wbase[wh] + (uint32_t)gg * 512u);
-      gload16_refill(wsl[sl * 3 + wh], a.w.lo + wbase[wh] + (uint32_t)gg * 512u);
+    for (int wh = 0; wh < NWB; ++wh) {
+      gload16_refill(wsh[sl * NWB + wh], a.w.hi + wbase[wh] + (uint32_t)gg * 512u);
+      gload16_refill(wsl[sl * NWB + wh], a.w.lo + wbase[wh] + (uint32_t)gg * 512u);
     }
   };
   issue_chunk(0, 0);
   static_for<WD>([&](auto s_tag) __attribute__((always_inline)) { issue_w(s_tag, decltype(s_tag)::value); });
 
   // ---- this head's per-column vectors, the rows' (mean, rstd), the additive key mask: built behind the prologue's requests
-  for (int i = tid; i < (FOLD ? 2 : 1) * 96; i += 64 * SB_WAVES) {
-    const int which_vec = i / 96, j = i - which_vec * 96, wh = j / 32, c = (j - wh * 32) * 4;
+  for (int i = tid; i < (FOLD ? 2 : 1) * 32 * NWB; i += 64 * SB_WAVES) {
+    const int which_vec = i / (32 * NWB), j = i - which_vec * (32 * NWB), wh = j / 32, c = (j - wh * 32) * 4;
     const float* src = (which_vec == 0 ? a.bias : a.colsum) + wh * D + head * 128 + c;
     st4(vec + which_vec * 384 + wh * 128 + c, ld4(src));
+  }
+  int kseq = seq;                                   // CROSS: local (branch, sample) -> sequence of the memory projections
+  if constexpr (CROSS) {
+    const int br = seq / a.B, bl = seq - br * a.B;
+    if (a.kv_B > 0) kseq = br * a.kv_B + a.kv_b0 + bl;
   }
   if (tid < SB_TR) {
     if constexpr (FOLD) {
@@ -146,8 +187,9 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
       stab[tid] = v;
     }
     // key `tid`: the lead tokens are always valid; frame f = key - lead by the count or by its bitmap bit; keys >= S never
-    bool ok = tid < S;
-    if (a.lengths != nullptr && ok) {
+    // (CROSS: the keys are the memory tokens, valid up to the prompt's token count)
+    bool ok = CROSS ? tid < min(a.ntok, a.text_lengths[seq % a.B]) : tid < S;
+    if (!CROSS && a.lengths != nullptr && ok) {
       const int bl = seq % a.B, cnt = a.lengths[bl];
       if (cnt >= 0) ok = tid < a.lead + cnt;
       else {
@@ -159,9 +201,43 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     kmask[tid] = ok ? 0.f : -INFINITY;
   }
 
-  f32x16 acc[3][2];                                   // block wh (Q, K transposed; V standard), row sub-tile t
+  if constexpr (CROSS) {
+    // ---- K and V^T images from the fp32 memory projections of this sequence and head (+ the step's time row): key-major rows are
+    // read as float4 (coalesced), K goes in as (row = key, k = d), V transposed as (row = d, k = key in the accumulator's key order:
+    // position p of a 16-key group holds key (p & 3) + 8 ((p >> 2) & 1) + 4 (p >> 3), attention_x3.h).  Keys >= ntok: zeros.
+    const float* kb = a.mk + (size_t)kseq * a.ntok * a.ldkv + head * 128;
+    const float* vb = a.mv + (size_t)kseq * a.ntok * a.ldkv + head * 128;
 #pragma unroll
-  for (int wh = 0; wh < 3; ++wh)
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 64 * SB_WAVES * i, key = idx >> 5, c4 = idx & 31, d = 4 * c4;      // 64 keys x 32 float4
+      float4 kv = zero4(), vv = zero4();
+      if (key < a.ntok) {
+        kv = ld4(kb + (size_t)key * a.ldkv + d);
+        vv = ld4(vb + (size_t)key * a.ldkv + d);
+        if (a.kadd != nullptr) { kv = add4(kv, ld4(a.kadd + head * 128 + d)); vv = add4(vv, ld4(a.vadd + head * 128 + d)); }
+      }
+      // K: token `key`, d .. d + 3: k-block d / 32, chunk (d % 32) / 8 swizzled by the row, half (d % 8) / 4
+      unsigned char* kd = lds + SB_K + (((d >> 5) * 2) * 4) * 1024 + key * 64 + ((((d >> 3) & 3) ^ ((key >> 2) & 3)) * 16) + (d & 4) * 2;
+      split4_store(reinterpret_cast<p16_t*>(kd), reinterpret_cast<p16_t*>(kd + 4 * 1024), kv);
+      // V^T: rows d .. d + 3, key position p inside its 16-key group
+      const int kt = key >> 5, s2 = (key >> 4) & 1, k16 = key & 15;
+      const int pos = (k16 & 3) + 4 * ((k16 >> 3) & 1) + 8 * ((k16 >> 2) & 1);
+      const float v4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int dr = d + e;
+        unsigned char* vd = lds + SB_V + ((kt * 2) * 8) * 1024 + dr * 64 + (((2 * s2 + (pos >> 3)) ^ ((dr >> 2) & 3)) * 16) + (pos & 7) * 2;
+        p16_t hi, lo;
+        split_p16(v4[e], hi, lo);
+        *reinterpret_cast<p16_t*>(vd) = hi;
+        *reinterpret_cast<p16_t*>(vd + 8 * 1024) = lo;
+      }
+    }
+  }
+
+  f32x16 acc[NWB][2];                                 // block wh (Q, K transposed; V standard), row sub-tile t
+#pragma unroll
+  for (int wh = 0; wh < NWB; ++wh)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -195,13 +271,15 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     // chunk c landed (this wave's pieces): younger = the LW * NSUB W loads issued since (NSUB == WD: gemm_x3s.h's short-chunk form)
     vmem_wait<LW * SB_NSUB>(wsh[0], wsl[0]);
     wg_barrier_nodrain();                 // every wave's pieces visible; every wave is past chunk c - 1, whose buffer refills now
+    if (c == 0) SB_STAMP(1);
     issue_chunk(min(c + 1, nchunks - 1), buf ^ 1);      // (last chunk: a harmless re-fetch keeps the counts uniform)
     read_frags(std::integral_constant<int, 0>{}, buf);
     static_for<SB_NSUB>([&](auto j_tag) __attribute__((always_inline)) {
       constexpr int j = decltype(j_tag)::value, sl = j % WD;
       if constexpr (j + 1 < SB_NSUB) read_frags(std::integral_constant<int, j + 1>{}, buf);
       // W(c, j) was issued in front of this chunk's pieces: younger = the WD - 1 sub-steps behind it + the pieces
-      vmem_wait<LW*(WD - 1) + PW>(wsh[sl * 3], wsl[sl * 3], wsh[sl * 3 + 1], wsl[sl * 3 + 1], wsh[sl * 3 + 2], wsl[sl * 3 + 2]);
+      if constexpr (CROSS) vmem_wait<LW*(WD - 1) + PW>(wsh[sl], wsl[sl]);
+      else vmem_wait<LW*(WD - 1) + PW>(wsh[sl * 3], wsl[sl * 3], wsh[sl * 3 + 1], wsl[sl * 3 + 1], wsh[sl * 3 + 2], wsl[sl * 3 + 2]);
       lds_wait<(j + 1 < SB_NSUB) ? 4 : 0>(fah[j & 1][0], fal[j & 1][0], fah[j & 1][1], fal[j & 1][1]);
 #ifndef MDM_EMU
       __builtin_amdgcn_sched_barrier(0);
@@ -209,21 +287,27 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
       // Q, K: acc = W . x^T (lane = token);  V: acc = x . W^T (lane = d).  Consecutive MFMAs on different accumulators.
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        acc[0][t] = mfma_p16(wsh[sl * 3 + 0], fal[j & 1][t], acc[0][t]);
-        acc[1][t] = mfma_p16(wsh[sl * 3 + 1], fal[j & 1][t], acc[1][t]);
-        acc[2][t] = mfma_p16(fal[j & 1][t], wsh[sl * 3 + 2], acc[2][t]);
+        acc[0][t] = mfma_p16(wsh[sl * NWB + 0], fal[j & 1][t], acc[0][t]);
+        if constexpr (!CROSS) {
+          acc[1][t] = mfma_p16(wsh[sl * NWB + 1], fal[j & 1][t], acc[1][t]);
+          acc[NWB - 1][t] = mfma_p16(fal[j & 1][t], wsh[sl * NWB + NWB - 1], acc[NWB - 1][t]);
+        }
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        acc[0][t] = mfma_p16(wsl[sl * 3 + 0], fah[j & 1][t], acc[0][t]);
-        acc[1][t] = mfma_p16(wsl[sl * 3 + 1], fah[j & 1][t], acc[1][t]);
-        acc[2][t] = mfma_p16(fah[j & 1][t], wsl[sl * 3 + 2], acc[2][t]);
+        acc[0][t] = mfma_p16(wsl[sl * NWB + 0], fah[j & 1][t], acc[0][t]);
+        if constexpr (!CROSS) {
+          acc[1][t] = mfma_p16(wsl[sl * NWB + 1], fah[j & 1][t], acc[1][t]);
+          acc[NWB - 1][t] = mfma_p16(fah[j & 1][t], wsl[sl * NWB + NWB - 1], acc[NWB - 1][t]);
+        }
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        acc[0][t] = mfma_p16(wsh[sl * 3 + 0], fah[j & 1][t], acc[0][t]);
-        acc[1][t] = mfma_p16(wsh[sl * 3 + 1], fah[j & 1][t], acc[1][t]);
-        acc[2][t] = mfma_p16(fah[j & 1][t], wsh[sl * 3 + 2], acc[2][t]);
+        acc[0][t] = mfma_p16(wsh[sl * NWB + 0], fah[j & 1][t], acc[0][t]);
+        if constexpr (!CROSS) {
+          acc[1][t] = mfma_p16(wsh[sl * NWB + 1], fah[j & 1][t], acc[1][t]);
+          acc[NWB - 1][t] = mfma_p16(fah[j & 1][t], wsh[sl * NWB + NWB - 1], acc[NWB - 1][t]);
+        }
       }
 #ifndef MDM_EMU
       __builtin_amdgcn_sched_barrier(0);
@@ -232,17 +316,18 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     });
   }
   // the tail's re-fetches (W slots, the spare A buffer) land before registers / LDS are reused; the wait NAMES every slot register
-  static_for<WD * 3 / 4>([&](auto q_tag) __attribute__((always_inline)) {
+  static_for<WD * NWB / 4>([&](auto q_tag) __attribute__((always_inline)) {
     constexpr int q = 4 * decltype(q_tag)::value;
     vmem_wait<0>(wsh[q], wsl[q], wsh[q + 1], wsl[q + 1], wsh[q + 2], wsl[q + 2], wsh[q + 3], wsl[q + 3]);
   });
+  SB_STAMP(2);
 
   // ---- epilogue: fold / bias / scale / split -> the three fragment images
   const float accs = a.acc_scale;
   {
     // Q (wh = 0) and K (wh = 1): lane = token 32 t + r; register quad g = d 8 g + 4 h .. + 3 of the wave's 32-d block (k-block wid)
 #pragma unroll
-    for (int wh = 0; wh < 2; ++wh) {
+    for (int wh = 0; wh < (CROSS ? 1 : 2); ++wh) {
       unsigned char* img = lds + (wh == 0 ? SB_Q : SB_K);
       const float mult = wh == 0 ? a.qscale : 1.f;
 #pragma unroll
@@ -268,6 +353,7 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     }
     // V (wh = 2): lane = d 32 wid + r; registers 8 s2 .. + 7 of sub-tile t = positions 8 h .. + 7 of 16-key group s2 of key tile t
     // (the accumulator's row order IS the V^T image's key order, attention_x3.h): one 16-byte store per plane
+    if constexpr (!CROSS) {
     const float vb = vec[256 + 32 * wid + r];
     float vc = 0.f;
     if constexpr (FOLD) vc = vec[384 + 256 + 32 * wid + r];
@@ -280,9 +366,9 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
         for (int j = 0; j < 8; ++j) {
           if constexpr (FOLD) {
             const float2 st = stab[32 * t + mfma_row(8 * s2 + j, h)];
-            vv[j] = st.y * (acc[2][t][8 * s2 + j] * accs - st.x * vc) + vb;
+            vv[j] = st.y * (acc[NWB - 1][t][8 * s2 + j] * accs - st.x * vc) + vb;
           } else {
-            vv[j] = acc[2][t][8 * s2 + j] * accs + vb;
+            vv[j] = acc[NWB - 1][t][8 * s2 + j] * accs + vb;
           }
         }
         p16x8 vh8, vl8;
@@ -291,8 +377,10 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
         *reinterpret_cast<p16x8*>(dst) = vh8;
         *reinterpret_cast<p16x8*>(dst + 8 * 1024) = vl8;
       }
+    }   // !CROSS
   }
   wg_barrier();             // the three images (and the key mask) are complete
+  SB_STAMP(3);
 
   // ================= attention: wave = (query tile qt, d half dh) =================
   const int qt = wid & 1, dh = wid >> 1;
@@ -372,6 +460,7 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
         o[dd] = mfma_p16(vh, ph, o[dd]);
       }
     }
+  SB_STAMP(4);
   // normalised output -> the attention planes: query 32 qt + r, d 32 (2 dh + dd) + 8 g + 4 h .. + 3
   const int tok = 32 * qt + r;
   if (tok < S && m0 + tok < M) {
@@ -385,29 +474,50 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
                                                        o[dd][4 * g + 3] * inv));
       }
   }
+  SB_STAMP(5);
 }
 
 #ifndef MDM_X3_KERNEL_ONLY
+#if defined(MDM_PROBES) && !defined(MDM_EMU)
+inline int& sb_tl_target() { static int v = -1; return v; }   // mdm_debug_set(11, n); < 0: off
+inline int& sb_tl_count() { static int v = 0; return v; }
+#endif
 inline bool selfattn_block_supported(int D, int S) { return S >= 1 && S <= SB_TR && D % 128 == 0 && D >= 128; }
+inline bool crossattn_block_supported(int D, int S, int ntok) { return selfattn_block_supported(D, S) && ntok >= 1 && ntok <= SB_TR; }
 
-// -1: hipFuncSetAttribute failed; -2: unsupported shape (callers check selfattn_block_supported first)
-inline int launch_selfattn_block(const SelfAttnArgs& a, bool fold, hipStream_t stream) {
-  if (!selfattn_block_supported(a.D, a.S) || a.M % a.S != 0 || a.H * 128 != a.D) return -2;
+template <int MODE>
+inline int launch_seqhead_block_t(const SelfAttnArgs& a, hipStream_t stream) {
+  auto kfn = &selfattn_block_kernel<MODE>;
   const int total = (a.M / a.S) * a.H;
 #ifndef MDM_EMU
   {
-    static bool configured[2][kMaxDevices] = {};
-    bool& done = configured[fold ? 1 : 0][rt_device_ordinal()];
+    static bool configured[kMaxDevices] = {};
+    bool& done = configured[rt_device_ordinal()];
     if (!done) {
-      const void* fn = fold ? reinterpret_cast<const void*>(&selfattn_block_kernel<true>) : reinterpret_cast<const void*>(&selfattn_block_kernel<false>);
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS) != hipSuccess) return -1;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS) != hipSuccess) return -1;
       done = true;
     }
   }
 #endif
-  if (fold) { auto kfn = &selfattn_block_kernel<true>; MDM_LAUNCH(kfn, dim3(total), dim3(64 * SB_WAVES), SB_LDS, stream, a, total); }
-  else { auto kfn = &selfattn_block_kernel<false>; MDM_LAUNCH(kfn, dim3(total), dim3(64 * SB_WAVES), SB_LDS, stream, a, total); }
+#if defined(MDM_PROBES) && !defined(MDM_EMU)
+  if (sb_tl_target() >= 0) {   // timeline probe: stamps on for exactly the selected launch (stream-ordered switch)
+    static int on_v[2] = {0, 1};
+    const int on = (sb_tl_count()++ == sb_tl_target()) ? 1 : 0;
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sb_tl_on), &on_v[on], sizeof(int), 0, hipMemcpyHostToDevice, stream) != hipSuccess) return -1;
+  }
+#endif
+  MDM_LAUNCH(kfn, dim3(total), dim3(64 * SB_WAVES), SB_LDS, stream, a, total);
   return 0;
+}
+
+// -1: hipFuncSetAttribute failed; -2: unsupported shape (callers check *_supported first).  mode: 0 self-attention with a plain
+// in_proj, 1 self-attention with the previous LayerNorm folded, 2 cross-attention over the memory projections
+inline int launch_seqhead_block(const SelfAttnArgs& a, int mode, hipStream_t stream) {
+  if (!selfattn_block_supported(a.D, a.S) || a.M % a.S != 0 || a.H * 128 != a.D) return -2;
+  if (mode == 2 && (a.ntok < 1 || a.ntok > SB_TR)) return -2;
+  if (mode == 0) return launch_seqhead_block_t<0>(a, stream);
+  if (mode == 1) return launch_seqhead_block_t<1>(a, stream);
+  return launch_seqhead_block_t<2>(a, stream);
 }
 #endif
 

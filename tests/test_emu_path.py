@@ -602,6 +602,7 @@ def test_engine_options_are_set_through_the_abi_not_the_environment(lib, monkeyp
 
 
 @pytest.mark.parametrize("B,C,P,text_lengths,lengths", [(3, 5, 12, [6, 3, 2], [12, 7, 12]),      # S = 17: one 17-row tile per sequence
+                                                         (2, 20, 40, [24, 64], None),            # DiP's window; a 64-token memory (2 key tiles)
                                                          (2, 3, 70, [70, 3], None),              # S = 73: 32 + 32 + 9 rows; 3 key tiles
                                                          (2, 0, 33, [40, 9], [33, 20])])         # no prefix; S = 33: 32 + 1; 2 key tiles
 def test_emulated_dip_fused_cross_attention_block(lib, engine_options, B, C, P, text_lengths, lengths):
@@ -627,7 +628,7 @@ def test_emulated_dip_fused_cross_attention_block(lib, engine_options, B, C, P, 
     want_l = dip.dip_sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), (B, 263, 1, P), y, seq[0], seq[1:],
                                  context_len=C, cfg=True, num_heads=2, mask_frames=masked)
     outs = {}
-    for fused in (1, 0):
+    for fused in (2, 1, 0):      # 2: projection + attention per (sequence, head) (selfattn_block.h CROSS; S = 73 / 70 tokens: falls to 1)
         engine_options(dec_fused_xattn=fused, small_gemm_row_tiles=1)
         model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P, mask_frames=masked)
         assert model.model.engine().get_option("dec_fused_xattn") == fused
@@ -636,6 +637,7 @@ def test_emulated_dip_fused_cross_attention_block(lib, engine_options, B, C, P, 
         assert maxabs(f, want_f) < 5e-5 and maxabs(lo, want_l) < 5e-5, fused
         outs[fused] = (f, lo)
     assert not torch.equal(outs[0][0], outs[1][0]) and maxabs(outs[0][0], outs[1][0]) < 2e-5
+    assert maxabs(outs[0][0], outs[2][0]) < 2e-5 and maxabs(outs[0][1], outs[2][1]) < 5e-5
 
 
 @pytest.mark.parametrize("B,C,P,text_lengths,holes", [(3, 5, 12, [6, 3, 2], True),       # S = 17: one sub-tile, 47 pad rows
