@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mask-frames", action="store_true", help="A/B: a model built without --mask_frames (NULL lengths)")
     ap.add_argument("--no-fused-xattn", action="store_true", help="A/B: the cross-attention block as three launches (round 4's form)")
-    ap.add_argument("--xattn", type=int, default=2, help="A/B: MDM_OPT_DEC_FUSED_XATTN (2 per (sequence, head) + GEMM, 1 one kernel, 0 three launches)")
+    ap.add_argument("--xattn", type=int, default=3, help="A/B: MDM_OPT_DEC_FUSED_XATTN (3 by size, 2 per (sequence, head) + GEMM, 1 one kernel, 0 three launches)")
     ap.add_argument("--no-fused-selfattn", action="store_true", help="A/B: in_proj + self-attention as two launches (round 4's form)")
     a = ap.parse_args()
     rank, world, local = mdist.init_from_env("nccl")

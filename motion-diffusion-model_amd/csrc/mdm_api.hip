@@ -169,9 +169,9 @@ struct mdm_model {
   float *c_out = nullptr, *b_out = nullptr;
   bool lnfold = false;                      // f16x3 mode without LayerNorm kernels (set by mdm_prepare)
   X3sOptions x3s;                           // which forwards run on gemm_x3s.h's small tiles (mdm_set_option)
-  int fused_xattn = 2;                      // trans_dec plane route, the cross-attention block: 2 = q projection + memory attention per
+  int fused_xattn = 3;                      // trans_dec plane route, the cross-attention block: 2 = q projection + memory attention per
                                             // (sequence, head) (selfattn_block.h CROSS) + out_proj GEMM; 1 = one kernel (xattn_block.h);
-                                            // 0 = q projection, exact-fp32 attention kernel, out_proj: three launches
+                                            // 0 = q projection, exact-fp32 attention kernel, out_proj: three launches; 3 = by size
   bool fused_selfattn = true;               // ... and in_proj + self-attention of a (sequence, head) as one kernel (selfattn_block.h)
   X3Weights out_planes{nullptr, nullptr};  // poseFinal.weight, rows padded to jf_out (f16x3 OutputProcess)
   float* out_bias_pad = nullptr;            // poseFinal.bias padded to jf_out
@@ -872,7 +872,7 @@ int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value) {
       m->x3s.row_tiles = value;
       return MDM_OK;
     case MDM_OPT_DEC_FUSED_XATTN:
-      if (value < 0 || value > 2) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_DEC_FUSED_XATTN must be 0, 1 or 2");
+      if (value < 0 || value > 3) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_DEC_FUSED_XATTN must be 0, 1, 2 or 3");
       m->fused_xattn = value;
       return MDM_OK;
     case MDM_OPT_DEC_FUSED_SELFATTN:
@@ -1268,6 +1268,7 @@ struct DecHoist {         // step k of a window loop: where the hoisted projecti
 // mode 1) then performs guidance combine + inpainting blend + clamp + posterior / DDIM update + inline Philox in place on x, exactly
 // as the encoder loop's tail does -- one launch and one [nseq, J, P] round trip through memory fewer per step than
 // OutputProcess -> sampler_step_kernel (same arithmetic, element for element).  `done` says whether the route applied it.
+constexpr int kXattnOneKernelWgs = 192;    // MDM_OPT_DEC_FUSED_XATTN = 3: from this many 32-row tiles on, xattn_block.h's one-kernel block
 struct DecTail {
   const float* scale = nullptr;      // [B] or null (single branch)
   float* x = nullptr;                // [B, J, F, P]: x_t in, x_{t-1} out
@@ -1364,8 +1365,13 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
     // ---- X = norm1(Y) + multihead_attn(norm1(Y), memory, memory).  One kernel (xattn_block.h: q projection with norm1 folded ->
     // attention over the memory -> out_proj + norm1 residual + row statistics) where its shapes are covered; else three launches:
     // fp32 queries (pre-scaled) from the small GEMM, the exact-fp32 attention kernel over k | v of the memory, the small GEMM again
-    const bool seqhead = m->fused_xattn == 2 && crossattn_block_supported(D, S, ntok);
-    const bool fused = !seqhead && m->fused_xattn != 0 && xattn_block_supported(D, ntok) && scols == 128;
+    // by size (3): the one-kernel block re-reads all of Wq | Wo per 32-row tile -- it pays once its nseq * ceil(S / 32) workgroups
+    // fill the chip (B = 64 per GPU: 256 workgroups, 795 vs 752 motions/s box-normalised; B = 32: 128 workgroups, 612 vs 638)
+    const int xb_wgs = nseq * ((S + XB_TR - 1) / XB_TR);
+    const int xmode = m->fused_xattn == 3 ? ((xb_wgs >= kXattnOneKernelWgs && xattn_block_supported(D, ntok) && scols == 128) ? 1 : 2)
+                                          : m->fused_xattn;
+    const bool seqhead = xmode == 2 && crossattn_block_supported(D, S, ntok);
+    const bool fused = !seqhead && xmode != 0 && xattn_block_supported(D, ntok) && scols == 128;
     if (!hoisted) {
       const float* wc = m->L(l, "multihead_attn.in_proj_weight");
       const float* bc = m->L(l, "multihead_attn.in_proj_bias");

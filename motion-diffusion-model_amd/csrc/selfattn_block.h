@@ -58,10 +58,13 @@ struct SelfAttnArgs {
 };
 
 constexpr int SB_WAVES = 4, SB_TR = 64;
-constexpr int SB_NSUB = 4;                                   // 16-deep sub-steps per A chunk (64 k)
-constexpr int SB_BUF = SB_NSUB * 32 * 2 * 64;                // one chunk of A: 2 k-blocks x (hi, lo) x 4 row groups x 1 KB = 16 KB
+constexpr int SB_NSUB = 8;                                   // 16-deep sub-steps per A chunk (128 k: four rendezvous per 512 k; the 64-k
+                                                             // chunks of the first version paid ~1.2 k cycles per boundary, r05c)
+constexpr int SB_BUF = SB_NSUB * 32 * 2 * 64;                // one chunk of A: 4 k-blocks x (hi, lo) x 4 row groups x 1 KB = 32 KB
 constexpr int SB_IMG = 32768;                                // Q, K: 64 tokens x 128 d; V^T: 128 d x 64 keys (hi | lo planes)
-constexpr int SB_Q = 2 * SB_BUF, SB_K = SB_Q + SB_IMG, SB_V = SB_K + SB_IMG;
+// The Q image ALIASES A buffer 0: it is written by the epilogue, when the contraction has retired (a barrier in between).  K and V^T
+// have regions of their own: in CROSS mode they are filled from the memory BEFORE the contraction.
+constexpr int SB_Q = 0, SB_K = 2 * SB_BUF, SB_V = SB_K + SB_IMG;
 constexpr int SB_VEC = SB_V + SB_IMG;                        // bias[384] | colsum[384] of this head
 constexpr int SB_TAB = SB_VEC + 2 * 384 * 4;                 // (mean, rstd) of the 64 rows
 constexpr int SB_MASK = SB_TAB + SB_TR * 8;                  // additive key mask (0 / -inf) of the 64 keys
@@ -89,8 +92,9 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
   constexpr int NWB = CROSS ? 1 : 3;           // W blocks per wave: Q (and K, V of the same 32 d)
   constexpr int WD = 4;                        // W ring: four sub-step slots per wave (hi + lo fragment of each of its blocks)
   constexpr int LW = 2 * NWB;                  // W loads per wave and sub-step
-  constexpr int PW = SB_NSUB * 2 / 2;          // LDS-DMA pieces (1 KB) per wave and chunk: 16 pieces over 4 waves
-  static_assert(SB_NSUB == WD && LW * (WD - 1) + PW <= 63, "slot <-> sub-step map across chunks (gemm_x3s.h: NSUB == D); vmcnt range");
+  constexpr int PW = SB_NSUB * 2 / 2;          // LDS-DMA pieces (1 KB) per wave and chunk: 32 pieces over 4 waves
+  static_assert(SB_NSUB > WD && SB_NSUB % WD == 0 && LW * (WD - 1) + PW <= 63 && LW * WD <= 63,
+                "slot <-> sub-step map across chunks (gemm_x3s.h: NSUB > D); vmcnt range");
 
   const int tid = threadIdx.x, lane = tid & 63;
 #if defined(MDM_PROBES) && !defined(MDM_EMU)
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
       const int q = wid + SB_WAVES * i;
-      const int g = q & 3, p = (q >> 2) & 1, ms = q >> 3;
+      const int g = q & 3, p = (q >> 2) & 1, ms = q >> 3;       // (32 pieces per chunk: ms = 0 .. 3)
       const int arow = min(m0 + g * 16 + (lane >> 2), M - 1);
       const p16_t* src = (p ? a.x.lo : a.x.hi) + (size_t)arow * D + (size_t)c * (SB_NSUB * 16) + ms * 32 + schunk * 8;
       glds16(src, lds + buf * SB_BUF + ((ms * 2 + p) * 4 + g) * 1024);
@@ -142,9 +146,11 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     }
   };
   issue_chunk(0, 0);
-  static_for<WD>([&](auto s_tag) __attribute__((always_inline)) { issue_w(s_tag, decltype(s_tag)::value); });
+  // (the W prologue is issued BEHIND the compiler-tracked loads below: hipcc retires a tracked load beside untracked ones with
+  // vmcnt(0), i.e. the first version waited for 96 KB of W slots per CU before it could build its tables: 7.7 k cycles to the
+  // first rendezvous, profiles/r05c_seqhead_blocks.md)
 
-  // ---- this head's per-column vectors, the rows' (mean, rstd), the additive key mask: built behind the prologue's requests
+  // ---- this head's per-column vectors, the rows' (mean, rstd), the additive key mask
   for (int i = tid; i < (FOLD ? 2 : 1) * 32 * NWB; i += 64 * SB_WAVES) {
     const int which_vec = i / (32 * NWB), j = i - which_vec * (32 * NWB), wh = j / 32, c = (j - wh * 32) * 4;
     const float* src = (which_vec == 0 ? a.bias : a.colsum) + wh * D + head * 128 + c;
@@ -202,38 +208,47 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
   }
 
   if constexpr (CROSS) {
-    // ---- K and V^T images from the fp32 memory projections of this sequence and head (+ the step's time row): key-major rows are
-    // read as float4 (coalesced), K goes in as (row = key, k = d), V transposed as (row = d, k = key in the accumulator's key order:
-    // position p of a 16-key group holds key (p & 3) + 8 ((p >> 2) & 1) + 4 (p >> 3), attention_x3.h).  Keys >= ntok: zeros.
+    // ---- K and V^T images from the fp32 memory projections of this sequence and head: key-major rows are read as float4
+    // (coalesced: 32 lanes = one key's 128 d).  K goes in as (row = key, k = d) WITHOUT the step's time row: it would add the same
+    // q . k_time to every key's score of a query, which the softmax removes.  V^T goes in as (row = d, k = key in the accumulator's
+    // key order: position p of a 16-key group holds key (p & 3) + 8 ((p >> 2) & 1) + 4 (p >> 3), attention_x3.h) with the time row
+    // added: a thread owns one 16-byte chunk (8 positions) of FOUR d rows -- 8 float4 loads, 4 x 2 ds_write_b128.  Keys >= ntok: zeros.
     const float* kb = a.mk + (size_t)kseq * a.ntok * a.ldkv + head * 128;
     const float* vb = a.mv + (size_t)kseq * a.ntok * a.ldkv + head * 128;
+    {
+      const int chunk = tid >> 5, dq = tid & 31, d = 4 * dq;          // chunk = (key tile kt, 16-key group s2, half hh)
+      const int kt = chunk >> 2, s2 = (chunk >> 1) & 1, hh = chunk & 1;
+      float4 va = zero4();
+      if (a.vadd != nullptr) va = ld4(a.vadd + head * 128 + d);
+      float4 vv[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + 64 * SB_WAVES * i, key = idx >> 5, c4 = idx & 31, d = 4 * c4;      // 64 keys x 32 float4
-      float4 kv = zero4(), vv = zero4();
-      if (key < a.ntok) {
-        kv = ld4(kb + (size_t)key * a.ldkv + d);
-        vv = ld4(vb + (size_t)key * a.ldkv + d);
-        if (a.kadd != nullptr) { kv = add4(kv, ld4(a.kadd + head * 128 + d)); vv = add4(vv, ld4(a.vadd + head * 128 + d)); }
+      for (int j = 0; j < 8; ++j) {
+        const int key = 32 * kt + 16 * s2 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        vv[j] = key < a.ntok ? add4(ld4(vb + (size_t)key * a.ldkv + d), va) : zero4();
       }
-      // K: token `key`, d .. d + 3: k-block d / 32, chunk (d % 32) / 8 swizzled by the row, half (d % 8) / 4
-      unsigned char* kd = lds + SB_K + (((d >> 5) * 2) * 4) * 1024 + key * 64 + ((((d >> 3) & 3) ^ ((key >> 2) & 3)) * 16) + (d & 4) * 2;
-      split4_store(reinterpret_cast<p16_t*>(kd), reinterpret_cast<p16_t*>(kd + 4 * 1024), kv);
-      // V^T: rows d .. d + 3, key position p inside its 16-key group
-      const int kt = key >> 5, s2 = (key >> 4) & 1, k16 = key & 15;
-      const int pos = (k16 & 3) + 4 * ((k16 >> 3) & 1) + 8 * ((k16 >> 2) & 1);
-      const float v4[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        float col[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) col[j] = e == 0 ? vv[j].x : e == 1 ? vv[j].y : e == 2 ? vv[j].z : vv[j].w;
+        p16x8 vh8, vl8;
+        split8(col, vh8, vl8);
         const int dr = d + e;
-        unsigned char* vd = lds + SB_V + ((kt * 2) * 8) * 1024 + dr * 64 + (((2 * s2 + (pos >> 3)) ^ ((dr >> 2) & 3)) * 16) + (pos & 7) * 2;
-        p16_t hi, lo;
-        split_p16(v4[e], hi, lo);
-        *reinterpret_cast<p16_t*>(vd) = hi;
-        *reinterpret_cast<p16_t*>(vd + 8 * 1024) = lo;
+        unsigned char* vd = lds + SB_V + ((kt * 2) * 8) * 1024 + dr * 64 + (((2 * s2 + hh) ^ ((dr >> 2) & 3)) * 16);
+        *reinterpret_cast<p16x8*>(vd) = vh8;
+        *reinterpret_cast<p16x8*>(vd + 8 * 1024) = vl8;
       }
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 64 * SB_WAVES * i, key = idx >> 5, d = 4 * (idx & 31);      // 64 keys x 32 float4
+      const float4 kv = key < a.ntok ? ld4(kb + (size_t)key * a.ldkv + d) : zero4();
+      // token `key`, d .. d + 3: k-block d / 32, chunk (d % 32) / 8 swizzled by the row, half (d % 8) / 4
+      unsigned char* kd = lds + SB_K + (((d >> 5) * 2) * 4) * 1024 + key * 64 + ((((d >> 3) & 3) ^ ((key >> 2) & 3)) * 16) + (d & 4) * 2;
+      split4_store(reinterpret_cast<p16_t*>(kd), reinterpret_cast<p16_t*>(kd + 4 * 1024), kv);
+    }
   }
+  static_for<WD>([&](auto s_tag) __attribute__((always_inline)) { issue_w(s_tag, decltype(s_tag)::value); });
 
   f32x16 acc[NWB][2];                                 // block wh (Q, K transposed; V standard), row sub-tile t
 #pragma unroll
@@ -268,8 +283,9 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
 
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    // chunk c landed (this wave's pieces): younger = the LW * NSUB W loads issued since (NSUB == WD: gemm_x3s.h's short-chunk form)
-    vmem_wait<LW * SB_NSUB>(wsh[0], wsl[0]);
+    // chunk c landed (this wave's pieces): c == 0 -- the WD W sub-steps of the prologue are younger; c > 0 -- the counted W waits of
+    // chunk c - 1 (sub-steps >= WD, all issued behind the pieces) have already retired them (gemm_x3s.h, NSUB > D)
+    if (c == 0) vmem_wait<LW * WD>(wsh[0], wsl[0]);
     wg_barrier_nodrain();                 // every wave's pieces visible; every wave is past chunk c - 1, whose buffer refills now
     if (c == 0) SB_STAMP(1);
     issue_chunk(min(c + 1, nchunks - 1), buf ^ 1);      // (last chunk: a harmless re-fetch keeps the counts uniform)
@@ -277,9 +293,10 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     static_for<SB_NSUB>([&](auto j_tag) __attribute__((always_inline)) {
       constexpr int j = decltype(j_tag)::value, sl = j % WD;
       if constexpr (j + 1 < SB_NSUB) read_frags(std::integral_constant<int, j + 1>{}, buf);
-      // W(c, j) was issued in front of this chunk's pieces: younger = the WD - 1 sub-steps behind it + the pieces
-      if constexpr (CROSS) vmem_wait<LW*(WD - 1) + PW>(wsh[sl], wsl[sl]);
-      else vmem_wait<LW*(WD - 1) + PW>(wsh[sl * 3], wsl[sl * 3], wsh[sl * 3 + 1], wsl[sl * 3 + 1], wsh[sl * 3 + 2], wsl[sl * 3 + 2]);
+      // W(c, j): younger = the WD - 1 sub-steps behind it (+ the next chunk's pieces when it was issued in front of them)
+      constexpr int NW = LW * (WD - 1) + (j < WD ? PW : 0);
+      if constexpr (CROSS) vmem_wait<NW>(wsh[sl], wsl[sl]);
+      else vmem_wait<NW>(wsh[sl * 3], wsl[sl * 3], wsh[sl * 3 + 1], wsl[sl * 3 + 1], wsh[sl * 3 + 2], wsl[sl * 3 + 2]);
       lds_wait<(j + 1 < SB_NSUB) ? 4 : 0>(fah[j & 1][0], fal[j & 1][0], fah[j & 1][1], fal[j & 1][1]);
 #ifndef MDM_EMU
       __builtin_amdgcn_sched_barrier(0);
@@ -320,6 +337,7 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     constexpr int q = 4 * decltype(q_tag)::value;
     vmem_wait<0>(wsh[q], wsl[q], wsh[q + 1], wsl[q + 1], wsh[q + 2], wsl[q + 2], wsh[q + 3], wsl[q + 3]);
   });
+  wg_barrier();             // every wave has retired its fragment reads and its last DMA: A buffer 0 becomes the Q image
   SB_STAMP(2);
 
   // ---- epilogue: fold / bias / scale / split -> the three fragment images
