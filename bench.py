@@ -67,6 +67,8 @@ def parse_args(argv=None):
     # gloo ranks, kernels in the CPU emulator, a tiny model.  Never a measurement.
     ap.add_argument("--force-pg", action="store_true",
                     help="N = 1 only: still create the (one-rank) RCCL process group and run the gather through it")
+    ap.add_argument("--engine-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B runs: a handle option of include/mdm_hip.h mdm_set_option by its Python name, e.g. attn_direct_out=1")
     ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--layers", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--latent-dim", type=int, default=512, help=argparse.SUPPRESS)
@@ -346,8 +348,9 @@ def main(argv=None):
     B, T, DS = a.batch, a.frames, a.diffusion_steps
     torch.manual_seed(0)                                   # random-init weights of the named architecture
     args = model_util.default_args(diffusion_steps=DS, layers=a.layers, latent_dim=a.latent_dim)
+    eopts = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in a.engine_option}
     mdm, diffusion = model_util.create_model_and_diffusion(args, precision=a.precision, _native_lib=native_lib,
-                                                           num_heads=a.latent_dim // 128)
+                                                           num_heads=a.latent_dim // 128, engine_options=eopts)
     state = {k: v.clone() for k, v in mdm.state_dict().items()}
     model = ClassifierFreeSampleModel(mdm).to(dev).eval()
     y = synthetic_y(B, T, dev, seed=1000 + rank)
@@ -475,6 +478,7 @@ def main(argv=None):
                       "gathered_shape": headline_shape},
             "build": {"csrc_sha256": csrc_sha256(), "lib_sha256": lib_sha256(),
                       "info": eng.lib.lib.mdm_build_info().decode() if hasattr(eng.lib.lib, "mdm_build_info") else None},
+            "engine_options": eopts or None,         # non-default handle options of this run (A/B lines only)
             "finite_check_in_timed_region": False,   # asserted on the last sample behind the clock (rounds 1-3: inside, ~0.1 ms per loop)
             "sample_steps_per_s": round(motions_s * DS, 1),
             "model_tflops": round(motions_s * DS * 2 * fwd / 1e12, 2),

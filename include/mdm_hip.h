@@ -116,6 +116,10 @@ void mdm_destroy(mdm_model_t* m);
 #define MDM_OPT_SMALL_GEMM_ROW_TILES 2
 #define MDM_OPT_DEC_FUSED_XATTN 3
 #define MDM_OPT_DEC_FUSED_SELFATTN 4
+/*   MDM_OPT_ATTN_DIRECT_OUT       the split-precision self-attention kernel (csrc/attention_x3.h) writes its output planes straight from
+ *                                 the accumulators and requests the next (sequence, head)'s first key tiles in front of those stores,
+ *                                 instead of staging the output through its LDS ring (A/B of round 5: profiles/r05e_attention_direct.md). */
+#define MDM_OPT_ATTN_DIRECT_OUT 5
 int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value);
 int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value);
 

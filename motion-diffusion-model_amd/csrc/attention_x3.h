@@ -59,7 +59,20 @@ static_assert(AX_SLOT + 4 * 32 * AX_OST * 4 <= AX_RING * AX_SLOT, "output stagin
 // ABL (timing experiments only, 0 in production; results are garbage): 1 = no MFMAs, 2 = no LDS fragment reads,
 // 4 = no softmax, 8 = no output staging / stores, 16 = no K / V^T streaming after the prologue, 32 = no per-tile barrier.
 // Results stay CORRECT with: 64 = non-temporal K / V^T LDS-DMA, 128 = non-temporal plane stores (A/B: profiles/r04b_ab.md).
-template <int NKT, int ABL = 0>
+// DIRECT (round 5; VERDICT r04 item 4, the item-boundary drain): the output leaves the accumulators as 8-byte plane stores
+// (lane = query row, 4 consecutive d per register quad) instead of being staged through ring slots 1-3 -- so those slots are free the
+// moment the item's last tile has been consumed, and the NEXT item's key tiles 1 and 2 are requested right behind the closing
+// rendezvous, in front of the stores; the item then starts without a queue drain: its first three tile waits count the stores that are
+// still in flight (32 per active wave; vmcnt counts stores on gfx9).  Planes only (the model's path); the fp32-output form of the
+// building-block API keeps the staged epilogue.
+template <int N> __device__ __forceinline__ void ax_vm_wait() {      // s_waitcnt vmcnt(N), N <= 63 (common.h's builtin form stops at 15)
+#ifdef MDM_EMU
+  emu::vm_wait(N);
+#else
+  asm volatile("s_waitcnt vmcnt(%0)" : : "i"(N) : "memory");
+#endif
+}
+template <int NKT, int ABL = 0, bool DIRECT = false>
 __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const int* __restrict__ lengths,
                                                                     int S, int D, int B, int lead, float* __restrict__ out,
                                                                     p16_t* __restrict__ oh, p16_t* __restrict__ ol,
@@ -123,6 +136,8 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
   };
   issue_tile((size_t)item_of(vb), 0, lane);
   load_q((size_t)item_of(vb));
+  bool first_item = true;     // DIRECT: items after the first start with tiles 1, 2 requested and the previous item's stores in flight
+  constexpr int AX_NST = 32;  // DIRECT: plane stores of an active wave per item (4 d blocks x 4 register quads x hi, lo)
 
   for (;;) {   // ---- one item = one (sequence, head); vb advances by the grid size
   const int item = item_of(vb);
@@ -152,10 +167,13 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
   asm volatile("" : "+v"(lv));   // opaque per item: nothing derived from it is hoisted out of the item loop
 #endif
 
-  wait_vmem_all();          // Q and tile 0 of this item (requested under the previous item), the previous item's stores
-  wg_barrier();             // every wave is done with the previous item's output staging (ring slots 1-3)
-  if (NTILES > 1) issue_tile(sh, 1, lv);
-  if (NTILES > 2) issue_tile(sh, 2, lv);
+  const bool carried = DIRECT && !first_item;     // tiles 1, 2 are on their way and the previous item's stores may be in flight
+  if (!carried) {
+    wait_vmem_all();          // Q and tile 0 of this item (requested under the previous item), the previous item's stores
+    wg_barrier();             // every wave is done with the previous item's output staging (ring slots 1-3)
+    if (NTILES > 1) issue_tile(sh, 1, lv);
+    if (NTILES > 2) issue_tile(sh, 2, lv);
+  }
 
   f32x16 p[NKT];
 #pragma unroll
@@ -178,7 +196,20 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
     constexpr int slot = t & (AX_RING - 1);
     // tile t landed?  tiles t+1, t+2 (4 pieces each of this wave) may stay in flight; LDS-DMA retires in order
     constexpr int ahead = (NTILES - 1 - t) < 2 ? (NTILES - 1 - t) : 2;
-    if constexpr (!(ABL & 16)) wait_vmem_upto<4 * ahead>();
+    if constexpr (DIRECT && t < 3 && NTILES > 3) {
+      // a carried item: behind tile t sit (t == 0: the 16 Q fragment loads,) the tiles requested since and the previous item's
+      // stores -- issued behind tile 2, in front of tile 3
+      // (the emulator's queue holds the untracked operations only -- LDS-DMA pieces; compiler-tracked loads and stores take effect
+      // at once there: kTrk = 0)
+#ifdef MDM_EMU
+      constexpr int kTrk = 0;
+#else
+      constexpr int kTrk = 1;
+#endif
+      if (carried && active) ax_vm_wait<4 * ahead + kTrk * (AX_NST + (t == 0 ? 16 : 0))>();
+      else if (carried) ax_vm_wait<4 * ahead + kTrk * (t == 0 ? 16 : 0)>();
+      else wait_vmem_upto<4 * ahead>();
+    } else if constexpr (!(ABL & 16)) wait_vmem_upto<4 * ahead>();
     if constexpr (!(ABL & 32)) wg_barrier();  // tile t visible to every wave; every wave is done with tile t-1 (whose slot is refilled now)
     if constexpr (t + 3 < NTILES && !(ABL & 16)) issue_tile(sh, t + 3, lv);
     if constexpr (t == NTILES - 1) {
@@ -327,6 +358,29 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
     }
   });
   wg_barrier();  // every wave is done reading the ring: slots 1-3 become the output staging area (slot 0 is being refilled)
+  if constexpr (DIRECT) {
+    // the next item's key tiles 1 and 2 into the free slots, then this item's output straight from the accumulators
+    if (has_next) {
+      if (NTILES > 1) issue_tile((size_t)item_of(vb_next), 1, lv);
+      if (NTILES > 2) issue_tile((size_t)item_of(vb_next), 2, lv);
+    }
+    if (active) {
+      const int qq = 32 * qt + r;
+      if (qq < S) {
+        const size_t obase = ((size_t)seq * S + qq) * D + head * AX_HD + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            split4_store(oh + obase + 32 * dt + 8 * g, ol + obase + 32 * dt + 8 * g,
+                         make_float4(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv));
+      }
+    }
+    first_item = false;
+    if (!has_next) break;
+    vb = vb_next;
+    continue;
+  }
 
   // ---- stage this wave's O[32 queries][128 d] in two passes of 64 d (fp32, row stride AX_OST, wave-private) and store
   // coalesced: accumulator rows mfma_row(4g..4g+3, h) are 4 consecutive d

@@ -173,6 +173,7 @@ struct mdm_model {
                                             // (sequence, head) (selfattn_block.h CROSS) + out_proj GEMM; 1 = one kernel (xattn_block.h);
                                             // 0 = q projection, exact-fp32 attention kernel, out_proj: three launches; 3 = by size
   bool fused_selfattn = true;               // ... and in_proj + self-attention of a (sequence, head) as one kernel (selfattn_block.h)
+  bool attn_direct = false;                 // attention_x3.h DIRECT: planes from the accumulators, next item's tiles 1, 2 in front of the stores
   X3Weights out_planes{nullptr, nullptr};  // poseFinal.weight, rows padded to jf_out (f16x3 OutputProcess)
   float* out_bias_pad = nullptr;            // poseFinal.bias padded to jf_out
   int jf_out = 0;                           // njoints*nfeats rounded up to a multiple of 4
@@ -288,10 +289,10 @@ int launch_attention(Profiler* pf, const float* qkv, float* out, const int* leng
 #ifdef MDM_PROBES
 int g_ax_ablate = 0;   // mdm_debug_set(3, code): timing experiments on the NKT = 7 attention kernel (attention_x3.h ABL)
 #endif
-template <int NKT, int ABL = 0>
+template <int NKT, int ABL = 0, bool DIRECT = false>
 int launch_attention_x3_t(const QkvPlanes& qp, const int* lengths, int nseq, int B, int S, int D, float* out, p16_t* oh,
                           p16_t* ol, hipStream_t s, int lead) {
-  auto k = &attention_x3_kernel<NKT, ABL>;
+  auto k = &attention_x3_kernel<NKT, ABL, DIRECT>;
   const size_t lds = attention_x3_lds_bytes(NKT);
   if (int rc = rt_allow_lds(k, lds)) return rc;
   // two workgroups (query halves) per (sequence, head); the item <-> block mapping pairs blocks b and b + 8 (same XCD),
@@ -307,10 +308,21 @@ int launch_attention_x3_t(const QkvPlanes& qp, const int* lengths, int nseq, int
 // `lead` tokens in front of the frames are never masked (trans_enc: the condition token; trans_dec: none -- its `lengths` count the
 // context_len prefix frames as frames)
 int launch_attention_x3(Profiler* pf, const QkvPlanes& qp, const int* lengths, int nseq, int B, int S, int D, float* out,
-                        p16_t* oh, p16_t* ol, hipStream_t s, int lead = 1) {
+                        p16_t* oh, p16_t* ol, hipStream_t s, int lead = 1, bool direct = false) {
   ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * qp.H * (double)S * S * AX_HD, s);
   if (D != qp.H * AX_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
   if (S < 1 || S > 224) return fail(MDM_EUNSUPPORTED, "attention: 1 <= S <= 224 tokens (T <= 223 frames)");
+  if (direct && out == nullptr && oh != nullptr) {   // planes straight from the accumulators (attention_x3.h DIRECT)
+    switch (qp.NKT) {
+      case 1: return launch_attention_x3_t<1, 0, true>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+      case 2: return launch_attention_x3_t<2, 0, true>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+      case 3: return launch_attention_x3_t<3, 0, true>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+      case 4: return launch_attention_x3_t<4, 0, true>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+      case 5: return launch_attention_x3_t<5, 0, true>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+      case 6: return launch_attention_x3_t<6, 0, true>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+      default: return launch_attention_x3_t<7, 0, true>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
+    }
+  }
   switch (qp.NKT) {
     case 1: return launch_attention_x3_t<1>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
     case 2: return launch_attention_x3_t<2>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
@@ -618,7 +630,7 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
         if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, xb, F.in_proj, F.b_qkv, a, nullptr, nullptr, nullptr, &ws.qp, M,
                                   3 * D, D, S, D, D, qscale, s)) return rc;
       }
-      if (int rc = launch_attention_x3(pf, ws.qp, lengths, nseq, B, S, D, nullptr, ws.atth, ws.attl, s)) return rc;
+      if (int rc = launch_attention_x3(pf, ws.qp, lengths, nseq, B, S, D, nullptr, ws.atth, ws.attl, s, 1, m->attn_direct)) return rc;
       {  // xa = att.Wo + bo + layer input (normalised on the fly for l >= 1), + row statistics
         LnArgs a = LN(); a.res = xb; a.ostat = ws.stat1;
         if (l >= 1) { a.rstat = ws.stat2; a.rgamma = m->L(l - 1, "norm2.weight"); a.rbeta = m->L(l - 1, "norm2.bias"); }
@@ -645,7 +657,7 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
     for (int l = 0; l < m->cfg.num_layers; ++l) {
       const mdm_model::LayerPlanes& P = m->planes[l];
       if (int rc = launch_in_proj_x3(pf, tokp, P.in_proj, m->L(l, "self_attn.in_proj_bias"), ws.qp, nseq, S, D, qscale, s)) return rc;
-      if (int rc = launch_attention_x3(pf, ws.qp, lengths, nseq, B, S, D, nullptr, ws.atth, ws.attl, s)) return rc;
+      if (int rc = launch_attention_x3(pf, ws.qp, lengths, nseq, B, S, D, nullptr, ws.atth, ws.attl, s, 1, m->attn_direct)) return rc;
       // the residual stream lives as planes only (value = hi + lo): the GEMM writes the pre-norm sum as fp32, LayerNorm
       // turns it back into planes and does NOT write fp32 (one 103 MB stream less per LayerNorm)
       if (int rc = launch_linear_x3(pf, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"), nullptr, ws.tok, nullptr,
@@ -879,6 +891,10 @@ int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value) {
       if (value != 0 && value != 1) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_DEC_FUSED_SELFATTN must be 0 or 1");
       m->fused_selfattn = value != 0;
       return MDM_OK;
+    case MDM_OPT_ATTN_DIRECT_OUT:
+      if (value != 0 && value != 1) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_ATTN_DIRECT_OUT must be 0 or 1");
+      m->attn_direct = value != 0;
+      return MDM_OK;
     default:
       return fail(MDM_EINVAL, "mdm_set_option: unknown key " + std::to_string(key));
   }
@@ -891,6 +907,7 @@ int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value) {
     case MDM_OPT_SMALL_GEMM_ROW_TILES: *value = m->x3s.row_tiles; return MDM_OK;
     case MDM_OPT_DEC_FUSED_XATTN: *value = m->fused_xattn; return MDM_OK;
     case MDM_OPT_DEC_FUSED_SELFATTN: *value = m->fused_selfattn ? 1 : 0; return MDM_OK;
+    case MDM_OPT_ATTN_DIRECT_OUT: *value = m->attn_direct ? 1 : 0; return MDM_OK;
     default: return fail(MDM_EINVAL, "mdm_get_option: unknown key " + std::to_string(key));
   }
 }
@@ -1354,7 +1371,7 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, X, P.in_proj, F.b_in, a, nullptr, nullptr, nullptr, &ws.qp, M, 3 * D, D,
                                 S, D, D, qscale, s)) return rc;
     }
-    if (int rc = launch_attention_x3(pf, ws.qp, len, nseq, B, S, D, nullptr, ws.atth, ws.attl, s, /*lead=*/0)) return rc;
+    if (int rc = launch_attention_x3(pf, ws.qp, len, nseq, B, S, D, nullptr, ws.atth, ws.attl, s, /*lead=*/0, m->attn_direct)) return rc;
     }   // !fused self-attention
     {
       LnArgs a = LN(); a.res = X; a.ostat = sY;

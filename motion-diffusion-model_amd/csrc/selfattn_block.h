@@ -146,9 +146,10 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     }
   };
   issue_chunk(0, 0);
-  // (the W prologue is issued BEHIND the compiler-tracked loads below: hipcc retires a tracked load beside untracked ones with
-  // vmcnt(0), i.e. the first version waited for 96 KB of W slots per CU before it could build its tables: 7.7 k cycles to the
-  // first rendezvous, profiles/r05c_seqhead_blocks.md)
+  static_for<WD>([&](auto s_tag) __attribute__((always_inline)) { issue_w(s_tag, decltype(s_tag)::value); });
+  // (the W prologue travels UNDER the compiler-tracked loads below -- hipcc retires those with vmcnt(0), i.e. behind the W slots;
+  // issuing the W prologue behind them instead was measured and is worse: two dependent round trips in front of the first MFMA,
+  // 8.5 k / 15.7 k cycles to the first rendezvous against 7.7 k / 10.8 k, profiles/r05c_seqhead_blocks.md section 4)
 
   // ---- this head's per-column vectors, the rows' (mean, rstd), the additive key mask
   for (int i = tid; i < (FOLD ? 2 : 1) * 32 * NWB; i += 64 * SB_WAVES) {
@@ -248,7 +249,6 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
       split4_store(reinterpret_cast<p16_t*>(kd), reinterpret_cast<p16_t*>(kd + 4 * 1024), kv);
     }
   }
-  static_for<WD>([&](auto s_tag) __attribute__((always_inline)) { issue_w(s_tag, decltype(s_tag)::value); });
 
   f32x16 acc[NWB][2];                                 // block wh (Q, K transposed; V standard), row sub-tile t
 #pragma unroll

@@ -670,3 +670,24 @@ def test_emulated_dip_fused_self_attention_block(lib, engine_options, B, C, P, t
         outs[fused] = model(x, t, y=dict(y))
         assert maxabs(outs[fused], want) < 5e-5, fused
     assert maxabs(outs[0], outs[1]) < 2e-5
+
+
+@pytest.mark.parametrize("T,lengths", [(40, [40, 13, 33]), (100, [100, 57, 3]), (9, [9, 4, 9])])
+def test_emulated_attention_direct_output_is_bit_identical(lib, engine_options, T, lengths):
+    """csrc/attention_x3.h DIRECT (round 5, the item-boundary drain of VERDICT r04 item 4): planes straight from the accumulators, the
+    next item's key tiles 1 and 2 requested in front of those stores, no queue drain at the item start (counted waits that include the
+    stores in flight).  Same arithmetic: the encoder forward must be bit-identical to the staged form; 6 sequences x 2 heads = 12
+    items on the emulator's 16 persistent workgroups, i.e. every workgroup of the first group of 8 carries a second item."""
+    B = 3
+    sd = small_state_dict(num_layers=2)
+    y = synth_y(B, T, seed=2, lengths=lengths)
+    g = torch.Generator().manual_seed(0)
+    x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([49, 0, 7])
+    outs = []
+    for direct in (1, 0):
+        engine_options(attn_direct_out=direct, small_gemm_max_seqs=0)       # (the sequence-tile route: what the headline batch runs)
+        model, _ = make_pair(sd, 50, "cpu", guided=True, native_lib=lib, precision="f16x3")
+        assert model.model.engine().get_option("attn_direct_out") == direct
+        outs.append(model(x, t, y=dict(y)))
+    assert torch.equal(outs[0], outs[1])
+    assert maxabs(outs[0], orc.cfg_forward(sd, x, t, y, num_heads=2)) < 5e-5

@@ -261,3 +261,41 @@ def test_dip_fused_self_attention_block_other_shapes(engine_options, B, C, P, te
     e1, e0 = maxabs(outs[0], want), maxabs(outs[1], want)
     print(f"[parity] DiP forward B={B} C={C} P={P} masked{' + holes' if holes else ''}: fused self-attention {e1:.3e}, two launches {e0:.3e} (max-abs vs oracle)")
     assert e1 < TOL_DIP_FWD and e0 < TOL_DIP_FWD
+
+
+_DIRECT_BIG = {}
+
+
+@pytest.mark.parametrize("direct", [1, 0])
+def test_attention_direct_output_matches_reference_goldens(golden_dir, engine_options, direct):
+    """attention_x3.h DIRECT (planes straight from the accumulators; the next item's key tiles requested in front of the stores; counted
+    waits that include the stores in flight) against the UPSTREAM reference's forward and 50-step loop goldens at T = 196 on the
+    sequence-tile route, and -- same arithmetic -- bit-identical to the staged form at the headline shape's kernel (B = 24 guided:
+    192 items over 512 persistent workgroups is one item each; B = 80: 640 items, every workgroup carries a second one)."""
+    from helpers import golden_loop_inputs, run_product_loop
+    engine_options(attn_direct_out=direct, small_gemm_max_seqs=0)
+    sd = memo("sd_enc0", lambda: synth_state_dict(seed=0))
+    g = _g(golden_dir, "fwd_B3_T196")
+    B, T = 3, 196
+    y = synth_y(B, T, seed=int(g["y_seed"]), lengths=list(g["lengths"]))
+    x = torch.randn(B, 263, 1, T, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    t = torch.from_numpy(g["t"])
+    model, _ = make_pair(sd, 50, DEV, guided=True)
+    assert model.model.engine().get_option("attn_direct_out") == direct
+    e_c = maxabs(model.model(x.to(DEV), t.to(DEV), y=dict(y)).cpu(), g["out_cond"])
+    e_g = maxabs(model(x.to(DEV), t.to(DEV), y=dict(y)).cpu(), g["out_cfg"])
+    gl = _g(golden_dir, "loop50_B2_T196")
+    out = run_product_loop(sd, golden_loop_inputs(gl), DEV)
+    e_l = maxabs(out.cpu(), gl["final"])
+    # a batch whose (sequence, head) items outnumber the persistent workgroups: the carried-item path
+    B2 = 80
+    y2 = synth_y(B2, T, seed=5, lengths=[196 - (7 * i) % 150 for i in range(B2)])
+    x2 = torch.randn(B2, 263, 1, T, generator=torch.Generator().manual_seed(3)).to(DEV)
+    t2 = (torch.arange(B2) % 50).to(DEV)
+    big = model(x2, t2, y=dict(y2)).cpu()
+    other = _DIRECT_BIG.get(1 - direct)
+    _DIRECT_BIG[direct] = big
+    print(f"[parity] attention {'DIRECT' if direct else 'staged'} output: forward vs reference {e_c:.3e} / guided {e_g:.3e}; loop50_B2_T196 {e_l:.3e}")
+    assert e_c < 3e-5 and e_g < 1.2e-4 and e_l < 1e-4 and torch.isfinite(big).all()
+    if other is not None:
+        assert torch.equal(big, other)
