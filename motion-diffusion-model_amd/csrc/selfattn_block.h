@@ -213,28 +213,27 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     // (coalesced: 32 lanes = one key's 128 d).  K goes in as (row = key, k = d) WITHOUT the step's time row: it would add the same
     // q . k_time to every key's score of a query, which the softmax removes.  V^T goes in as (row = d, k = key in the accumulator's
     // key order: position p of a 16-key group holds key (p & 3) + 8 ((p >> 2) & 1) + 4 (p >> 3), attention_x3.h) with the time row
-    // added: a thread owns one 16-byte chunk (8 positions) of FOUR d rows -- 8 float4 loads, 4 x 2 ds_write_b128.  Keys >= ntok: zeros.
+    // added, 16 bytes (8 key positions) per store.  Keys >= ntok: zeros.
     const float* kb = a.mk + (size_t)kseq * a.ntok * a.ldkv + head * 128;
     const float* vb = a.mv + (size_t)kseq * a.ntok * a.ldkv + head * 128;
     {
-      const int chunk = tid >> 5, dq = tid & 31, d = 4 * dq;          // chunk = (key tile kt, 16-key group s2, half hh)
-      const int kt = chunk >> 2, s2 = (chunk >> 1) & 1, hh = chunk & 1;
-      float4 va = zero4();
-      if (a.vadd != nullptr) va = ld4(a.vadd + head * 128 + d);
-      float4 vv[8];
+      // a thread owns d row `dr` and four of its eight 16-byte chunks (8 key positions each): consecutive lanes = consecutive rows, the
+      // image's own conflict-free pattern (64-byte rows, chunk ^ ((row >> 2) & 3)); 8 coalesced dword loads per chunk.  (A first
+      // mapping -- one chunk of FOUR rows per thread from float4 loads -- put the lanes of a wave 256 bytes apart: 8-way bank
+      // conflicts on every ds_write_b128, 15.5 k cycles to the first rendezvous instead of 10.8 k; profiles/r05c section 4.)
+      const int dr = tid & 127, cg = tid >> 7;
+      const float va = a.vadd != nullptr ? a.vadd[head * 128 + dr] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int key = 32 * kt + 16 * s2 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-        vv[j] = key < a.ntok ? add4(ld4(vb + (size_t)key * a.ldkv + d), va) : zero4();
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int c = 0; c < 4; ++c) {
+        const int chunk = 4 * cg + c, kt = chunk >> 2, s2 = (chunk >> 1) & 1, hh = chunk & 1;
         float col[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) col[j] = e == 0 ? vv[j].x : e == 1 ? vv[j].y : e == 2 ? vv[j].z : vv[j].w;
+        for (int j = 0; j < 8; ++j) {
+          const int key = 32 * kt + 16 * s2 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+          col[j] = key < a.ntok ? vb[(size_t)key * a.ldkv + dr] + va : 0.f;
+        }
         p16x8 vh8, vl8;
         split8(col, vh8, vl8);
-        const int dr = d + e;
         unsigned char* vd = lds + SB_V + ((kt * 2) * 8) * 1024 + dr * 64 + (((2 * s2 + hh) ^ ((dr >> 2) & 3)) * 16);
         *reinterpret_cast<p16x8*>(vd) = vh8;
         *reinterpret_cast<p16x8*>(vd + 8 * 1024) = vl8;
