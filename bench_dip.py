@@ -68,6 +68,31 @@ def cpu_baseline(state, budget_s=12.0):
                       f"{DSTEPS} steps per motion ({per_step * 1e3:.0f} ms per batch-step)"}
 
 
+DIP_PMC_PROFILE = os.path.join("profiles", "r05_dip_pmc.json")
+
+
+def pmc_traffic_per_launch():
+    """Fabric-side bytes per launch of the decoder's GEMM-class kernels (the `linear` profiling class: gemm_x3s_kernel, the
+    (sequence, head) attention blocks, xattn_block_kernel) from the committed rocprofv3 PMC passes of THIS command at B = 32
+    (tools/gpu_r5_dip_pmc.sh + tools/dip_pmc_to_json.py), call-weighted; quoted only while the kernel sources are the ones the
+    passes were taken on (bench.csrc_sha256)."""
+    path = os.path.join(ROOT, DIP_PMC_PROFILE)
+    if not os.path.isfile(path):
+        return None, f"{DIP_PMC_PROFILE} absent"
+    try:
+        import bench
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("csrc_sha256") != bench.csrc_sha256():
+            return None, f"{DIP_PMC_PROFILE}: taken on OTHER kernel sources / build flags, not quoted"
+        rows = [v for k, v in d["kernels"].items() if ("gemm_x3s" in k or "seqhead" in k or "cross_attention_block" in k)
+                and "fabric_bytes" in v and v.get("calls")]
+        calls = sum(v["calls"] for v in rows)
+        return int(sum(v["fabric_bytes"] * v["calls"] for v in rows) / calls), f"{DIP_PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this command)"
+    except (KeyError, ValueError, OSError, ZeroDivisionError) as e:
+        return None, f"{DIP_PMC_PROFILE} unreadable ({type(e).__name__})"
+
+
 def measure(dev, rank, world, B, steps, warmup, cpu=True, mask_frames=True, engine_options=None):
     """Time `steps` whole 196-frame generations of B motions per rank on `dev`; returns the JSON record (rank 0) or None.
     bench.py embeds this record as its `dip` sub-line so that the driver's BENCH file carries it."""
@@ -131,7 +156,8 @@ def measure(dev, rank, world, B, steps, warmup, cpu=True, mask_frames=True, engi
                        "parallelism": f"dp{world}: batch shards, all_gather of final samples"},
             "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3s_kernel on operand planes + xattn_block_kernel (q projection, memory attention and out_proj of the cross-attention block in one launch); K / V of the text memory: gemm_f32_kernel<X3>") + ")",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "traffic": None, "launches": lin["launches"],
+                         "traffic": pmc_traffic_per_launch()[0] if B == 32 else None, "traffic_source": pmc_traffic_per_launch()[1],
+                         "launches": lin["launches"],
                          "avg_launch_us": round(lin["ms"] * 1e3 / max(lin["launches"], 1), 2)},
             "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
             "launches_per_motion_batch": int(sum(v["launches"] for v in prof.values()))}
