@@ -157,6 +157,7 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     const float* src = (which_vec == 0 ? a.bias : a.colsum) + wh * D + head * 128 + c;
     st4(vec + which_vec * 384 + wh * 128 + c, ld4(src));
   }
+  const int nkt = ((CROSS ? a.ntok : S) + 31) / 32;     // 32-key tiles in use (DiP's 24-token memory: one -- the second is skipped)
   int kseq = seq;                                   // CROSS: local (branch, sample) -> sequence of the memory projections
   if constexpr (CROSS) {
     const int br = seq / a.B, bl = seq - br * a.B;
@@ -213,39 +214,39 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     // (coalesced: 32 lanes = one key's 128 d).  K goes in as (row = key, k = d) WITHOUT the step's time row: it would add the same
     // q . k_time to every key's score of a query, which the softmax removes.  V^T goes in as (row = d, k = key in the accumulator's
     // key order: position p of a 16-key group holds key (p & 3) + 8 ((p >> 2) & 1) + 4 (p >> 3), attention_x3.h) with the time row
-    // added, 16 bytes (8 key positions) per store.  Keys >= ntok: zeros.
+    // added.  Keys >= ntok: zeros.
     const float* kb = a.mk + (size_t)kseq * a.ntok * a.ldkv + head * 128;
     const float* vb = a.mv + (size_t)kseq * a.ntok * a.ldkv + head * 128;
-    {
-      // a thread owns d row `dr` and four of its eight 16-byte chunks (8 key positions each): consecutive lanes = consecutive rows, the
-      // image's own conflict-free pattern (64-byte rows, chunk ^ ((row >> 2) & 3)); 8 coalesced dword loads per chunk.  (A first
-      // mapping -- one chunk of FOUR rows per thread from float4 loads -- put the lanes of a wave 256 bytes apart: 8-way bank
-      // conflicts on every ds_write_b128, 15.5 k cycles to the first rendezvous instead of 10.8 k; profiles/r05c section 4.)
-      const int dr = tid & 127, cg = tid >> 7;
-      const float va = a.vadd != nullptr ? a.vadd[head * 128 + dr] : 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int chunk = 4 * cg + c, kt = chunk >> 2, s2 = (chunk >> 1) & 1, hh = chunk & 1;
-        float col[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int key = 32 * kt + 16 * s2 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-          col[j] = key < a.ntok ? vb[(size_t)key * a.ldkv + dr] + va : 0.f;
-        }
-        p16x8 vh8, vl8;
-        split8(col, vh8, vl8);
-        unsigned char* vd = lds + SB_V + ((kt * 2) * 8) * 1024 + dr * 64 + (((2 * s2 + hh) ^ ((dr >> 2) & 3)) * 16);
-        *reinterpret_cast<p16x8*>(vd) = vh8;
-        *reinterpret_cast<p16x8*>(vd + 8 * 1024) = vl8;
-      }
-    }
+    // (Two other mappings of the V^T fill were measured and are slower, profiles/r05c section 4: one 16-byte chunk of four d rows per
+    // thread from float4 loads -- lanes 256 bytes apart, 8-way bank conflicts: 15.5 k cycles to the first rendezvous; one d row per
+    // lane from dword loads -- conflict-free stores, but four dependent load -> split -> store rounds: 25.4 k.  This one issues all
+    // 16 float4 loads of a thread up front and pays 2-byte scattered stores: 10.8 k.)
+    const float4 va = a.vadd != nullptr ? ld4(a.vadd + head * 128 + 4 * (tid & 31)) : zero4();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+      if ((i >> 2) >= nkt) continue;                   // keys 32 (i >> 2) .. + 31 of this round: a key tile nobody reads
       const int idx = tid + 64 * SB_WAVES * i, key = idx >> 5, d = 4 * (idx & 31);      // 64 keys x 32 float4
-      const float4 kv = key < a.ntok ? ld4(kb + (size_t)key * a.ldkv + d) : zero4();
-      // token `key`, d .. d + 3: k-block d / 32, chunk (d % 32) / 8 swizzled by the row, half (d % 8) / 4
+      float4 kv = zero4(), vv = zero4();
+      if (key < a.ntok) {
+        kv = ld4(kb + (size_t)key * a.ldkv + d);
+        vv = add4(ld4(vb + (size_t)key * a.ldkv + d), va);
+      }
+      // K: token `key`, d .. d + 3: k-block d / 32, chunk (d % 32) / 8 swizzled by the row, half (d % 8) / 4
       unsigned char* kd = lds + SB_K + (((d >> 5) * 2) * 4) * 1024 + key * 64 + ((((d >> 3) & 3) ^ ((key >> 2) & 3)) * 16) + (d & 4) * 2;
       split4_store(reinterpret_cast<p16_t*>(kd), reinterpret_cast<p16_t*>(kd + 4 * 1024), kv);
+      // V^T: rows d .. d + 3, key position `pos` inside its 16-key group
+      const int kt = key >> 5, s2 = (key >> 4) & 1, k16 = key & 15;
+      const int pos = (k16 & 3) + 4 * ((k16 >> 3) & 1) + 8 * ((k16 >> 2) & 1);
+      const float v4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int dr = d + e;
+        unsigned char* vd = lds + SB_V + ((kt * 2) * 8) * 1024 + dr * 64 + (((2 * s2 + (pos >> 3)) ^ ((dr >> 2) & 3)) * 16) + (pos & 7) * 2;
+        p16_t hi, lo;
+        split_p16(v4[e], hi, lo);
+        *reinterpret_cast<p16_t*>(vd) = hi;
+        *reinterpret_cast<p16_t*>(vd + 8 * 1024) = lo;
+      }
     }
   }
 
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) p[kt][e] = 0.f;
+      if (kt < nkt)
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
         const unsigned char* src = lds + SB_K + (((st / 2) * 2) * 4) * 1024 + kt * 2048 + ((st & 1) ? fr1 : fr0);
@@ -461,6 +463,7 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     for (int e = 0; e < 16; ++e) o[dd][e] = 0.f;
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
+    if (kt < nkt)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       float pv[8];
