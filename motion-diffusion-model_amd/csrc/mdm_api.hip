@@ -937,19 +937,19 @@ size_t mdm_const_bytes(const mdm_model_t* m) {
     const size_t planes = align_up(3 * D * D * 4, 256) + 3 * align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
     // OutputProcess with the last norm3 folded in (the plane path of decoder_pass): fp32 copy, 2 vectors, planes
     const size_t outp = align_up((size_t)m->jf * D * 4, 256) + 2 * align_up((size_t)32 * ((m->jf_out + 31) / 32) * 4, 256) +
-                        align_up(x3_packed_weight_elems(m->jf_out, (int)D) * 4, 256);
+                        align_up(x3_packed_weight_elems(m->jf, (int)D) * 4, 256);
     return 256 /* range flag */ + align_up(D * m->jf_pad * sizeof(float), 256) +
            2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) + (size_t)m->cfg.num_layers * (fold + planes) + outp;
   }
   const size_t per_layer = align_up(3 * D * D * 4, 256) + align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
   return 256 /* range flag */ + align_up(D * m->jf_pad * sizeof(float), 256) +
-         2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) + (size_t)m->cfg.num_layers * per_layer + align_up(x3_packed_weight_elems(m->jf_out, (int)D) * 4, 256) +
+         2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) + (size_t)m->cfg.num_layers * per_layer + align_up(x3_packed_weight_elems(m->jf, (int)D) * 4, 256) +
          align_up((size_t)m->jf_out * sizeof(float), 256) +
          // folded-LayerNorm constants: per layer gamma-scaled in_proj / linear1 planes + 2 vectors each; OutputProcess;
          // one fp32 scratch matrix for the scaled weights before they are packed
          (size_t)m->cfg.num_layers * (align_up(3 * D * D * 4, 256) + align_up(FF * D * 4, 256) +
                                       2 * align_up(3 * D * 4, 256) + 2 * align_up(FF * 4, 256)) +
-         align_up(x3_packed_weight_elems(m->jf_out, (int)D) * 4, 256) + 2 * align_up((size_t)32 * ((m->jf_out + 31) / 32) * 4, 256) +
+         align_up(x3_packed_weight_elems(m->jf, (int)D) * 4, 256) + 2 * align_up((size_t)32 * ((m->jf_out + 31) / 32) * 4, 256) +
          align_up(std::max<size_t>(3 * D, FF) * D * 4, 256) + align_up((size_t)D * m->jf_k * 4, 256);
 }
 
@@ -986,7 +986,8 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
                              m->W("embed_timestep.time_embed.2.bias"), nullptr, m->time_table, R, D, D, ACT_NONE, 0,
                              1.f, s))
     return rc;
-  if (m->cfg.arch == MDM_ARCH_TRANS_DEC) {   // the DiP decoder splits its fp32 operands inside the GEMM (gemm_f32.h X3): no planes
+  if (m->cfg.arch == MDM_ARCH_TRANS_DEC) {   // the DiP decoder: gamma-folded fp32 copies (fp32 skeleton) AND fragment-ordered planes of
+                                             // every layer weight (the operand-plane route of the default f16x3 mode)
     // LayerNorm folded into the consumers of its output (gemm_f32.h LnFold)
     base += align_up((size_t)R * D * sizeof(float), 256);
     const int L = m->cfg.num_layers, FFd = m->cfg.ff_size;
@@ -1184,7 +1185,8 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
   return rt_launch_status();
 }
 
-// ---- DiP: trans_dec denoiser, exact fp32 -----------------------------------------------------------
+// ---- DiP: trans_dec denoiser: the fp32 skeleton (f32 mode; MDM_OPT_SMALL_GEMM_MAX_SEQS = 0) and, in the
+// default f16x3 mode, the operand-plane route with its (sequence, head) attention blocks (decoder_layers_planes) ---------------
 namespace {
 struct DecWorkspace {
   float *tok, *qkv, *att, *ffn, *mem, *kv, *proj;
@@ -1285,7 +1287,7 @@ struct DecHoist {         // step k of a window loop: where the hoisted projecti
 // mode 1) then performs guidance combine + inpainting blend + clamp + posterior / DDIM update + inline Philox in place on x, exactly
 // as the encoder loop's tail does -- one launch and one [nseq, J, P] round trip through memory fewer per step than
 // OutputProcess -> sampler_step_kernel (same arithmetic, element for element).  `done` says whether the route applied it.
-constexpr int kXattnOneKernelWgs = 192;    // MDM_OPT_DEC_FUSED_XATTN = 3: from this many 32-row tiles on, xattn_block.h's one-kernel block
+constexpr int kXattnOneKernelWgs = 160;    // MDM_OPT_DEC_FUSED_XATTN = 3: from this many 32-row tiles on, xattn_block.h's one-kernel block
 struct DecTail {
   const float* scale = nullptr;      // [B] or null (single branch)
   float* x = nullptr;                // [B, J, F, P]: x_t in, x_{t-1} out
@@ -1383,7 +1385,8 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
     // attention over the memory -> out_proj + norm1 residual + row statistics) where its shapes are covered; else three launches:
     // fp32 queries (pre-scaled) from the small GEMM, the exact-fp32 attention kernel over k | v of the memory, the small GEMM again
     // by size (3): the one-kernel block re-reads all of Wq | Wo per 32-row tile -- it pays once its nseq * ceil(S / 32) workgroups
-    // fill the chip (B = 64 per GPU: 256 workgroups, 795 vs 752 motions/s box-normalised; B = 32: 128 workgroups, 612 vs 638)
+    // fill the chip (same-box, motions/s, one kernel vs (sequence, head) form: B = 32 per GPU / 128 tiles 598 vs 630, B = 48 / 192 tiles
+    // 641 vs 605, B = 64 / 256 tiles 736 vs 707: profiles/r05c section 5)
     const int xb_wgs = nseq * ((S + XB_TR - 1) / XB_TR);
     const int xmode = m->fused_xattn == 3 ? ((xb_wgs >= kXattnOneKernelWgs && xattn_block_supported(D, ntok) && scols == 128) ? 1 : 2)
                                           : m->fused_xattn;

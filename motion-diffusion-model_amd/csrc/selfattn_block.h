@@ -157,7 +157,9 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
     const float* src = (which_vec == 0 ? a.bias : a.colsum) + wh * D + head * 128 + c;
     st4(vec + which_vec * 384 + wh * 128 + c, ld4(src));
   }
-  const int nkt = ((CROSS ? a.ntok : S) + 31) / 32;     // 32-key tiles in use (DiP's 24-token memory: one -- the second is skipped)
+  // 32-key tiles in use.  CROSS: by the memory's token count (DiP's 24 tokens: one -- the second is neither filled nor multiplied).
+  // Self-attention: always both (a compile-time 2: as a run-time bound the branches cost 1.5 k cycles per launch, r05c section 4)
+  const int nkt = CROSS ? (a.ntok + 31) / 32 : 2;
   int kseq = seq;                                   // CROSS: local (branch, sample) -> sequence of the memory projections
   if constexpr (CROSS) {
     const int br = seq / a.B, bl = seq - br * a.B;
