@@ -154,7 +154,7 @@ def measure(dev, rank, world, B, steps, warmup, cpu=True, mask_frames=True, engi
                                    (" (the DiP.md:181 recipe: a frame mask on every forward)" if mask_frames else " (no frame mask reaches the kernels: A/B only)"),
                        "global_batch": GB, "mask_frames": bool(mask_frames),
                        "parallelism": f"dp{world}: batch shards, all_gather of final samples"},
-            "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3s_kernel on operand planes + xattn_block_kernel (q projection, memory attention and out_proj of the cross-attention block in one launch); K / V of the text memory: gemm_f32_kernel<X3>") + ")",
+            "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3s_kernel on operand planes + the (sequence, head) attention blocks selfattn_block_kernel<0|1|2> (in_proj + self-attention; cross q projection + memory attention) -- from 160 row tiles on xattn_block_kernel (the whole cross-attention block in one launch); K / V of the text memory: gemm_f32_kernel<X3>") + ")",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": pmc_traffic_per_launch()[0] if B == 32 else None, "traffic_source": pmc_traffic_per_launch()[1],
                          "launches": lin["launches"],
