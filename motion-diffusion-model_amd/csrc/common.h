@@ -242,8 +242,15 @@ __host__ __device__ __forceinline__ void split_p16(float x, p16_t& hi, p16_t& lo
   lo = f32_to_p16(x - p16_to_f32(hi));
 }
 
-// Two values -> packed (hi, hi) and (lo, lo) dwords.  On the device the fp16 form is written on 2-vectors so that hipcc selects
-// the packed conversions: per PAIR 2 v_med3 + v_cvt_pk_f16_f32 + 2 v_cvt_f32_f16 (SDWA halves) + 2 v_sub + v_cvt_pk_f16_f32.
+// Two values -> packed (hi, hi) and (lo, lo) dwords.  On the device (fp16 planes): hi = v_cvt_pk_f16_f32 (a packed CONVERSION),
+// lo = fp16(x - float(hi)) in ONE instruction per value: v_fma_mix{lo,hi}_f16 takes the fp16 half of `hi2` and the fp32 value as
+// mixed-precision sources (hi * -1.0 + x: exact in fp32, then one RNE rounding to fp16) -- bit for bit the value of the two-step form
+// (tests/test_gpu_round4.py::test_operand_split_is_bit_exact...), 3 instructions per pair instead of 6, same speed (366.7 / 366.5 vs
+// 366.7 / 367.1 motions/s, profiles/r04b_ab.md).  Default since round 5 BECAUSE IT CONTAINS NO PACKED fp32 VALU MATH: the two-step form
+// subtracts on a 2-vector (v_pk_add_f32) -- the one packed fp32 instruction that was left in the product library (4,327 instances)
+// after -fno-slp-vectorize, i.e. the instruction class of the unexplained co-residency corruption (include/mdm_hip.h CONCURRENCY,
+// profiles/r04c_packed_math.md).  tests/test_abi.py disassembles the product library and fails on any v_pk_*_f32.
+// -DMDM_SPLIT_PKSUB builds the two-step form for A/B runs.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2_p16(float a, float b, uint32_t& hi2, uint32_t& lo2) {
@@ -252,18 +259,13 @@ __device__ __forceinline__ void split2_p16(float a, float b, uint32_t& hi2, uint
     const f32x2 v = {a, b};
     const f16x2 h = __builtin_convertvector(v, f16x2);       // v_cvt_pk_f16_f32
     hi2 = __builtin_bit_cast(uint32_t, h);
-#ifdef MDM_SPLIT_FMAMIX
-    // (A/B build, round 4) lo = fp16(x - float(hi)) in ONE instruction per value: v_fma_mix{lo,hi}_f16 takes the fp16 half of
-    // `hi2` and the fp32 value as mixed-precision sources (hi * -1.0 + x: exact in fp32, then one RNE rounding to fp16 -- bit
-    // for bit the value of the form below, tests/test_gpu_round4.py::test_operand_split_is_bit_exact...).  Per pair 3 instructions
-    // instead of 6 -- and NOT faster: 366.7 / 366.5 vs 366.7 / 367.1 motions/s on the same box (profiles/r04b_ab.md): the epilogues
-    // are not bound by these conversions.  Not the default.
+#ifndef MDM_SPLIT_PKSUB
     uint32_t l;
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi2), "v"(a));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi2), "v"(b));
     lo2 = l;
 #else
-    const f32x2 r = v - __builtin_convertvector(h, f32x2);
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);   // v_pk_add_f32
     const f16x2 l = __builtin_convertvector(r, f16x2);
     lo2 = __builtin_bit_cast(uint32_t, l);
 #endif
