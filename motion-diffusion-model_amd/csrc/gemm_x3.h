@@ -56,6 +56,13 @@ constexpr int X3_A_BYTES = X3_TM * X3_BK * 2;                    // one A plane 
 constexpr int X3_A_STAGE = 2 * X3_A_BYTES;                       // Ah|Al: 28672
 constexpr int X3_A_RING = 2;                                     // stages of the step-synchronous k-loop
 constexpr int X3_PIPE_RING = 4;                                  // stages of the pipelined k-loop (PIPE): A runs 3 steps ahead
+// -DMDM_X3_EPI_AHEAD=1: the epilogue reads round j+1's patch BEFORE it finishes round j (a wave's LDS operations execute in order, so the
+// one patch is enough: read j+1, then write j+2 behind it) -- the patch round trip is two rounds of VALU work away from its use
+// instead of one wait away (4 more VGPRs)
+#ifndef MDM_X3_EPI_AHEAD
+#define MDM_X3_EPI_AHEAD 0
+#endif
+constexpr bool X3_EPI_AHEAD = MDM_X3_EPI_AHEAD != 0;
 // -DMDM_X3_PIPE_BADWAIT: a deliberately too lenient middle-of-step wait -- the check that the emulator's LATE mode
 // (tests/emu/hip_emu.h) really catches a wrong count (profiles/r03a_pipe_emulator.md); never defined in a product build
 #ifdef MDM_X3_PIPE_BADWAIT
@@ -1052,13 +1059,33 @@ __global__ __launch_bounds__(64 * WAVES, NCB == 2 ? 1 : 2) void gemm_x3_kernel(X
           const int nkt = ep.qkv.NKT;
           patch_write(std::integral_constant<int, 0>{});
           float2 st_cur = row_stats(std::integral_constant<int, 0>{});
+          float4 v_cur = zero4();
+          if constexpr (X3_EPI_AHEAD) {
+            wave_lds_fence();
+            v_cur = ld4(&patch[prow * 32 + pc4]);
+            wave_lds_fence();
+            patch_write(std::integral_constant<int, 1>{});
+          }
           static_for<NROUNDS>([&](auto j_tag) __attribute__((always_inline)) {
             constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
-            wave_lds_fence();
-            float4 v4 = ld4(&patch[prow * 32 + pc4]);
-            const float2 st_next = row_stats(std::integral_constant<int, j + 1>{});
-            wave_lds_fence();
-            patch_write(std::integral_constant<int, j + 1>{});
+            float4 v4;
+            float2 st_next;
+            if constexpr (X3_EPI_AHEAD) {
+              wave_lds_fence();
+              float4 v_next = zero4();
+              if constexpr (j + 1 < NROUNDS) v_next = ld4(&patch[prow * 32 + pc4]);
+              st_next = row_stats(std::integral_constant<int, j + 1>{});
+              wave_lds_fence();
+              patch_write(std::integral_constant<int, j + 2>{});
+              v4 = v_cur;
+              v_cur = v_next;
+            } else {
+              wave_lds_fence();
+              v4 = ld4(&patch[prow * 32 + pc4]);
+              st_next = row_stats(std::integral_constant<int, j + 1>{});
+              wave_lds_fence();
+              patch_write(std::integral_constant<int, j + 1>{});
+            }
             const float2 st = st_cur;
             st_cur = st_next;
             if (t < nkt) {
@@ -1138,6 +1165,13 @@ __global__ __launch_bounds__(64 * WAVES, NCB == 2 ? 1 : 2) void gemm_x3_kernel(X
       float2* part = reinterpret_cast<float2*>(lds + x3_part_base(NBLK, RINGN)) + wblk * X3_TM;   // OSTAT: this column block's partials
       patch_write(std::integral_constant<int, 0>{});
       float2 st_cur = row_stats(std::integral_constant<int, 0>{});
+      float4 v_cur = zero4();
+      if constexpr (X3_EPI_AHEAD) {
+        wave_lds_fence();
+        v_cur = ld4(&patch[prow * 32 + pc4]);
+        wave_lds_fence();
+        patch_write(std::integral_constant<int, 1>{});
+      }
       static_for<NROUNDS>([&](auto j_tag) __attribute__((always_inline)) {
         constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
         if constexpr (HAS_RES && g == 0) {
@@ -1146,11 +1180,24 @@ __global__ __launch_bounds__(64 * WAVES, NCB == 2 ? 1 : 2) void gemm_x3_kernel(X
             res_wait(std::integral_constant<int, t>{});
           }
         }
-        wave_lds_fence();
-        float4 v4 = ld4(&patch[prow * 32 + pc4]);
-        const float2 st_next = row_stats(std::integral_constant<int, j + 1>{});
-        wave_lds_fence();
-        patch_write(std::integral_constant<int, j + 1>{});
+        float4 v4;
+        float2 st_next;
+        if constexpr (X3_EPI_AHEAD) {
+          wave_lds_fence();
+          float4 v_next = zero4();
+          if constexpr (j + 1 < NROUNDS) v_next = ld4(&patch[prow * 32 + pc4]);
+          st_next = row_stats(std::integral_constant<int, j + 1>{});
+          wave_lds_fence();
+          patch_write(std::integral_constant<int, j + 2>{});
+          v4 = v_cur;
+          v_cur = v_next;
+        } else {
+          wave_lds_fence();
+          v4 = ld4(&patch[prow * 32 + pc4]);
+          st_next = row_stats(std::integral_constant<int, j + 1>{});
+          wave_lds_fence();
+          patch_write(std::integral_constant<int, j + 1>{});
+        }
         const float2 st = st_cur;
         st_cur = st_next;
         const int row_in_tile = t * 32 + 8 * g + prow;

@@ -25,6 +25,12 @@
 
 namespace mdm {
 
+// -DMDM_X3S_EPI_AHEAD=1: the epilogue reads round j+1's patch before it finishes round j (gemm_x3.h MDM_X3_EPI_AHEAD)
+#ifndef MDM_X3S_EPI_AHEAD
+#define MDM_X3S_EPI_AHEAD 0
+#endif
+constexpr bool X3S_EPI_AHEAD = MDM_X3S_EPI_AHEAD != 0;
+
 constexpr int X3S_WAVES = 4;
 constexpr int x3s_tn(int ncb) { return 128 * ncb; }   // columns per tile: 4 waves x NCB blocks of 32
 // W sub-steps in flight per wave (hi + lo fragment per column block, 8 VGPRs each): 16 KB per wave.  Twice the depth for the
@@ -334,6 +340,14 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
     if constexpr (COL_SCALE) { v4.x *= mult4; v4.y *= mult4; v4.z *= mult4; v4.w *= mult4; }
     return v4;
   };
+  // round j of column block cb: accumulator registers 4g .. 4g+3 of both lane halves -> the wave's patch (no-op past the last round)
+  auto patch_write = [&](auto cb_tag, auto j_tag) __attribute__((always_inline)) {
+    constexpr int cb = decltype(cb_tag)::value, j = decltype(j_tag)::value, t = j / 4, g = j % 4;
+    if constexpr (j < 4 * RT) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = acc[cb * RT + t][4 * g + e];
+    }
+  };
   float2* const part_all = reinterpret_cast<float2*>(lds + x3s_part_base(RT, NSUB, MULTI));   // OSTAT: [block][row] partials
 
   static_for<NCB>([&](auto cb_tag) __attribute__((always_inline)) {
@@ -377,34 +391,66 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
         } else {
           p16_t* dh = (which == 0 ? ep.qkv.qh : ep.qkv.kh) + shq * SPq * AX_HD + d0 + pc4;
           p16_t* dl = (which == 0 ? ep.qkv.ql : ep.qkv.kl) + shq * SPq * AX_HD + d0 + pc4;
-#pragma unroll
-          for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = acc[cb * RT + t][4 * g + e];
-              wave_lds_fence();
-              float4 v4 = ld4(&patch[prow * 32 + pc4]);
-              wave_lds_fence();
+          float4 v_cur = zero4();
+          if constexpr (X3S_EPI_AHEAD) {
+            patch_write(std::integral_constant<int, cb>{}, std::integral_constant<int, 0>{});
+            wave_lds_fence();
+            v_cur = ld4(&patch[prow * 32 + pc4]);
+            wave_lds_fence();
+            patch_write(std::integral_constant<int, cb>{}, std::integral_constant<int, 1>{});
+          }
+          static_for<4 * RT>([&](auto j_tag) __attribute__((always_inline)) {
+              constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
+              float4 v4;
+              if constexpr (X3S_EPI_AHEAD) {
+                wave_lds_fence();
+                float4 v_next = zero4();
+                if constexpr (j + 1 < 4 * RT) v_next = ld4(&patch[prow * 32 + pc4]);
+                wave_lds_fence();
+                patch_write(std::integral_constant<int, cb>{}, std::integral_constant<int, j + 2>{});
+                v4 = v_cur;
+                v_cur = v_next;
+              } else {
+                patch_write(std::integral_constant<int, cb>{}, j_tag);
+                wave_lds_fence();
+                v4 = ld4(&patch[prow * 32 + pc4]);
+                wave_lds_fence();
+              }
               const int rit = t * 32 + 8 * g + prow, tok = tig * TR + rit;
               float2 st = make_float2(0.f, 1.f);
               if constexpr (FOLD) st = stab[rit];
               v4 = finish4(v4, st, cb);
               if (rit < rows_valid && tok < ep.S) split4_store(dh + (size_t)tok * AX_HD, dl + (size_t)tok * AX_HD, v4);
-            }
+          });
         }
       }
     } else {
       float2* part = part_all + (wid * NCB + cb) * TR;
-#pragma unroll
-      for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) patch[((e + 4 * h) << 5) + r] = acc[cb * RT + t][4 * g + e];
-          wave_lds_fence();
-          float4 v4 = ld4(&patch[prow * 32 + pc4]);
-          wave_lds_fence();
+      float4 v_cur = zero4();
+      if constexpr (X3S_EPI_AHEAD) {
+        patch_write(std::integral_constant<int, cb>{}, std::integral_constant<int, 0>{});
+        wave_lds_fence();
+        v_cur = ld4(&patch[prow * 32 + pc4]);
+        wave_lds_fence();
+        patch_write(std::integral_constant<int, cb>{}, std::integral_constant<int, 1>{});
+      }
+      static_for<4 * RT>([&](auto j_tag) __attribute__((always_inline)) {
+          constexpr int j = decltype(j_tag)::value, t = j / 4, g = j % 4;
+          float4 v4;
+          if constexpr (X3S_EPI_AHEAD) {
+            wave_lds_fence();
+            float4 v_next = zero4();
+            if constexpr (j + 1 < 4 * RT) v_next = ld4(&patch[prow * 32 + pc4]);
+            wave_lds_fence();
+            patch_write(std::integral_constant<int, cb>{}, std::integral_constant<int, j + 2>{});
+            v4 = v_cur;
+            v_cur = v_next;
+          } else {
+            patch_write(std::integral_constant<int, cb>{}, j_tag);
+            wave_lds_fence();
+            v4 = ld4(&patch[prow * 32 + pc4]);
+            wave_lds_fence();
+          }
           const int rit = t * 32 + 8 * g + prow, m = m0 + rit;
           const bool row_ok = rit < rows_valid && m < M;
           float2 st = make_float2(0.f, 1.f);
@@ -445,7 +491,7 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
               if constexpr (OUT_F32) st4(ep.out + o, v4);
             }
           }
-        }
+      });
     }
   });
   if constexpr (OSTAT && !OUT_QKV) {   // rows x blocks partials -> one (sum, M2) pair per row and tile (OSTAT launches: N % TN == 0)
