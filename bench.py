@@ -237,7 +237,7 @@ def measure_small_batch(model, dev, sync, T, layers, latent_dim, dsteps, batches
     """The latency regime the reference's own callers run (sample/generate.py:76,98: `--num_samples` = the batch, default 6;
     README.md:13 quotes per-call latency): the SAME 50-step CFG p_sample_loop at batch 1 (BASELINE.json configs[0]'s shape, the
     one `cpu_baseline` times on the host), 6 and 10 -- milliseconds per call, mean of `passes` calls after one warm-up call.
-    Below 40 sequences the encoder GEMMs run on csrc/gemm_x3s.h's 32 / 64-row tiles."""
+    Up to 80 sequences the encoder GEMMs run on csrc/gemm_x3s.h's 32 / 64-row tiles."""
     import torch
     from mdm_amd import model_util
     diff = model_util.create_gaussian_diffusion(model_util.default_args(diffusion_steps=dsteps, layers=layers, latent_dim=latent_dim))

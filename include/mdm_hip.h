@@ -97,13 +97,13 @@ void mdm_destroy(mdm_model_t* m);
  * its route once; set options between calls, not from another thread during one).  No counterpart in the reference.
  *   MDM_OPT_SMALL_GEMM_MAX_SEQS   up to how many token sequences (B, or 2B under guidance) a forward runs its GEMMs on the
  *                                 32 / 64-row tiles of the latency regime (csrc/gemm_x3s.h) instead of the sequence-sized tiles
- *                                 (csrc/gemm_x3.h).  Default 40 (the measured cross-over).  0: never -- which also sends the
+ *                                 (csrc/gemm_x3.h).  Default 80 (the measured cross-over, profiles/r05k_crossovers.md).  0: never -- which also sends the
  *                                 trans_dec (DiP) decoder to its fp32-skeleton route (csrc/gemm_f32.h).  The parity tests use it
  *                                 to hold every route against the reference's fixtures.
  *   MDM_OPT_SMALL_GEMM_ROW_TILES  0 (default): 32-row tiles up to 12 sequences, 64-row tiles above; 1 / 2: pin 32 / 64 rows.
  *   MDM_OPT_DEC_FUSED_XATTN       the cross-attention block of a trans_dec layer on the operand-plane route -- query projection with
  *                                 norm1 folded, attention over the text memory, out_proj + residual + row statistics (model/mdm.py:
- *                                 85-93, :263-265).  3 (default): by size -- 2 below 160 32-row tiles (DiP's 32 motions per GPU), 1
+ *                                 85-93, :263-265).  3 (default): by size -- 2 below 144 32-row tiles (DiP's 32 motions per GPU: 120), 1
  *                                 from there on.  2: projection + attention of a (sequence, head) in one kernel
  *                                 (csrc/selfattn_block.h, CROSS mode: windows and memories of at most 64 tokens), then the out_proj
  *                                 GEMM; 1: the whole block as ONE kernel (csrc/xattn_block.h: latent_dim 256 / 512, <= 96 memory

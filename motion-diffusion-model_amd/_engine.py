@@ -59,7 +59,7 @@ class Engine:
             pass
 
     def set_option(self, name, value):
-        """include/mdm_hip.h mdm_set_option: 'small_gemm_max_seqs' (default 40; 0 = sequence-sized tiles / DiP fp32 skeleton
+        """include/mdm_hip.h mdm_set_option: 'small_gemm_max_seqs' (default 80; 0 = sequence-sized tiles / DiP fp32 skeleton
         only), 'small_gemm_row_tiles' (0 = by size, 1 = 32 rows, 2 = 64).  Takes effect with the next call."""
         if name not in nat.OPTIONS:
             raise ValueError(f"unknown engine option {name!r}: one of {sorted(nat.OPTIONS)}")

@@ -25,9 +25,12 @@
 
 namespace mdm {
 
-// -DMDM_X3S_EPI_AHEAD=1: the epilogue reads round j+1's patch before it finishes round j (gemm_x3.h MDM_X3_EPI_AHEAD)
+// MDM_X3S_EPI_AHEAD (default 1; -DMDM_X3S_EPI_AHEAD=0: one round trip per round): the epilogue reads round j+1's patch before it finishes
+// round j (a wave's LDS operations execute in order: read j+1, then write j+2 behind it, one patch).  Same-box A/B, 8 of 8 pairs
+// positive: DiP B = 32 +0.45 %, the 50-step loop at B = 1 / 6 / 10 -0.45 / -0.3 / -0.3 % (profiles/r05j_epilogue_ahead.md); the same
+// change in gemm_x3.h (MDM_X3_EPI_AHEAD) measured neutral on the headline and stays off
 #ifndef MDM_X3S_EPI_AHEAD
-#define MDM_X3S_EPI_AHEAD 0
+#define MDM_X3S_EPI_AHEAD 1
 #endif
 constexpr bool X3S_EPI_AHEAD = MDM_X3S_EPI_AHEAD != 0;
 
@@ -517,9 +520,12 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
 #ifndef MDM_X3_KERNEL_ONLY
 // Which forwards take this kernel, and on which tile height: per-model options (include/mdm_hip.h mdm_set_option, ABI 9;
 // rounds 3-4 read environment variables here, on every launch).
-//   max_seqs   up to how many token sequences a forward runs on these tiles (default 40, i.e. 20 motions under guidance; 0
-//              disables the kernel): the measured cross-over with gemm_x3.h's sequence-sized tiles lies between 32 sequences
-//              (65 vs 80 ms per 50-step loop) and 48 (93 vs ~95), profiles/r04a_small_batch.md;
+//   max_seqs   up to how many token sequences a forward runs on these tiles (default 80, i.e. 40 motions under guidance; 0
+//              disables the kernel).  Round 4 put the cross-over with gemm_x3.h's sequence-sized tiles at 40 sequences
+//              (profiles/r04a_small_batch.md); re-measured on the final kernels of round 5 (profiles/r05k_crossovers.md, ms per
+//              50-step loop, row tiles / sequence tiles): 48 sequences 88.2 / 101.1, 64: 114.2 / 112.9, 80: 135.7 / 137.2, 96:
+//              159.7 / 154.5, 128: 212.1 / 178.3 -- and on a box whose power-limited clocks ran the big kernel 20 % slower the row
+//              tiles won everything up to 80 sequences by 16-28 %;
 //   row_tiles  0 = by size, 1 / 2 = pin 32- / 64-row tiles.
 // ONE shape for all GEMMs of a forward, because the row statistics a producer leaves (per tile width) are what its consumer
 // merges.  By size: 32-row tiles up to 12 sequences (B <= 6 under guidance: 22.0 vs 26.5 ms per 50-step loop at B = 1, 30.7 vs
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
 inline int& x3s_tl_target() { static int v = -1; return v; }   // mdm_debug_set(9, n); < 0: off
 inline int& x3s_tl_count() { static int v = 0; return v; }
 #endif
-struct X3sOptions { int max_seqs = 40; int row_tiles = 0; int ncb = 1; };
+struct X3sOptions { int max_seqs = 80; int row_tiles = 0; int ncb = 1; };
 struct X3sShape { int rt, ncb; };
 inline X3sShape x3s_shape(const X3sOptions& o, int nseq) {
   X3sShape sh{nseq <= 12 ? 1 : 2, 1};

@@ -1287,7 +1287,7 @@ struct DecHoist {         // step k of a window loop: where the hoisted projecti
 // mode 1) then performs guidance combine + inpainting blend + clamp + posterior / DDIM update + inline Philox in place on x, exactly
 // as the encoder loop's tail does -- one launch and one [nseq, J, P] round trip through memory fewer per step than
 // OutputProcess -> sampler_step_kernel (same arithmetic, element for element).  `done` says whether the route applied it.
-constexpr int kXattnOneKernelWgs = 160;    // MDM_OPT_DEC_FUSED_XATTN = 3: from this many 32-row tiles on, xattn_block.h's one-kernel block
+constexpr int kXattnOneKernelWgs = 144;    // MDM_OPT_DEC_FUSED_XATTN = 3: from this many 32-row tiles on, xattn_block.h's one-kernel block
 struct DecTail {
   const float* scale = nullptr;      // [B] or null (single branch)
   float* x = nullptr;                // [B, J, F, P]: x_t in, x_{t-1} out

@@ -76,7 +76,7 @@ def engine_options(monkeypatch):
 @pytest.fixture(params=["small", "big"])
 def gemm_path(request, engine_options):
     """Which of the two split-precision encoder GEMM kernels a small-batch test runs on: csrc/gemm_x3s.h's 32-row tiles (the
-    default below 32 sequences) or csrc/gemm_x3.h's sequence-sized tiles (small_gemm_max_seqs = 0; what large batches run).  Both
+    default up to 80 sequences) or csrc/gemm_x3.h's sequence-sized tiles (small_gemm_max_seqs = 0; what large batches run).  Both
     are product code."""
     engine_options(**GEMM_PATHS[request.param])
     return request.param

@@ -62,7 +62,7 @@ def test_product_library_reads_no_environment_variable(lib):
     lib.check(lib.mdm_create(C.byref(cfg), C.byref(h)), "mdm_create")
     v = C.c_int32(-1)
     lib.check(lib.mdm_get_option(h, _native.OPTIONS["small_gemm_max_seqs"], C.byref(v)), "mdm_get_option")
-    assert v.value == 40
+    assert v.value == 80
     lib.check(lib.mdm_set_option(h, _native.OPTIONS["small_gemm_max_seqs"], 0), "mdm_set_option")
     lib.check(lib.mdm_get_option(h, _native.OPTIONS["small_gemm_max_seqs"], C.byref(v)), "mdm_get_option")
     assert v.value == 0

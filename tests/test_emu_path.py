@@ -593,11 +593,11 @@ def test_engine_options_are_set_through_the_abi_not_the_environment(lib, monkeyp
     monkeypatch.setenv("MDM_X3S_RT", "2")
     if not lib.has_probes:      # (the probe / emulator builds preset new handles from these two variables for tools/' A/B scripts)
         e = Engine(cfg, lib=lib)
-        assert e.get_option("small_gemm_max_seqs") == 40 and e.get_option("small_gemm_row_tiles") == 0
+        assert e.get_option("small_gemm_max_seqs") == 80 and e.get_option("small_gemm_row_tiles") == 0
     monkeypatch.delenv("MDM_X3S_MAX_SEQS")
     monkeypatch.delenv("MDM_X3S_RT")
     e = Engine(cfg, lib=lib, options={"small_gemm_row_tiles": 2})
-    assert e.get_option("small_gemm_max_seqs") == 40 and e.get_option("small_gemm_row_tiles") == 2
+    assert e.get_option("small_gemm_max_seqs") == 80 and e.get_option("small_gemm_row_tiles") == 2
     e.set_option("small_gemm_max_seqs", 0)
     assert e.get_option("small_gemm_max_seqs") == 0
     with pytest.raises(Exception, match="ROW_TILES"):

@@ -210,7 +210,7 @@ def test_bench_force_pg_brings_up_rccl_as_a_one_rank_group():
 def test_small_batch_loop_matches_oracle(sd, gemm_path, B, lengths):
     """The latency regime (sample/generate.py's default `--num_samples 6`; README.md:13's per-call latency; BASELINE.json
     configs[0]'s batch 1): the 50-step CFG loop at T = 196, B = 1 and B = 6, on BOTH encoder GEMM kernels -- csrc/gemm_x3s.h's
-    32 / 64-row tiles (what runs below 40 sequences) and csrc/gemm_x3.h's sequence tiles -- against the oracle on the same
+    32 / 64-row tiles (what runs up to 80 sequences) and csrc/gemm_x3.h's sequence tiles -- against the oracle on the same
     injected noise; and the two kernels against each other."""
     steps, T = 50, 196
     shape = (B, 263, 1, T)
