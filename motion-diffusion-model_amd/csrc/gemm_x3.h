@@ -58,7 +58,9 @@ constexpr int X3_A_RING = 2;                                     // stages of th
 constexpr int X3_PIPE_RING = 4;                                  // stages of the pipelined k-loop (PIPE): A runs 3 steps ahead
 // -DMDM_X3_EPI_AHEAD=1: the epilogue reads round j+1's patch BEFORE it finishes round j (a wave's LDS operations execute in order, so the
 // one patch is enough: read j+1, then write j+2 behind it) -- the patch round trip is two rounds of VALU work away from its use
-// instead of one wait away (4 more VGPRs)
+// instead of one wait away (0-4 more VGPRs).  Measured NEUTRAL on the headline (GEMM class 291.9, 291.5 vs 291.2, 292.7 ms per loop,
+// profiles/r05j_epilogue_ahead.md): this kernel's epilogue does not wait for its 28 LDS round trips -- which also closes the 16-row-round
+// variant of VERDICT r04 -- so the switch stays off; gemm_x3s.h's twin gains 0.3-0.5 % and is on
 #ifndef MDM_X3_EPI_AHEAD
 #define MDM_X3_EPI_AHEAD 0
 #endif
@@ -1317,7 +1319,11 @@ inline int x3_grid_limit(int per_cu) {
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
-  const int wgs = per_cu * cus / 8 * 8;  // xcd_remap keeps a workgroup on one XCD only if the stride is a multiple of 8
+  int wgs = per_cu * cus / 8 * 8;  // xcd_remap keeps a workgroup on one XCD only if the stride is a multiple of 8
+#ifdef MDM_PROBES   // lab/probes/two_chains.py: two half-batch chains share the chip, each launch takes 1 / div of the CUs
+  static const int div = [] { const char* e = getenv("MDM_X3_GRID_DIV"); return e != nullptr && atoi(e) > 1 ? atoi(e) : 1; }();
+  wgs = wgs / div / 8 * 8;
+#endif
   return wgs > 0 ? wgs : 8;
 #endif
 }

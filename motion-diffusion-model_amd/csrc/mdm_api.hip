@@ -616,6 +616,9 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
     // planes or the 207 MB of GELU planes stay inside the 256 MB Infinity Cache between producer and consumer, was built and
     // measured in round 4: attention 2 x 59.4 us against 111.5, in_proj 2 x 132.1 against 257.3, whole loop 1.0-1.5 % SLOWER on the
     // same box -- profiles/r04i_halves.md -- and removed.)
+    // (Running the batch as TWO concurrent half-batch chains on two streams, each GEMM launch on half the CUs, so that one chain's
+    // epilogue store bursts fall into the other's k-loops: round 5, probe-library hooks MDM_CHAIN_FREE / MDM_X3_GRID_DIV,
+    // lab/probes/two_chains.py -- 3.5 % SLOWER, bit-identical results: profiles/r05l_two_chains.md.)
     for (int l = 0; l < m->cfg.num_layers; ++l) {
       const mdm_model::LayerPlanes& P = m->planes[l];
       const mdm_model::LayerFold& F = m->fold[l];
@@ -736,7 +739,12 @@ struct ChainGuard {
   hipStream_t s;
   explicit ChainGuard(void* stream) : c(g_chain[rt_device_ordinal()]), s(static_cast<hipStream_t>(stream)) {
     c.mu.lock();
-    if (c.has && c.last != s) {
+#ifdef MDM_PROBES   // lab/probes/two_chains.py: chains on different streams are NOT ordered against each other (probe library only)
+    static const bool chain_free = [] { const char* e = getenv("MDM_CHAIN_FREE"); return e != nullptr && e[0] == '1'; }();
+#else
+    constexpr bool chain_free = false;
+#endif
+    if (c.has && c.last != s && !chain_free) {
       // A stream that is being CAPTURED into a hipGraph (torch.cuda.graph captures on a side stream of its own, so the warm-up
       // ran on another one) must not wait for an event recorded outside the capture: that invalidates the capture.
       // Nothing is enqueued while capturing, so there is nothing to order here; ordering the REPLAYS against other users of the
