@@ -154,7 +154,7 @@ def measure(dev, rank, world, B, steps, warmup, cpu=True, mask_frames=True, engi
                                    (" (the DiP.md:181 recipe: a frame mask on every forward)" if mask_frames else " (no frame mask reaches the kernels: A/B only)"),
                        "global_batch": GB, "mask_frames": bool(mask_frames),
                        "parallelism": f"dp{world}: batch shards, all_gather of final samples"},
-            "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3s_kernel on operand planes + the (sequence, head) attention blocks selfattn_block_kernel<0|1|2> (in_proj + self-attention; cross q projection + memory attention) -- from 160 row tiles on xattn_block_kernel (the whole cross-attention block in one launch); K / V of the text memory: gemm_f32_kernel<X3>") + ")",
+            "roofline": {"bound": "mfma", "kernel": "decoder GEMMs (" + ("gemm_f32_kernel" if prec == "f32" else "gemm_x3s_kernel on operand planes + the (sequence, head) attention blocks selfattn_block_kernel<0|1|2> (in_proj + self-attention; cross q projection + memory attention) -- from 144 row tiles on xattn_block_kernel (the whole cross-attention block in one launch); K / V of the text memory: gemm_f32_kernel<X3>") + ")",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": pmc_traffic_per_launch()[0] if B == 32 else None, "traffic_source": pmc_traffic_per_launch()[1],
                          "launches": lin["launches"],
@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--no-mask-frames", action="store_true", help="A/B: a model built without --mask_frames (NULL lengths)")
     ap.add_argument("--no-fused-xattn", action="store_true", help="A/B: the cross-attention block as three launches (round 4's form)")
     ap.add_argument("--xattn", type=int, default=3, help="A/B: MDM_OPT_DEC_FUSED_XATTN (3 by size, 2 per (sequence, head) + GEMM, 1 one kernel, 0 three launches)")
+    ap.add_argument("--row-tiles", type=int, default=0, help="A/B: MDM_OPT_SMALL_GEMM_ROW_TILES (0 by size, 1 = 32-row tiles, 2 = 64-row tiles)")
     ap.add_argument("--no-fused-selfattn", action="store_true", help="A/B: in_proj + self-attention as two launches (round 4's form)")
     a = ap.parse_args()
     rank, world, local = mdist.init_from_env("nccl")
@@ -183,7 +184,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     line = measure(dev, rank, world, a.batch, a.steps, a.warmup, cpu=not a.no_cpu_baseline, mask_frames=not a.no_mask_frames,
-                   engine_options={"dec_fused_xattn": 0 if a.no_fused_xattn else a.xattn, "dec_fused_selfattn": 0 if a.no_fused_selfattn else 1})
+                   engine_options={"dec_fused_xattn": 0 if a.no_fused_xattn else a.xattn, "dec_fused_selfattn": 0 if a.no_fused_selfattn else 1,
+                                   **({"small_gemm_row_tiles": a.row_tiles} if a.row_tiles else {})})
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
