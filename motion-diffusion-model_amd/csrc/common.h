@@ -261,8 +261,13 @@ __device__ __forceinline__ void split2_p16(float a, float b, uint32_t& hi2, uint
     hi2 = __builtin_bit_cast(uint32_t, h);
 #ifndef MDM_SPLIT_PKSUB
     uint32_t l;
+    // HARDWARE FINDING (round 5, profiles/r05m_fma_mix_hazard.md): a v_mfma that reads a register written by v_fma_mix{lo,hi}_f16 needs
+    // wait states in between, and hipcc's hazard recognizer does not look into inline asm -- it put the MFMA one instruction behind the
+    // pair, and xattn_block_kernel<4, 3> (70 memory tokens: its K / V / P fragments go from this split straight into MFMAs) returned
+    // 7e-2 errors that changed from run to run; every other kernel got its distance by luck of the schedule.  Two wait states behind
+    // the pair cure it (bisected on the MI355X: the two-step form and this form pass, the bare pair and the pair as one statement fail).
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi2), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi2), "v"(b));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(l) : "v"(hi2), "v"(b));
     lo2 = l;
 #else
     const f32x2 r = v - __builtin_convertvector(h, f32x2);   // v_pk_add_f32

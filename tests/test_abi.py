@@ -94,6 +94,12 @@ def test_product_library_contains_no_packed_fp32_valu_math(lib, tmp_path):
     packed = sorted(set(re.findall(r"\bv_pk_[a-z0-9_]*f32\b", asm)))
     assert packed == [], {m: asm.count(m) for m in packed}
     assert asm.count("v_fma_mixlo_f16") > 1000
+    # ... and every v_fma_mixhi_f16 of the split is followed by its two wait states: a v_mfma that reads the split's result one
+    # instruction behind the bare pair returned wrong, run-to-run different values (xattn_block_kernel<4, 3>; common.h split2_p16,
+    # profiles/r05m_fma_mix_hazard.md) -- hipcc's hazard recognizer does not see into inline asm
+    ops = [ln.split("\t")[1].split()[0:2] for ln in asm.splitlines() if ln.startswith("\t") and len(ln.split("\t")) > 1 and ln.split("\t")[1].strip()]
+    bare = sum(1 for a, b in zip(ops, ops[1:]) if a[0] == "v_fma_mixhi_f16" and b != ["s_nop", "1"])
+    assert bare == 0, f"{bare} v_fma_mixhi_f16 without 's_nop 1' behind them"
 
 
 def test_no_cuda_or_torch_in_the_abi():

@@ -40,7 +40,7 @@ def test_dip_masked_forward_on_every_route_matches_reference_golden(golden_dir, 
     g = _g(golden_dir, "dip_fwd_masked_B3")
     B = 3
     model, _ = make_pair(sd_dip, 10, DEV, guided=True, context_len=20, pred_len=40, mask_frames=True)
-    assert model.model.engine().get_option("small_gemm_max_seqs") == ROUTES[route].get("small_gemm_max_seqs", 40)
+    assert model.model.engine().get_option("small_gemm_max_seqs") == ROUTES[route].get("small_gemm_max_seqs", 80)
     y_cpu = synth_dip_y(B, 40, 20, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]), lengths=list(g["lengths"]))
     y = to_dev(y_cpu, DEV)
     x_cpu = torch.randn(B, 263, 1, 40, generator=torch.Generator().manual_seed(int(g["x_seed"])))
