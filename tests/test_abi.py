@@ -100,6 +100,34 @@ def test_product_library_contains_no_packed_fp32_valu_math(lib, tmp_path):
     ops = [ln.split("\t")[1].split()[0:2] for ln in asm.splitlines() if ln.startswith("\t") and len(ln.split("\t")) > 1 and ln.split("\t")[1].strip()]
     bare = sum(1 for a, b in zip(ops, ops[1:]) if a[0] == "v_fma_mixhi_f16" and b != ["s_nop", "1"])
     assert bare == 0, f"{bare} v_fma_mixhi_f16 without 's_nop 1' behind them"
+    # the general form of the same audit, over every VALU instruction this library issues from inline asm (which hipcc's hazard
+    # recognizer cannot see): a v_mfma never reads a register such an instruction wrote fewer than two wait states earlier
+    asm_valu = ("v_fma_mixlo_f16", "v_fma_mixhi_f16", "v_fma_mix_f32", "v_permlane16_swap_b32", "v_permlane32_swap_b32")
+    lines = [ln.split("\t")[1].split("//")[0].strip() for ln in asm.splitlines() if ln.startswith("\t") and len(ln.split("\t")) > 1]
+    lines = [ln for ln in lines if ln]
+
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return range(int(m.group(1)), int(m.group(2)) + 1)
+        m = re.match(r"v(\d+)$", tok)
+        return range(int(m.group(1)), int(m.group(1)) + 1) if m else ()
+
+    close_calls = 0
+    for i, ln in enumerate(lines):
+        if not ln.startswith("v_mfma"):
+            continue
+        srcs = {r for tok in re.split(r"[ ,]+", ln)[2:] for r in regs(tok)}
+        waits = 0
+        for back in range(1, 3):                       # the two instructions in front of the MFMA
+            prev = lines[i - back] if i - back >= 0 else ""
+            op = prev.split()[0] if prev else ""
+            if op.startswith(asm_valu) and waits < 2:
+                written = {r for tok in re.split(r"[ ,]+", prev)[1:3] for r in regs(tok)} if "swap" in op else set(regs(re.split(r"[ ,]+", prev)[1]))
+                if written & srcs:
+                    close_calls += 1
+            waits += (int(prev.split()[1]) + 1) if op == "s_nop" else 1
+    assert close_calls == 0, f"{close_calls} v_mfma read an inline-asm VALU result fewer than two wait states behind its write"
 
 
 def test_no_cuda_or_torch_in_the_abi():
