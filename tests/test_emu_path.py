@@ -703,3 +703,23 @@ def test_emulated_attention_direct_output_is_bit_identical(lib, engine_options, 
         outs.append(model(x, t, y=dict(y)))
     assert torch.equal(outs[0], outs[1])
     assert maxabs(outs[0], orc.cfg_forward(sd, x, t, y, num_heads=2)) < 5e-5
+
+
+def test_default_route_runs_row_tiles_up_to_80_sequences(lib, engine_options):
+    """MDM_OPT_SMALL_GEMM_MAX_SEQS defaults to 80 since the cross-over was re-measured (profiles/r05k_crossovers.md): a guided forward of
+    B = 24 (48 sequences -- the sequence-tile kernel under round 4's threshold of 40) takes csrc/gemm_x3s.h's row tiles by default.  The
+    two kernels round differently (row statistics per 128 / per 256 columns; the small-batch tests hold them against each other), so
+    the route shows in the bits: default == pinned row tiles.  (The other side -- 82 sequences on the sequence tiles -- costs the
+    emulator minutes and is what every large-batch GPU test runs.)"""
+    sd = small_state_dict(num_layers=1)
+    B, T = 24, 3
+    y = synth_y(B, T, seed=4, lengths=[3, 2] * 12)
+    g = torch.Generator().manual_seed(1)
+    x, t = torch.randn(B, 263, 1, T, generator=g), torch.arange(B) % 50
+    outs = {}
+    for name, opts in (("default", {}), ("rows", {"small_gemm_max_seqs": 128})):
+        engine_options(**opts)
+        model, _ = make_pair(sd, 50, "cpu", guided=True, native_lib=lib, precision="f16x3")
+        outs[name] = model(x, t, y=dict(y))
+    assert maxabs(outs["rows"], orc.cfg_forward(sd, x, t, y, num_heads=2)) < 5e-5
+    assert torch.equal(outs["default"], outs["rows"])
