@@ -24,7 +24,7 @@ def _cpu_workers(config):
         if getattr(config.option, "collectonly", False) or getattr(config.option, "usepdb", False):
             return 0
         n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        return min(8, n - 2) if n >= 4 else 0
+        return min(16, n - 1) if n >= 4 else 0
     except Exception:       # whatever goes wrong here must not keep the suite from running serially
         return 0
 
@@ -34,6 +34,8 @@ def pytest_cmdline_main(config):
     n = _cpu_workers(config)
     if n >= 2:
         config.option.numprocesses = n      # (registered after the xdist plugin, so this runs before its own cmdline hook reads it)
+        if getattr(config.option, "dist", "no") in ("no", "load"):
+            config.option.dist = "worksteal"    # the emulator cases last 1-170 s each: idle workers take over the queues' tails
     return None
 
 
