@@ -447,7 +447,15 @@ def main(argv=None):
         # BASELINE.json configs[4] (DiP, 256 motions over 8 GPUs = 32 per GPU) at EVERY world size since round 5: each rank
         # generates its 32 motions (Philox streams by global sample index), the final all_gather is inside the timed region
         import bench_dip
-        dip = bench_dip.measure(dev, rank=rank, world=world, B=32, steps=3, warmup=1, cpu=False)
+        if world == 1:
+            dip = bench_dip.measure(dev, rank=rank, world=world, B=32, steps=3, warmup=1, cpu=False)
+        else:
+            # N > 1: this leg has only ever run as one rank on real hardware (no multi-GPU box has been offered);
+            # a failure in it must not cost the headline line the driver's scaling record is made of -- it is reported IN the line
+            try:
+                dip = bench_dip.measure(dev, rank=rank, world=world, B=32, steps=3, warmup=1, cpu=False)
+            except Exception as e:      # noqa: BLE001
+                dip = {"error": f"{type(e).__name__}: {e}"} if rank == 0 else None
 
     if rank == 0:
         traffic, traffic_stale, traffic_src = pmc_traffic_per_gemm_launch()
