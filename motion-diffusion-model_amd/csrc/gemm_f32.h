@@ -730,7 +730,11 @@ template <bool X3, class AL, class BL, class EP>
 inline void launch_gemm_f32_t(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, hipStream_t stream,
                               int weight_is_a) {
   const int tiles_m = (M + GEMM_BM - 1) / GEMM_BM, tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-  if (BL::kFragments || (tiles_m * tiles_n < 512 && (size_t)M * N >= 64 * 64 * 4)) {
+  // X3: ALWAYS the 64-row form (in-workgroup split-K, KS = 2).  The two forms associate the k-sum differently, and a tile shape that
+  // follows the row count makes a sample's result depend on how many OTHER samples share the launch: DiP's hoisted memory
+  // projection re-associated when a batch was sharded over ranks (SURVEY 8e promises output invariant to the
+  // number of GPUs).  The exact-fp32 form accumulates in one k order under either tile shape and keeps the size rule.
+  if (BL::kFragments || X3 || (tiles_m * tiles_n < 512 && (size_t)M * N >= 64 * 64 * 4)) {
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
     constexpr int KS = X3 ? GEMM_X3_KSPLIT : 1;
     constexpr int LDS = gemm_f32_lds_total(64, X3, BL::kFragments);

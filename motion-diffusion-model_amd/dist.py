@@ -51,7 +51,10 @@ def shard_y(y, lo, hi):
             out[k] = v[:, lo:hi]                         # [1, B, clip_dim]
         elif k == "text_embed" and isinstance(v, tuple):  # DiP: (tokens [Ntok, B, 768], pad mask [B or 1, Ntok]) (model/mdm.py:180-187)
             tok, pad = v
-            out[k] = (tok[:, lo:hi], pad if pad.shape[0] == 1 else pad[lo:hi])
+            if tok.dim() == 4:       # dynamic text (generate.py:139-140): (enc [B, Ntok, P, 768], pad [B, P, Ntok]) -- sample-major
+                out[k] = (tok[lo:hi], pad[lo:hi])
+            else:
+                out[k] = (tok[:, lo:hi], pad if pad.shape[0] == 1 else pad[lo:hi])
         elif k == "text" and isinstance(v, (list, tuple)):
             out[k] = list(v[lo:hi])
         elif k in _SHARDED_KEYS and torch.is_tensor(v) and v.dim() >= 1:

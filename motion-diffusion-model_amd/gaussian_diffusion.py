@@ -388,7 +388,15 @@ class GaussianDiffusion:
         shape = tuple(int(s) for s in shape)
         B, J, Fe, T = shape
         if 'text' in y.keys() and 'text_embed' not in y.keys():
-            # encoding once instead of each iteration (gaussian_diffusion.py:633-635); caches into the caller's dict
+            # encoding once instead of each iteration (gaussian_diffusion.py:633-635); caches into the caller's dict.
+            # THE ONE DELIBERATE DIFFERENCE OF THIS SEAM: upstream re-encodes y['text'] on every p_sample_loop call even when
+            # y['text_embed'] is already there (it overwrites the cache with the same tensor: generate.py:130-132 made it with the
+            # same call on the same prompts, and the encoders are frozen, eval-mode, deterministic).  Here a cached embedding is
+            # USED -- the text encoders are outside the hot path (north_star: "the cached CLIP text embedding is consumed
+            # as-is") and absent offline.  The only caller for which upstream's overwrite changes the VALUE is DiP's dynamic-text
+            # mode, whose sampler hands over a sample-major slice upstream never reads: sampler_util.AutoRegressiveSampler here
+            # hands over the token-major embedding of the window's prompts instead, which is what the re-encode yields
+            # (tests/golden/dip_dynamic_text_*.npz: the reference run itself).
             y['text_embed'] = model.encode_text(y['text'])
         if mdm.arch == 'trans_dec' and self.dip_stepwise:
             # the window loop one native forward + one step kernel at a time (what p_sample composes); kept as the

@@ -176,8 +176,11 @@ class MDM(nn.Module):
     def encode_text(self, raw_text):
         """model/mdm.py:163-178 clip_encode_text (bert_encode_text :180-187 needs DistilBERT weights: cache instead)."""
         if self.text_encoder_type == 'bert':
-            raise RuntimeError("DistilBERT is not available in this environment: pass the cached embedding as "
-                               "y['text_embed'] = (last_hidden_state [Ntok, B, 768], pad_mask [B, Ntok])")
+            if getattr(self, 'clip_model', None) is None:
+                raise RuntimeError("no DistilBERT attached (assign model.clip_model = load_bert(path), model/mdm.py:119): pass the "
+                                   "cached embedding as y['text_embed'] = (last_hidden_state [Ntok, B, 768], pad_mask [B, Ntok])")
+            enc_text, mask = self.clip_model(raw_text)        # model/mdm.py:180-187 bert_encode_text
+            return enc_text.permute(1, 0, 2), ~mask
         if getattr(self, 'clip_model', None) is None:
             raise RuntimeError("CLIP is not available in this environment: pass the cached embedding as "
                                "y['text_embed'] ([1, B, clip_dim]); see sample/generate.py:130-132")
@@ -326,7 +329,13 @@ class MDM(nn.Module):
             else:                                            # CLIP: one memory token per sample (mdm.py:262)
                 tok, tl = enc, torch.ones(bs, dtype=torch.int64, device=dev)
             tok = tok.to(device=dev, dtype=torch.float32).contiguous()
-            assert tok.dim() == 3 and tok.shape[1] == bs and tok.shape[2] == self.clip_dim, tok.shape
+            if tok.dim() != 3 or tok.shape[1] != bs or tok.shape[2] != self.clip_dim or tl.shape[0] != bs or \
+                    (isinstance(enc, tuple) and pad.shape[1] != tok.shape[0]):
+                raise ValueError(f"y['text_embed'] must be TOKEN-major: embedding [Ntok, B={bs}, {self.clip_dim}] with pad mask "
+                                 f"[B, Ntok] (what bert_encode_text returns, model/mdm.py:185); got {tuple(tok.shape)}"
+                                 + (f" and {tuple(enc[1].shape)}" if isinstance(enc, tuple) else "")
+                                 + " -- a [B, Ntok, dim] block (e.g. upstream's dynamic-text slice, utils/sampler_util.py:69) is "
+                                   "sample-major: permute(1, 0, 2) it")
             lengths = None
             if use_mask:
                 m2 = mask[..., :x.shape[-1]].reshape(bs, -1).to(dev).to(torch.bool)

@@ -117,16 +117,27 @@ def dip_sample_loop(sd, tab, shape, y, x_T, step_noise, *, context_len, cfg=True
 
 
 def autoregressive_sample(sd, tab, shape, y, noise_chunks, *, context_len, pred_len, required_frames,
-                          include_prefix=False, **kw):
-    """AutoRegressiveSampler.sample (utils/sampler_util.py:47-81), static text.  noise_chunks[i] = (x_T, [eps_k])."""
+                          include_prefix=False, encode_text=None, **kw):
+    """AutoRegressiveSampler.sample (utils/sampler_util.py:47-81).  noise_chunks[i] = (x_T, [eps_k]).
+
+    Static text: every window runs on y['text_embed'].  Dynamic text (`--dynamic_text_path`; y['text'][b] is the LIST of prompts
+    of sample b, utils/sampler_util.py:52): window i keeps prompt i of every sample (:66-68) and -- the line that decides what
+    upstream computes -- p_sample_loop RE-ENCODES y['text'] whenever that key is present (diffusion/gaussian_diffusion.py:633-635),
+    so the sampler's slice of the cached embedding (:69) is overwritten before any forward reads it: window i runs on
+    `encode_text([prompt i of sample b for b])`."""
     n_iter = required_frames // pred_len + int(required_frames % pred_len > 0)
     cur_prefix = y["prefix"].clone()
     buf = [cur_prefix] if include_prefix else []
     ar_shape = list(shape)
     ar_shape[-1] = pred_len
+    dynamic = "text" in y and type(y["text"][0]) == list
     for i in range(n_iter):
         x_T, eps = noise_chunks[i]
-        sample = dip_sample_loop(sd, tab, ar_shape, {**y, "prefix": cur_prefix}, x_T, eps, context_len=context_len, **kw)
+        yi = {**y, "prefix": cur_prefix}
+        if dynamic:
+            yi["text"] = [s[i] for s in y["text"]]
+            yi["text_embed"] = encode_text(yi["text"])
+        sample = dip_sample_loop(sd, tab, ar_shape, yi, x_T, eps, context_len=context_len, **kw)
         buf.append(sample[..., -pred_len:].clone())
         cur_prefix = sample[..., -context_len:].clone()
     return torch.cat(buf, dim=-1)[..., :required_frames]

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 from oracle import ref_harness as rh          # noqa: E402
 from oracle import mdm_oracle as orc          # noqa: E402
 from oracle import dip_oracle as dip          # noqa: E402
-from oracle.synth import synth_dip_state_dict, synth_dip_y  # noqa: E402
+from oracle.synth import synth_bert, synth_bert_encode_text, synth_dip_dynamic_y, synth_dip_state_dict, synth_dip_y  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 CONTEXT, PRED = 20, 40
@@ -36,7 +36,9 @@ class _StubBert(nn.Module):
     preset = None
 
     def forward(self, texts):
-        return self.preset
+        # `preset`: the cached synthetic embedding of the static-text cases; else the functional stand-in (a prompt -> its own seeded
+        # token rows, oracle/synth.py synth_bert) that the dynamic-text cases need, where upstream re-encodes per window
+        return self.preset if self.preset is not None else synth_bert(texts)
 
 
 def ref_dip_model(sd, **over):
@@ -59,12 +61,61 @@ def maxabs(a, b):
     return float((torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max())
 
 
+DYNAMIC_CASES = {
+    # name: (B, prompts, seed).  Token counts (words + 2) 5 / 7 / 4 != B; second case B == Ntok == 4 (a sample-major slice passes
+    # every shape check there)
+    "dip_dynamic_text_B2_P3": (2, ["a person walks forward", "the person turns around and waves", "sits down"], 41),
+    "dip_dynamic_text_B4_P2": (4, ["jumps high", "runs"], 43),
+}
+
+
+def dynamic_text(sd, model, stub, cfgm, rep):
+    """`--dynamic_text_path` (sample/generate.py:63-65, :134-142; utils/sampler_util.py:52, :66-71; the re-encode of
+    diffusion/gaussian_diffusion.py:633-635): one prompt per 40-frame prediction window, CFG 7.5, run through the reference's own
+    AutoRegressiveSampler + p_sample_loop with a functional BERT stand-in."""
+    from utils.sampler_util import AutoRegressiveSampler
+    steps = 10
+    diff = rh.build_reference_diffusion(steps=steps)
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    stub.preset = None
+    args = types.SimpleNamespace(pred_len=PRED, context_len=CONTEXT, autoregressive_include_prefix=False)
+    for name, (B, prompts, seed) in DYNAMIC_CASES.items():
+        frames = len(prompts) * PRED                               # generate.py:65
+        y = synth_dip_dynamic_y(B, PRED, CONTEXT, seed=seed + 1000, prompts=prompts)
+        sampler = AutoRegressiveSampler(args, diff.p_sample_loop, frames)
+        shape = (B, 263, 1, frames)
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            ref = sampler.sample(cfgm, shape, clip_denoised=False, model_kwargs={"y": deepcopy(y)}, skip_timesteps=0,
+                                 init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False)
+        chunks = dip.make_noise_chunks((B, 263, 1, PRED), steps, seed, len(prompts))
+        mine = dip.autoregressive_sample(sd, tab, shape, y, chunks, context_len=CONTEXT, pred_len=PRED,
+                                         required_frames=frames, cfg=True, encode_text=synth_bert_encode_text)
+        # what the semantics is NOT: every window on the first prompt
+        y_static = {**y, "text": [prompts[0]] * B, "text_embed": synth_bert_encode_text([prompts[0]] * B)}
+        other = dip.autoregressive_sample(sd, tab, shape, y_static, chunks, context_len=CONTEXT, pred_len=PRED,
+                                          required_frames=frames, cfg=True)
+        rep[name] = {"final": maxabs(ref, mine), "ref_absmax": float(ref.abs().max()),
+                     "vs_first_prompt_everywhere": maxabs(ref, other)}
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), steps=steps, B=B, frames=frames, seed=seed, y_seed=seed + 1000,
+                            prompts=np.array(prompts), scale=7.5, final=ref.numpy())
+
+
 def main():
     torch.set_num_threads(8)
     rep = {}
     sd = synth_dip_state_dict(seed=0)
     model, stub = ref_dip_model(sd)
     cfgm = rh.reference_cfg(model)
+    if "--only-dynamic" in sys.argv:      # the fixtures of round 6 alone (the others regenerate bit-identically, but take minutes)
+        dynamic_text(sd, model, stub, cfgm, rep)
+        path = os.path.join(OUT, "PIN_REPORT.json")
+        report = json.load(open(path))
+        report.setdefault("dip", {}).update(rep)
+        with open(path, "w") as f:
+            json.dump(report, f, indent=1, sort_keys=True)
+        print(json.dumps(rep, indent=1, sort_keys=True))
+        return
 
     # ---- single forward: cond / uncond / CFG, ragged text lengths
     B = 3
@@ -115,6 +166,8 @@ def main():
     rep["ar10_B2_F100"] = {"final": maxabs(ref, mine), "ref_absmax": float(ref.abs().max())}
     np.savez_compressed(os.path.join(OUT, "dip_ar10_B2_F100.npz"), steps=steps, B=B, frames=frames, seed=seed,
                         y_seed=seed + 1000, text_lengths=[9, 15], scale=7.5, final=ref.numpy())
+
+    dynamic_text(sd, model, stub, cfgm, rep)
 
     keys = {k: list(v.shape) for k, v in rh.reference_state_dict(model).items()}
     with open(os.path.join(OUT, "dip_state_dict_keys.json"), "w") as f:

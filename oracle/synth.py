@@ -153,3 +153,46 @@ def synth_dip_y(B, pred_len, context_len, seed, text_lengths, scale=7.5, lengths
             "text_embed": (torch.randn(ntok, B, bert_dim, generator=g), torch.arange(ntok)[None, :] >= tl[:, None]),
             "prefix": torch.randn(B, njoints, 1, context_len, generator=g),
             "scale": torch.ones(B) * scale}
+
+
+def synth_bert(texts, bert_dim=768, junk=5.0):
+    """Functional stand-in for model/BERT/BERT_encoder.py:26-32 `BERT.forward(texts)`: -> (last_hidden_state [len(texts), Ntok, 768],
+    attention_mask bool [len(texts), Ntok]).  A prompt maps to a block of (words + 2) token rows -- [CLS] w1 .. wn [SEP], as the
+    tokenizer counts them -- drawn from a generator seeded by the CRC of the string, so the SAME prompt gives the SAME rows in
+    whatever batch it is encoded (what a deterministic encoder with an attention mask does); the batch is right-padded to its
+    longest prompt (`padding=True`) and the pad rows are filled with junk (a real encoder leaves arbitrary values there: they must be
+    masked, never read).  Used to pin `--dynamic_text_path` (sample/generate.py:63-65, :134-142), where upstream re-encodes one
+    prompt per prediction window."""
+    import zlib
+    blocks = []
+    for s in texts:
+        g = torch.Generator().manual_seed(zlib.crc32(s.encode("utf-8")))
+        blocks.append(torch.randn(len(s.split()) + 2, bert_dim, generator=g))
+    ntok = max(b.shape[0] for b in blocks)
+    out = torch.empty(len(texts), ntok, bert_dim)
+    mask = torch.zeros(len(texts), ntok, dtype=torch.bool)
+    gj = torch.Generator().manual_seed(ntok * 7919 + len(texts))
+    for i, b in enumerate(blocks):
+        out[i, :b.shape[0]] = b
+        out[i, b.shape[0]:] = junk * torch.randn(ntok - b.shape[0], bert_dim, generator=gj)
+        mask[i, :b.shape[0]] = True
+    return out, mask
+
+
+def synth_bert_encode_text(texts):
+    """model/mdm.py:180-187 `bert_encode_text` over `synth_bert`: -> (enc [Ntok, B, 768], pad [B, Ntok], True = no token)."""
+    out, mask = synth_bert(texts)
+    return out.permute(1, 0, 2), ~mask
+
+
+def synth_dip_dynamic_y(B, pred_len, context_len, seed, prompts, scale=7.5, njoints=263):
+    """`model_kwargs['y']` as sample/generate.py:130-142 leaves it under `--dynamic_text_path`: the P prompts of the file encoded
+    ONCE as a batch, then `y['text']` = the prompt list per sample and `y['text_embed']` = (enc [B, Ntok, P, 768] -- the token-major
+    [Ntok, P, 768] encoding repeated per sample --, pad [B, P, Ntok])."""
+    g = torch.Generator().manual_seed(seed)
+    enc, pad = synth_bert_encode_text(list(prompts))                  # [Ntok, P, 768], [P, Ntok]
+    return {"mask": torch.ones(B, 1, 1, pred_len, dtype=torch.bool), "lengths": torch.full((B,), pred_len, dtype=torch.long),
+            "text": [list(prompts)] * B,
+            "text_embed": (enc.unsqueeze(0).repeat(B, 1, 1, 1), pad.unsqueeze(0).repeat(B, 1, 1)),
+            "prefix": torch.randn(B, njoints, 1, context_len, generator=g),
+            "scale": torch.ones(B) * scale}

@@ -723,3 +723,80 @@ def test_default_route_runs_row_tiles_up_to_80_sequences(lib, engine_options):
         outs[name] = model(x, t, y=dict(y))
     assert maxabs(outs["rows"], orc.cfg_forward(sd, x, t, y, num_heads=2)) < 5e-5
     assert torch.equal(outs["default"], outs["rows"])
+
+
+# ---- round 6 ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,prompts", [(2, ["walks forward slowly", "turns", "sits down on a chair now"]),   # Ntok 5 / 3 / 8, B = 2
+                                       (4, ["jumps high", "runs"])])                                            # B == Ntok == 4
+def test_emulated_dip_dynamic_text_is_a_prompt_per_window(lib, B, prompts):
+    """`--dynamic_text_path` (sample/generate.py:63-65, :134-142; utils/sampler_util.py:52, :66-71).  Upstream
+    computes "window i <- prompt i of every sample" because p_sample_loop re-encodes y['text'] (gaussian_diffusion.py:633-635);
+    round 5 handed the decoder upstream's SAMPLE-major slice of the cached embedding: an assert for B != Ntok and a silently
+    different motion for B == Ntok.  Both shapes against the oracle's restatement (pinned to the reference run itself by
+    tests/golden/dip_dynamic_text_*.npz), with y exactly as generate.py:130-142 leaves it; and the result is NOT what any fixed
+    prompt gives."""
+    from types import SimpleNamespace
+    from mdm_amd.sampler_util import AutoRegressiveSampler
+    from oracle.synth import synth_bert_encode_text, synth_dip_dynamic_y
+    C, P, steps = 5, 12, 2
+    frames = P * len(prompts)
+    sd = dip_small_state_dict(num_layers=1)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P)
+    y = synth_dip_dynamic_y(B, P, C, seed=11, prompts=prompts, scale=2.5)
+    chunks = dip.make_noise_chunks((B, 263, 1, P), steps, 5, len(prompts))
+    it = iter(chunks)
+
+    def sample_fn(mdl, shape, **kw):
+        x_T, eps = next(it)
+        return diffusion.p_sample_loop(mdl, shape, noise_sequence=[x_T] + [e.contiguous() for e in eps], **kw)
+
+    args = SimpleNamespace(pred_len=P, context_len=C, autoregressive_include_prefix=False)
+    got = AutoRegressiveSampler(args, sample_fn, frames).sample(model, (B, 263, 1, frames), clip_denoised=False,
+                                                                model_kwargs={"y": y})
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    kw = dict(context_len=C, pred_len=P, required_frames=frames, cfg=True, num_heads=2)
+    want = dip.autoregressive_sample(sd, tab, (B, 263, 1, frames), y, chunks, encode_text=synth_bert_encode_text, **kw)
+    assert maxabs(got, want) < 5e-5
+    y0 = {**y, "text": [prompts[0]] * B, "text_embed": synth_bert_encode_text([prompts[0]] * B)}
+    assert maxabs(got, dip.autoregressive_sample(sd, tab, (B, 263, 1, frames), y0, chunks, **kw)) > 1e-2
+    assert isinstance(y["text"][0], list) and y["text_embed"][0].dim() == 4         # the caller's dict is not rewritten
+
+
+def test_dec_inputs_refuse_a_sample_major_text_embedding(lib):
+    """model/mdm.py:185: bert_encode_text returns the embedding TOKEN-major [Ntok, B, 768].  A [B, Ntok, 768] block (upstream's
+    dynamic-text slice) is a ValueError that names the layout, not a bare assert."""
+    B, C, P = 2, 5, 12
+    sd = dip_small_state_dict(num_layers=1)
+    model, _ = make_pair(sd, 2, "cpu", guided=False, native_lib=lib, context_len=C, pred_len=P)
+    y = synth_dip_y(B, P, C, seed=4, text_lengths=[6, 3])
+    enc, pad = y["text_embed"]
+    y["text_embed"] = (enc.permute(1, 0, 2).contiguous(), pad)
+    x = torch.randn(B, 263, 1, P)
+    with pytest.raises(ValueError, match="TOKEN-major"):
+        model(x, torch.tensor([1, 0]), y=y)
+
+
+def test_bert_encode_text_runs_an_attached_encoder(lib):
+    """model/mdm.py:119, :180-187: `clip_model` is the DistilBERT wrapper; encode_text = permute + inverted mask.  None is attached
+    offline (RuntimeError that says so); with one attached, a loop given only y['text'] encodes once and caches into the caller's
+    dict (gaussian_diffusion.py:633-635) and equals the loop given the cached embedding."""
+    from oracle.synth import synth_bert, synth_bert_encode_text
+    B, C, P, steps = 2, 5, 12, 2
+    sd = dip_small_state_dict(num_layers=1)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, context_len=C, pred_len=P)
+    texts = ["walks forward", "a person sits down"]
+    with pytest.raises(RuntimeError, match="DistilBERT"):
+        model.encode_text(texts)
+    model.model.clip_model = synth_bert
+    enc, pad = model.encode_text(texts)
+    ref = synth_bert_encode_text(texts)
+    assert torch.equal(enc, ref[0]) and torch.equal(pad, ref[1])
+    y = synth_dip_y(B, P, C, seed=4, text_lengths=[6, 3], scale=2.5)
+    seq = [torch.randn(B, 263, 1, P, generator=torch.Generator().manual_seed(i)) for i in range(1 + steps)]
+    y1 = {k: v for k, v in y.items() if k != "text_embed"}
+    y1["text"] = texts
+    a = diffusion.p_sample_loop(model, (B, 263, 1, P), clip_denoised=False, model_kwargs={"y": y1}, noise_sequence=seq)
+    assert "text_embed" in y1
+    y2 = {**y, "text": texts, "text_embed": ref}
+    b = diffusion.p_sample_loop(model, (B, 263, 1, P), clip_denoised=False, model_kwargs={"y": y2}, noise_sequence=seq)
+    assert torch.equal(a, b)

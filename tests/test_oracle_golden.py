@@ -142,6 +142,8 @@ def test_dip_pin_report_is_tight(golden_dir):
     assert max(rep["fwd_B3"][k] for k in ("cond", "uncond", "cfg")) < DIP_TOL_FWD
     assert rep["fwd_masked_B3"]["cond"] < DIP_TOL_FWD
     assert rep["ar10_B2_F100"]["final"] < DIP_TOL_AR
+    for name in ("dip_dynamic_text_B2_P3", "dip_dynamic_text_B4_P2"):      # round 6: --dynamic_text_path
+        assert rep[name]["final"] < DIP_TOL_AR and rep[name]["vs_first_prompt_everywhere"] > 1.0
 
 
 def test_dip_forward_golden(golden_dir):
@@ -178,4 +180,25 @@ def test_dip_autoregressive_golden(golden_dir):
     out = dip.autoregressive_sample(sdd, tab, (B, 263, 1, frames), y, chunks, context_len=20, pred_len=40,
                                     required_frames=frames, cfg=True)
     assert out.shape == (B, 263, 1, frames)
+    assert np.abs(out.numpy() - g["final"]).max() < DIP_TOL_AR
+
+
+@pytest.mark.parametrize("name", ["dip_dynamic_text_B2_P3", "dip_dynamic_text_B4_P2"])
+def test_dip_dynamic_text_golden(golden_dir, name):
+    """`--dynamic_text_path` (sample/generate.py:63-65, :134-142): the reference's own AutoRegressiveSampler + p_sample_loop run
+    with a functional BERT stand-in (oracle/synth.py synth_bert) -- window i runs on prompt i of every sample, re-encoded per window
+    (diffusion/gaussian_diffusion.py:633-635) -- against the oracle's restatement of that.  B != Ntok and B == Ntok."""
+    from oracle import dip_oracle as dip
+    from oracle.synth import synth_bert_encode_text, synth_dip_dynamic_y, synth_dip_state_dict
+    g = _load(golden_dir, name)
+    steps, B, frames, seed = int(g["steps"]), int(g["B"]), int(g["frames"]), int(g["seed"])
+    prompts = [str(p) for p in g["prompts"]]
+    assert frames == 40 * len(prompts)
+    sdd = synth_dip_state_dict(seed=0)
+    y = synth_dip_dynamic_y(B, 40, 20, seed=int(g["y_seed"]), prompts=prompts, scale=float(g["scale"]))
+    assert y["text_embed"][0].shape[:3] == (B, max(len(p.split()) for p in prompts) + 2, len(prompts))
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    chunks = dip.make_noise_chunks((B, 263, 1, 40), steps, seed, len(prompts))
+    out = dip.autoregressive_sample(sdd, tab, (B, 263, 1, frames), y, chunks, context_len=20, pred_len=40,
+                                    required_frames=frames, cfg=True, encode_text=synth_bert_encode_text)
     assert np.abs(out.numpy() - g["final"]).max() < DIP_TOL_AR
