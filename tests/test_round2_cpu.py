@@ -112,6 +112,36 @@ def test_bench_self_launches_two_ranks_from_a_bare_shell():
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
 
 
+def test_bench_dry_run_at_the_real_world_size_of_eight_ranks():
+    """VERDICT r05 item 7 / SURVEY 8e: BASELINE.json configs[3] / [4] run on 8 GPUs and no multi-GPU box has been offered to this
+    repository -- so the launcher is exercised at the REAL world size on CPU: `python bench.py --gpus 8 --emulate` from a bare shell
+    self-launches eight gloo ranks (kernels in the emulator, a tiny model), every rank samples its own shard with `sample_base`, the
+    final samples are all-gathered, the `dip` leg (configs[4]'s path: per-rank window loops + its own gather, behind the collective
+    `ok` flag of ADVICE r05) runs too, and rank 0 prints ONE JSON line, last on stdout.  (Shards cannot be ragged here: the bench is
+    weak-scaling, a fixed batch per GPU; ragged shards are tests/test_dist_gloo.py's.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    from emu_lib import emu
+    emu()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--emulate", "--layers", "1", "--latent-dim", "256",
+           "--batch", "1", "--frames", "6", "--diffusion-steps", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    env = _clean_env()
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    lines = [ln for ln in out_lines if ln.startswith("{")]
+    assert len(lines) == 1 and out_lines[-1] == lines[0], r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
+    assert d["ranks"]["world_size"] == 8 and d["ranks"]["backend"].startswith("gloo")
+    assert len(d["ranks"]["loop_ms_per_rank"]) == 8 and all(v > 0 for v in d["ranks"]["loop_ms_per_rank"])
+    assert d["ranks"]["gathered_shape"] == [8, 263, 1, 6]
+    dip = d["dip"]
+    assert "error" not in dip, dip
+    assert dip["n_gpus"] == 8 and dip["config"]["global_batch"] == 16 and dip["value"] > 0
+    assert "NOT a measurement" in dip["data"]
+
+
 @pytest.mark.skipif(not os.path.isfile("/root/reference/utils/model_util.py"), reason="needs the reference tree (build container)")
 def test_integration_md_drop_in_launcher_and_reference_handover():
     """tests/dropin_replay.py: the rebinding of INTEGRATION.md section 1 through the REFERENCE's create_model_and_diffusion /
