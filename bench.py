@@ -453,7 +453,7 @@ def main(argv=None):
         # the real world size, tests/test_round2_cpu.py) runs the same leg on a tiny model in the emulator.
         import bench_dip
         if a.emulate:
-            dip = bench_dip.measure(dev, rank=rank, world=world, B=2, steps=1, warmup=0, cpu=False, native_lib=native_lib, tiny=True)
+            dip = bench_dip.measure(dev, rank=rank, world=world, B=1, steps=1, warmup=0, cpu=False, native_lib=native_lib, tiny=True)
         else:
             dip = bench_dip.measure(dev, rank=rank, world=world, B=32, steps=3, warmup=1, cpu=False, small_batch=(world == 1))
 

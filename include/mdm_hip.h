@@ -23,8 +23,12 @@
  *     resident on the same CU at the same time -- measured with this library's own chains on side streams AND with another
  *     library's fused attention kernels (scaled-dot-product attention) on a foreign stream (17 of 60 DiP window loops differed); never on disjoint CUs,
  *     never in the f32 mode, and not on the encoder path (trans_enc: its kernels own a CU's whole LDS; 0 of 120 forwards
- *     beside the same foreign stream).  Not cache coherence, not kernel ordering; cause not identified
- *     (profiles/r03g_dip_groups.md).  What cures it is building without packed fp32 VALU math (-fno-slp-vectorize, the
+ *     beside the same foreign stream).  Not cache coherence, not kernel ordering (profiles/r03g_dip_groups.md); and NOT a
+ *     wait-state hazard that a disassembly can show: round 6 pointed the static auditor that found round 5's
+ *     `v_fma_mix -> v_mfma` hazard (tools/hazard_audit.py: VALU write -> MFMA read, MFMA write -> VALU / memory read or
+ *     overwrite, every kernel, fall-through paths) at the SLP build that corrupts -- 12,806 v_pk_{add,mul,fma}_f32, 0 sites, hipcc
+ *     pads its packed instructions exactly like its plain ones (profiles/r06b_slp_hazard_audit.md).  The cause stays
+ *     unidentified -- looked for with the tool, not found.  What cures it is building without packed fp32 VALU math (-fno-slp-vectorize, the
  *     way __graft_entry__.build() builds this library: 0 of 520 window loops in the regimes that corrupted 100 of 520).
  *     PRECAUTION FOR CALLERS, because the effect is not understood: while mdm_forward_dec / mdm_sample_loop_dec work is in
  *     flight on a device and the results matter, keep other LDS-using kernels off it; never build the library with SLP

@@ -130,6 +130,23 @@ def test_product_library_contains_no_packed_fp32_valu_math(lib, tmp_path):
     assert close_calls == 0, f"{close_calls} v_mfma read an inline-asm VALU result fewer than two wait states behind its write"
 
 
+def test_static_wait_state_audit_of_the_product_library(lib):
+    """tools/hazard_audit.py -- the generalisation of the v_fma_mix audit above to EVERY VALU -> v_mfma read
+    (>= 2 wait states) and every v_mfma write -> VALU / LDS / memory read or overwrite (>= passes + 2, the distance hipcc itself pads
+    to) -- over the shipped gfx950 code object: no site.  (Run over the SLP build too, by hand: profiles/r06b_slp_hazard_audit.md.)"""
+    import importlib.util
+    from mdm_amd import _native
+    if not os.path.isfile("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump of the ROCm toolchain is not installed")
+    spec = importlib.util.spec_from_file_location("hazard_audit", os.path.join(ROOT, "tools", "hazard_audit.py"))
+    ha = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ha)
+    res = ha.audit(ha.disassemble(_native.LIB_PATH))
+    assert res["kernels"] > 90 and res["A"]["checked"] > 1000 and res["B"]["checked"] > 10      # (it found the pairs it is about)
+    assert res["A"]["sites"] == 0 and res["A"]["min_wait"] >= 2, res["A"]
+    assert res["B"]["sites"] == 0 and res["B"]["min_margin"] >= 0, res["B"]
+
+
 def test_no_cuda_or_torch_in_the_abi():
     src = open(os.path.join(ROOT, "include", "mdm_hip.h")).read()
     assert "torch" not in src.lower().replace("pytorch", "").replace("a torch tensor", "")

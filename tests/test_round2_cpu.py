@@ -138,7 +138,7 @@ def test_bench_dry_run_at_the_real_world_size_of_eight_ranks():
     assert d["ranks"]["gathered_shape"] == [8, 263, 1, 6]
     dip = d["dip"]
     assert "error" not in dip, dip
-    assert dip["n_gpus"] == 8 and dip["config"]["global_batch"] == 16 and dip["value"] > 0
+    assert dip["n_gpus"] == 8 and dip["config"]["global_batch"] == 8 and dip["value"] > 0
     assert "NOT a measurement" in dip["data"]
 
 
