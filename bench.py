@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 
 # algorithmic flops of one MDM forward of one sample (S=197, d=512, ff=1024, L=8, J=263)
 PEAKS_TFLOPS = {"f32": 157.3, "f16x3": 2500.0}      # MI355X_MICROARCH.md: fp32 MFMA / dense fp16 MFMA
-PMC_PROFILE = os.path.join("profiles", "r05_pmc.json")
+PMC_PROFILE = os.path.join("profiles", "r06_pmc.json")
 
 
 def algorithmic_flops_per_forward(T, d=512, ff=1024, L=8, J=263):

@@ -68,7 +68,7 @@ def cpu_baseline(state, budget_s=12.0):
                       f"{DSTEPS} steps per motion ({per_step * 1e3:.0f} ms per batch-step)"}
 
 
-DIP_PMC_PROFILE = os.path.join("profiles", "r05_dip_pmc.json")
+DIP_PMC_PROFILE = os.path.join("profiles", "r06_dip_pmc.json")
 
 
 def pmc_traffic_per_launch():

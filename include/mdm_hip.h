@@ -38,7 +38,9 @@
  *     call besides its kernel launches and device-to-device copies: the per-device guard is a host mutex).  The warm-up may have
  *     run on ANOTHER stream (graph-capture helpers of ML frameworks capture on a side stream of their own): since ABI 9 the guard asks hipStreamIsCapturing and
  *     skips its cross-stream event while `stream` is being captured (tests/test_gpu_round5.py replays such a capture).  Run one
- *     warm-up call of the same shapes first (first-use hipFuncSetAttribute calls), keep mdm_profile_enable off, and order the
+ *     warm-up call of the SAME shapes (batch, frames, text tokens) first: a kernel instantiation opts in to its dynamic LDS on first
+ *     use, and a first use on a capturing stream is refused with MDM_EUNSUPPORTED (round 6; it used to issue the function-attribute
+ *     call inside the capture).  Keep mdm_profile_enable off, and order the
  *     graph's REPLAYS against other users of the device yourself.  Not supported: a capture that contains calls from two
  *     different streams.
  *   - all tensors are fp32, dense, in the reference's layouts: poses [B, njoints, nfeats, T] (T contiguous).
@@ -111,8 +113,8 @@ void mdm_destroy(mdm_model_t* m);
  *                                 from there on.  2: projection + attention of a (sequence, head) in one kernel
  *                                 (csrc/selfattn_block.h, CROSS mode: windows and memories of at most 64 tokens), then the out_proj
  *                                 GEMM; 1: the whole block as ONE kernel (csrc/xattn_block.h: latent_dim 256 / 512, <= 96 memory
- *                                 tokens); 0: as three launches around the exact-fp32 attention kernel (round 4's form).  A value
- *                                 whose shapes are not covered falls through to the next lower one.
+ *                                 tokens); 0: as three launches around the exact-fp32 attention kernel (round 4's form).  An explicit
+ *                                 1 or 2 whose shapes are not covered takes the other fused form if that one applies, else 0.
  *   MDM_OPT_DEC_FUSED_SELFATTN    1 (default): in_proj + self-attention of a trans_dec layer on the operand-plane route run as ONE
  *                                 kernel per (sequence, head) for sequences of at most 64 tokens (csrc/selfattn_block.h: DiP's 20 + 40);
  *                                 0: in_proj into Q / K / V^T planes + the attention kernel (two launches; A/B and tests). */

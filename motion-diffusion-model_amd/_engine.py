@@ -59,8 +59,19 @@ class Engine:
             pass
 
     def set_option(self, name, value):
-        """include/mdm_hip.h mdm_set_option: 'small_gemm_max_seqs' (default 80; 0 = sequence-sized tiles / DiP fp32 skeleton
-        only), 'small_gemm_row_tiles' (0 = by size, 1 = 32 rows, 2 = 64).  Takes effect with the next call."""
+        """include/mdm_hip.h mdm_set_option (the header has the full text); takes effect with the next call.
+          'small_gemm_max_seqs'   default 80: up to how many sequences a forward runs on the row-tile GEMM kernel (gemm_x3s.h);
+                                  0 = sequence-sized tiles only, which also sends trans_dec (DiP) to its fp32-skeleton route
+          'small_gemm_row_tiles'  0 = by size (default), 1 = 32-row tiles, 2 = 64-row tiles
+          'dec_fused_xattn'       trans_dec cross-attention block: 3 = by size (default: 2 below 144 row tiles, 1 from there on),
+                                  2 = q projection + memory attention per (sequence, head) in one kernel + the out_proj GEMM,
+                                  1 = the whole block as one kernel, 0 = three launches.  An explicit 1 / 2 whose shapes are not
+                                  covered (1: latent_dim 256 / 512 and <= 96 memory tokens; 2: windows and memories of <= 64
+                                  tokens) takes the other fused form if that applies, else 0
+          'dec_fused_selfattn'    1 (default) = in_proj + self-attention of a trans_dec layer as one kernel per (sequence, head)
+                                  for sequences of <= 64 tokens, 0 = two launches
+          'attn_direct_out'       0 (default); 1 = the encoder attention kernel stores its output planes straight from the
+                                  accumulators (measured slower, profiles/r05e_attention_direct.md; A/B only)"""
         if name not in nat.OPTIONS:
             raise ValueError(f"unknown engine option {name!r}: one of {sorted(nat.OPTIONS)}")
         self.lib.check(self.lib.mdm_set_option(self.handle, nat.OPTIONS[name], int(value)), f"mdm_set_option({name})")

@@ -72,6 +72,20 @@ template <int N> __device__ __forceinline__ void ax_vm_wait() {      // s_waitcn
   asm volatile("s_waitcnt vmcnt(%0)" : : "i"(N) : "memory");
 #endif
 }
+// DIRECT's plane stores are COUNTED by the next item's first tile waits (AX_NST = 32 per active wave): they are issued from inline
+// asm, one instruction per plane and register quad, so that the count cannot follow a compiler decision to merge, split or reorder
+// them (the C++ form relied on hipcc emitting exactly two 8-byte stores per call).
+__device__ __forceinline__ void ax_split4_store_counted(p16_t* hi_p, p16_t* lo_p, float4 v) {
+#ifdef MDM_EMU
+  split4_store(hi_p, lo_p, v);
+#else
+  uint32_t h01, l01, h23, l23;
+  split2_p16(v.x, v.y, h01, l01);
+  split2_p16(v.z, v.w, h23, l23);
+  asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(hi_p), "v"(u32x2{h01, h23}) : "memory");
+  asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(lo_p), "v"(u32x2{l01, l23}) : "memory");
+#endif
+}
 template <int NKT, int ABL = 0, bool DIRECT = false>
 __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const int* __restrict__ lengths,
                                                                     int S, int D, int B, int lead, float* __restrict__ out,
@@ -372,8 +386,8 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(QkvPlanes P, const
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            split4_store(oh + obase + 32 * dt + 8 * g, ol + obase + 32 * dt + 8 * g,
-                         make_float4(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv));
+            ax_split4_store_counted(oh + obase + 32 * dt + 8 * g, ol + obase + 32 * dt + 8 * g,
+                                    make_float4(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv));
       }
     }
     first_item = false;

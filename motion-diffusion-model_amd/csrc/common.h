@@ -37,6 +37,24 @@ inline int rt_device_ordinal() {
 #endif
 }
 
+#ifndef MDM_EMU
+// The one-time opt-in of a kernel instantiation to more than 64 KB of dynamic LDS, per device (`configured` = that instantiation's
+// static bool[kMaxDevices]).  0: set (now or earlier); -1: the HIP call failed; -3: this would be the instantiation's FIRST use and
+// `stream` is being captured into a hipGraph -- a function-attribute call does not belong inside a capture (a warm-up
+// with another token count / window shape leaves an instantiation unconfigured): the caller reports MDM_EUNSUPPORTED and asks for a
+// warm-up call of the same shapes outside the capture (include/mdm_hip.h "hipGraph CAPTURE").  The capture query runs on a first
+// use only: a configured instantiation costs one array read per launch.
+template <class KF> inline int rt_dyn_lds_once(KF kfn, int bytes, bool* configured, hipStream_t stream) {
+  bool& done = configured[rt_device_ordinal()];
+  if (done) return 0;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return -3;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -1;
+  done = true;
+  return 0;
+}
+#endif
+
 // v_mfma_f32_32x32x2_f32: exact-fp32 matrix FMA (64 cyc/SIMD, 157 TF chip peak).
 //   lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
 //   D[reg] is row i = (reg&3) + 8*(reg>>2) + 4*(l>>5), column j = l&31.

@@ -712,15 +712,14 @@ __global__ __launch_bounds__(GEMM_THREADS * KS, 2 * KS) void gemm_f32_kernel(AL 
 
 // 128x128 tiles unless they would leave more than half of the chip's workgroup slots (2 per CU) empty
 template <class KF>
-inline void gemm_f32_allow_lds(KF kfn, int bytes) {
+inline void gemm_f32_allow_lds(KF kfn, int bytes, hipStream_t stream) {
 #ifndef MDM_EMU
   if (bytes > 65536) {
     static bool configured[kMaxDevices] = {};   // per instantiation (KF) and device
-    bool& done = configured[rt_device_ordinal()];
-    if (!done) done = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    (void)rt_dyn_lds_once(kfn, bytes, configured, stream);   // (a failure -- or a first use inside a stream capture -- surfaces as the launch's own error)
   }
 #else
-  (void)kfn; (void)bytes;
+  (void)kfn; (void)bytes; (void)stream;
 #endif
 }
 // (X3 tile choice, measured on the DiP bench: taking 128x128 tiles from 100 / 200 workgroups on instead of 512 is 30 % / 23 %
@@ -739,13 +738,13 @@ inline void launch_gemm_f32_t(const AL& al, const BL& bl, const EP& ep, int M, i
     constexpr int KS = X3 ? GEMM_X3_KSPLIT : 1;
     constexpr int LDS = gemm_f32_lds_total(64, X3, BL::kFragments);
     auto kfn = &gemm_f32_kernel<AL, BL, EP, 64, X3, KS>;
-    gemm_f32_allow_lds(kfn, LDS);
+    gemm_f32_allow_lds(kfn, LDS, stream);
     MDM_LAUNCH(kfn, dim3(tm * tn), dim3(GEMM_THREADS * KS), LDS, stream, al, bl, ep, M, N, K, tn, weight_is_a);
     return;
   }
   if constexpr (!BL::kFragments) {
   auto kfn = &gemm_f32_kernel<AL, BL, EP, 128, X3>;
-  gemm_f32_allow_lds(kfn, gemm_f32_lds_total(128, X3));
+  gemm_f32_allow_lds(kfn, gemm_f32_lds_total(128, X3), stream);
   MDM_LAUNCH(kfn, dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), gemm_f32_lds_total(128, X3), stream, al, bl, ep, M, N, K, tiles_n, weight_is_a);
   }
 }

@@ -1360,13 +1360,7 @@ inline int launch_gemm_x3_w(const X3Operand& A, const X3Weights& W, const X3Epil
 #ifndef MDM_EMU
   if (x3_lds_bytes(NBLK, LN, RINGN) > 65536) {
     static bool configured[kMaxDevices] = {};  // per instantiation and device (the attribute belongs to the device's code object)
-    bool& done = configured[rt_device_ordinal()];
-    if (!done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              x3_lds_bytes(NBLK, LN, RINGN)) != hipSuccess)
-        return -1;
-      done = true;
-    }
+    if (const int rc = rt_dyn_lds_once(kfn, x3_lds_bytes(NBLK, LN, RINGN), configured, stream)) return rc;
   }
 #endif
   const int grid = std::min(total, x3_grid_limit((WAVES == 4 && NCB == 1) ? 2 : 1));

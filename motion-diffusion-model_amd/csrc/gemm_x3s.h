@@ -562,11 +562,7 @@ inline int launch_gemm_x3s_t(const X3Operand& A, const X3Weights& W, const X3Epi
 #ifndef MDM_EMU
   if (LDS > 65536) {
     static bool configured[kMaxDevices] = {};
-    bool& done = configured[rt_device_ordinal()];
-    if (!done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
-      done = true;
-    }
+    if (const int rc = rt_dyn_lds_once(kfn, LDS, configured, stream)) return rc;
   }
 #endif
   const int TR = 32 * RT, TN = x3s_tn(NCB);

@@ -75,6 +75,14 @@ template <class K> inline int rt_allow_lds(K kernel, size_t bytes) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// launcher return codes -1 / -3 of the dynamic-LDS opt-in (common.h rt_dyn_lds_once)
+inline int lds_fail(int rc, const char* what) {
+  if (rc == -3)
+    return fail(MDM_EUNSUPPORTED, std::string(what) + ": first use of this kernel instantiation while the stream is being captured into a "
+                "hipGraph -- run one warm-up call of the SAME shapes (batch, frames, text tokens) outside the capture first");
+  return fail(MDM_EHIP, std::string(what) + ": hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+}
+
 }  // namespace
 
 // Opt-in per-launch timing (mdm_profile_enable): one hipEvent pair per kernel launch, bucketed by kernel class.
@@ -506,7 +514,7 @@ int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w,
     // a quarter of the workgroups of a sequence-aligned launch would do 8 % of a tile's work (B = 6: 37 row tiles instead of 48)
     const int group_rows = (kind == 0 || kind == 6) ? S : (kind == 5 ? ln.emb_T : M);
     const int rc = launch_gemm_x3s(kind, ln.shape, a, w, ep, M, N, K, group_rows, s);
-    if (rc == -1) return fail(MDM_EHIP, "f16x3 linear (small tiles): hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    if (rc == -1 || rc == -3) return lds_fail(rc, "f16x3 linear (small tiles)");
     if (rc == -2) return fail(MDM_EUNSUPPORTED, "f16x3 linear (small tiles): unsupported shape (K must be 288 or a multiple of 256)");
 #if defined(MDM_PROBES) && !defined(MDM_EMU)
     if (getenv("MDM_X3S_TRACE")) {      // bring-up: which launch faults
@@ -524,7 +532,7 @@ int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w,
   }
   const int rpt = (kind == 0) ? S : x3_rows_per_tile(M, kind == 5 ? ln.emb_T : S);
   const int rc = launch_gemm_x3_ln(kind, a, w, ep, M, N, K, rpt, s);
-  if (rc == -1) return fail(MDM_EHIP, "f16x3 linear: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  if (rc == -1 || rc == -3) return lds_fail(rc, "f16x3 linear");
   if (rc == -2) return fail(MDM_EUNSUPPORTED, "f16x3 linear: unsupported folded-LayerNorm GEMM kind");
   return rt_launch_status();
 }
@@ -1368,7 +1376,7 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       sa.M = M; sa.S = S; sa.D = D; sa.H = H; sa.stat_parts = parts; sa.stat_cols = scols; sa.inv_dim = inv_dim; sa.acc_scale = kX3AccScale;
       ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * 3.0 * D * (double)D + 4.0 * nseq * H * (double)S * S * ATT_HD, s);
       const int rc = launch_seqhead_block(sa, l != 0 ? 1 : 0, s);
-      if (rc == -1) return fail(MDM_EHIP, "self-attention block: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      if (rc == -1 || rc == -3) return lds_fail(rc, "self-attention block");
       if (rc != 0) return fail(MDM_EUNSUPPORTED, "self-attention block: unsupported shape");
       if (int rc2 = rt_launch_status()) return rc2;
     } else {
@@ -1398,8 +1406,11 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
     const int xb_wgs = nseq * ((S + XB_TR - 1) / XB_TR);
     const int xmode = m->fused_xattn == 3 ? ((xb_wgs >= kXattnOneKernelWgs && xattn_block_supported(D, ntok) && scols == 128) ? 1 : 2)
                                           : m->fused_xattn;
-    const bool seqhead = xmode == 2 && crossattn_block_supported(D, S, ntok);
-    const bool fused = !seqhead && xmode != 0 && xattn_block_supported(D, ntok) && scols == 128;
+    // a form whose shapes are not covered falls to the OTHER fused form before the three-launch one (an explicit 1 at
+    // latent_dim 768 / 1024 used to drop straight to 0 although 2 applies)
+    const bool can_sh = crossattn_block_supported(D, S, ntok), can_one = xattn_block_supported(D, ntok) && scols == 128;
+    const bool seqhead = (xmode == 2 && can_sh) || (xmode == 1 && !can_one && can_sh);
+    const bool fused = !seqhead && xmode != 0 && can_one;
     if (!hoisted) {
       const float* wc = m->L(l, "multihead_attn.in_proj_weight");
       const float* bc = m->L(l, "multihead_attn.in_proj_bias");
@@ -1421,7 +1432,7 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       {
         ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)D * D + 4.0 * M * (double)ntok * D, s);
         const int rc = launch_seqhead_block(ca, 2, s);
-        if (rc == -1) return fail(MDM_EHIP, "cross-attention (sequence, head) kernel: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        if (rc == -1 || rc == -3) return lds_fail(rc, "cross-attention (sequence, head) kernel");
         if (rc != 0) return fail(MDM_EUNSUPPORTED, "cross-attention (sequence, head) kernel: unsupported shape");
         if (int rc2 = rt_launch_status()) return rc2;
       }
@@ -1445,7 +1456,7 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       // (profiled as ONE launch of the GEMM class: 2 D^2 per row twice + the attention contractions)
       ProfScope ps(pf, MDM_PROF_LINEAR, 4.0 * M * (double)D * D + 4.0 * M * (double)ntok * D, s);
       const int rc = launch_xattn_block(xa, D, s);
-      if (rc == -1) return fail(MDM_EHIP, "cross-attention block: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      if (rc == -1 || rc == -3) return lds_fail(rc, "cross-attention block");
       if (rc != 0) return fail(MDM_EUNSUPPORTED, "cross-attention block: unsupported shape");
       if (int rc2 = rt_launch_status()) return rc2;
     } else {
@@ -2078,7 +2089,7 @@ int mdm_linear_f16f6(const float* in, const float* w, const float* bias, const f
                   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1.f, 1, 1, 1, 1.f};
     const X3Operand a{reinterpret_cast<const p16_t*>(pa.h16), reinterpret_cast<const p16_t*>(pa.rec)};
     const int rc = launch_gemm_f16f6(a, X3Weights{wfh, wfl}, ep, M, N, K, act, s);
-    if (rc == -1) return fail(MDM_EHIP, "mdm_linear_f16f6: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    if (rc == -1 || rc == -3) return lds_fail(rc, "mdm_linear_f16f6");
     if (rc == -2) return fail(MDM_EUNSUPPORTED, "mdm_linear_f16f6: unsupported (activation, residual) combination");
     return rt_launch_status();
   }

@@ -514,11 +514,7 @@ inline int launch_seqhead_block_t(const SelfAttnArgs& a, hipStream_t stream) {
 #ifndef MDM_EMU
   {
     static bool configured[kMaxDevices] = {};
-    bool& done = configured[rt_device_ordinal()];
-    if (!done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS) != hipSuccess) return -1;
-      done = true;
-    }
+    if (const int rc = rt_dyn_lds_once(kfn, SB_LDS, configured, stream)) return rc;
   }
 #endif
 #if defined(MDM_PROBES) && !defined(MDM_EMU)

@@ -490,11 +490,7 @@ inline int launch_xattn_block_t(const XattnArgs& a, hipStream_t stream) {
 #ifndef MDM_EMU
   if (LDS > 65536) {
     static bool configured[kMaxDevices] = {};
-    bool& done = configured[rt_device_ordinal()];
-    if (!done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
-      done = true;
-    }
+    if (const int rc = rt_dyn_lds_once(kfn, LDS, configured, stream)) return rc;
   }
 #endif
   const int tpg = (a.S + XB_TR - 1) / XB_TR, total = (a.M / a.S) * tpg;

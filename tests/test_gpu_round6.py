@@ -88,3 +88,49 @@ def test_dip_shard_invariance_is_bitwise_in_both_modes(prec):
     d = maxabs(parts.cpu(), whole.cpu())
     print(f"[parity] DiP B=32 as 12 + 20 shards vs one batch, {prec}: max-abs = {d:.3e}")
     assert torch.equal(parts, whole)
+
+
+def test_first_use_of_a_kernel_instantiation_inside_a_capture_is_refused(tmp_path):
+    """ADVICE r05 (mdm_api.hip ChainGuard / the static `configured[]` arrays): a kernel instantiation opts in to > 64 KB of dynamic LDS
+    on its FIRST use.  When the warm-up ran at another shape (here: 4 sequences -> gemm_x3s.h's row tiles) and the capture is the first
+    user of the sequence-tile kernels (88 sequences -> gemm_x3.h), the function-attribute call would run inside the capture.  Now the
+    call is refused -- MDM_EUNSUPPORTED, naming the remedy -- and after a warm-up of the same shape the same capture succeeds and
+    replays bit-identically.  A fresh process: the configured[] flags are per process."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    script = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import make_pair, synth_state_dict, synth_y, to_dev
+from mdm_amd._native import MdmError
+DEV = "cuda:0"
+model, diffusion = make_pair(synth_state_dict(seed=0), 2, DEV, guided=True)
+diffusion.check_finite = False
+ys = {B: to_dev(synth_y(B, 64, seed=9), DEV) for B in (2, 44)}
+def loop(B, x):
+    return diffusion.p_sample_loop(model, (B, 263, 1, 64), noise=x, clip_denoised=False, model_kwargs={"y": dict(ys[B])}, seed=7)
+xs = {B: torch.randn(B, 263, 1, 64, device=DEV) for B in (2, 44)}
+loop(2, xs[2]); torch.cuda.synchronize()          # warm-up at ANOTHER shape: only the row-tile kernels are configured
+g = torch.cuda.CUDAGraph()
+refused = False
+try:
+    with torch.cuda.graph(g):
+        out = loop(44, xs[44])
+except Exception as e:                            # MdmError (or torch's complaint about the broken capture on top of it)
+    refused = "first use of this kernel instantiation" in str(e) or "first use" in repr(e.__context__ or "")
+    msg = str(e)
+print("REFUSED" if refused else "NOT REFUSED", flush=True)
+torch.cuda.synchronize()
+want = loop(44, xs[44]).clone(); torch.cuda.synchronize()   # the warm-up at the SAME shape ...
+g2 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g2):
+    out2 = loop(44, xs[44])
+g2.replay(); torch.cuda.synchronize()
+print("REPLAY_EQUAL" if torch.equal(out2, want) else "REPLAY_DIFFERS", flush=True)
+'''
+    p = tmp_path / "capture_first_use.py"
+    p.write_text(script)
+    r = subprocess.run([sys.executable, str(p), ROOT], capture_output=True, text=True, timeout=600)
+    assert "REFUSED" in r.stdout and "NOT REFUSED" not in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "REPLAY_EQUAL" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
