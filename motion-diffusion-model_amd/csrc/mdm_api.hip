@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "attention_x3.h"
+#include "attention_long.h"
 #include "attention_f32.h"
 #include "common.h"
 #include "elementwise.h"
@@ -272,8 +273,12 @@ int launch_attention_args(Profiler* pf, const AttnF32Args& a, float* out, int ns
                           hipStream_t s) {
   ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * H * (double)a.Sq * a.Sk * ATT_HD, s);
   if (D != H * ATT_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
-  if (a.Sq < 1 || a.Sq > 224 || a.Sk < 1 || a.Sk > 224)
-    return fail(MDM_EUNSUPPORTED, "attention: 1 <= tokens <= 224 on both sides (T <= 223 frames)");
+  if (a.Sq < 1 || a.Sk < 1) return fail(MDM_EUNSUPPORTED, "attention: no tokens");
+  if (a.Sq > 224 || a.Sk > 224) {   // streaming softmax over 32-key tiles (attention_long.h): any length
+    const int nqb = al_query_blocks(a.Sq);
+    MDM_LAUNCH(attention_f32_long_kernel, dim3(nseq * H * nqb), dim3(256), al_f32_lds_bytes(), s, a, out, D, H, oh, ol, nqb);
+    return rt_launch_status();
+  }
   switch ((a.Sk + 31) / 32) {
     case 1: return launch_attention_t<1>(a, out, nseq, D, H, oh, ol, s);
     case 2: return launch_attention_t<2>(a, out, nseq, D, H, oh, ol, s);
@@ -319,7 +324,13 @@ int launch_attention_x3(Profiler* pf, const QkvPlanes& qp, const int* lengths, i
                         p16_t* oh, p16_t* ol, hipStream_t s, int lead = 1, bool direct = false) {
   ProfScope ps(pf, MDM_PROF_ATTENTION, 4.0 * nseq * qp.H * (double)S * S * AX_HD, s);
   if (D != qp.H * AX_HD) return fail(MDM_EUNSUPPORTED, "attention: head_dim must be 128");
-  if (S < 1 || S > 224) return fail(MDM_EUNSUPPORTED, "attention: 1 <= S <= 224 tokens (T <= 223 frames)");
+  if (S < 1) return fail(MDM_EUNSUPPORTED, "attention: no tokens");
+  if (S > 224) {   // streaming softmax over the same operand planes (attention_long.h): any length
+    if (qp.NKT != (S + 31) / 32 || qp.SP != 32 * qp.NKT) return fail(MDM_EINVAL, "attention: the operand planes do not match the sequence length");
+    const int nqb = al_query_blocks(S);
+    MDM_LAUNCH(attention_x3_long_kernel, dim3(nseq * qp.H * nqb), dim3(256), al_x3_lds_bytes(), s, qp, lengths, S, D, B, lead, out, oh, ol, nqb);
+    return rt_launch_status();
+  }
   if (direct && out == nullptr && oh != nullptr) {   // planes straight from the accumulators (attention_x3.h DIRECT)
     switch (qp.NKT) {
       case 1: return launch_attention_x3_t<1, 0, true>(qp, lengths, nseq, B, S, D, out, oh, ol, s, lead);
@@ -487,9 +498,11 @@ struct LnArgs {
   X3sShape shape{1, 1};    // ... and on ONE tile shape of it (x3s_shape(m->x3s, nseq))
   int stat_cols = 256;     // columns per partial of astat / rstat (what the PRODUCER's kernel wrote)
 };
-// The latency regime (gemm_x3s.h): a forward of at most MDM_OPT_SMALL_GEMM_MAX_SEQS sequences runs its GEMMs on 32 / 64-row tiles
+// The latency regime (gemm_x3s.h): a forward of at most MDM_OPT_SMALL_GEMM_MAX_SEQS sequences runs its GEMMs on 32 / 64-row tiles --
+// and so does EVERY forward whose sequences are longer than gemm_x3.h's 224-row sequence tile (round 6: the row tiles do not care how
+// long a sequence is; attention_long.h takes the attention)
 inline bool use_small_gemm(const mdm_model* m, int nseq, int S) {
-  return m->precision == MDM_PREC_F16X3 && m->lnfold && nseq <= m->x3s.max_seqs && S <= X3_TM &&
+  return m->precision == MDM_PREC_F16X3 && m->lnfold && (nseq <= m->x3s.max_seqs || S > X3_TM) &&
          m->cfg.latent_dim % 128 == 0 && m->cfg.latent_dim % 256 == 0 && m->cfg.ff_size % 256 == 0;
 }
 int launch_x3_ln(Profiler* pf, int prof_cat, int kind, X3Operand a, X3Weights w, const float* bias, const LnArgs& ln,
@@ -572,7 +585,9 @@ int embed_frames_x3(mdm_model* m, const Workspace& ws, const float* x, int B, in
                       nullptr, ws.tokh, ws.tokl, nullptr, B * T, D, KP, T + 1, D, 0, 1.f, s);
 }
 inline bool use_embed_x3(const mdm_model* m, int T) {
-  return m->precision == MDM_PREC_F16X3 && x3_waves_setting() == 8 && T + 1 <= X3_TM;
+  // (longer sequences: the row-tile form of the same GEMM where it exists -- 263 features -- else the fp32-operand embedding below)
+  return m->precision == MDM_PREC_F16X3 && x3_waves_setting() == 8 &&
+         (T + 1 <= X3_TM || (use_small_gemm(m, 1, T + 1) && m->jf_k == 288));
 }
 
 // Tokens for every sequence: frame tokens via the InputProcess GEMM, token 0 via cond_token_kernel.
@@ -605,7 +620,7 @@ int encoder(mdm_model* m, const Workspace& ws, int nseq, int B, int S, const int
   Profiler* pf = &m->prof;
   const int D = m->cfg.latent_dim, FF = m->cfg.ff_size, H = m->cfg.num_heads, M = nseq * S;
   const float qscale = 1.0f / sqrtf((float)(D / H));
-  if (m->precision == MDM_PREC_F16X3 && m->lnfold && x3_waves_setting() == 8 && S <= X3_TM) {
+  if (m->precision == MDM_PREC_F16X3 && m->lnfold && x3_waves_setting() == 8 && (S <= X3_TM || use_small_gemm(m, nseq, S))) {
     // No LayerNorm kernels: xb = tokh|tokl holds the layer input / the post-FFN PRE-norm sum, xa the post-attention
     // pre-norm sum, each with per-row partial (sum, sum^2) written by its producer; consumers fold the normalisation
     // (gemm_x3.h X3Epilogue).  Layer 0's input (the embedding) is not normalised: plain in_proj, plain residual.
@@ -706,7 +721,7 @@ int outproj_x3(mdm_model* m, const Workspace& ws, int nseq, int B, int T, const 
   const int D = m->cfg.latent_dim, S = T + 1, ldo = m->jf_out;
   float* out_tok = ws.qkv;
   ProfScope ps(&m->prof, MDM_PROF_OUTPROJ, 2.0 * nseq * T * (double)D * m->jf, s);
-  if (m->lnfold && x3_waves_setting() == 8 && S <= X3_TM) {   // the final LayerNorm is folded into this GEMM
+  if (m->lnfold && x3_waves_setting() == 8 && (S <= X3_TM || use_small_gemm(m, nseq, S))) {   // the final LayerNorm is folded into this GEMM
     LnArgs a; a.astat = ws.stat2; a.colsum = m->c_out; a.inv_dim = 1.0f / (float)D;
     a.small = use_small_gemm(m, nseq, S);            // (the same decision the encoder took: who wrote stat2)
     a.shape = x3s_shape(m->x3s, nseq);
@@ -1171,7 +1186,7 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
   if (int rc = check_ready(m)) return rc;
   if (m->cfg.arch != MDM_ARCH_TRANS_ENC) return fail(MDM_ESTATE, "mdm_forward: trans_dec models go through mdm_forward_dec");
   if (x == nullptr || timesteps == nullptr || out == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_forward: null pointer");
-  if (B <= 0 || T <= 0 || T + 1 > 224) return fail(MDM_EINVAL, "mdm_forward: need B >= 1 and 1 <= T <= 223");
+  if (B <= 0 || T <= 0 || T + 1 > m->cfg.max_len) return fail(MDM_EINVAL, "mdm_forward: need B >= 1 and 1 <= T < the positional table's length");
   if (branches < 0 || branches > 2) return fail(MDM_EINVAL, "mdm_forward: bad branches");
   if (branches != MDM_BRANCH_UNCOND && text_embed == nullptr) return fail(MDM_EINVAL, "mdm_forward: text_embed required");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1283,8 +1298,8 @@ int check_dec_shapes(const mdm_model_t* m, const char* who, const float* prefix,
   const std::string w(who);
   if (m->cfg.arch != MDM_ARCH_TRANS_DEC) return fail(MDM_ESTATE, w + ": the model was created as trans_enc");
   if ((C > 0) != (prefix != nullptr)) return fail(MDM_EINVAL, w + ": prefix must be given iff context_len > 0");
-  if (B <= 0 || pred_len <= 0 || S > 224) return fail(MDM_EINVAL, w + ": need B >= 1 and context_len + pred_len <= 224");
-  if (ntok <= 0 || ntok > 224) return fail(MDM_EINVAL, w + ": 1 <= text tokens <= 224");
+  if (B <= 0 || pred_len <= 0 || S > m->cfg.max_len) return fail(MDM_EINVAL, w + ": need B >= 1 and context_len + pred_len <= the positional table's length");
+  if (ntok <= 0 || ntok > 512) return fail(MDM_EINVAL, w + ": 1 <= text tokens <= 512");
   if (S > m->cfg.max_len) return fail(MDM_EINVAL, w + ": window longer than the positional table");
   return MDM_OK;
 }
@@ -1330,7 +1345,7 @@ struct DecTail {
 // size measured (B = 32: 544 vs 391 motions/s, B = 64: 660 vs 448; profiles/r04h_dip_planes.md).
 inline bool dec_on_planes(const mdm_model* m, int M, int S, const DecHoist& hz, int B) {
   (void)M;
-  return m->precision == MDM_PREC_F16X3 && S <= X3_TM && m->x3s.max_seqs > 0 &&
+  return m->precision == MDM_PREC_F16X3 && m->x3s.max_seqs > 0 &&
          m->cfg.latent_dim % 256 == 0 && m->cfg.ff_size % 256 == 0 && m->out_planes_f.hi != nullptr &&
          (hz.step < 0 || (hz.kv_b0 == 0 && hz.kv_B == B));
 }
@@ -1691,7 +1706,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
   if (m->cfg.arch != MDM_ARCH_TRANS_ENC) return fail(MDM_ESTATE, "mdm_sample_loop: the fused loop drives the trans_enc denoiser");
   if (p == nullptr || x == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop: null pointer");
   const int B = p->B, T = p->T;
-  if (B <= 0 || T <= 0 || T + 1 > 224) return fail(MDM_EINVAL, "mdm_sample_loop: need B >= 1 and 1 <= T <= 223");
+  if (B <= 0 || T <= 0 || T + 1 > m->cfg.max_len) return fail(MDM_EINVAL, "mdm_sample_loop: need B >= 1 and 1 <= T < the positional table's length");
   if (p->num_timesteps <= 0 || p->start_index < 0 || p->start_index >= p->num_timesteps)
     return fail(MDM_EINVAL, "mdm_sample_loop: bad start_index / num_timesteps");
   if (!p->a_x0 || !p->a_xt || !p->sigma || !p->timestep_map) return fail(MDM_EINVAL, "mdm_sample_loop: null schedule table");

@@ -119,8 +119,8 @@ class MDM(nn.Module):
 
         if arch not in ('trans_enc', 'trans_dec'):
             raise NotImplementedError(f"arch={arch!r}: trans_enc and trans_dec (DiP) only (SURVEY.md 8f)")
-        if arch == 'trans_dec' and self.total_len > self.MAX_TOKENS:
-            raise NotImplementedError(f"context_len + pred_len = {self.total_len} tokens: {self._cap_reason}")
+        if arch == 'trans_dec' and self.total_len > kargs.get('pos_embed_max_len', 5000):
+            raise ValueError(f"context_len + pred_len = {self.total_len} tokens do not fit the positional table")
         if activation != "gelu":
             raise NotImplementedError("only activation='gelu' (the reference's fixed choice, utils/model_util.py:64)")
         if data_rep == 'rot_vel' or self.multi_target_cond or self.emb_policy != 'add':
@@ -205,18 +205,27 @@ class MDM(nn.Module):
         return cond
 
     # ---- native engine management ---------------------------------------------------------------------
-    # ---- the one size limit of the seam: a sequence is at most 224 tokens.  The attention kernels keep all scores of a query
-    # row in registers (seven 32-key tiles: the softmax is exact, no online rescaling) and the encoder GEMMs put one
-    # sequence in one 208 / 224-row tile.  HumanML3D / KIT motions are <= 196 frames (sample/generate.py:32); the reference
-    # itself is bounded by its positional table only (5000 rows, model/mdm.py:55).  Longer inputs raise (MdmError), loudly.
-    MAX_TOKENS = 224
-    MAX_FRAMES = 223          # trans_enc: the condition token takes one of the 224
-    _cap_reason = ("the MI355X path holds a sequence in one GEMM tile and its attention scores in registers: at most 224 tokens "
-                   "(trans_enc: 223 frames + the condition token; trans_dec: context_len + pred_len <= 224)")
+    # ---- sequence length.  Up to 224 tokens (trans_enc: 223 frames + the condition token; HumanML3D / KIT stop at 196,
+    # sample/generate.py:32) a query row's attention scores stay in registers (exact softmax) and, at large batch, a sequence is one
+    # GEMM tile: the kernels every BASELINE configuration runs.  Longer sequences -- the reference is bounded by its positional table
+    # only (5000 rows, model/mdm.py:55, :251-253) -- run the GEMMs on row tiles at every batch size and the attention with a
+    # streaming softmax over 32-key tiles (csrc/attention_long.h, round 6), both arithmetic modes.  What remains bounded: the
+    # positional table itself, and frame masks WITH HOLES at 256 frames (the kernels' bitmap; prefix masks -- what collate builds --
+    # have no bound).
+    FAST_TOKENS = 224         # up to here: the exact-softmax attention kernels / sequence-sized GEMM tiles
+
+    @property
+    def MAX_TOKENS(self):
+        return int(self.sequence_pos_encoder.pe.shape[0])
+
+    @property
+    def MAX_FRAMES(self):     # trans_enc: the condition token takes one row of the positional table
+        return self.MAX_TOKENS - 1 if self.arch == 'trans_enc' else self.MAX_TOKENS - int(self.context_len)
 
     def _check_frames(self, T):
         if (T + 1 if self.arch == 'trans_enc' else self.context_len + T) > self.MAX_TOKENS:
-            raise nat.MdmError(f"{T} frames: {self._cap_reason}")
+            raise nat.MdmError(f"{T} frames: the sequence does not fit the positional table ({self.MAX_TOKENS} rows, "
+                               f"pos_embed_max_len; model/mdm.py:55)")
 
     def _native_state(self):
         sd = {k: v for k, v in self.state_dict().items()
@@ -255,12 +264,12 @@ class MDM(nn.Module):
         data_loaders/tensors.py:3-8 builds, the kernels' fast path --, else [9 B]: counts, with -1 for the rows that have
         holes, followed by eight bitmap words per sample (bit j of word i: frame 32 i + j is valid)."""
         B, F = valid.shape
-        if F > 256:
-            raise NotImplementedError(f"frame masks of more than 256 frames ({F}) do not fit the kernels' bitmap")
         counts = valid.sum(dim=1)
         prefix = (valid == (torch.arange(F, device=valid.device)[None, :] < counts[:, None])).all(dim=1)
         if bool(prefix.all()):
             return counts.to(torch.int32).contiguous()
+        if F > 256:      # (prefix masks -- counts -- have no bound)
+            raise NotImplementedError(f"frame masks WITH HOLES of more than 256 frames ({F}) do not fit the kernels' bitmap")
         bits = torch.zeros(B, 256, dtype=torch.int64, device=valid.device)
         bits[:, :F] = valid.to(torch.int64)
         words = (bits.view(B, 8, 32) << torch.arange(32, device=valid.device)).sum(dim=-1)     # < 2^32

@@ -350,7 +350,10 @@ def test_mdm_layernorm(rows, D):
 
 
 @pytest.mark.parametrize("nseq,B,S,lengths", [(2, 2, 197, None), (6, 3, 197, [196, 120, 57]), (4, 4, 1, None),
-                                              (2, 1, 33, [5]), (3, 3, 224, [223, 1, 100])])
+                                              (2, 1, 33, [5]), (3, 3, 224, [223, 1, 100]),
+                                              # round 6, csrc/attention_long.h (streaming softmax above 224 tokens): a count in the
+                                              # first tile, in a middle tile, at the end; no mask; 3 query blocks of 128
+                                              (3, 3, 225, [224, 3, 100]), (2, 2, 401, None), (4, 2, 300, [299, 150])])
 def test_mdm_attention(nseq, B, S, lengths):
     D, H, hd = 512, 4, 128
     g = torch.Generator().manual_seed(S)
@@ -412,9 +415,9 @@ def test_sampler_step_kernel_matches_oracle():
 def test_errors_are_loud(sd):
     from mdm_amd._native import MdmError
     model, diffusion = make_pair(sd, 50, DEV, guided=False)
-    y = synth_y(2, 300, seed=0)
-    with pytest.raises(MdmError):          # T + 1 > 224 tokens is outside the attention kernel's range
-        model(torch.zeros(2, 263, 1, 300, device=DEV), torch.zeros(2, dtype=torch.long, device=DEV), y=y)
+    y = synth_y(2, 5000, seed=0)
+    with pytest.raises(MdmError):          # T + 1 = 5001 tokens do not fit the positional table (model/mdm.py:55); 224+ tokens run since round 6
+        model(torch.zeros(2, 263, 1, 5000, device=DEV), torch.zeros(2, dtype=torch.long, device=DEV), y=y)
     with pytest.raises(MdmError):          # CPU tensors never fall back to a CPU path
         model.cpu()(torch.zeros(2, 263, 1, 8), torch.zeros(2, dtype=torch.long), y=synth_y(2, 8, seed=0))
 
