@@ -45,7 +45,7 @@ struct AttnF32Args {
   int lead;
   int B;
   // optional rows [D] added to every key / value row while it is staged: the DiP window loop keeps the text part of the
-  // projected memory (constant over a window's steps) and adds the step's projected time embedding here (mdm_api.hip)
+  // projected memory (constant over a window's steps) and adds the step's projected time embedding here (decoder.h)
   const float* kadd = nullptr;
   const float* vadd = nullptr;
   // the K / V source may hold MORE samples than this launch covers (a sample group of a larger batch, mdm_sample_loop_dec):

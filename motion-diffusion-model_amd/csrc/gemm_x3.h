@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64 * WAVES, NCB == 2 ? 1 : 2) void gemm_x3_kernel(X
       // as it holds any float of the matrix; units entirely past it read a valid address instead.  With an odd number of
       // partials per row (D = 256, 768) a tile that starts on an odd row is only 8-byte aligned and its last unit may straddle
       // the end of the array by up to 12 bytes: the workspace carves every statistics array with 16 spare bytes for this
-      // (mdm_api.hip carve).  (Round 3 clamped straddling units to the last 16 bytes of the array, which moved the last row's
+      // (api_launch.h carve).  (Round 3 clamped straddling units to the last 16 bytes of the array, which moved the last row's
       // partials to the wrong table slot: wrong last token row for D = 256 when the last tile starts on an odd row.)
       const long long total_f = (long long)M * ep.stat_parts * 2;
       long long fo = (long long)m0s * ep.stat_parts * 2 + 4LL * (64 * pc + lane);

@@ -20,7 +20,7 @@
 //   * attention as in attention_x3.h (St = K Q^T, exact softmax in registers with the per-key additive mask, Ot = V^T P^T): wave w
 //     takes query tile w & 1 and the d half w >> 1 of the output (both waves of a query tile compute its 64 x 32 scores: 48 MFMAs);
 //     the output goes to the attention planes [M][D] that out_proj reads, 8 bytes per lane.
-// Sequences of more than 64 tokens keep the two-launch form (mdm_api.hip).
+// Sequences of more than 64 tokens keep the two-launch form (decoder.h).
 //
 // CROSS mode (MODE 2) -- the same decomposition for the cross-attention of the layer (model/mdm.py:263-265: multihead_attn(x, memory,
 // memory) with x = norm1(y)): the workgroup of (sequence, head) projects ONLY the head's 128 query columns (norm1 folded; one W block

@@ -5,7 +5,7 @@
 //     q   = norm1(y) . Wq^T + bq                    (norm1 folded: Wq' = Wq diag(gamma1), rstd (Wq'.y - mean colsum) + bq')
 //     att = softmax(q K^T / sqrt(128) + memory_key_padding_mask) V        per head; K | V = the projected text memory
 //     x'  = att . Wo^T + bo + norm1(y)              (pre-norm2 sum, written as operand planes + row statistics)
-// which round 4 ran as THREE dependent launches on 3,840 rows (mdm_api.hip decoder_layers_planes: gemm_x3s kind 4 -> fp32 q,
+// which round 4 ran as THREE dependent launches on 3,840 rows (decoder.h decoder_layers_planes: gemm_x3s kind 4 -> fp32 q,
 // attention_f32_kernel<1> at 7 % matrix-pipe duty, gemm_x3s kind 2): 10.7 + 16.1 + 14.8 us per layer, of which ~5 us per launch are
 // entry -> first MFMA and drain (profiles/r04j_x3s_timeline.md).  Everything between the two GEMMs is row-local given the
 // sequence's memory, so one workgroup carries a 32-row tile of ONE sequence through all three stages:

@@ -289,7 +289,7 @@ def test_emulated_dip_decoder_forward(lib, masked, prec):
 
 
 def test_emulated_dip_decoder_planes_and_fp32_skeleton(lib, engine_options):
-    """The f16x3 trans_dec stack has two routes (csrc/mdm_api.hip dec_on_planes): operand planes through gemm_x3s.h /
+    """The f16x3 trans_dec stack has two routes (csrc/decoder.h dec_on_planes): operand planes through gemm_x3s.h /
     attention_x3.h (what DiP's callers run) and the fp32 skeleton of gemm_f32.h (small_gemm_max_seqs = 0 forces it).  Both
     against the oracle, on 32- and 64-row tiles; the two are different arithmetic, so agreeing bit for bit would mean the switch
     did nothing."""

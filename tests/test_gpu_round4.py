@@ -137,7 +137,7 @@ def test_trans_dec_with_a_clip_memory_token_matches_reference(golden_dir, prec):
 
 @pytest.mark.parametrize("route", ["planes32", "planes64", "skeleton"])
 def test_dip_decoder_routes_match_reference_goldens(golden_dir, engine_options, route):
-    """The f16x3 trans_dec stack on its two routes (csrc/mdm_api.hip dec_on_planes): operand planes through gemm_x3s.h +
+    """The f16x3 trans_dec stack on its two routes (csrc/decoder.h dec_on_planes): operand planes through gemm_x3s.h +
     attention_x3.h -- what the DiP callers' sizes take; 32- and 64-row tiles -- and the fp32 skeleton of gemm_f32.h (forced here by
     small_gemm_max_seqs = 0).  Each against the UPSTREAM reference's own outputs: the
     B = 3 forward (both branches, guided) and the 100-frame autoregressive generation (3 windows x 10 steps, CFG 7.5)."""

@@ -91,7 +91,7 @@ def test_dip_shard_invariance_is_bitwise_in_both_modes(prec):
 
 
 def test_first_use_of_a_kernel_instantiation_inside_a_capture_is_refused(tmp_path):
-    """ADVICE r05 (mdm_api.hip ChainGuard / the static `configured[]` arrays): a kernel instantiation opts in to > 64 KB of dynamic LDS
+    """ADVICE r05 (csrc/api_runtime.h ChainGuard / the static `configured[]` arrays): a kernel instantiation opts in to > 64 KB of dynamic LDS
     on its FIRST use.  When the warm-up ran at another shape (here: 4 sequences -> gemm_x3s.h's row tiles) and the capture is the first
     user of the sequence-tile kernels (88 sequences -> gemm_x3.h), the function-attribute call would run inside the capture.  Now the
     call is refused -- MDM_EUNSUPPORTED, naming the remedy -- and after a warm-up of the same shape the same capture succeeds and
