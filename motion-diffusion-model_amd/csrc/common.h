@@ -316,22 +316,8 @@ __device__ __forceinline__ void split4_store(p16_t* hi_p, p16_t* lo_p, float4 v)
   uint32_t h01, l01, h23, l23;
   split2_p16(v.x, v.y, h01, l01);
   split2_p16(v.z, v.w, h23, l23);
-#if defined(MDM_STORE_VARIANT) && !defined(MDM_EMU)
-  // A/B builds only (lab/sessions/gpu_r6_s4.sh, profiles/r06c_store_policy.md): the cache policy of the plane stores -- 1 non-temporal,
-  // 2 write-through (agent-scope relaxed store: `sc1`) -- to see whether less dirty L2 at a kernel's end shortens the 2.6 us
-  // boundary to its successor.  Not defined in the product build.
-  typedef uint32_t sv_u32x2 __attribute__((ext_vector_type(2)));
-#if MDM_STORE_VARIANT == 1
-  __builtin_nontemporal_store(sv_u32x2{h01, h23}, reinterpret_cast<sv_u32x2*>(hi_p));
-  __builtin_nontemporal_store(sv_u32x2{l01, l23}, reinterpret_cast<sv_u32x2*>(lo_p));
-#else
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(hi_p), ((unsigned long long)h23 << 32) | h01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(lo_p), ((unsigned long long)l23 << 32) | l01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-#else
   *reinterpret_cast<uint2*>(hi_p) = make_uint2(h01, h23);
   *reinterpret_cast<uint2*>(lo_p) = make_uint2(l01, l23);
-#endif
 }
 
 // Direct global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the LDS destination is
