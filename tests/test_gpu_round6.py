@@ -188,3 +188,29 @@ def test_dip_window_and_text_memory_longer_than_224_tokens():
         err = maxabs(model(x.to(DEV), t.to(DEV), y=to_dev(y, DEV)).cpu(), want)
         print(f"[parity] DiP 20 + 300-frame window, 260-token memory, {prec}: max-abs vs oracle = {err:.3e}")
         assert err < 3e-5
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_long_sequences_match_the_reference_goldens(golden_dir, prec):
+    """`fwd_B2_T400` / `loop10_B2_T400` are the UPSTREAM reference's own outputs at T = 400 (oracle/make_golden_r6.py): MDM.forward
+    (cond and under guidance, lengths 400 / 41) and a 10-step guided p_sample_loop with the reference's CPU noise stream injected."""
+    from helpers import synth_state_dict, synth_y
+    sd = memo("sd_enc0", lambda: synth_state_dict(seed=0))
+    g = np.load(os.path.join(golden_dir, "fwd_B2_T400.npz"))
+    B, T = 2, 400
+    model, _ = make_pair(sd, 10, DEV, guided=True, precision=prec)
+    y = to_dev(synth_y(B, T, seed=int(g["y_seed"]), lengths=list(g["lengths"])), DEV)
+    x = torch.randn(B, 263, 1, T, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV)
+    t = torch.from_numpy(g["t"]).to(DEV)
+    e_c = maxabs(model.model(x, t, y=dict(y)).cpu(), g["out_cond"])
+    e_g = maxabs(model(x, t, y=dict(y)).cpu(), g["out_cfg"])
+    g = np.load(os.path.join(golden_dir, "loop10_B2_T400.npz"))
+    steps, seed = int(g["steps"]), int(g["seed"])
+    model, diffusion = make_pair(sd, steps, DEV, guided=True, precision=prec)
+    y = to_dev(synth_y(B, T, seed=seed + 1000, lengths=list(g["lengths"])), DEV)
+    x_T, noises = orc.make_noise((B, 263, 1, T), steps, seed)
+    out = diffusion.p_sample_loop(model, (B, 263, 1, T), clip_denoised=False, model_kwargs={"y": y},
+                                  noise_sequence=[x_T] + [n.contiguous() for n in noises])
+    e_l = maxabs(out.cpu(), g["final"])
+    print(f"[parity] reference fixtures at T = 400, {prec}: forward cond {e_c:.3e}, guided {e_g:.3e}, 10-step loop {e_l:.3e}")
+    assert e_c < 2e-5 and e_g < 5e-5 and e_l < 1e-4

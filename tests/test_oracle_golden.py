@@ -202,3 +202,18 @@ def test_dip_dynamic_text_golden(golden_dir, name):
     out = dip.autoregressive_sample(sdd, tab, (B, 263, 1, frames), y, chunks, context_len=20, pred_len=40,
                                     required_frames=frames, cfg=True, encode_text=synth_bert_encode_text)
     assert np.abs(out.numpy() - g["final"]).max() < DIP_TOL_AR
+
+
+def test_long_sequence_goldens(golden_dir):
+    """Round 6: the reference's own forward and 10-step guided loop at T = 400 (401 tokens; oracle/make_golden_r6.py) -- the oracle is
+    pinned beyond the 196 frames of every earlier fixture, where csrc/attention_long.h takes over on the device."""
+    rep = json.load(open(os.path.join(golden_dir, "PIN_REPORT_r6.json")))["cases"]
+    assert max(rep["fwd_B2_T400"][k] for k in ("cond", "uncond", "cfg")) < 1e-5 and rep["loop10_B2_T400"]["final"] < 2e-5
+    sd = synth_state_dict(0)
+    g = _load(golden_dir, "fwd_B2_T400")
+    B, T = 2, 400
+    y = synth_y(B, T, seed=int(g["y_seed"]), lengths=list(g["lengths"]))
+    x = torch.randn(B, 263, 1, T, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    t = torch.from_numpy(g["t"])
+    assert np.abs(orc.mdm_forward(sd, x, t, y).numpy() - g["out_cond"]).max() < 1e-5
+    assert np.abs(orc.cfg_forward(sd, x, t, y).numpy() - g["out_cfg"]).max() < 2e-5
