@@ -80,7 +80,7 @@ DIP_PMC_PROFILE = os.path.join("profiles", "r06_dip_pmc.json")
 def pmc_traffic_per_launch():
     """Fabric-side bytes per launch of the decoder's GEMM-class kernels (the `linear` profiling class: gemm_x3s_kernel, the
     (sequence, head) attention blocks, xattn_block_kernel) from the committed rocprofv3 PMC passes of THIS command at B = 32
-    (tools/gpu_r5_dip_pmc.sh + tools/dip_pmc_to_json.py), call-weighted; quoted only while the kernel sources are the ones the
+    (tools/gpu_dip_pmc.sh + tools/dip_pmc_to_json.py), call-weighted; quoted only while the kernel sources are the ones the
     passes were taken on (bench.csrc_sha256)."""
     path = os.path.join(ROOT, DIP_PMC_PROFILE)
     if not os.path.isfile(path):

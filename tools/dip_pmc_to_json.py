@@ -1,9 +1,9 @@
-"""Condense the PMC passes of the DiP bench (tools/gpu_r5_dip_pmc.sh: rocprofv3 --kernel-trace --pmc ... -- bench_dip.py, one pass per
+"""Condense the PMC passes of the DiP bench (tools/gpu_dip_pmc.sh: rocprofv3 --kernel-trace --pmc ... -- bench_dip.py, one pass per
 counter group) into profiles/<name>.json: per kernel class the mean duration (kernel trace), FETCH_SIZE / WRITE_SIZE (KB as reported)
 and the fabric-side bytes per launch -- FETCH_SIZE x 2 (128-byte requests tallied at 64 B: calibrated this round for 16-byte streaming,
 64-byte-row LDS-DMA and 8-byte-row loads alike, profiles/r05d_pmc_calibration.md), WRITE_SIZE as is -- and the MFMA busy fraction.  Tied to
 the kernel sources by bench.csrc_sha256() like profiles/r0N_pmc.json.
-Usage: python tools/dip_pmc_to_json.py gpurun_out/<tag> profiles/r05_dip_pmc.json"""
+Usage: python tools/dip_pmc_to_json.py gpurun_out/<tag> profiles/r06_dip_pmc.json"""
 import json
 import os
 import subprocess
@@ -80,6 +80,6 @@ try:
     out["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
     out["commit"] = None
-out["source"] = f"tools/gpu_r5_dip_pmc.sh {os.path.basename(src.rstrip('/'))} (rocprofv3 --kernel-trace --pmc around bench_dip.py, separate passes)"
+out["source"] = f"tools/gpu_dip_pmc.sh {os.path.basename(src.rstrip('/'))} (rocprofv3 --kernel-trace --pmc around bench_dip.py, separate passes)"
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -30,7 +30,7 @@ if [ $? -ne 0 ]; then echo "GPU suite not green on this binary: NO bench line is
 bash tools/gpu_prof.sh $TAG/prof pmc > $OUT/prof.log 2>&1
 head -12 $OUT/prof/kernel_stats.md | cut -c1-170
 python tools/pmc_to_json.py $OUT/prof profiles/r06_pmc.json > $OUT/pmc_to_json.log 2>&1; cp profiles/r06_pmc.json $OUT/r06_pmc.json
-bash tools/gpu_r5_dip_pmc.sh $TAG/dippmc > $OUT/dippmc.log 2>&1
+bash tools/gpu_dip_pmc.sh $TAG/dippmc > $OUT/dippmc.log 2>&1
 python tools/dip_pmc_to_json.py $OUT/dippmc profiles/r06_dip_pmc.json > $OUT/dip_pmc_to_json.log 2>&1; cp profiles/r06_dip_pmc.json $OUT/r06_dip_pmc.json
 head -8 $OUT/dippmc/kernel_stats.md | cut -c1-170
 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
