@@ -169,7 +169,7 @@ def measure(dev, rank, world, B, steps, warmup, cpu=True, mask_frames=True, engi
     bench.py embeds this record as its `dip` sub-line so that the driver's BENCH file carries it.
 
     `tiny` + `native_lib` (test infrastructure: `bench.py --emulate`): the same launcher / sharding / gather / record code on gloo
-    ranks with the kernels in the CPU emulator and a one-layer d = 256 model, 20 frames = 2 windows x 2 steps.  Never a measurement.
+    ranks with the kernels in the CPU emulator and a one-layer d = 256 model, 12 frames = 1 window x 2 steps.  Never a measurement.
 
     N > 1: a failure on ONE rank must not leave the others blocked in this leg's collectives.  The first generation
     runs WITHOUT a collective inside try / except, the ranks then agree on an `ok` flag (one MIN all-reduce every rank reaches), and
@@ -177,7 +177,7 @@ def measure(dev, rank, world, B, steps, warmup, cpu=True, mask_frames=True, engi
     global CONTEXT, PRED, FRAMES, DSTEPS, NTOK
     saved = (CONTEXT, PRED, FRAMES, DSTEPS, NTOK)
     if tiny:
-        CONTEXT, PRED, FRAMES, DSTEPS, NTOK = 5, 12, 20, 2, 6
+        CONTEXT, PRED, FRAMES, DSTEPS, NTOK = 5, 12, 12, 2, 6
     try:
         return _measure(dev, rank, world, B, steps, warmup, cpu, mask_frames, engine_options, native_lib, tiny, small_batch)
     finally:

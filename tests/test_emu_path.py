@@ -803,14 +803,15 @@ def test_bert_encode_text_runs_an_attached_encoder(lib):
 
 
 @pytest.mark.parametrize("prec,T,lengths,guided,loop", [("f16x3", 230, [230, 37], True, True), ("f32", 226, [100, 226], False, False),
-                                                         ("f16x3", 259, [259, 224], False, False)])
+                                                         ("f16x3", 259, [259, 224], False, False),
+                                                         ("f16x3", 225, [200], False, False)])     # (the case tests/test_emu_late.py re-runs)
 def test_emulated_sequences_longer_than_224_tokens(lib, prec, T, lengths, guided, loop):
     """VERDICT r05 "What's missing" 5: the reference is bounded by its positional table only (model/mdm.py:55, :251-253); this seam
     stopped at 224 tokens (exact-softmax attention kernels, sequence-sized GEMM tiles).  Longer sequences now run the GEMMs on row
     tiles and the attention with a streaming softmax over 32-key tiles (csrc/attention_long.h) in both arithmetic modes: ragged
     lengths (a count inside the first tiles: the tiles past it are not walked; a count in the last tile; a prefix mask of more than
     256 frames), a forward or a guided 2-step loop against the oracle, at the tolerances of the short-sequence cases."""
-    B = 2
+    B = len(lengths)
     sd = small_state_dict(num_layers=1)
     model, diffusion = make_pair(sd, 2, "cpu", guided=guided, native_lib=lib, precision=prec)
     y = synth_y(B, T, seed=3, lengths=lengths)
@@ -821,7 +822,7 @@ def test_emulated_sequences_longer_than_224_tokens(lib, prec, T, lengths, guided
         want = orc.sample_loop(sd, orc.Tables(orc.named_betas("cosine", 2)), (B, 263, 1, T), y, seq[0], seq[1:], cfg=True, num_heads=2)
         assert maxabs(got, want) < 5e-5
     else:
-        x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([1, 0])
+        x, t = torch.randn(B, 263, 1, T, generator=g), torch.tensor([1, 0][:B])
         assert maxabs(model(x, t, y=dict(y)), orc.mdm_forward(sd, x, t, y, num_heads=2)) < 5e-5
 
 
