@@ -347,7 +347,8 @@ def main(argv=None):
 
     B, T, DS = a.batch, a.frames, a.diffusion_steps
     torch.manual_seed(0)                                   # random-init weights of the named architecture
-    args = model_util.default_args(diffusion_steps=DS, layers=a.layers, latent_dim=a.latent_dim)
+    args = model_util.default_args(diffusion_steps=DS, layers=a.layers, latent_dim=a.latent_dim,
+                                   **({"pos_embed_max_len": 64} if a.emulate else {}))    # (emulator dry runs: a short timestep table)
     eopts = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in a.engine_option}
     mdm, diffusion = model_util.create_model_and_diffusion(args, precision=a.precision, _native_lib=native_lib,
                                                            num_heads=a.latent_dim // 128, engine_options=eopts)

@@ -186,7 +186,7 @@ def measure(dev, rank, world, B, steps, warmup, cpu=True, mask_frames=True, engi
 
 def _measure(dev, rank, world, B, steps, warmup, cpu, mask_frames, engine_options, native_lib, tiny, small_batch):
     torch.manual_seed(0)
-    over = dict(layers=1, latent_dim=256) if tiny else {}
+    over = dict(layers=1, latent_dim=256, pos_embed_max_len=64) if tiny else {}
     args = model_util.default_args(diffusion_steps=DSTEPS, arch="trans_dec", text_encoder_type="bert", context_len=CONTEXT,
                                    pred_len=PRED, mask_frames=mask_frames, guidance_param=7.5, **over)      # DiP.md:181: `--mask_frames`
     extra = dict(_native_lib=native_lib, num_heads=2) if tiny else {}

@@ -25,6 +25,12 @@ def make_pair(sd, steps, device, guided=True, native_lib=None, precision="f16x3"
     if dec:   # DiP: `--arch trans_dec --text_encoder_type bert --context_len 20 --pred_len 40` (DiP.md)
         arg_over = {"arch": "trans_dec", "text_encoder_type": "bert", "mask_frames": True, **arg_over}   # DiP.md:181 trains with --mask_frames
     d = sd["input_process.poseEmbedding.weight"].shape[0]
+    if native_lib is not None:
+        # CPU emulator runs: a 512-row positional / timestep table instead of the reference's 5000 (utils/parser_util.py
+        # pos_embed_max_len).  mdm_prepare evaluates the TimestepEmbedder for EVERY row of the table -- two [max_len, d] x [d, d] GEMMs
+        # -- which the lock-step emulator spends ~7 s on per engine, i.e. a third of the CPU suite's time over its ~200 engines.  The GPU
+        # suite binds the full table; tests/test_emu_path.py::test_emulated_cfg_loop_matches_oracle keeps the 5000-row one on the emulator.
+        arg_over = {"pos_embed_max_len": 512, **arg_over}
     args = model_util.default_args(diffusion_steps=steps, layers=layers, latent_dim=d, **arg_over)
     model, diffusion = model_util.create_model_and_diffusion(args, _native_lib=native_lib, num_heads=d // 128,
                                                              precision=precision)

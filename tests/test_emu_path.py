@@ -35,7 +35,8 @@ def test_emulated_cfg_loop_matches_oracle(lib, gemm_path, prec, tol):
     _skip_redundant(gemm_path, prec)
     steps, B, T = 2, 2, 9
     sd = small_state_dict(num_layers=1)
-    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, precision=prec)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, precision=prec,
+                                 pos_embed_max_len=5000)     # (the reference's table length; the other emulator cases bind 512 rows)
     y = synth_y(B, T, seed=5, lengths=[T, 4])
     shape = (B, 263, 1, T)
     x_T, noises = orc.make_noise(shape, steps, 11)
