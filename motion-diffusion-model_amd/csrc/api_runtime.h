@@ -145,6 +145,9 @@ struct mdm_model {
   int jf_k = 0;                             // njoints*nfeats rounded up to a multiple of 32
   X3Weights out_planes_f{nullptr, nullptr};
   float *c_out = nullptr, *b_out = nullptr;
+  // trans_dec: the key | value rows of every layer's cross-attention in_proj stacked into ONE matrix [L * 2D][D] (+ bias [L * 2D]), so
+  // that a window loop projects its text memory / its steps' time rows for all layers in one launch each (round 6: 16 launches -> 2)
+  float *wkv_all = nullptr, *bkv_all = nullptr;
   bool lnfold = false;                      // f16x3 mode without LayerNorm kernels (set by mdm_prepare)
   X3sOptions x3s;                           // which forwards run on gemm_x3s.h's small tiles (mdm_set_option)
   int fused_xattn = 3;                      // trans_dec plane route, the cross-attention block: 2 = q projection + memory attention per

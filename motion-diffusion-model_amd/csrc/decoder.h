@@ -16,8 +16,8 @@ struct DecWorkspace {
   QkvPlanes qp;
   // window loop only (nsteps > 0): what is constant over the steps of one p_sample_loop
   float *out;        // [nseq][J*F*pred_len] model output of the current step
-  float *kv_text;    // [L][nseq*ntok][2D]   Wkv_l . (text part of the memory)            (no bias)
-  float *kv_time;    // [L][nsteps][2D]      Wkv_l . time_table[timestep of step k] + b_kv_l
+  float *kv_text;    // [nseq*ntok][L][2D]   Wkv_l . (text part of the memory)            (no bias)
+  float *kv_time;    // [nsteps][L][2D]      Wkv_l . time_table[timestep of step k] + b_kv_l
   float *time_rows;  // [nsteps][D]          the gathered time-embedding rows
   size_t bytes;
 };
@@ -87,8 +87,8 @@ int check_dec_shapes(const mdm_model_t* m, const char* who, const float* prefix,
 struct DecHoist {         // step k of a window loop: where the hoisted projections of the (whole) batch live
   int step = -1;          // < 0: not hoisted
   int nsteps = 0;
-  const float* kv_text = nullptr;   // [L][nbranch * kv_B * ntok][2D]
-  const float* kv_time = nullptr;   // [L][nsteps][2D]
+  const float* kv_text = nullptr;   // [nbranch * kv_B * ntok][L][2D]: row stride L * 2D, layer l at + l * 2D
+  const float* kv_time = nullptr;   // [nsteps][L][2D]
   int kv_B = 0, kv_b0 = 0;          // this pass covers samples kv_b0 .. kv_b0 + B - 1 of kv_B
 };
 // The sampler update of a window-loop step, handed DOWN to the plane route: its transposing tail kernel (outproj_finish_kernel
@@ -216,11 +216,11 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       if (!hoisted) {
         ca.mk = ws.kv; ca.mv = ws.kv + D; ca.kadd = ca.vadd = nullptr; ca.kv_B = 0; ca.kv_b0 = 0;
       } else {
-        const float* kvt = hz.kv_text + (size_t)l * ((size_t)nbranch * hz.kv_B * ntok) * 2 * D;
-        const float* row = hz.kv_time + ((size_t)l * hz.nsteps + hz.step) * 2 * D;
+        const float* kvt = hz.kv_text + (size_t)l * 2 * D;
+        const float* row = hz.kv_time + ((size_t)hz.step * m->cfg.num_layers + l) * 2 * D;
         ca.mk = kvt; ca.mv = kvt + D; ca.kadd = row; ca.vadd = row + D; ca.kv_B = hz.kv_B; ca.kv_b0 = hz.kv_b0;
       }
-      ca.ldkv = 2 * D; ca.text_lengths = text_lengths; ca.ntok = ntok;
+      ca.ldkv = hoisted ? m->cfg.num_layers * 2 * D : 2 * D; ca.text_lengths = text_lengths; ca.ntok = ntok;
       {
         ProfScope ps(pf, MDM_PROF_LINEAR, 2.0 * M * (double)D * D + 4.0 * M * (double)ntok * D, s);
         const int rc = launch_seqhead_block(ca, 2, s);
@@ -237,11 +237,11 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       if (!hoisted) {
         xa.k = ws.kv; xa.v = ws.kv + D; xa.kadd = xa.vadd = nullptr; xa.kv_B = 0; xa.kv_b0 = 0;
       } else {
-        const float* kvt = hz.kv_text + (size_t)l * ((size_t)nbranch * hz.kv_B * ntok) * 2 * D;
-        const float* row = hz.kv_time + ((size_t)l * hz.nsteps + hz.step) * 2 * D;
+        const float* kvt = hz.kv_text + (size_t)l * 2 * D;
+        const float* row = hz.kv_time + ((size_t)hz.step * m->cfg.num_layers + l) * 2 * D;
         xa.k = kvt; xa.v = kvt + D; xa.kadd = row; xa.vadd = row + D; xa.kv_B = hz.kv_B; xa.kv_b0 = hz.kv_b0;
       }
-      xa.ldkv = 2 * D; xa.text_lengths = text_lengths; xa.ntok = ntok; xa.B = B;
+      xa.ldkv = hoisted ? m->cfg.num_layers * 2 * D : 2 * D; xa.text_lengths = text_lengths; xa.ntok = ntok; xa.B = B;
       xa.wo = P.out_proj2; xa.bo = m->L(l, "multihead_attn.out_proj.bias");
       xa.gamma = m->L(l, "norm1.weight"); xa.beta = m->L(l, "norm1.bias");
       xa.oh = Xh; xa.ol = Xl; xa.ostat = sX; xa.M = M; xa.S = S; xa.inv_dim = inv_dim; xa.acc_scale = kX3AccScale;
@@ -261,9 +261,9 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       const AttnF32Args a{q32, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
       if (int rc = launch_attention_args(pf, a, nullptr, nseq, D, H, ws.atth, ws.attl, s)) return rc;
     } else {
-      const float* kvt = hz.kv_text + (size_t)l * ((size_t)nbranch * hz.kv_B * ntok) * 2 * D;
-      const float* row = hz.kv_time + ((size_t)l * hz.nsteps + hz.step) * 2 * D;
-      AttnF32Args a{q32, D, kvt, kvt + D, 2 * D, S, ntok, text_lengths, 0, B};
+      const float* kvt = hz.kv_text + (size_t)l * 2 * D;
+      const float* row = hz.kv_time + ((size_t)hz.step * m->cfg.num_layers + l) * 2 * D;
+      AttnF32Args a{q32, D, kvt, kvt + D, m->cfg.num_layers * 2 * D, S, ntok, text_lengths, 0, B};
       a.kadd = row;
       a.vadd = row + D;
       a.kv_B = hz.kv_B;
@@ -388,9 +388,9 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
       const AttnF32Args a{ws.qkv, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
       if (int rc = launch_attention_args(pf, a, ws.att, nseq, D, H, nullptr, nullptr, s)) return rc;
     } else {
-      const float* kvt = hz.kv_text + (size_t)l * ((size_t)nbranch * hz.kv_B * ntok) * 2 * D;
-      const float* row = hz.kv_time + ((size_t)l * hz.nsteps + hz.step) * 2 * D;
-      AttnF32Args a{ws.qkv, D, kvt, kvt + D, 2 * D, S, ntok, text_lengths, 0, B};
+      const float* kvt = hz.kv_text + (size_t)l * 2 * D;
+      const float* row = hz.kv_time + ((size_t)hz.step * m->cfg.num_layers + l) * 2 * D;
+      AttnF32Args a{ws.qkv, D, kvt, kvt + D, m->cfg.num_layers * 2 * D, S, ntok, text_lengths, 0, B};
       a.kadd = row;
       a.vadd = row + D;
       a.kv_B = hz.kv_B;

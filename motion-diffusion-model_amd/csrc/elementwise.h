@@ -99,6 +99,17 @@ __global__ __launch_bounds__(256) void text_memory_kernel(float* __restrict__ me
   }
 }
 
+// Rows idx[0 .. n) of `table` [rows][D] -> dst [n][D]: the time-embedding rows of a window loop's steps (mdm_sample_loop_dec) in ONE
+// launch instead of one device-to-device copy per step (round 6).  Up to 64 rows per launch (the indices travel in the kernel argument).
+struct RowGather {
+  int idx[64];
+};
+__global__ __launch_bounds__(128) void gather_rows_kernel(float* __restrict__ dst, const float* __restrict__ table, RowGather g, int D) {
+  const int row = blockIdx.x;
+  const float* src = table + (size_t)g.idx[row] * D;
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) st4(dst + (size_t)row * D + c, ld4(src + c));
+}
+
 // Stand-alone fused sampler update: classifier-free-guidance combine
 // (utils/sampler_util.py:34), inpainting blend (gaussian_diffusion.py:300-304), optional clamp (:347-353),
 // posterior mean / DDIM mean with host-folded coefficients, noise add with the t != 0 mask folded into

@@ -149,17 +149,17 @@ int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float
                (branches == MDM_BRANCH_UNCOND) ? 0 : 1, (int)m->cfg.max_len);
     if (int rc = rt_launch_status()) return rc;
   }
-  for (int k = 0; k < nsteps; ++k)
-    if (int rc = rt_copy(ws.time_rows + (size_t)k * D, m->time_table + (size_t)p->timestep_map[p->start_index - k] * D,
-                         (size_t)D * sizeof(float), s)) return rc;
-  for (int l = 0; l < L; ++l) {
-    const float* wkv = m->L(l, "multihead_attn.in_proj_weight") + (size_t)D * D;
-    const float* bkv = m->L(l, "multihead_attn.in_proj_bias") + D;
-    if (int rc = launch_linear(pf, ws.mem, D, wkv, nullptr, nullptr, ws.kv_text + (size_t)l * Mm * 2 * D, Mm, 2 * D, D,
-                               ACT_NONE, 0, 1.f, s, x3)) return rc;
-    if (int rc = launch_linear(pf, ws.time_rows, D, wkv, bkv, nullptr, ws.kv_time + (size_t)l * nsteps * 2 * D, nsteps, 2 * D, D,
-                               ACT_NONE, 0, 1.f, s, x3)) return rc;
+  for (int k0 = 0; k0 < nsteps; k0 += 64) {     // the steps' time-embedding rows: one gather launch per 64 steps
+    RowGather g{};
+    const int n = std::min(64, nsteps - k0);
+    for (int k = 0; k < n; ++k) g.idx[k] = p->timestep_map[p->start_index - (k0 + k)];
+    ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
+    MDM_LAUNCH(gather_rows_kernel, dim3(n), dim3(128), 0, s, ws.time_rows + (size_t)k0 * D, (const float*)m->time_table, g, D);
+    if (int rc = rt_launch_status()) return rc;
   }
+  // ALL layers in one launch each (round 6; 2 L launches of 15 us before): rows of kv_text / kv_time are [L * 2D] wide, layer l at + l * 2D
+  if (int rc = launch_linear(pf, ws.mem, D, m->wkv_all, nullptr, nullptr, ws.kv_text, Mm, L * 2 * D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
+  if (int rc = launch_linear(pf, ws.time_rows, D, m->wkv_all, m->bkv_all, nullptr, ws.kv_time, nsteps, L * 2 * D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
 
   // ---- the steps.  The loop is written over G sample groups (each owns the rows [g * Mg, (g + 1) * Mg) of the activation
   // buffers and reads the hoisted text K / V of the whole batch through the attention kernel's (branch, sample) remap);

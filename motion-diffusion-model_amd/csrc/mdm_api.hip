@@ -207,8 +207,9 @@ size_t mdm_const_bytes(const mdm_model_t* m) {
     // OutputProcess with the last norm3 folded in (the plane path of decoder_pass): fp32 copy, 2 vectors, planes
     const size_t outp = align_up((size_t)m->jf * D * 4, 256) + 2 * align_up((size_t)32 * ((m->jf_out + 31) / 32) * 4, 256) +
                         align_up(x3_packed_weight_elems(m->jf, (int)D) * 4, 256);
+    const size_t kv_all = align_up((size_t)m->cfg.num_layers * 2 * D * D * 4, 256) + align_up((size_t)m->cfg.num_layers * 2 * D * 4, 256);
     return 256 /* range flag */ + align_up(D * m->jf_pad * sizeof(float), 256) +
-           2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) + (size_t)m->cfg.num_layers * (fold + planes) + outp;
+           2 * align_up((size_t)m->cfg.max_len * D * sizeof(float), 256) + (size_t)m->cfg.num_layers * (fold + planes) + outp + kv_all;
   }
   const size_t per_layer = align_up(3 * D * D * 4, 256) + align_up(D * D * 4, 256) + 2 * align_up(FF * D * 4, 256);
   return 256 /* range flag */ + align_up(D * m->jf_pad * sizeof(float), 256) +
@@ -308,6 +309,14 @@ int mdm_prepare(mdm_model_t* m, void* const_ws, size_t const_ws_bytes, void* str
                  m->b_out, m->jf, D, jf32);
       if (int rc = rt_launch_status()) return rc;
       if (int rc = make_planes(wf, m->jf, D, m->out_planes_f)) return rc;
+    }
+    // the cross-attention key | value projections of all layers as one [L * 2D][D] matrix (mdm_sample_loop_dec's hoisted projections)
+    m->wkv_all = take((size_t)L * 2 * D * D);
+    m->bkv_all = take((size_t)L * 2 * D);
+    for (int l = 0; l < L; ++l) {
+      if (int rc = rt_copy(m->wkv_all + (size_t)l * 2 * D * D, m->L(l, "multihead_attn.in_proj_weight") + (size_t)D * D,
+                           (size_t)2 * D * D * sizeof(float), s)) return rc;
+      if (int rc = rt_copy(m->bkv_all + (size_t)l * 2 * D, m->L(l, "multihead_attn.in_proj_bias") + D, (size_t)2 * D * sizeof(float), s)) return rc;
     }
     if ((size_t)(base - static_cast<char*>(const_ws)) > const_ws_bytes) return fail(MDM_ENOSPC, "mdm_prepare: const workspace too small");
     m->prepared = true;
