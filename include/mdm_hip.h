@@ -183,6 +183,10 @@ size_t mdm_workspace_bytes(const mdm_model_t* m, int32_t nseq, int32_t nframes);
  *                  lengths[B + 8 b .. B + 8 b + 7] (bit j of word i set: frame 32 i + j is a valid key; frames >= T ignored);
  *                  the condition token is always a valid key.  NULL = no key-padding mask (all frames valid, or
  *                  mask_frames == 0).  The same two forms hold wherever this header says `lengths_dev`
+ *   T              1 <= T < cfg.max_len (the positional table, model/mdm.py:55; the condition token takes one row).  Up to 223
+ *                  frames the attention keeps a query's scores in registers (exact softmax); longer sequences run the GEMMs on row
+ *                  tiles at every batch size and the attention with a streaming softmax (csrc/attention_long.h, round 6).  A
+ *                  BITMAP covers 256 frames: frames beyond it are masked -- use counts for longer prefix masks
  *   out_dev        [B or 2B, njoints, nfeats, T]                                                   */
 int mdm_forward(mdm_model_t* m, const float* x_dev, const int64_t* timesteps_dev, const float* text_embed_dev,
                 const int32_t* lengths_dev, int32_t B, int32_t T, int32_t branches, float* out_dev, void* ws_dev,

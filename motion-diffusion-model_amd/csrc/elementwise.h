@@ -226,6 +226,57 @@ __global__ __launch_bounds__(256) void pose_to_planes_kernel(const float* __rest
   }
 }
 
+// pose_to_planes_kernel AND cond_token_kernel in one launch (round 6: the two are independent and back to back in every step of the
+// f16x3 encoder loop; a dependent launch costs 2.2-2.7 us + the kernel's own latency chain, profiles/r06a_phase_barrier.md).  Linear grid:
+// blocks [0, nt * nj * B) transpose a 32 x 32 tile of the poses, blocks [nt * nj * B, ... + nseq) write token 0 of a sequence.
+struct CondTokArgs {
+  float* tok;
+  const float* cond_emb;
+  const float* text_bias;
+  const float* time_table;
+  const long long* timesteps;   // [B] or null: then every sample is at t_uniform
+  int t_uniform;
+  const float* pe;
+  int B, S, D, uncond_from_branch, table_rows;
+  p16_t *th, *tl;
+};
+__global__ __launch_bounds__(256) void pose_planes_cond_kernel(const float* __restrict__ x, p16_t* __restrict__ ph, p16_t* __restrict__ pl,
+                                                               int T, int JF, int KP, int nB, CondTokArgs ct) {
+  __shared__ float tile[32][33];
+  const int nt = (T + 31) / 32, nj = KP / 32, pose_blocks = nt * nj * nB;
+  if ((int)blockIdx.x >= pose_blocks) {          // ---- cond_token_kernel's body (block-uniform branch: no barrier on this side)
+    const int seq = (int)blockIdx.x - pose_blocks, b = seq % ct.B, br = seq / ct.B;
+    long long t = (ct.timesteps != nullptr) ? ct.timesteps[b] : (long long)ct.t_uniform;
+    if (t < 0) t = 0;
+    if (t >= ct.table_rows) t = ct.table_rows - 1;
+    for (int c = threadIdx.x * 4; c < ct.D; c += blockDim.x * 4) {
+      const float4 e = (br >= ct.uncond_from_branch || ct.cond_emb == nullptr) ? ld4(ct.text_bias + c) : ld4(ct.cond_emb + (size_t)b * ct.D + c);
+      const float4 tt = ld4(ct.time_table + (size_t)t * ct.D + c);
+      const float4 p0 = ld4(ct.pe + c);
+      const float4 o = make_float4(e.x + tt.x + p0.x, e.y + tt.y + p0.y, e.z + tt.z + p0.z, e.w + tt.w + p0.w);
+      st4(ct.tok + (size_t)seq * ct.S * ct.D + c, o);
+      if (ct.th != nullptr) split4_store(ct.th + (size_t)seq * ct.S * ct.D + c, ct.tl + (size_t)seq * ct.S * ct.D + c, o);
+    }
+    return;
+  }
+  // ---- pose_to_planes_kernel's body
+  const int bx = (int)blockIdx.x % nt, by = ((int)blockIdx.x / nt) % nj, b = (int)blockIdx.x / (nt * nj);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int t0 = bx * 32, j0 = by * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = j0 + ty + 8 * i, t = t0 + tx;
+    tile[ty + 8 * i][tx] = (j < JF && t < T) ? x[((size_t)b * JF + j) * T + t] : 0.f;
+  }
+  __syncthreads();
+  const int tl = threadIdx.x >> 3, jq = (threadIdx.x & 7) * 4;
+  const int t = t0 + tl;
+  if (t < T) {
+    const size_t o = ((size_t)b * T + t) * KP + j0 + jq;
+    split4_store(ph + o, pl + o, make_float4(tile[jq + 0][tl], tile[jq + 1][tl], tile[jq + 2][tl], tile[jq + 3][tl]));
+  }
+}
+
 // LayerNorm folded into the linear layer that consumes it (mdm_prepare; gemm_x3.h X3Epilogue):
 //   wf[n][k] = w[n][k] * gamma[k];  colsum[n] = sum_k wf[n][k];  biasf[n] = bias[n] + sum_k w[n][k] * beta[k]
 // so that  W.LN(x) + b = rstd * (Wf.x - mean * colsum) + biasf.  One wave per output row; rows N..Npad-1 of the

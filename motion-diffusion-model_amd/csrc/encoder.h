@@ -6,12 +6,13 @@ namespace {
 
 // InputProcess in split precision (8-wave kernel): poses -> planes [B*T][jf_k] (in the dead ffn region) -> GEMM whose epilogue
 // adds the positional rows and writes the frame tokens of every branch as planes.
-int embed_frames_x3(mdm_model* m, const Workspace& ws, const float* x, int B, int T, int nbranch, hipStream_t s) {
+// `ct`: the condition tokens of the nbranch * B sequences are written by the same launch as the pose transpose.
+int embed_frames_x3(mdm_model* m, const Workspace& ws, const float* x, int B, int T, int nbranch, hipStream_t s, const CondTokArgs& ct) {
   const int D = m->cfg.latent_dim, KP = m->jf_k;
   ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
   p16_t* ph = reinterpret_cast<p16_t*>(ws.ffn);
   p16_t* pl = ph + (size_t)B * T * KP;
-  MDM_LAUNCH(pose_to_planes_kernel, dim3((T + 31) / 32, KP / 32, B), dim3(256), 0, s, x, ph, pl, T, m->jf, KP);
+  MDM_LAUNCH(pose_planes_cond_kernel, dim3(((T + 31) / 32) * (KP / 32) * B + nbranch * B), dim3(256), 0, s, x, ph, pl, T, m->jf, KP, B, ct);
   if (int rc = rt_launch_status()) return rc;
   LnArgs a;
   a.res_f32 = m->W("sequence_pos_encoder.pe");
@@ -38,8 +39,10 @@ int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long l
   const bool x3 = m->precision == MDM_PREC_F16X3;
   EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D,
                    nbranch, x3 ? ws.tokh : nullptr, x3 ? ws.tokl : nullptr};
-  if (use_embed_x3(m, T)) {
-    if (int rc = embed_frames_x3(m, ws, x, B, T, nbranch, s)) return rc;
+  if (use_embed_x3(m, T)) {   // token 0 of every sequence rides in the transpose kernel of the frame embedding: one launch fewer per step
+    const CondTokArgs ct{ws.tok, cond_emb, m->W("embed_text.bias"), m->time_table, timesteps, 0, m->W("sequence_pos_encoder.pe"), B, S, D,
+                         uncond_from_branch, (int)m->cfg.max_len, ws.tokh, ws.tokl};
+    return embed_frames_x3(m, ws, x, B, T, nbranch, s, ct);
   } else {
     ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
     launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);

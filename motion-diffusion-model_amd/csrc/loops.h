@@ -46,19 +46,23 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
       const bool x3 = m->precision == MDM_PREC_F16X3;
       EmbedEpilogue ep{ws.tok, m->W("input_process.poseEmbedding.bias"), m->W("sequence_pos_encoder.pe"), B, T, S, D, nbranch,
                        x3 ? ws.tokh : nullptr, x3 ? ws.tokl : nullptr};
-      if (use_embed_x3(m, T)) {
-        if (int rc = embed_frames_x3(m, ws, x, B, T, nbranch, s)) return rc;
+      if (use_embed_x3(m, T)) {   // (token 0 of every sequence rides in the transpose kernel of the frame embedding)
+        const CondTokArgs ct{ws.tok, ws.cond, m->W("embed_text.bias"), m->time_table, nullptr, (int)p->timestep_map[i],
+                             m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from, (int)m->cfg.max_len, ws.tokh, ws.tokl};
+        if (int rc = embed_frames_x3(m, ws, x, B, T, nbranch, s, ct)) return rc;
       } else {
-        ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
-        launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
+        {
+          ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
+          launch_gemm_f32(al, bl, ep, B * T, D, m->jf_pad, s);
+        }
+        if (int rc = rt_launch_status()) return rc;
+        ProfScope ps(&m->prof, MDM_PROF_ELEMENTWISE, 0.0, s);
+        MDM_LAUNCH(cond_token_kernel, dim3(nseq), dim3(128), 0, s, ws.tok, (const float*)ws.cond,
+                   m->W("embed_text.bias"), (const float*)m->time_table, (const long long*)nullptr,
+                   (int)p->timestep_map[i], m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from,
+                   (int)m->cfg.max_len, x3 ? ws.tokh : (p16_t*)nullptr, x3 ? ws.tokl : (p16_t*)nullptr);
+        if (int rc = rt_launch_status()) return rc;
       }
-      if (int rc = rt_launch_status()) return rc;
-      ProfScope ps(&m->prof, MDM_PROF_ELEMENTWISE, 0.0, s);
-      MDM_LAUNCH(cond_token_kernel, dim3(nseq), dim3(128), 0, s, ws.tok, (const float*)ws.cond,
-                 m->W("embed_text.bias"), (const float*)m->time_table, (const long long*)nullptr,
-                 (int)p->timestep_map[i], m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from,
-                 (int)m->cfg.max_len, x3 ? ws.tokh : (p16_t*)nullptr, x3 ? ws.tokl : (p16_t*)nullptr);
-      if (int rc = rt_launch_status()) return rc;
     }
     if (int rc = encoder(m, ws, nseq, B, S, len, s)) return rc;
     // this step's eps: injected, or the counter-based stream -- drawn inline by the split-precision tail kernel, into the
