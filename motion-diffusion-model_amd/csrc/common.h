@@ -55,6 +55,26 @@ template <class KF> inline int rt_dyn_lds_once(KF kfn, int bytes, bool* configur
 }
 #endif
 
+// MDM_EARLY_KERNARGS (default 1; -DMDM_EARLY_KERNARGS=0 is the A/B build): pin the scalar loads of the kernel arguments a kernel's FIRST
+// vector loads depend on into its entry block.  hipcc sinks part of them behind the first s_waitcnt + the (branchy) tile arithmetic --
+// gemm_x3s_kernel: sizes first, wait, tile index, THEN the operand pointers; selfattn_block_kernel: the plane pointer re-read from the
+// kernarg segment with a run-time offset at its point of use -- i.e. two dependent scalar-memory round trips in front of the first
+// LDS-DMA request of kernels that last 10-30 us.  An empty asm statement that names the values as inputs makes them live at the top, so
+// all s_loads go out in one batch.  Used in the two kernels of the latency regime only (round 6, profiles/r06e_early_kernargs.md: DiP
+// +1.0 % same box, per 40-frame call -1.4 %); the persistent kernels of the headline pay their prologue once per 150-250 us and are left alone.
+#ifndef MDM_EARLY_KERNARGS
+#define MDM_EARLY_KERNARGS 1
+#endif
+#if MDM_EARLY_KERNARGS && !defined(MDM_EMU)
+#define MDM_KERNARGS_NOW(...) asm volatile("" ::__VA_ARGS__)
+// a kernel-argument pointer as an opaque SGPR value: `(p ? a.lo : a.hi)` on the raw arguments makes hipcc index the kernarg SEGMENT
+// with a run-time offset (s_load ... s46) -- another dependent scalar-memory round trip at the point of use
+template <class T> __device__ __forceinline__ T* rt_sgpr_ptr(T* p) { asm volatile("" : "+s"(p)); return p; }
+#else
+#define MDM_KERNARGS_NOW(...) do { } while (0)
+template <class T> __device__ __forceinline__ T* rt_sgpr_ptr(T* p) { return p; }
+#endif
+
 // v_mfma_f32_32x32x2_f32: exact-fp32 matrix FMA (64 cyc/SIMD, 157 TF chip peak).
 //   lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
 //   D[reg] is row i = (reg&3) + 8*(reg>>2) + 4*(l>>5), column j = l&31.

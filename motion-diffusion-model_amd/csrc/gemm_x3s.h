@@ -86,6 +86,7 @@ __global__ __launch_bounds__(64 * X3S_WAVES, 2) void gemm_x3s_kernel(X3Operand A
   const bool tl_on = g_x3s_tl_on != 0;
 #endif
   X3S_STAMP(0);
+  MDM_KERNARGS_NOW("s"(A.hi), "s"(A.lo), "s"(W.hi), "s"(W.lo), "s"(M), "s"(N), "s"(K), "s"(group_rows), "s"(tiles_per_group), "s"(tiles_n), "s"(total));
   const int lane = tid & 63;
 #ifdef MDM_EMU
   const int wid = tid >> 6;

@@ -101,6 +101,11 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
   const bool tl_on = g_sb_tl_on != 0;
 #endif
   SB_STAMP(0);
+  MDM_KERNARGS_NOW("s"(a.x.hi), "s"(a.x.lo), "s"(a.w.hi), "s"(a.w.lo), "s"(a.xstat), "s"(a.bias), "s"(a.colsum), "s"(a.H), "s"(a.D), "s"(a.M), "s"(a.S), "s"(total));
+  const p16_t* const xh_p = rt_sgpr_ptr(a.x.hi);
+  const p16_t* const xl_p = rt_sgpr_ptr(a.x.lo);
+  const float* const bias_p = rt_sgpr_ptr(a.bias);
+  const float* const colsum_p = rt_sgpr_ptr(a.colsum);
 #ifdef MDM_EMU
   const int wid = tid >> 6;
 #else
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
       const int q = wid + SB_WAVES * i;
       const int g = q & 3, p = (q >> 2) & 1, ms = q >> 3;       // (32 pieces per chunk: ms = 0 .. 3)
       const int arow = min(m0 + g * 16 + (lane >> 2), M - 1);
-      const p16_t* src = (p ? a.x.lo : a.x.hi) + (size_t)arow * D + (size_t)c * (SB_NSUB * 16) + ms * 32 + schunk * 8;
+      const p16_t* src = (p ? xl_p : xh_p) + (size_t)arow * D + (size_t)c * (SB_NSUB * 16) + ms * 32 + schunk * 8;
       glds16(src, lds + buf * SB_BUF + ((ms * 2 + p) * 4 + g) * 1024);
     }
   };
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(64 * SB_WAVES, 1) void selfattn_block_kernel(SelfAt
   // ---- this head's per-column vectors, the rows' (mean, rstd), the additive key mask
   for (int i = tid; i < (FOLD ? 2 : 1) * 32 * NWB; i += 64 * SB_WAVES) {
     const int which_vec = i / (32 * NWB), j = i - which_vec * (32 * NWB), wh = j / 32, c = (j - wh * 32) * 4;
-    const float* src = (which_vec == 0 ? a.bias : a.colsum) + wh * D + head * 128 + c;
+    const float* src = (which_vec == 0 ? bias_p : colsum_p) + wh * D + head * 128 + c;
     st4(vec + which_vec * 384 + wh * 128 + c, ld4(src));
   }
   // 32-key tiles in use.  CROSS: by the memory's token count (DiP's 24 tokens: one -- the second is neither filled nor multiplied).
