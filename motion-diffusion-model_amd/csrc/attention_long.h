@@ -34,7 +34,8 @@ __device__ __forceinline__ bool al_key_valid(const uint32_t* kbits, int key, int
 // grid = nseq * H * nqb workgroups of 4 waves; workgroup (item, qb) owns queries [128 qb, 128 qb + 128) of (sequence, head) `item`.
 // K and V^T tiles alternate through the ring of four 16 KB slots: tile u = (key tile u >> 1, V^T if u & 1), three tiles ahead,
 // one counted vmcnt + one barrier per tile (attention_x3.h's scheme with a run-time tile count).
-__global__ __launch_bounds__(256, 2) void attention_x3_long_kernel(QkvPlanes P, const int* __restrict__ lengths, int S, int D, int B,
+// (launch bounds without a residency promise: with two workgroups per CU promised the kernel spilled 88 bytes per lane)
+__global__ __launch_bounds__(256) void attention_x3_long_kernel(QkvPlanes P, const int* __restrict__ lengths, int S, int D, int B,
                                                                    int lead, float* __restrict__ out, p16_t* __restrict__ oh,
                                                                    p16_t* __restrict__ ol, int nqb) {
   MDM_DYN_SMEM(unsigned char, lds);
