@@ -62,7 +62,7 @@ extern "C" {
 #define MDM_EHIP (-4)     /* a HIP runtime call failed                         */
 #define MDM_EUNSUPPORTED (-5)
 
-#define MDM_ABI_VERSION 9
+#define MDM_ABI_VERSION 10
 
 typedef struct mdm_model mdm_model_t;
 
@@ -128,6 +128,18 @@ void mdm_destroy(mdm_model_t* m);
 #define MDM_OPT_ATTN_DIRECT_OUT 5
 int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value);
 int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value);
+
+/* y['target_cond'] -- the target-location condition of the `--multi_target_cond` checkpoints (model/mdm.py:197-199; the target-conditioned
+ * DiP of DiP.md:105) -- reaches the denoiser as a per-sample vector ADDED TO THE TIMESTEP EMBEDDING, in every guidance branch
+ * (`time_emb += mask_cond(embed_target_cond(...), force_mask=y.get('target_uncond'))`): through it into the condition token of the
+ * trans_enc sequence (mdm.py:219-220, :251) or into every row of the trans_dec text memory (:217-219, :263-265).  The embedding
+ * itself (a SiLU MLP over <= 8 joints x 4 numbers per sample, model/mdm.py:399-479) does not depend on x or t: the host evaluates it
+ * once per loop, like the text encoder, and binds the result here (ABI 10):
+ *   add_dev  [B, latent_dim] fp32, caller-owned, alive until the consuming call's work on its stream is done; NULL clears a binding.
+ * ONE-SHOT: the next mdm_forward / mdm_forward_dec / mdm_sample_loop / mdm_sample_loop_dec call on this handle consumes the binding
+ * (and fails with MDM_EINVAL, consuming it, if its batch is not B); calls after it run without one.  Under MDM_BRANCH_BOTH / guidance,
+ * row b is added to sample b of both branches.  A force-masked target (y['target_uncond']) is simply no binding. */
+int mdm_set_time_add(mdm_model_t* m, const float* add_dev, int32_t B);
 
 /* load_state_dict (utils/model_util.py:8-15): register the device pointer of one state-dict tensor under
  * its REFERENCE key, e.g. "seqTransEncoder.layers.3.self_attn.in_proj_weight".  `numel` is checked against

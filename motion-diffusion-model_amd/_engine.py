@@ -167,11 +167,24 @@ class Engine:
             out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value}
         return out
 
+    def _bind_time_add(self, time_add, B):
+        """include/mdm_hip.h mdm_set_time_add: the target-location embedding [B, latent_dim] (model/mdm.py:197-199) the NEXT native
+        call adds to the timestep embedding of its samples, both guidance branches; one-shot, so every call binds its own."""
+        if time_add is None:
+            return
+        if time_add.dim() != 2 or time_add.shape[0] != B or time_add.shape[1] != self.cfg.latent_dim or \
+                time_add.dtype != torch.float32 or not time_add.is_contiguous():
+            raise ValueError(f"time_add must be a contiguous float32 [B={B}, {self.cfg.latent_dim}] block; got {tuple(time_add.shape)} "
+                             f"{time_add.dtype}")
+        self._check_device(time_add)
+        self.lib.check(self.lib.mdm_set_time_add(self.handle, time_add.data_ptr(), B), "mdm_set_time_add")
+
     # ---- MDM.forward ------------------------------------------------------------------------
     @_on_own_device
-    def forward(self, x, timesteps, text_embed, lengths, branches):
+    def forward(self, x, timesteps, text_embed, lengths, branches, time_add=None):
         B, J, Fe, T = x.shape
         self._check_device(x)
+        self._bind_time_add(time_add, B)
         nb = 2 if branches == nat.BRANCH_BOTH else 1
         out = torch.empty((nb * B, J, Fe, T), dtype=torch.float32, device=x.device)
         ws = self.workspace(nb * B, T)
@@ -182,7 +195,7 @@ class Engine:
 
     # ---- MDM.forward, trans_dec (DiP) ----------------------------------------------------------
     @_on_own_device
-    def forward_dec(self, x, prefix, timesteps, text_tokens, text_lengths, lengths, branches):
+    def forward_dec(self, x, prefix, timesteps, text_tokens, text_lengths, lengths, branches, time_add=None):
         """x [B,J,F,pred_len], prefix [B,J,F,context_len] | None, text_tokens [ntok,B,dim],
         text_lengths [B] int32, lengths [B] int32 | None  ->  [B or 2B, J, F, pred_len]."""
         B, J, Fe, P = x.shape
@@ -194,6 +207,7 @@ class Engine:
         if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._bind_time_add(time_add, B)
         self.lib.check(self.lib.mdm_forward_dec(self.handle, x.data_ptr(), _ptr(prefix), timesteps.data_ptr(),
                                                 _ptr(text_tokens), text_lengths.data_ptr(), _ptr(lengths), B, P, ntok,
                                                 branches, out.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
@@ -255,7 +269,8 @@ class Engine:
     @_on_own_device
     def sample_loop_dec(self, x, *, prefix, text_tokens, text_lengths, a_x0, a_xt, sigma, timestep_map, start_index, scale,
                         lengths, inpaint_mask=None, inpaint_motion=None, noise=None, seed=0, sample_base=0,
-                        clip_denoised=False, force_uncond=False, want_x0=False, dump_steps=None, const_noise=False):
+                        clip_denoised=False, force_uncond=False, want_x0=False, dump_steps=None, const_noise=False,
+                        time_add=None):
         """In-place window loop of the trans_dec (DiP) denoiser on x [B,J,F,pred_len]; inputs as forward_dec."""
         B, J, Fe, P = x.shape
         self._check_device(x)
@@ -269,6 +284,7 @@ class Engine:
         if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._bind_time_add(time_add, B)
         self.lib.check(self.lib.mdm_sample_loop_dec(self.handle, C.byref(pd), x.data_ptr(), self._ws.data_ptr(),
                                                     self._ws.numel(), self.stream()), "mdm_sample_loop_dec")
         del keep
@@ -277,7 +293,7 @@ class Engine:
     @_on_own_device
     def sample_loop(self, x, *, a_x0, a_xt, sigma, timestep_map, start_index, text_embed, scale, lengths,
                     inpaint_mask=None, inpaint_motion=None, noise=None, seed=0, sample_base=0, clip_denoised=False,
-                    force_uncond=False, want_x0=False, dump_steps=None, const_noise=False):
+                    force_uncond=False, want_x0=False, dump_steps=None, const_noise=False, time_add=None):
         """In-place loop on x [B,J,F,T] (x at index start_index).  Returns (x, x0 or None, dumps or None)."""
         B, J, Fe, T = x.shape
         self._check_device(x)
@@ -286,6 +302,7 @@ class Engine:
                                                clip_denoised, force_uncond, want_x0, dump_steps, const_noise)
         nb = 2 if scale is not None else 1
         ws = self.workspace(nb * B, T)
+        self._bind_time_add(time_add, B)
         self.lib.check(self.lib.mdm_sample_loop(self.handle, C.byref(p), x.data_ptr(), ws.data_ptr(), ws.numel(),
                                                 self.stream()), "mdm_sample_loop")
         del keep

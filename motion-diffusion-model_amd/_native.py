@@ -24,11 +24,11 @@ EXPORTED_SYMBOLS = [
     "mdm_linear", "mdm_layernorm", "mdm_attention", "mdm_profile_enable", "mdm_profile_read", "mdm_profile_reset",
     "mdm_set_precision", "mdm_linear_x3", "mdm_linear_x3_scratch_bytes", "mdm_attention_x3", "mdm_attention_x3_scratch_bytes",
     "mdm_recover_from_ric", "mdm_workspace_bytes_dec", "mdm_forward_dec", "mdm_workspace_bytes_dec_loop",
-    "mdm_sample_loop_dec", "mdm_weights_in_range", "mdm_set_option", "mdm_get_option",
+    "mdm_sample_loop_dec", "mdm_weights_in_range", "mdm_set_option", "mdm_get_option", "mdm_set_time_add",
 ]
 # include/mdm_hip_probe.h: exported by the probe build only
 PROBE_SYMBOLS = ["mdm_debug_set", "mdm_debug_get", "mdm_linear_f16f6", "mdm_linear_f16f6_scratch_bytes", "mdm_probe_in_proj"]
-ABI_VERSION = 9
+ABI_VERSION = 10
 # include/mdm_hip.h MDM_OPT_*: per-handle run-time options (the library reads no environment variable)
 OPTIONS = {"small_gemm_max_seqs": 1, "small_gemm_row_tiles": 2, "dec_fused_xattn": 3, "dec_fused_selfattn": 4, "attn_direct_out": 5}
 ARCH = {"trans_enc": 0, "trans_dec": 1}
@@ -111,6 +111,7 @@ class MdmLib:
             "mdm_profile_reset": (C.c_int, [vp]),
             "mdm_set_option": (C.c_int, [vp, i32, i32]),
             "mdm_get_option": (C.c_int, [vp, i32, P(i32)]),
+            "mdm_set_time_add": (C.c_int, [vp, vp, i32]),
         }
         probe_sig = {
             "mdm_debug_set": (C.c_int, [C.c_int, C.c_int]),

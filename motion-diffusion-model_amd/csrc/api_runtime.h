@@ -126,6 +126,11 @@ struct mdm_model {
   int* range_flag = nullptr;    // device word in the const workspace: a weight left the 16-bit planes' range (mdm_prepare)
   float* w_in_pad = nullptr;    // [D][JFpad]
   float* time_table = nullptr;  // [max_len][D]
+  // mdm_set_time_add (ABI 10): `time_add_next` is the one-shot binding ([time_add_B][D], caller-owned), `time_add` what the call
+  // in flight adds to the timestep embedding of its samples (TimeAddScope; null outside a call and for calls without a binding)
+  const float* time_add_next = nullptr;
+  int time_add_B = 0;
+  const float* time_add = nullptr;
   int jf = 0, jf_pad = 0;
   int precision = MDM_PREC_F16X3;
   struct LayerPlanes { X3Weights in_proj, out_proj, linear1, linear2; };
@@ -228,5 +233,25 @@ int check_ready(const mdm_model* m) {
   if (!m->prepared) return fail(MDM_ESTATE, "mdm_prepare has not been called (or weights changed since)");
   return 0;
 }
+
+// The one-shot target embedding of mdm_set_time_add: consumed by the entry point that constructs this scope (its batch must be the
+// bound one), visible to the call's kernels as m->time_add, cleared on every way out -- a failed call consumes it too.
+struct TimeAddScope {
+  mdm_model* m;
+  int rc = 0;
+  TimeAddScope(mdm_model* m_, int B, const char* who) : m(m_) {
+    if (m->time_add_next == nullptr) return;
+    if (m->time_add_B != B)
+      rc = fail(MDM_EINVAL, std::string(who) + ": mdm_set_time_add bound " + std::to_string(m->time_add_B) + " samples, this call has " +
+                                std::to_string(B));
+    else
+      m->time_add = m->time_add_next;
+    m->time_add_next = nullptr;
+    m->time_add_B = 0;
+  }
+  ~TimeAddScope() { m->time_add = nullptr; }
+  TimeAddScope(const TimeAddScope&) = delete;
+  TimeAddScope& operator=(const TimeAddScope&) = delete;
+};
 
 }  // namespace

@@ -331,7 +331,7 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
     ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
     MDM_LAUNCH(text_memory_kernel, dim3(Mm), dim3(128), 0, s, ws.mem, (const float*)ws.proj, m->W("embed_text.bias"),
                (const float*)m->time_table, reinterpret_cast<const long long*>(timesteps), B, ntok, D,
-               (branches == MDM_BRANCH_UNCOND) ? 0 : 1, (int)m->cfg.max_len);
+               (branches == MDM_BRANCH_UNCOND) ? 0 : 1, (int)m->cfg.max_len, m->time_add);
     if (int rc = rt_launch_status()) return rc;
   }
   if (dec_on_planes(m, M, S, hz, B))

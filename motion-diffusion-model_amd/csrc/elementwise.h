@@ -54,6 +54,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
 // Token 0 of every sequence: embed_text(cond) (or its bias for the uncond branch) + time-MLP(pe[t]) + pe[0]
 // (mdm.py:195, :218-220, :251-252).  cond_emb may be null for a branch => bias only (mask_cond zeroes the
 // input: mdm.py:155-156).  Grid = nbranch*B blocks, D/4 threads... each thread 4 consecutive channels.
+// `tadd` (null or [B][D]): the target-location embedding the reference adds to the timestep embedding of sample b in EVERY branch
+// (`time_emb += mask_cond(embed_target_cond(...))`, mdm.py:197-199; include/mdm_hip.h mdm_set_time_add).
+__device__ __forceinline__ float4 time_row(const float* __restrict__ time_table, long long t, const float* __restrict__ tadd, int b, int D,
+                                           int c) {
+  float4 tt = ld4(time_table + (size_t)t * D + c);
+  if (tadd != nullptr) {
+    const float4 g = ld4(tadd + (size_t)b * D + c);
+    tt = make_float4(tt.x + g.x, tt.y + g.y, tt.z + g.z, tt.w + g.w);
+  }
+  return tt;
+}
 __global__ __launch_bounds__(256) void cond_token_kernel(float* __restrict__ tok, const float* __restrict__ cond_emb,
                                                          const float* __restrict__ text_bias,
                                                          const float* __restrict__ time_table,
@@ -61,7 +72,8 @@ __global__ __launch_bounds__(256) void cond_token_kernel(float* __restrict__ tok
                                                          int t_uniform,  // used when timesteps == null
                                                          const float* __restrict__ pe, int B, int S, int D,
                                                          int uncond_from_branch, int table_rows,
-                                                         p16_t* __restrict__ th, p16_t* __restrict__ tl) {
+                                                         p16_t* __restrict__ th, p16_t* __restrict__ tl,
+                                                         const float* __restrict__ tadd) {
   const int seq = blockIdx.x, b = seq % B, br = seq / B;
   long long t = (timesteps != nullptr) ? timesteps[b] : (long long)t_uniform;
   if (t < 0) t = 0;
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(256) void cond_token_kernel(float* __restrict__ tok
   for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
     const float4 e = (br >= uncond_from_branch || cond_emb == nullptr) ? ld4(text_bias + c)
                                                                       : ld4(cond_emb + (size_t)b * D + c);
-    const float4 tt = ld4(time_table + (size_t)t * D + c);
+    const float4 tt = time_row(time_table, t, tadd, b, D, c);
     const float4 p0 = ld4(pe + c);
     const float4 o = make_float4(e.x + tt.x + p0.x, e.y + tt.y + p0.y, e.z + tt.z + p0.z, e.w + tt.w + p0.w);
     st4(tok + (size_t)seq * S * D + c, o);
@@ -85,7 +97,8 @@ __global__ __launch_bounds__(256) void text_memory_kernel(float* __restrict__ me
                                                           const float* __restrict__ text_bias,
                                                           const float* __restrict__ time_table,
                                                           const long long* __restrict__ timesteps, int B, int ntok, int D,
-                                                          int uncond_from_branch, int table_rows) {
+                                                          int uncond_from_branch, int table_rows,
+                                                          const float* __restrict__ tadd) {
   const int row = blockIdx.x, seq = row / ntok, j = row - seq * ntok, b = seq % B, br = seq / B;
   // timesteps == null: the text part alone (the window loop adds the projected time row inside the attention kernel)
   long long t = timesteps != nullptr ? timesteps[b] : 0;
@@ -94,7 +107,12 @@ __global__ __launch_bounds__(256) void text_memory_kernel(float* __restrict__ me
   for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
     const float4 e = (br >= uncond_from_branch || proj == nullptr) ? ld4(text_bias + c)
                                                                   : ld4(proj + ((size_t)j * B + b) * D + c);
-    const float4 tt = timesteps != nullptr ? ld4(time_table + (size_t)t * D + c) : zero4();
+    // (`tadd`, mdm.py:197-199: part of the timestep embedding; in a window loop it rides with the text part, which is built once)
+    float4 tt = timesteps != nullptr ? ld4(time_table + (size_t)t * D + c) : zero4();
+    if (tadd != nullptr) {
+      const float4 g = ld4(tadd + (size_t)b * D + c);
+      tt = make_float4(tt.x + g.x, tt.y + g.y, tt.z + g.z, tt.w + g.w);
+    }
     st4(mem + (size_t)row * D + c, make_float4(e.x + tt.x, e.y + tt.y, e.z + tt.z, e.w + tt.w));
   }
 }
@@ -239,6 +257,7 @@ struct CondTokArgs {
   const float* pe;
   int B, S, D, uncond_from_branch, table_rows;
   p16_t *th, *tl;
+  const float* tadd;            // null or [B][D]: added to the timestep embedding (mdm.py:197-199)
 };
 __global__ __launch_bounds__(256) void pose_planes_cond_kernel(const float* __restrict__ x, p16_t* __restrict__ ph, p16_t* __restrict__ pl,
                                                                int T, int JF, int KP, int nB, CondTokArgs ct) {
@@ -251,7 +270,7 @@ __global__ __launch_bounds__(256) void pose_planes_cond_kernel(const float* __re
     if (t >= ct.table_rows) t = ct.table_rows - 1;
     for (int c = threadIdx.x * 4; c < ct.D; c += blockDim.x * 4) {
       const float4 e = (br >= ct.uncond_from_branch || ct.cond_emb == nullptr) ? ld4(ct.text_bias + c) : ld4(ct.cond_emb + (size_t)b * ct.D + c);
-      const float4 tt = ld4(ct.time_table + (size_t)t * ct.D + c);
+      const float4 tt = time_row(ct.time_table, t, ct.tadd, b, ct.D, c);
       const float4 p0 = ld4(ct.pe + c);
       const float4 o = make_float4(e.x + tt.x + p0.x, e.y + tt.y + p0.y, e.z + tt.z + p0.z, e.w + tt.w + p0.w);
       st4(ct.tok + (size_t)seq * ct.S * ct.D + c, o);

@@ -41,7 +41,7 @@ int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long l
                    nbranch, x3 ? ws.tokh : nullptr, x3 ? ws.tokl : nullptr};
   if (use_embed_x3(m, T)) {   // token 0 of every sequence rides in the transpose kernel of the frame embedding: one launch fewer per step
     const CondTokArgs ct{ws.tok, cond_emb, m->W("embed_text.bias"), m->time_table, timesteps, 0, m->W("sequence_pos_encoder.pe"), B, S, D,
-                         uncond_from_branch, (int)m->cfg.max_len, ws.tokh, ws.tokl};
+                         uncond_from_branch, (int)m->cfg.max_len, ws.tokh, ws.tokl, m->time_add};
     return embed_frames_x3(m, ws, x, B, T, nbranch, s, ct);
   } else {
     ProfScope ps(&m->prof, MDM_PROF_EMBED, 2.0 * B * T * (double)D * m->jf, s);
@@ -51,7 +51,7 @@ int embed_tokens(mdm_model* m, const Workspace& ws, const float* x, const long l
   ProfScope ps(&m->prof, MDM_PROF_ELEMENTWISE, 0.0, s);
   MDM_LAUNCH(cond_token_kernel, dim3(nbranch * B), dim3(128), 0, s, ws.tok, cond_emb, m->W("embed_text.bias"),
              (const float*)m->time_table, timesteps, 0, m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from_branch,
-             (int)m->cfg.max_len, x3 ? ws.tokh : (p16_t*)nullptr, x3 ? ws.tokl : (p16_t*)nullptr);
+             (int)m->cfg.max_len, x3 ? ws.tokh : (p16_t*)nullptr, x3 ? ws.tokl : (p16_t*)nullptr, m->time_add);
   return rt_launch_status();
 }
 

@@ -11,6 +11,8 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
   if (m->cfg.arch != MDM_ARCH_TRANS_ENC) return fail(MDM_ESTATE, "mdm_sample_loop: the fused loop drives the trans_enc denoiser");
   if (p == nullptr || x == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop: null pointer");
   const int B = p->B, T = p->T;
+  TimeAddScope time_add(m, B, "mdm_sample_loop");
+  if (time_add.rc) return time_add.rc;
   if (B <= 0 || T <= 0 || T + 1 > m->cfg.max_len) return fail(MDM_EINVAL, "mdm_sample_loop: need B >= 1 and 1 <= T < the positional table's length");
   if (p->num_timesteps <= 0 || p->start_index < 0 || p->start_index >= p->num_timesteps)
     return fail(MDM_EINVAL, "mdm_sample_loop: bad start_index / num_timesteps");
@@ -48,7 +50,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
                        x3 ? ws.tokh : nullptr, x3 ? ws.tokl : nullptr};
       if (use_embed_x3(m, T)) {   // (token 0 of every sequence rides in the transpose kernel of the frame embedding)
         const CondTokArgs ct{ws.tok, ws.cond, m->W("embed_text.bias"), m->time_table, nullptr, (int)p->timestep_map[i],
-                             m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from, (int)m->cfg.max_len, ws.tokh, ws.tokl};
+                             m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from, (int)m->cfg.max_len, ws.tokh, ws.tokl, m->time_add};
         if (int rc = embed_frames_x3(m, ws, x, B, T, nbranch, s, ct)) return rc;
       } else {
         {
@@ -60,7 +62,7 @@ int mdm_sample_loop(mdm_model_t* m, const mdm_sample_params_t* p, float* x, void
         MDM_LAUNCH(cond_token_kernel, dim3(nseq), dim3(128), 0, s, ws.tok, (const float*)ws.cond,
                    m->W("embed_text.bias"), (const float*)m->time_table, (const long long*)nullptr,
                    (int)p->timestep_map[i], m->W("sequence_pos_encoder.pe"), B, S, D, uncond_from,
-                   (int)m->cfg.max_len, x3 ? ws.tokh : (p16_t*)nullptr, x3 ? ws.tokl : (p16_t*)nullptr);
+                   (int)m->cfg.max_len, x3 ? ws.tokh : (p16_t*)nullptr, x3 ? ws.tokl : (p16_t*)nullptr, m->time_add);
         if (int rc = rt_launch_status()) return rc;
       }
     }
@@ -117,6 +119,8 @@ int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float
   if (pd == nullptr || x == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop_dec: null pointer");
   const mdm_sample_params_t* p = &pd->loop;
   const int B = p->B, P = p->T, ntok = pd->ntok;
+  TimeAddScope time_add(m, B, "mdm_sample_loop_dec");
+  if (time_add.rc) return time_add.rc;
   if (int rc = check_dec_shapes(m, "mdm_sample_loop_dec", pd->prefix_dev, B, P, ntok)) return rc;
   if (pd->text_lengths_dev == nullptr) return fail(MDM_EINVAL, "mdm_sample_loop_dec: text_lengths required");
   if (p->num_timesteps <= 0 || p->start_index < 0 || p->start_index >= p->num_timesteps)
@@ -150,7 +154,7 @@ int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float
     ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
     MDM_LAUNCH(text_memory_kernel, dim3(Mm), dim3(128), 0, s, ws.mem, (const float*)ws.proj, m->W("embed_text.bias"),
                (const float*)m->time_table, (const long long*)nullptr, B, ntok, D,
-               (branches == MDM_BRANCH_UNCOND) ? 0 : 1, (int)m->cfg.max_len);
+               (branches == MDM_BRANCH_UNCOND) ? 0 : 1, (int)m->cfg.max_len, m->time_add);
     if (int rc = rt_launch_status()) return rc;
   }
   for (int k0 = 0; k0 < nsteps; k0 += 64) {     // the steps' time-embedding rows: one gather launch per 64 steps

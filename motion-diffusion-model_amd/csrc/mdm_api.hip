@@ -169,6 +169,15 @@ int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value) {
   }
 }
 
+// ABI 10: y['target_cond'] (model/mdm.py:197-199).  One-shot, caller-owned; see include/mdm_hip.h.
+int mdm_set_time_add(mdm_model_t* m, const float* add_dev, int32_t B) {
+  if (m == nullptr) return fail(MDM_EINVAL, "mdm_set_time_add: null model");
+  if (add_dev != nullptr && B <= 0) return fail(MDM_EINVAL, "mdm_set_time_add: B must be >= 1");
+  m->time_add_next = add_dev;
+  m->time_add_B = add_dev != nullptr ? B : 0;
+  return MDM_OK;
+}
+
 int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value) {
   if (m == nullptr || value == nullptr) return fail(MDM_EINVAL, "mdm_get_option: null argument");
   switch (key) {
@@ -431,6 +440,8 @@ int mdm_forward(mdm_model_t* m, const float* x, const int64_t* timesteps, const 
                 size_t ws_bytes, void* stream) {
   ChainGuard chain_guard(stream);
   if (int rc = check_ready(m)) return rc;
+  TimeAddScope time_add(m, B, "mdm_forward");
+  if (time_add.rc) return time_add.rc;
   if (m->cfg.arch != MDM_ARCH_TRANS_ENC) return fail(MDM_ESTATE, "mdm_forward: trans_dec models go through mdm_forward_dec");
   if (x == nullptr || timesteps == nullptr || out == nullptr || ws_dev == nullptr) return fail(MDM_EINVAL, "mdm_forward: null pointer");
   if (B <= 0 || T <= 0 || T + 1 > m->cfg.max_len) return fail(MDM_EINVAL, "mdm_forward: need B >= 1 and 1 <= T < the positional table's length");
@@ -480,6 +491,8 @@ int mdm_forward_dec(mdm_model_t* m, const float* x, const float* prefix, const i
                     int32_t branches, float* out, void* ws_dev, size_t ws_bytes, void* stream) {
   ChainGuard chain_guard(stream);
   if (int rc = check_ready(m)) return rc;
+  TimeAddScope time_add(m, B, "mdm_forward_dec");
+  if (time_add.rc) return time_add.rc;
   if (x == nullptr || timesteps == nullptr || out == nullptr || ws_dev == nullptr || text_lengths == nullptr)
     return fail(MDM_EINVAL, "mdm_forward_dec: null pointer");
   if (int rc = check_dec_shapes(m, "mdm_forward_dec", prefix, B, pred_len, ntok)) return rc;

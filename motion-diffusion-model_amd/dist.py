@@ -11,7 +11,8 @@ import os
 import torch
 import torch.distributed as dist
 
-_SHARDED_KEYS = ("mask", "lengths", "scale", "inpainting_mask", "inpainted_motion", "prefix")
+_SHARDED_KEYS = ("mask", "lengths", "scale", "inpainting_mask", "inpainted_motion", "prefix", "action", "target_cond")
+_SHARDED_LISTS = ("text", "action_text", "target_joint_names", "is_heading")     # per-sample python lists (data_loaders/tensors.py)
 
 
 def init_from_env(backend=None, force=False):
@@ -55,8 +56,10 @@ def shard_y(y, lo, hi):
                 out[k] = (tok[lo:hi], pad[lo:hi])
             else:
                 out[k] = (tok[:, lo:hi], pad if pad.shape[0] == 1 else pad[lo:hi])
-        elif k == "text" and isinstance(v, (list, tuple)):
+        elif k in _SHARDED_LISTS and isinstance(v, (list, tuple)):
             out[k] = list(v[lo:hi])
+        elif k == "is_heading" and torch.is_tensor(v):
+            out[k] = v[lo:hi]
         elif k in _SHARDED_KEYS and torch.is_tensor(v) and v.dim() >= 1:
             out[k] = v[lo:hi]
         else:

@@ -428,12 +428,10 @@ class GaussianDiffusion:
 
             dec = mdm.arch == 'trans_dec'
             if dec:
-                for k in ('target_cond', 'action'):
-                    if k in y:
-                        raise NotImplementedError(f"y[{k!r}] is outside the MI355X hot path")
                 prefix, tokens, tok_lengths, lengths = mdm._dec_inputs(img, y)
             else:
-                te = mdm.text_embedding(y, device) if 'text' in mdm.cond_mode and not y.get('uncond', False) else None
+                te = mdm.text_embedding(y, device) if mdm.cond_mode != 'no_cond' and not y.get('uncond', False) else None
+            time_add = mdm.target_embedding(y, device)            # y['target_cond'], model/mdm.py:197-199: once per loop
             scale = None
             if guided:
                 scale = y['scale'].to(device=device, dtype=torch.float32).reshape(-1).contiguous()
@@ -459,7 +457,8 @@ class GaussianDiffusion:
             kept = sorted(set(int(k) for k in dump_steps if 0 <= int(k) <= start)) if dump_steps is not None else None
             common = dict(a_x0=a_x0, a_xt=a_xt, sigma=sigma, timestep_map=self.timestep_map, start_index=start,
                           scale=scale, lengths=lengths, inpaint_mask=im, inpaint_motion=imo, noise=nz, seed=seed,
-                          sample_base=base, clip_denoised=clip_denoised, dump_steps=kept, const_noise=const_noise)
+                          sample_base=base, clip_denoised=clip_denoised, dump_steps=kept, const_noise=const_noise,
+                          time_add=time_add)
             if dec:      # one DiP prediction window (sample/generate.py's autoregressive loop calls this per window)
                 out, _, dumps = eng.sample_loop_dec(img, prefix=prefix, text_tokens=tokens, text_lengths=tok_lengths,
                                                     force_uncond=bool(y.get('uncond', False)), **common)

@@ -67,6 +67,97 @@ class OutputProcess(nn.Module):
         self.poseFinal = nn.Linear(latent_dim, input_feats)
 
 
+class EmbedAction(nn.Module):
+    """model/mdm.py:389-397: one learned row per action class (`cond_mode='action'`, the humanact12 / uestc checkpoints)."""
+
+    def __init__(self, num_actions, latent_dim):
+        super().__init__()
+        self.action_embedding = nn.Parameter(torch.randn(num_actions, latent_dim))
+
+    def forward(self, input):
+        return self.action_embedding[input[:, 0].to(torch.long)]
+
+
+class _TargetLocBase(nn.Module):
+    """What the three target-location encoders of model/mdm.py:399-479 share: the joint list (`all_goal_joint_names` + 'traj' +
+    'heading') and the per-sample choice of joints, here as one [B, n_ext] 0/1 matrix instead of the reference's loops."""
+
+    def __init__(self, all_goal_joint_names, latent_dim):
+        super().__init__()
+        self.extended_goal_joint_names = list(all_goal_joint_names) + ['traj', 'heading']
+        self.latent_dim = latent_dim
+
+    def chosen(self, input, target_joint_names, target_heading):
+        sel = torch.zeros(input.shape[0], len(self.extended_goal_joint_names))
+        for b, names in enumerate(target_joint_names):
+            for j in list(names) + (['heading'] if target_heading[b] else []):
+                sel[b, self.extended_goal_joint_names.index(str(j))] = 1.0
+        return sel.to(device=input.device, dtype=input.dtype)
+
+    @staticmethod
+    def _mlp(n_in, width, num_layers):
+        layers = [nn.Linear(n_in, width)]
+        for _ in range(num_layers):
+            layers += [nn.SiLU(), nn.Linear(width, width)]
+        return nn.Sequential(*layers)
+
+
+class EmbedTargetLocSingle(_TargetLocBase):
+    """model/mdm.py:399-419 (`--multi_encoder_type single`): ONE MLP over every joint's (x, y, z, chosen) numbers."""
+
+    def __init__(self, all_goal_joint_names, latent_dim, num_layers=1):
+        super().__init__(all_goal_joint_names, latent_dim)
+        self.target_cond_dim = 4 * len(self.extended_goal_joint_names)
+        self.mlp = self._mlp(self.target_cond_dim, latent_dim, num_layers)
+
+    def forward(self, input, target_joint_names, target_heading):
+        sel = self.chosen(input, target_joint_names, target_heading)
+        return self.mlp(torch.cat([input, sel[..., None]], dim=-1).flatten(1))
+
+
+class EmbedTargetLocSplit(_TargetLocBase):
+    """model/mdm.py:422-449 (`split`): a narrow MLP per joint, outputs concatenated along the channel axis."""
+
+    def __init__(self, all_goal_joint_names, latent_dim, num_layers=1):
+        super().__init__(all_goal_joint_names, latent_dim)
+        n = len(self.extended_goal_joint_names)
+        assert latent_dim % n == 0
+        self.target_cond_dim, self.splited_dim = 4, latent_dim // n
+        self.mini_mlps = nn.ModuleList([self._mlp(4, self.splited_dim, num_layers) for _ in range(n)])
+
+    def forward(self, input, target_joint_names, target_heading):
+        mi = torch.cat([input, self.chosen(input, target_joint_names, target_heading)[..., None]], dim=-1)
+        return torch.cat([mlp(mi[:, j]) for j, mlp in enumerate(self.mini_mlps)], dim=-1)
+
+
+class WeightedSum(nn.Module):
+    """utils/misc.py:5-16: rows combined with learned weights normalised by their SUM (not a softmax)."""
+
+    def __init__(self, num_rows):
+        super().__init__()
+        self.weights = nn.Parameter(torch.randn(num_rows))
+
+    def forward(self, x):
+        return torch.matmul(self.weights / self.weights.sum(), x)
+
+
+class EmbedTargetLocMulti(_TargetLocBase):
+    """model/mdm.py:451-479 (`multi`): an MLP per joint over its (x, y, z); the rows of the joints a sample did NOT choose are zero;
+    WeightedSum over the joints.  (The reference keeps the per-joint MLPs in an nn.ParameterDict; a ModuleDict has the same keys.)"""
+
+    def __init__(self, all_goal_joint_names, latent_dim):
+        super().__init__(all_goal_joint_names, latent_dim)
+        self.n_extended_goal_joints = len(self.extended_goal_joint_names)
+        self.target_loc_emb = nn.ModuleDict({n: self._mlp(3, latent_dim, 1) for n in self.extended_goal_joint_names})
+        self.target_all_loc_emb = WeightedSum(self.n_extended_goal_joints)
+
+    def forward(self, input, target_joint_names, target_heading):
+        sel = self.chosen(input, target_joint_names, target_heading)
+        rows = torch.stack([self.target_loc_emb[n](input[:, j]) * sel[:, j:j + 1]
+                            for j, n in enumerate(self.extended_goal_joint_names)], dim=1)          # [B, n_ext, d]
+        return self.target_all_loc_emb(rows)
+
+
 class _IdentityRot2xyz:
     """Stand-in for model/rotation2xyz.py: for data_rep='hml_vec' the callers use pose_rep='xyz', for which the
     reference returns its input unchanged (rotation2xyz.py:20-21; sample/generate.py:167)."""
@@ -107,6 +198,8 @@ class MDM(nn.Module):
         self.is_prefix_comp = self.total_len > 0
         self.all_goal_joint_names = kargs.get('all_goal_joint_names', [])
         self.multi_target_cond = kargs.get('multi_target_cond', False)
+        self.multi_encoder_type = kargs.get('multi_encoder_type', 'multi')
+        self.target_enc_layers = kargs.get('target_enc_layers', 1)
         self.text_encoder_type = kargs.get('text_encoder_type', 'clip')
         self.clip_version = clip_version
         self._native_lib = kargs.get('_native_lib', None)      # tests inject the CPU emulation here
@@ -123,10 +216,12 @@ class MDM(nn.Module):
             raise ValueError(f"context_len + pred_len = {self.total_len} tokens do not fit the positional table")
         if activation != "gelu":
             raise NotImplementedError("only activation='gelu' (the reference's fixed choice, utils/model_util.py:64)")
-        if data_rep == 'rot_vel' or self.multi_target_cond or self.emb_policy != 'add':
-            raise NotImplementedError("rot_vel / target conditioning / emb_policy!='add' are out of scope")
-        if self.cond_mode not in ('no_cond', 'text'):
-            raise NotImplementedError(f"cond_mode={self.cond_mode!r}: text or no_cond only")
+        if data_rep == 'rot_vel' or self.emb_policy != 'add':
+            raise NotImplementedError("rot_vel / emb_policy!='add' are out of scope")
+        if self.cond_mode not in ('no_cond', 'text', 'action'):
+            raise NotImplementedError(f"cond_mode={self.cond_mode!r}: text, action or no_cond")
+        if self.multi_target_cond and self.multi_encoder_type not in ('multi', 'single', 'split'):
+            raise ValueError(f"multi_encoder_type={self.multi_encoder_type!r}: multi, single or split (utils/parser_util.py:126)")
         if arch == 'trans_enc':
             if self.is_prefix_comp:
                 raise NotImplementedError("prefix completion belongs to the DiP (trans_dec) path")
@@ -151,6 +246,15 @@ class MDM(nn.Module):
                                                dropout=dropout, activation=activation)
             self.seqTransDecoder = nn.TransformerDecoder(layer, num_layers=num_layers)
         self.embed_timestep = TimestepEmbedder(latent_dim, self.sequence_pos_encoder)
+        if self.multi_target_cond:                       # model/mdm.py:67-73
+            if self.multi_encoder_type == 'multi':
+                self.embed_target_cond = EmbedTargetLocMulti(self.all_goal_joint_names, latent_dim)
+            elif self.multi_encoder_type == 'single':
+                self.embed_target_cond = EmbedTargetLocSingle(self.all_goal_joint_names, latent_dim, self.target_enc_layers)
+            else:
+                self.embed_target_cond = EmbedTargetLocSplit(self.all_goal_joint_names, latent_dim, self.target_enc_layers)
+        if 'action' in self.cond_mode:                   # model/mdm.py:128-130
+            self.embed_action = EmbedAction(self.num_actions, latent_dim)
         if 'text' in self.cond_mode:
             self.embed_text = nn.Linear(clip_dim, latent_dim)
             # the text encoder itself (CLIP / DistilBERT) is outside the hot path: callers cache y['text_embed']
@@ -231,10 +335,23 @@ class MDM(nn.Module):
         sd = {k: v for k, v in self.state_dict().items()
               if not k.startswith('clip_model.') and k != 'embed_timestep.sequence_pos_encoder.pe'}
         sd['sequence_pos_encoder.pe'] = sd['sequence_pos_encoder.pe'].reshape(-1, self.latent_dim)
-        if 'embed_text.weight' not in sd:   # no_cond: the condition token is time-only -> zero text embedding
+        # the host-side condition encoders (evaluated once per call / loop by target_embedding / text_embedding below)
+        sd = {k: v for k, v in sd.items() if not k.startswith(('embed_target_cond.', 'embed_action.'))}
+        if 'action' in self.cond_mode:
+            # emb = time_emb + mask_cond(action_embedding[y['action']]) (model/mdm.py:224-226): the class row IS the condition vector, so
+            # the library's embed_text slot holds the identity (zero bias = the masked, unconditional branch) and `text_embedding`
+            # hands over the gathered rows
+            sd['embed_text.weight'] = torch.eye(self.latent_dim, device=sd['input_process.poseEmbedding.weight'].device)
+            sd['embed_text.bias'] = torch.zeros(self.latent_dim)
+        elif 'embed_text.weight' not in sd:   # no_cond: the condition token is time-only -> zero text embedding
             sd['embed_text.weight'] = torch.zeros(self.latent_dim, self.clip_dim)
             sd['embed_text.bias'] = torch.zeros(self.latent_dim)
         return sd
+
+    @property
+    def cond_dim(self):
+        """Width of the per-sample condition block the library projects: clip_dim for text, latent_dim for an action row."""
+        return self.latent_dim if 'action' in self.cond_mode else self.clip_dim
 
     def engine(self):
         """Native handle bound to the current parameters (rebuilt when they move or change).  The key is rebuilt on EVERY call
@@ -249,7 +366,7 @@ class MDM(nn.Module):
             tuple((q.data_ptr(), q._version) for q in params)
         if self._engine is None or self._engine_key != key:
             cfg = dict(njoints=self.njoints, nfeats=self.nfeats, latent_dim=self.latent_dim, ff_size=self.ff_size,
-                       num_layers=self.num_layers, num_heads=self.num_heads, clip_dim=self.clip_dim,
+                       num_layers=self.num_layers, num_heads=self.num_heads, clip_dim=self.cond_dim,
                        max_len=self.sequence_pos_encoder.pe.shape[0], mask_frames=int(bool(self.mask_frames)),
                        arch=nat.ARCH[self.arch], context_len=int(self.context_len) if self.arch == 'trans_dec' else 0)
             eng = Engine(cfg, lib=self._native_lib, precision=self.precision, options=self.engine_options)
@@ -295,8 +412,36 @@ class MDM(nn.Module):
         self._len_cache = (key, mask, lengths)
         return lengths
 
+    def target_embedding(self, y, device):
+        """y['target_cond'] -> the [B, latent_dim] block the reference adds to the timestep embedding of BOTH guidance branches
+        (`time_emb += mask_cond(embed_target_cond(...)[None], force_mask=y.get('target_uncond', False))`, model/mdm.py:197-199), or
+        None (no target in y / force-masked).  It depends on neither x nor t: evaluated once per call or loop on the host side
+        (torch, <= 8 joints x 4 numbers per sample through a SiLU MLP) and handed to the library through mdm_set_time_add; cached per
+        target tensor like the frame mask."""
+        if y is None or 'target_cond' not in y:
+            return None
+        if not self.multi_target_cond:
+            raise ValueError("y['target_cond'] needs a checkpoint trained with --multi_target_cond (model/mdm.py:67-73)")
+        if y.get('target_uncond', False):
+            return None
+        tc = y['target_cond']
+        key = (tc.data_ptr(), tc._version, tuple(tc.shape), str(device), tuple(tuple(str(j) for j in n) for n in y['target_joint_names']),
+               tuple(bool(h) for h in y['is_heading']), self._engine_key)
+        cached = getattr(self, '_tgt_cache', None)
+        if cached is not None and cached[0] == key and cached[1] is tc:
+            return cached[2]
+        with torch.no_grad():
+            g = self.embed_target_cond(tc.to(device=device, dtype=torch.float32), y['target_joint_names'], y['is_heading'])
+        g = g.to(torch.float32).contiguous()
+        self._tgt_cache = (key, tc, g)
+        return g
+
     def text_embedding(self, y, device):
-        """The [B, clip_dim] block the library projects with embed_text (model/mdm.py:209-218)."""
+        """The [B, cond_dim] block the library projects with embed_text (model/mdm.py:209-218; the gathered class rows for
+        cond_mode='action', :224-226, :393-396)."""
+        if 'action' in self.cond_mode:
+            with torch.no_grad():
+                return self.embed_action(y['action'].to(device)).to(device=device, dtype=torch.float32).contiguous()
         if 'text' not in self.cond_mode:
             return None
         if 'text_embed' in y.keys():
@@ -358,14 +503,12 @@ class MDM(nn.Module):
         return prefix, tok, tl, lengths
 
     def _forward_dec(self, x, timesteps, y, branches):
-        for k in ('target_cond', 'action'):
-            if k in y:
-                raise NotImplementedError(f"y[{k!r}] is outside the MI355X hot path")
         x = x.to(torch.float32).contiguous()
         assert x.shape[1] == self.njoints and x.shape[2] == self.nfeats
         ts = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
         prefix, enc, tl, lengths = self._dec_inputs(x, y)
-        return self.engine().forward_dec(x, prefix, ts, enc, tl, lengths, branches)
+        eng = self.engine()
+        return eng.forward_dec(x, prefix, ts, enc, tl, lengths, branches, time_add=self.target_embedding(y, x.device))
 
     # ---- the seam ----------------------------------------------------------------------------------
     def forward(self, x, timesteps, y=None):
@@ -376,9 +519,8 @@ class MDM(nn.Module):
         if self.arch == 'trans_dec':
             uncond = bool(y.get('uncond', False))
             return self._forward_dec(x, timesteps, y, nat.BRANCH_UNCOND if uncond else nat.BRANCH_COND)
-        for k in ('target_cond', 'prefix', 'action'):
-            if k in y:
-                raise NotImplementedError(f"y[{k!r}] is outside the MI355X hot path")
+        if 'prefix' in y:
+            raise NotImplementedError("y['prefix'] (prefix completion) belongs to the trans_dec (DiP) path")
         bs, njoints, nfeats, nframes = x.shape
         assert njoints == self.njoints and nfeats == self.nfeats
         self._check_frames(nframes)
@@ -392,7 +534,8 @@ class MDM(nn.Module):
         lengths = self.lengths_from_mask(y, nframes)
         if lengths is not None:
             lengths = lengths.to(x.device)
-        return eng.forward(x, ts, te, lengths, nat.BRANCH_UNCOND if uncond else nat.BRANCH_COND)
+        return eng.forward(x, ts, te, lengths, nat.BRANCH_UNCOND if uncond else nat.BRANCH_COND,
+                           time_add=self.target_embedding(y, x.device))
 
     def forward_both(self, x, timesteps, y):
         """cond and uncond branches batched through one native call -> (out_cond, out_uncond)."""
@@ -408,11 +551,11 @@ class MDM(nn.Module):
         lengths = self.lengths_from_mask(y, x.shape[-1])
         if lengths is not None:
             lengths = lengths.to(x.device)
-        out = eng.forward(x, ts, te, lengths, nat.BRANCH_BOTH)
+        out = eng.forward(x, ts, te, lengths, nat.BRANCH_BOTH, time_add=self.target_embedding(y, x.device))
         return out[:bs], out[bs:]
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._engine = None   # parameters moved: rebind lazily
-        self._len_cache = self._dec_cache = None
+        self._len_cache = self._dec_cache = self._tgt_cache = None
         return r

@@ -1,8 +1,8 @@
 """Factory seam: the pieces of utils/model_util.py (:8-15, :18-21, :24-71, :75-116, :118-132) that
 `sample/generate.py` goes through to obtain (model, diffusion), rebuilt on the MI355X classes.
 
-Only what the sampling hot path needs is honoured: HumanML3D / KIT `hml_vec` shapes,
-`trans_enc`, START_X + FIXED_SMALL/LARGE, no respacing.  Everything else raises in the class constructors.
+Only what the sampling hot path needs is honoured: HumanML3D / KIT `hml_vec` shapes and the 25 x 6 rot6d
+features of the action datasets, START_X + FIXED_SMALL/LARGE, no respacing.  Everything else raises in the class constructors.
 """
 from types import SimpleNamespace
 
@@ -15,6 +15,8 @@ from .respace import SpacedDiffusion, space_timesteps
 # utils/model_util.py:63-64 pins these; they are not argparse flags in the reference
 FF_SIZE, NUM_HEADS, DROPOUT, ACTIVATION, CLIP_VERSION = 1024, 4, 0.1, "gelu", "ViT-B/32"
 _POSE_DIMS = {"humanml": 263, "kit": 251}      # utils/model_util.py:41-49
+# data_loaders/humanml_utils.py:30 + utils/model_util.py:45: the goal joints of a --multi_target_cond (target-conditioned DiP) checkpoint
+HML_GOAL_JOINT_NAMES = ["pelvis", "left_foot", "right_foot", "left_wrist", "right_wrist", "head"]
 
 
 def default_args(**over):
@@ -35,19 +37,26 @@ def get_cond_mode(args):
 
 
 def get_model_args(args, data=None):
-    """utils/model_util.py:24-71, restricted to the hml_vec datasets."""
-    if args.dataset not in _POSE_DIMS:
-        raise NotImplementedError(f"dataset={args.dataset!r}: only the hml_vec datasets are on the MI355X hot path")
+    """utils/model_util.py:24-71.  The hml_vec datasets (263 / 251 features) or, for the action datasets (humanact12 / uestc), the
+    SMPL defaults of :33-37: 25 joints x 6 rot6d features, `num_actions` from the dataset object (:29-32; args.num_actions when no
+    dataset object is at hand).  SMPL forward kinematics for rendering those (rot2xyz) stays outside the hot path."""
     g = vars(args).get
-    return dict(modeltype="", njoints=_POSE_DIMS[args.dataset], nfeats=1, num_actions=1, translation=True,
+    if args.dataset in _POSE_DIMS:
+        njoints, nfeats, data_rep, num_actions = _POSE_DIMS[args.dataset], 1, "hml_vec", 1
+    else:
+        njoints, nfeats, data_rep = 25, 6, "rot6d"
+        num_actions = getattr(getattr(data, "dataset", None), "num_actions", g("num_actions", 1))
+    return dict(modeltype="", njoints=njoints, nfeats=nfeats, num_actions=num_actions, translation=True,
                 pose_rep="rot6d", glob=True, glob_rot=True, latent_dim=args.latent_dim, ff_size=FF_SIZE,
                 num_layers=args.layers, num_heads=NUM_HEADS, dropout=DROPOUT, activation=ACTIVATION,
-                data_rep="hml_vec", cond_mode=get_cond_mode(args), cond_mask_prob=args.cond_mask_prob,
+                data_rep=data_rep, cond_mode=get_cond_mode(args), cond_mask_prob=args.cond_mask_prob,
                 action_emb="tensor", arch=args.arch, emb_trans_dec=g("emb_trans_dec", False),
                 clip_version=CLIP_VERSION, dataset=args.dataset, text_encoder_type=g("text_encoder_type", "clip"),
                 pos_embed_max_len=g("pos_embed_max_len", 5000), mask_frames=g("mask_frames", False),
                 pred_len=g("pred_len", 0), context_len=g("context_len", 0), emb_policy=g("emb_policy", "add"),
-                all_goal_joint_names=[], multi_target_cond=g("multi_target_cond", False))
+                all_goal_joint_names=list(HML_GOAL_JOINT_NAMES) if args.dataset == "humanml" else [],
+                multi_target_cond=g("multi_target_cond", False), multi_encoder_type=g("multi_encoder_type", "multi"),
+                target_enc_layers=g("target_enc_layers", 1))
 
 
 def create_gaussian_diffusion(args):

@@ -55,7 +55,8 @@ def decoder_layer(sd, i, x, mem, tgt_pad, mem_pad, num_heads, dtype):
     return ln(x + orc._lin(h, sd, p + "linear2", dtype), "norm3")
 
 
-def dip_forward(sd, x, timesteps, y, *, context_len, num_heads=4, mask_frames=False, pe=None, dtype=torch.float32):
+def dip_forward(sd, x, timesteps, y, *, context_len, num_heads=4, mask_frames=False, pe=None, dtype=torch.float32,
+                goal_joint_names=()):
     """MDM.forward for arch='trans_dec', text_encoder_type='bert' (mdm.py:189-283).
 
     x [B, J, 1, pred_len]; y: 'prefix' [B, J, 1, context_len], 'text_embed' = (enc [Ntok, B, 768], pad [B, Ntok] bool,
@@ -67,6 +68,9 @@ def dip_forward(sd, x, timesteps, y, *, context_len, num_heads=4, mask_frames=Fa
         pe = orc.positional_table(5000, d, dtype)
     x = x.to(dtype)
     time_emb = orc.timestep_embedding(sd, timesteps, pe, dtype)                   # [B, d]           mdm.py:195
+    tgt = orc.target_embedding(sd, y, goal_joint_names, dtype)                    # mdm.py:197-199 (the target-conditioned DiP, DiP.md:105)
+    if tgt is not None:
+        time_emb = time_emb + tgt
     mask = y["mask"]
     if context_len > 0:                                                           # mdm.py:203-206
         x = torch.cat([y["prefix"].to(dtype), x], dim=-1)
@@ -103,7 +107,7 @@ def dip_cfg_forward(sd, x, timesteps, y, **kw):
 
 
 def dip_sample_loop(sd, tab, shape, y, x_T, step_noise, *, context_len, cfg=True, num_heads=4, mask_frames=False,
-                    dtype=torch.float32):
+                    dtype=torch.float32, goal_joint_names=()):
     """p_sample_loop (gaussian_diffusion.py:591-727) of one prediction window with an injected noise sequence."""
     B = shape[0]
     pe = orc.positional_table(5000, sd["input_process.poseEmbedding.weight"].shape[0], dtype)
@@ -111,7 +115,8 @@ def dip_sample_loop(sd, tab, shape, y, x_T, step_noise, *, context_len, cfg=True
     img = x_T.to(dtype)
     for k, i in enumerate(range(tab.num_timesteps)[::-1]):
         t = torch.full((B,), i, dtype=torch.long)
-        x0 = fwd(sd, img, t, y, context_len=context_len, num_heads=num_heads, mask_frames=mask_frames, pe=pe, dtype=dtype)
+        x0 = fwd(sd, img, t, y, context_len=context_len, num_heads=num_heads, mask_frames=mask_frames, pe=pe, dtype=dtype,
+                 goal_joint_names=goal_joint_names)
         img = orc.ddpm_step(tab, img, x0, t, step_noise[k].to(dtype))
     return img
 

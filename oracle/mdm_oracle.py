@@ -103,6 +103,55 @@ def timestep_embedding(sd, timesteps, pe, dtype):
     return _lin(h, sd, "embed_timestep.time_embed.2", dtype)
 
 
+def _silu_mlp(sd, prefix, h, dtype):
+    """nn.Sequential(Linear, (SiLU, Linear) x n) whose Linear layers sit at the even indices of `prefix` (model/mdm.py:405-408)."""
+    n = 1 + max(int(k[len(prefix):].split(".")[0]) for k in sd if k.startswith(prefix) and k.endswith(".weight"))
+    for i in range(0, n, 2):
+        if i > 0:
+            h = h * torch.sigmoid(h)
+        h = _lin(h, sd, prefix + str(i), dtype)
+    return h
+
+
+def target_embedding(sd, y, names, dtype=torch.float32):
+    """`self.mask_cond(self.embed_target_cond(y['target_cond'], y['target_joint_names'], y['is_heading'])[None],
+    force_mask=y.get('target_uncond', False))` (model/mdm.py:197-199) -> [B, d], or None when y carries no target.  The encoder
+    flavour (`--multi_encoder_type`) is read off the checkpoint's keys: EmbedTargetLocSingle (model/mdm.py:399-419), Split (:422-449),
+    Multi (:451-479, with utils/misc.py:5-16 WeightedSum).  `names` = the model's all_goal_joint_names (utils/model_util.py:45)."""
+    if "target_cond" not in y:
+        return None
+    ext = list(names) + ["traj", "heading"]
+    inp = y["target_cond"].to(dtype)                                              # [B, n_ext, 3]
+    B = inp.shape[0]
+    chosen = []
+    for b in range(B):                                                            # :413-416 / :440-443 / :471-472
+        js = [str(j) for j in y["target_joint_names"][b]]
+        chosen.append(js + ["heading"] if y["is_heading"][b] else js)
+    p = "embed_target_cond."
+    if p + "mlp.0.weight" in sd or p + "mini_mlps.0.0.weight" in sd:
+        validity = torch.zeros(B, len(ext), 1, dtype=dtype)
+        for b in range(B):
+            for j in chosen[b]:
+                validity[b, ext.index(j)] = 1.0
+        mi = torch.cat([inp, validity], dim=-1)                                   # [B, n_ext, 4]
+        if p + "mlp.0.weight" in sd:                                              # single: one MLP over the flattened joints
+            out = _silu_mlp(sd, p + "mlp.", mi.reshape(B, -1), dtype)
+        else:                                                                     # split: one narrow MLP per joint, concatenated
+            out = torch.cat([_silu_mlp(sd, p + f"mini_mlps.{i}.", mi[:, i], dtype) for i in range(len(ext))], dim=-1)
+    else:                                                                         # multi: per-joint MLPs of the CHOSEN joints, weighted sum
+        d = sd[p + f"target_loc_emb.{ext[0]}.2.weight"].shape[0]
+        w = sd[p + "target_all_loc_emb.weights"].to(dtype)
+        out = torch.zeros(B, d, dtype=dtype)
+        for b in range(B):
+            rows = torch.zeros(len(ext), d, dtype=dtype)
+            for j in chosen[b]:
+                rows[ext.index(j)] = _silu_mlp(sd, p + f"target_loc_emb.{j}.", inp[b, ext.index(j)], dtype)
+            out[b] = torch.matmul(w / w.sum(), rows)
+    if y.get("target_uncond", False):                                             # mask_cond(force_mask=True): mdm.py:155-156
+        out = torch.zeros_like(out)
+    return out
+
+
 def encoder_layer(sd, i, x, key_pad, num_heads, dtype):
     """One post-norm nn.TransformerEncoderLayer (mdm.py:77-81; torch transformer.py:951-983):
     x = LN1(x + out_proj(MHA(x)));  x = LN2(x + W2 gelu_erf(W1 x)).   x: [N, S, d] (batch first here)."""
@@ -128,11 +177,12 @@ def encoder_layer(sd, i, x, key_pad, num_heads, dtype):
     return x
 
 
-def mdm_forward(sd, x, timesteps, y, num_heads=4, mask_frames=True, pe=None, dtype=torch.float32):
-    """MDM.forward for arch='trans_enc', cond_mode='text', data_rep='hml_vec'  (mdm.py:189-283).
+def mdm_forward(sd, x, timesteps, y, num_heads=4, mask_frames=True, pe=None, dtype=torch.float32, goal_joint_names=()):
+    """MDM.forward for arch='trans_enc', data_rep='hml_vec' | 'rot6d'  (mdm.py:189-283); cond_mode 'text', or 'action' when the
+    state dict holds `embed_action.action_embedding` (mdm.py:224-226, :389-397), or 'no_cond' when it holds neither (:227-229).
 
-    x [B, J, 1, T]; timesteps [B] int64; y: {'text_embed' [1,B,clip], 'mask' [B,1,1,T] bool, 'uncond'?}.
-    Returns [B, J, 1, T].
+    x [B, J, F, T]; timesteps [B] int64; y: {'text_embed' [1,B,clip] | 'action' [B,1] int, 'mask' [B,1,1,T] bool, 'uncond'?,
+    'target_cond'? (+ 'target_joint_names', 'is_heading', 'target_uncond'?: mdm.py:197-199)}.  Returns [B, J, F, T].
     """
     sd = {k: v for k, v in sd.items()}
     B, J, Fe, T = x.shape
@@ -142,10 +192,21 @@ def mdm_forward(sd, x, timesteps, y, num_heads=4, mask_frames=True, pe=None, dty
         pe = positional_table(5000, d, dtype)
     x = x.to(dtype)
     time_emb = timestep_embedding(sd, timesteps, pe, dtype)                      # mdm.py:195
-    enc_text = y["text_embed"].to(dtype)[0]                                      # mdm.py:210-211  [B, clip]
-    if y.get("uncond", False):                                                   # mdm.py:155-156, :208
-        enc_text = torch.zeros_like(enc_text)
-    emb = _lin(enc_text, sd, "embed_text", dtype) + time_emb                     # mdm.py:218-220  [B, d]
+    tgt = target_embedding(sd, y, goal_joint_names, dtype)                       # mdm.py:197-199
+    if tgt is not None:
+        time_emb = time_emb + tgt
+    if "embed_action.action_embedding" in sd:                                    # mdm.py:224-226, :393-396
+        act = sd["embed_action.action_embedding"].to(dtype)[y["action"][:, 0].to(torch.long)]
+        if y.get("uncond", False):
+            act = torch.zeros_like(act)
+        emb = time_emb + act
+    elif "embed_text.weight" not in sd:                                          # mdm.py:227-229 (no_cond)
+        emb = time_emb
+    else:
+        enc_text = y["text_embed"].to(dtype)[0]                                  # mdm.py:210-211  [B, clip]
+        if y.get("uncond", False):                                               # mdm.py:155-156, :208
+            enc_text = torch.zeros_like(enc_text)
+        emb = _lin(enc_text, sd, "embed_text", dtype) + time_emb                 # mdm.py:218-220  [B, d]
     h = x.permute(0, 3, 1, 2).reshape(B, T, J * Fe)                              # mdm.py:345 (batch-first here)
     h = _lin(h, sd, "input_process.poseEmbedding", dtype)                        # mdm.py:348
     key_pad = None
@@ -213,7 +274,7 @@ def ddim_step(tab, x, x0, t, noise, eta=0.0):
 
 def sample_loop(sd, tab, shape, y, x_T, step_noise, *, cfg=True, ddim=False, eta=0.0, clip_denoised=False,
                 skip_timesteps=0, init_image=None, timestep_map=None, num_heads=4, mask_frames=True,
-                dtype=torch.float32, return_all=False, const_noise=False, fixed_large=False):
+                dtype=torch.float32, return_all=False, const_noise=False, fixed_large=False, goal_joint_names=()):
     """p_sample_loop / ddim_sample_loop with an injected noise sequence.
 
     x_T: the torch.randn(*shape) of gaussian_diffusion.py:691; step_noise[k]: the k-th randn_like of
@@ -226,7 +287,8 @@ def sample_loop(sd, tab, shape, y, x_T, step_noise, *, cfg=True, ddim=False, eta
 
     def model_fn(x, t, yy):
         tt = t if timestep_map is None else torch.as_tensor(timestep_map, dtype=torch.long)[t]
-        return fwd(sd, x, tt, yy, num_heads=num_heads, mask_frames=mask_frames, pe=pe, dtype=dtype)
+        return fwd(sd, x, tt, yy, num_heads=num_heads, mask_frames=mask_frames, pe=pe, dtype=dtype,
+                   goal_joint_names=goal_joint_names)
 
     img = x_T.to(dtype)
     indices = list(range(tab.num_timesteps - skip_timesteps))[::-1]

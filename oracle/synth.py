@@ -196,3 +196,65 @@ def synth_dip_dynamic_y(B, pred_len, context_len, seed, prompts, scale=7.5, njoi
             "text_embed": (enc.unsqueeze(0).repeat(B, 1, 1, 1), pad.unsqueeze(0).repeat(B, 1, 1)),
             "prefix": torch.randn(B, njoints, 1, context_len, generator=g),
             "scale": torch.ones(B) * scale}
+
+
+# ---- conditions beside the text (round 6, second part): target locations (model/mdm.py:197-199, :399-479) and action classes (:224-226, :389-397)
+HML_GOAL_JOINT_NAMES = ["pelvis", "left_foot", "right_foot", "left_wrist", "right_wrist", "head"]     # utils/model_util.py:45
+
+
+def synth_target_params(kind, seed=0, latent_dim=512, names=HML_GOAL_JOINT_NAMES, num_layers=1):
+    """The `embed_target_cond.*` entries of a `--multi_target_cond` checkpoint (`--multi_encoder_type` single | split | multi:
+    EmbedTargetLocSingle / Split / Multi, model/mdm.py:399-479) with the reference's key names and shapes."""
+    g = torch.Generator().manual_seed(seed + 77)
+    ext = list(names) + ["traj", "heading"]
+
+    def linear(prefix, out_f, in_f, sd):
+        b = 1.0 / math.sqrt(in_f)
+        sd[prefix + ".weight"] = (torch.rand(out_f, in_f, generator=g) * 2.0 - 1.0) * b
+        sd[prefix + ".bias"] = (torch.rand(out_f, generator=g) * 2.0 - 1.0) * b
+
+    sd, p = {}, "embed_target_cond."
+    if kind == "single":
+        linear(p + "mlp.0", latent_dim, 4 * len(ext), sd)
+        for i in range(num_layers):
+            linear(p + f"mlp.{2 * i + 2}", latent_dim, latent_dim, sd)
+    elif kind == "split":
+        w = latent_dim // len(ext)
+        for j in range(len(ext)):
+            linear(p + f"mini_mlps.{j}.0", w, 4, sd)
+            for i in range(num_layers):
+                linear(p + f"mini_mlps.{j}.{2 * i + 2}", w, w, sd)
+    elif kind == "multi":
+        for n in ext:
+            linear(p + f"target_loc_emb.{n}.0", latent_dim, 3, sd)
+            linear(p + f"target_loc_emb.{n}.2", latent_dim, latent_dim, sd)
+        sd[p + "target_all_loc_emb.weights"] = 0.5 + torch.rand(len(ext), generator=g)     # (the reference inits randn: sum may be ~0)
+    else:
+        raise ValueError(kind)
+    return sd
+
+
+def synth_target_y(B, seed, names=HML_GOAL_JOINT_NAMES, first=0):
+    """y['target_cond'] [B, n_ext, 3], y['target_joint_names'] (per sample: an array of goal joints, from none to all, 'traj' among
+    them), y['is_heading'] [B] -- what data_loaders/humanml/data/dataset.py hands the model under --multi_target_cond."""
+    import numpy as np
+    g = torch.Generator().manual_seed(seed + 99)
+    ext = list(names) + ["traj"]
+    sel = []
+    for b in range(B):
+        k = [0, 1, len(ext), 3][(b + first) % 4]
+        perm = torch.randperm(len(ext), generator=g)[:k].tolist()
+        sel.append(np.array([ext[i] for i in sorted(perm)], dtype=str))
+    return {"target_cond": torch.randn(B, len(names) + 2, 3, generator=g),
+            "target_joint_names": sel, "is_heading": [bool((b // 2) % 2 == 0) for b in range(B)]}
+
+
+def synth_a2m_state_dict(seed=0, num_actions=12, latent_dim=512, num_layers=8, input_feats=150):
+    """An action-to-motion checkpoint (`cond_mode='action'`: humanact12 / uestc, utils/model_util.py:33-37, :47-52): the encoder of
+    synth_state_dict over njoints * nfeats = 25 * 6 rot6d features, `embed_action.action_embedding` [num_actions, d]
+    (model/mdm.py:389-397) in place of embed_text."""
+    sd = synth_state_dict(seed=seed, latent_dim=latent_dim, num_layers=num_layers, input_feats=input_feats)
+    del sd["embed_text.weight"], sd["embed_text.bias"]
+    g = torch.Generator().manual_seed(seed + 55)
+    sd["embed_action.action_embedding"] = torch.randn(num_actions, latent_dim, generator=g)
+    return sd

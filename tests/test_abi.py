@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib.lib, n), f"{n} declared in include/mdm_hip.h but not exported"
     assert sorted(_native.EXPORTED_SYMBOLS) == names       # the ctypes view covers the whole header
-    assert lib.mdm_abi_version() == 9
+    assert lib.mdm_abi_version() == 10
 
 
 def test_probe_surface_is_not_in_the_production_library(lib):

@@ -1,0 +1,165 @@
+"""GPU parity tests (`-m gpu`) of seam B1's other conditions against the UPSTREAM REFERENCE's own outputs (tests/golden/a2m_*,
+target_*, dip_target_*.npz; oracle/make_golden_r6b.py): cond_mode='action' (model/mdm.py:224-226, :389-397 -- the action-to-motion
+checkpoints, 25 joints x 6 rot6d features) and --multi_target_cond (model/mdm.py:197-199, :399-479 -- the target-conditioned DiP of
+DiP.md:105), full-size models (latent_dim 512, 8 layers), both arithmetic modes, through the Python seams -> C ABI -> HIP kernels."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import dip, make_pair, maxabs, memo, orc, synth_dip_state_dict, synth_dip_y, synth_state_dict, synth_y, to_dev
+from oracle.synth import synth_a2m_state_dict, synth_target_params, synth_target_y
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL_FWD, TOL_LOOP, TOL_DIP_AR = 1e-4, 1e-4, 2e-4     # the tolerances of the text-conditioned suites (north_star: 1e-3)
+A2M = dict(dataset="humanact12", num_actions=12)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from mdm_amd import _native
+    assert _native.load_native().path.endswith("libmdm_hip.so")
+
+
+def a2m_y(B, T, seed, lengths, action, scale=2.5):
+    y = synth_y(B, T, seed, lengths=lengths, scale=scale)
+    del y["text_embed"]
+    y["action"] = torch.as_tensor(action)
+    assert torch.equal(y["action"], torch.randint(0, 12, (B, 1), generator=torch.Generator().manual_seed(seed + 5)))
+    return y
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_action_conditioned_forward_matches_reference_golden(golden_dir, gemm_path, prec):
+    if prec == "f32" and gemm_path != "small":
+        pytest.skip("the f32 mode has one GEMM kernel")
+    g = np.load(os.path.join(golden_dir, "a2m_fwd_B3_T60.npz"))
+    B, T = 3, 60
+    sd = memo("sd_a2m", lambda: synth_a2m_state_dict(seed=0))
+    model, _ = make_pair(sd, 10, DEV, guided=True, precision=prec, **A2M)
+    y = to_dev(a2m_y(B, T, int(g["y_seed"]), list(g["lengths"]), g["action"], float(g["scale"])), DEV)
+    x = torch.randn(B, 25, 6, T, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV)
+    t = torch.as_tensor(g["t"]).to(DEV)
+    errs = {"cond": maxabs(model.model(x, t, y=dict(y)).cpu(), g["out_cond"]),
+            "uncond": maxabs(model.model(x, t, y={**y, "uncond": True}).cpu(), g["out_uncond"]),
+            "cfg": maxabs(model(x, t, y=dict(y)).cpu(), g["out_cfg"])}
+    print(f"[parity] a2m_fwd_B3_T60 {prec} {gemm_path}: max-abs vs reference = {errs}")
+    assert max(errs.values()) < TOL_FWD, errs
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_action_conditioned_loop_matches_reference_golden(golden_dir, prec):
+    """10-step p_sample_loop over the reference's CPU noise stream: under the guidance wrapper and as the bare model
+    (sample/generate.py:93-94 wraps only when guidance_param != 1)."""
+    g = np.load(os.path.join(golden_dir, "a2m_loop10_B2_T60.npz"))
+    steps, B, T, seed = int(g["steps"]), int(g["B"]), int(g["T"]), int(g["seed"])
+    sd = memo("sd_a2m", lambda: synth_a2m_state_dict(seed=0))
+    shape = (B, 25, 6, T)
+    x_T, noises = orc.make_noise(shape, steps, seed)
+    seq = [x_T] + [n.contiguous() for n in noises]
+    y = to_dev(a2m_y(B, T, seed + 1000, list(g["lengths"]), g["action"], float(g["scale"])), DEV)
+    model, diffusion = make_pair(sd, steps, DEV, guided=True, precision=prec, **A2M)
+    for name, mdl in (("cfg", model), ("nocfg", model.model)):
+        out = diffusion.p_sample_loop(mdl, shape, clip_denoised=False, model_kwargs={"y": dict(y)}, noise_sequence=seq)
+        err = maxabs(out.cpu(), g["final_" + name])
+        print(f"[parity] a2m_loop10_B2_T60 {name} {prec}: max-abs vs reference = {err:.3e}")
+        assert err < TOL_LOOP, (name, err)
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_target_condition_on_the_encoder_matches_reference_golden(golden_dir, gemm_path, prec):
+    if prec == "f32" and gemm_path != "small":
+        pytest.skip("the f32 mode has one GEMM kernel")
+    g = np.load(os.path.join(golden_dir, "target_enc_fwd_B4_T48.npz"))
+    B, T = 4, 48
+    sd = memo("sd_tgt_enc", lambda: {**synth_state_dict(seed=0), **synth_target_params("single", seed=0)})
+    model, _ = make_pair(sd, 10, DEV, guided=True, precision=prec, multi_target_cond=True, multi_encoder_type="single")
+    ys = int(g["y_seed"])
+    y = to_dev({**synth_y(B, T, seed=ys, lengths=list(g["lengths"]), scale=float(g["scale"])), **synth_target_y(B, seed=ys)}, DEV)
+    x = torch.randn(B, 263, 1, T, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV)
+    t = torch.as_tensor(g["t"]).to(DEV)
+    errs = {"cond": maxabs(model.model(x, t, y=dict(y)).cpu(), g["out_cond"]),
+            "cfg": maxabs(model(x, t, y=dict(y)).cpu(), g["out_cfg"]),
+            "target_uncond": maxabs(model.model(x, t, y={**y, "target_uncond": True}).cpu(), g["out_target_uncond"])}
+    print(f"[parity] target_enc_fwd_B4_T48 {prec} {gemm_path}: max-abs vs reference = {errs}")
+    assert max(errs.values()) < TOL_FWD, errs
+    assert maxabs(g["out_cond"], g["out_target_uncond"]) > 100 * TOL_FWD       # (the fixture's target moves the output: 2.6e-2)
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+@pytest.mark.parametrize("kind", ["single", "split", "multi"])
+def test_target_conditioned_dip_forward_matches_reference_golden(golden_dir, kind, prec):
+    g = np.load(os.path.join(golden_dir, "dip_target_fwd_B4.npz"))
+    B = 4
+    sd = memo("sd_tgt_dip_" + kind, lambda: {**synth_dip_state_dict(seed=0), **synth_target_params(kind, seed=0)})
+    model, _ = make_pair(sd, 10, DEV, guided=True, context_len=20, pred_len=40, mask_frames=False, precision=prec,
+                         multi_target_cond=True, multi_encoder_type=kind)
+    ys = int(g["y_seed"])
+    y = to_dev({**synth_dip_y(B, 40, 20, seed=ys, text_lengths=list(g["text_lengths"])), **synth_target_y(B, seed=ys)}, DEV)
+    x = torch.randn(B, 263, 1, 40, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV)
+    t = torch.as_tensor(g["t"]).to(DEV)
+    errs = {"cond": maxabs(model.model(x, t, y=dict(y)).cpu(), g["out_cond_" + kind]),
+            "uncond": maxabs(model.model(x, t, y={**y, "uncond": True}).cpu(), g["out_uncond_" + kind])}
+    print(f"[parity] dip_target_fwd_B4 {kind} {prec}: max-abs vs reference = {errs}")
+    assert max(errs.values()) < TOL_FWD, errs
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_target_conditioned_dip_autoregressive_matches_reference_golden(golden_dir, prec):
+    """The reference's AutoRegressiveSampler over two 40-frame windows of the target-conditioned DiP, CFG 7.5: here through this
+    repository's sampler and mdm_sample_loop_dec (target folded into the hoisted text memory of each window)."""
+    from mdm_amd.sampler_util import AutoRegressiveSampler
+    g = np.load(os.path.join(golden_dir, "dip_target_ar10_B2_F80.npz"))
+    steps, B, frames, seed = int(g["steps"]), int(g["B"]), int(g["frames"]), int(g["seed"])
+    sd = memo("sd_tgt_dip_single", lambda: {**synth_dip_state_dict(seed=0), **synth_target_params("single", seed=0)})
+    model, diffusion = make_pair(sd, steps, DEV, guided=True, context_len=20, pred_len=40, mask_frames=False, precision=prec,
+                                 multi_target_cond=True, multi_encoder_type="single")
+    y = {**synth_dip_y(B, 40, 20, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]), scale=float(g["scale"])),
+         **synth_target_y(B, seed=seed, first=1)}
+    y = to_dev({k: v for k, v in y.items() if k != "text"}, DEV)
+    chunks = iter(dip.make_noise_chunks((B, 263, 1, 40), steps, seed, 2))
+
+    def sample_fn(mdl, shape, **kw):
+        x_T, eps = next(chunks)
+        return diffusion.p_sample_loop(mdl, shape, noise_sequence=[x_T] + [e.contiguous() for e in eps], **kw)
+
+    args = SimpleNamespace(pred_len=40, context_len=20, autoregressive_include_prefix=False)
+    out = AutoRegressiveSampler(args, sample_fn, frames).sample(
+        model, (B, 263, 1, frames), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, init_image=None,
+        progress=False, dump_steps=None, noise=None, const_noise=False)
+    err = maxabs(out.cpu(), g["final"])
+    print(f"[parity] dip_target_ar10_B2_F80 {prec}: max-abs vs reference = {err:.3e}")
+    assert out.shape == (B, 263, 1, frames) and err < TOL_DIP_AR
+
+
+def test_target_condition_is_shard_invariant_and_fills_the_batch():
+    """SURVEY 8e with a target: B = 32 windows of the target-conditioned DiP as one batch and as the shards 12 + 20 (`shard_y` slices
+    the per-sample target entries with the batch) -- equal bit for bit."""
+    from mdm_amd.dist import shard_y
+    B, steps, C, P = 32, 10, 20, 40
+    sd = memo("sd_tgt_dip_single", lambda: {**synth_dip_state_dict(seed=0), **synth_target_params("single", seed=0)})
+    model, diffusion = make_pair(sd, steps, DEV, guided=True, context_len=C, pred_len=P, mask_frames=True,
+                                 multi_target_cond=True, multi_encoder_type="single")
+    tl = [2 + (5 * i) % 23 for i in range(B)]
+    y = to_dev({**synth_dip_y(B, P, C, seed=43, text_lengths=tl, lengths=[40 - (3 * i) % 17 for i in range(B)], scale=7.5),
+                **synth_target_y(B, seed=43)}, DEV)
+
+    def run(lo, hi):
+        diffusion.sample_base = lo
+        try:
+            return diffusion.p_sample_loop(model, (hi - lo, 263, 1, P), clip_denoised=False, model_kwargs={"y": shard_y(y, lo, hi)},
+                                           seed=600)
+        finally:
+            diffusion.sample_base = 0
+    whole = run(0, B)
+    assert torch.isfinite(whole).all()
+    assert torch.equal(torch.cat([run(0, 12), run(12, B)]), whole)
+    y_off = {**y, "target_uncond": True}
+    diffusion.sample_base = 0
+    other = diffusion.p_sample_loop(model, (B, 263, 1, P), clip_denoised=False, model_kwargs={"y": y_off}, seed=600)
+    assert maxabs(other.cpu(), whole.cpu()) > 1e-3
