@@ -179,6 +179,24 @@ class Engine:
         self._check_device(time_add)
         self.lib.check(self.lib.mdm_set_time_add(self.handle, time_add.data_ptr(), B), "mdm_set_time_add")
 
+    @_on_own_device
+    def linear(self, h, weight, bias, silu=False):
+        """act(h [M, K] . weight [N, K]^T + bias) by the library's exact-fp32 GEMM (include/mdm_hip.h mdm_linear; act = SiLU or none).
+        Its k order is independent of M (csrc/gemm_f32.h launch_gemm_f32_t), so a row's result does not depend on which other rows
+        share the launch -- what the per-loop condition encoders need to stay shard-invariant.  K is padded to a multiple of 4."""
+        h = h.to(dtype=torch.float32)
+        w = weight.detach().to(dtype=torch.float32)
+        K = h.shape[1]
+        if K % 4:
+            h = torch.nn.functional.pad(h, (0, 4 - K % 4))
+            w = torch.nn.functional.pad(w, (0, 4 - K % 4))
+        h, w, b = h.contiguous(), w.contiguous(), bias.detach().to(dtype=torch.float32).contiguous()
+        self._check_device(h)
+        out = torch.empty((h.shape[0], w.shape[0]), dtype=torch.float32, device=h.device)
+        self.lib.check(self.lib.mdm_linear(h.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), h.shape[0], w.shape[0],
+                                           h.shape[1], 2 if silu else 0, self.stream()), "mdm_linear")
+        return out
+
     # ---- MDM.forward ------------------------------------------------------------------------
     @_on_own_device
     def forward(self, x, timesteps, text_embed, lengths, branches, time_add=None):

@@ -78,9 +78,17 @@ class EmbedAction(nn.Module):
         return self.action_embedding[input[:, 0].to(torch.long)]
 
 
+def _torch_linear(h, weight, bias, silu):
+    h = torch.nn.functional.linear(h, weight, bias)
+    return h * torch.sigmoid(h) if silu else h
+
+
 class _TargetLocBase(nn.Module):
     """What the three target-location encoders of model/mdm.py:399-479 share: the joint list (`all_goal_joint_names` + 'traj' +
-    'heading') and the per-sample choice of joints, here as one [B, n_ext] 0/1 matrix instead of the reference's loops."""
+    'heading'), the per-sample choice of joints -- here one [B, n_ext] 0/1 matrix instead of the reference's loops -- and the
+    Linear (SiLU Linear)* stacks.  `linear(h, weight, bias, silu)` is the dense layer the stacks run on: torch by default (a module
+    called on its own, as in the reference); MDM.target_embedding passes the library's own fp32 GEMM (Engine.linear), whose k order
+    does not depend on the row count, so that a sample's embedding is the same bits in whatever batch or shard it is evaluated."""
 
     def __init__(self, all_goal_joint_names, latent_dim):
         super().__init__()
@@ -101,6 +109,13 @@ class _TargetLocBase(nn.Module):
             layers += [nn.SiLU(), nn.Linear(width, width)]
         return nn.Sequential(*layers)
 
+    @staticmethod
+    def _run(seq, h, linear):
+        lins = [m for m in seq if isinstance(m, nn.Linear)]
+        for i, lin in enumerate(lins):
+            h = linear(h.contiguous(), lin.weight, lin.bias, i + 1 < len(lins))
+        return h
+
 
 class EmbedTargetLocSingle(_TargetLocBase):
     """model/mdm.py:399-419 (`--multi_encoder_type single`): ONE MLP over every joint's (x, y, z, chosen) numbers."""
@@ -110,9 +125,9 @@ class EmbedTargetLocSingle(_TargetLocBase):
         self.target_cond_dim = 4 * len(self.extended_goal_joint_names)
         self.mlp = self._mlp(self.target_cond_dim, latent_dim, num_layers)
 
-    def forward(self, input, target_joint_names, target_heading):
+    def forward(self, input, target_joint_names, target_heading, linear=_torch_linear):
         sel = self.chosen(input, target_joint_names, target_heading)
-        return self.mlp(torch.cat([input, sel[..., None]], dim=-1).flatten(1))
+        return self._run(self.mlp, torch.cat([input, sel[..., None]], dim=-1).flatten(1), linear)
 
 
 class EmbedTargetLocSplit(_TargetLocBase):
@@ -125,9 +140,9 @@ class EmbedTargetLocSplit(_TargetLocBase):
         self.target_cond_dim, self.splited_dim = 4, latent_dim // n
         self.mini_mlps = nn.ModuleList([self._mlp(4, self.splited_dim, num_layers) for _ in range(n)])
 
-    def forward(self, input, target_joint_names, target_heading):
+    def forward(self, input, target_joint_names, target_heading, linear=_torch_linear):
         mi = torch.cat([input, self.chosen(input, target_joint_names, target_heading)[..., None]], dim=-1)
-        return torch.cat([mlp(mi[:, j]) for j, mlp in enumerate(self.mini_mlps)], dim=-1)
+        return torch.cat([self._run(mlp, mi[:, j], linear) for j, mlp in enumerate(self.mini_mlps)], dim=-1)
 
 
 class WeightedSum(nn.Module):
@@ -137,8 +152,12 @@ class WeightedSum(nn.Module):
         super().__init__()
         self.weights = nn.Parameter(torch.randn(num_rows))
 
-    def forward(self, x):
-        return torch.matmul(self.weights / self.weights.sum(), x)
+    def forward(self, x):          # x [..., num_rows, d]: accumulated row by row (the same bits for a sample in any batch)
+        w = self.weights / self.weights.sum()
+        out = w[0] * x[..., 0, :]
+        for j in range(1, x.shape[-2]):
+            out = out + w[j] * x[..., j, :]
+        return out
 
 
 class EmbedTargetLocMulti(_TargetLocBase):
@@ -151,9 +170,9 @@ class EmbedTargetLocMulti(_TargetLocBase):
         self.target_loc_emb = nn.ModuleDict({n: self._mlp(3, latent_dim, 1) for n in self.extended_goal_joint_names})
         self.target_all_loc_emb = WeightedSum(self.n_extended_goal_joints)
 
-    def forward(self, input, target_joint_names, target_heading):
+    def forward(self, input, target_joint_names, target_heading, linear=_torch_linear):
         sel = self.chosen(input, target_joint_names, target_heading)
-        rows = torch.stack([self.target_loc_emb[n](input[:, j]) * sel[:, j:j + 1]
+        rows = torch.stack([self._run(self.target_loc_emb[n], input[:, j], linear) * sel[:, j:j + 1]
                             for j, n in enumerate(self.extended_goal_joint_names)], dim=1)          # [B, n_ext, d]
         return self.target_all_loc_emb(rows)
 
@@ -430,8 +449,10 @@ class MDM(nn.Module):
         cached = getattr(self, '_tgt_cache', None)
         if cached is not None and cached[0] == key and cached[1] is tc:
             return cached[2]
+        eng = self.engine()
         with torch.no_grad():
-            g = self.embed_target_cond(tc.to(device=device, dtype=torch.float32), y['target_joint_names'], y['is_heading'])
+            g = self.embed_target_cond(tc.to(device=device, dtype=torch.float32), y['target_joint_names'], y['is_heading'],
+                                       linear=eng.linear)
         g = g.to(torch.float32).contiguous()
         self._tgt_cache = (key, tc, g)
         return g
