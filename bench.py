@@ -20,6 +20,7 @@ Prints ONE JSON line on rank 0.  Besides the contract fields it carries
   dip           the DiP configuration (BASELINE.json configs[4] per GPU: trans_dec, 5 windows x 10 steps) -- N = 1 only,
   steps1000     BASELINE.json configs[2] (1000-step DDPM, batch 64) -- two timed passes, N = 1 only,
   small_batch   the same loop at batch 1 / 6 / 10 (what sample/generate.py runs by default; B1 = configs[0]'s shape), ms per call,
+  trans_dec     the same loop on the reference's trans_dec + DistilBERT text-to-motion denoiser (README.md:254) at the headline batch,
   cpu_baseline  BASELINE.json configs[0]: the whole 50-step CFG loop at batch 1 on this box's host cores, twice -- the
                 reference's own p_sample_loop where the upstream tree is mounted, else the oracle port (N = 1, rank 0),
   ranks         what the process group looked like (backend, world size) -- the evidence that RCCL carried the gather.
@@ -233,6 +234,43 @@ def measure_steps1000(mdm, model, dev, sync, T, layers, latent_dim, B=64, dsteps
                        "global_batch": B, "diffusion_steps": dsteps}}
 
 
+def measure_trans_dec(dev, sync, T, dsteps, B=128, ntok=24, passes=2):
+    """The reference's newest text-to-motion checkpoint shape (README.md:254 `humanml_trans_dec_512_bert-50steps`, trained by
+    README.md:451: `--arch trans_dec --text_encoder_type bert --mask_frames`, NO prefix): sample/generate.py's plain 50-step CFG
+    p_sample_loop over T frames at the headline batch -- the encoder's workload with a cross-attention block over the DistilBERT
+    tokens in every layer (model/mdm.py:85-93, :255-270).  From 81 sequences on the decoder's GEMMs run on gemm_x3.h's
+    sequence-sized tiles like the encoder's (csrc/decoder.h dec_sequence_tiles); one warm-up loop + `passes` timed loops."""
+    import torch
+    from mdm_amd import model_util
+    from mdm_amd.cfg_sampler import ClassifierFreeSampleModel
+    torch.manual_seed(0)
+    args = model_util.default_args(diffusion_steps=dsteps, arch="trans_dec", text_encoder_type="bert", mask_frames=True)
+    mdm, diff = model_util.create_model_and_diffusion(args)
+    model = ClassifierFreeSampleModel(mdm).to(dev).eval()
+    g = torch.Generator().manual_seed(5000)
+    tl = torch.randint(6, ntok + 1, (B,), generator=g)
+    tl[0] = ntok
+    y = {"mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev), "lengths": torch.full((B,), T, dtype=torch.long, device=dev),
+         "text_embed": (torch.randn(ntok, B, 768, generator=g).to(dev), (torch.arange(ntok)[None, :] >= tl[:, None]).to(dev)),
+         "scale": torch.full((B,), 2.5, device=dev)}
+    shape = (B, 263, 1, T)
+    diff.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, seed=1)
+    sync()
+    dts = []
+    for k in range(passes):
+        t0 = time.perf_counter()
+        out = diff.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, seed=2 + k)
+        sync()
+        dts.append(time.perf_counter() - t0)
+        assert out.shape[0] == B and bool(torch.isfinite(out).all())
+    dt = sum(dts) / len(dts)
+    return {"value": round(B / dt, 3), "unit": "motions/s", "sample_steps_per_s": round(B * dsteps / dt, 1),
+            "ms_per_step": round(dt * 1e3, 2), "steps": passes,
+            "config": {"workload": f"HumanML3D text2motion on the trans_dec + DistilBERT denoiser (README.md:254, :451), {dsteps}-step "
+                                   f"p_sample_loop with CFG 2.5, batch={B}, T={T}, {ntok} text tokens, mask_frames, f16x3; mean of "
+                                   f"{passes} timed loops", "global_batch": B, "diffusion_steps": dsteps}}
+
+
 def measure_small_batch(model, dev, sync, T, layers, latent_dim, dsteps, batches=(1, 6, 10), passes=3):
     """The latency regime the reference's own callers run (sample/generate.py:76,98: `--num_samples` = the batch, default 6;
     README.md:13 quotes per-call latency): the SAME 50-step CFG p_sample_loop at batch 1 (BASELINE.json configs[0]'s shape, the
@@ -444,6 +482,9 @@ def main(argv=None):
     small_batch = None
     if extras and a.precision != "f32" and not a.no_small_batch:
         small_batch = measure_small_batch(model, dev, sync, T, a.layers, a.latent_dim, DS)
+    trans_dec = None
+    if extras and a.precision != "f32" and not a.no_small_batch and a.layers == 8 and a.latent_dim == 512:
+        trans_dec = measure_trans_dec(dev, sync, T, DS)
     if extras or (world > 1 and not a.no_extras):
         # BASELINE.json configs[4] (DiP, 256 motions over 8 GPUs = 32 per GPU) at EVERY world size since round 5: each rank
         # generates its 32 motions (Philox streams by global sample index), the final all_gather is inside the timed region.
@@ -513,6 +554,8 @@ def main(argv=None):
             line["steps1000"] = steps1000
         if small_batch is not None:
             line["small_batch"] = small_batch
+        if trans_dec is not None:
+            line["trans_dec"] = trans_dec
         if dip is not None:
             line["dip"] = dip
         if world == 1 and not a.no_cpu_baseline and not a.emulate:

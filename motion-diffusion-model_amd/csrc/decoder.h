@@ -120,6 +120,10 @@ struct DecTail {
 // 0) forces the skeleton (tests, A/B runs).  There is no upper row count: the alternative
 // is not gemm_x3.h's sequence tiles (a 60-token sequence fills a quarter of one) but the skeleton, and the planes win at every
 // size measured (B = 32: 544 vs 391 motions/s, B = 64: 660 vs 448; profiles/r04h_dip_planes.md).
+// (sequences of 129 .. 224 tokens, more of them than MDM_OPT_SMALL_GEMM_MAX_SEQS: see decoder_layers_planes)
+inline bool dec_sequence_tiles(const mdm_model* m, int nseq, int S) {
+  return nseq > m->x3s.max_seqs && S > 128 && S <= X3_TM && x3_waves_setting() == 8;
+}
 inline bool dec_on_planes(const mdm_model* m, int M, int S, const DecHoist& hz, int B) {
   (void)M;
   return m->precision == MDM_PREC_F16X3 && m->x3s.max_seqs > 0 &&
@@ -146,9 +150,14 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
     if (int rc = rt_launch_status()) return rc;
   }
   const X3sShape shape = x3s_shape(m->x3s, (M + 196) / 197);   // the encoder's 32- / 64-row threshold, in its token rows
-  const int scols = x3s_tn(shape.ncb), parts = (D + scols - 1) / scols;
+  // Which GEMM kernel: the row tiles of gemm_x3s.h (DiP's windows at every batch size: a 60-token sequence fills a quarter of a
+  // sequence tile) -- or, for LONG sequences at LARGE batch, gemm_x3.h's sequence-sized tiles exactly as the encoder chooses them
+  // (use_small_gemm): the reference's full-length trans_dec checkpoint (README.md:254 humanml_trans_dec_512_bert-50steps: 196 frames,
+  // no prefix, plain p_sample_loop) at the headline batch is the encoder's shape with a cross-attention block per layer.
+  const bool small = !dec_sequence_tiles(m, nseq, S);
+  const int scols = small ? x3s_tn(shape.ncb) : 256, parts = (D + scols - 1) / scols;
   const float inv_dim = 1.0f / (float)D;
-  auto LN = [&]() { LnArgs a; a.small = true; a.shape = shape; a.stat_cols = scols; a.parts = parts; a.inv_dim = inv_dim; return a; };
+  auto LN = [&]() { LnArgs a; a.small = small; a.shape = shape; a.stat_cols = scols; a.parts = parts; a.inv_dim = inv_dim; return a; };
   const X3Operand attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
   float* q32 = ws.tok;   // the projected cross-attention queries [M][D]
   for (int l = 0; l < m->cfg.num_layers; ++l) {

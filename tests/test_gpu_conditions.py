@@ -163,3 +163,32 @@ def test_target_condition_is_shard_invariant_and_fills_the_batch():
     diffusion.sample_base = 0
     other = diffusion.p_sample_loop(model, (B, 263, 1, P), clip_denoised=False, model_kwargs={"y": y_off}, seed=600)
     assert maxabs(other.cpu(), whole.cpu()) > 1e-3
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+@pytest.mark.parametrize("route", ["row_tiles", "sequence_tiles"])
+def test_full_length_trans_dec_matches_reference_golden(golden_dir, engine_options, route, prec):
+    """README.md:254 `humanml_trans_dec_512_bert-50steps` -- the trans_dec + DistilBERT denoiser OUTSIDE DiP's windows (no prefix, 196
+    frames, sample/generate.py's plain p_sample_loop): forward (cond / CFG) and a 10-step guided loop against the reference's own run.
+    Both GEMM routes of csrc/decoder.h: gemm_x3s.h's row tiles (up to 80 sequences) and gemm_x3.h's sequence-sized tiles (what a large
+    batch runs; forced at 4 sequences with small_gemm_max_seqs = 1)."""
+    if prec == "f32" and route != "row_tiles":
+        pytest.skip("the f32 mode has one GEMM kernel")
+    engine_options(**({"small_gemm_max_seqs": 1} if route == "sequence_tiles" else {}))
+    g = np.load(os.path.join(golden_dir, "transdec_B2_T196.npz"))
+    B, T, steps, seed = 2, 196, int(g["steps"]), int(g["seed"])
+    model, diffusion = make_pair(memo("sd_dip0", lambda: synth_dip_state_dict(seed=0)), steps, DEV, guided=True, context_len=0,
+                                 pred_len=0, mask_frames=True, precision=prec)
+    y = synth_dip_y(B, T, 1, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]), lengths=list(g["lengths"]), scale=float(g["scale"]))
+    y.pop("prefix")
+    y = to_dev(y, DEV)
+    x = torch.randn(B, 263, 1, T, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV)
+    t = torch.as_tensor(g["t"]).to(DEV)
+    errs = {"cond": maxabs(model.model(x, t, y=dict(y)).cpu(), g["out_cond"]), "cfg": maxabs(model(x, t, y=dict(y)).cpu(), g["out_cfg"])}
+    shape = (B, 263, 1, T)
+    x_T, noises = orc.make_noise(shape, steps, seed)
+    out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": dict(y)},
+                                  noise_sequence=[x_T] + [n.contiguous() for n in noises])
+    errs["loop10"] = maxabs(out.cpu(), g["final"])
+    print(f"[parity] transdec_B2_T196 {route} {prec}: max-abs vs reference = {errs}")
+    assert max(errs.values()) < TOL_LOOP, errs

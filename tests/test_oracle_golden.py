@@ -217,3 +217,55 @@ def test_long_sequence_goldens(golden_dir):
     t = torch.from_numpy(g["t"])
     assert np.abs(orc.mdm_forward(sd, x, t, y).numpy() - g["out_cond"]).max() < 1e-5
     assert np.abs(orc.cfg_forward(sd, x, t, y).numpy() - g["out_cfg"]).max() < 2e-5
+
+
+def test_condition_goldens(golden_dir):
+    """Seam B1's other conditions: the restatement against the reference's own outputs for cond_mode='action' and --multi_target_cond
+    (oracle/make_golden_r6b.py; PIN_REPORT_r6b.json) -- forward of every flavour here, the loops through the pin report."""
+    from oracle import dip_oracle as dip
+    from oracle.synth import (HML_GOAL_JOINT_NAMES, synth_a2m_state_dict, synth_dip_state_dict, synth_dip_y, synth_target_params,
+                              synth_target_y)
+    rep = json.load(open(os.path.join(golden_dir, "PIN_REPORT_r6b.json")))
+    assert len(rep["cases"]) == 10
+    for name, rec in rep["cases"].items():
+        for k, v in rec.items():
+            if k == "effect_of_target":
+                assert v > 1e-2, (name, v)
+            elif k != "ref_absmax":
+                assert v < (5e-5 if "ar10" in name else TOL), (name, k, v)
+    # action-to-motion forward
+    g = _load(golden_dir, "a2m_fwd_B3_T60")
+    sd = synth_a2m_state_dict(seed=0)
+    y = synth_y(3, 60, seed=int(g["y_seed"]), lengths=list(g["lengths"]))
+    del y["text_embed"]
+    y["action"] = torch.from_numpy(g["action"])
+    x = torch.randn(3, 25, 6, 60, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    t = torch.from_numpy(g["t"])
+    assert np.abs(orc.mdm_forward(sd, x, t, y).numpy() - g["out_cond"]).max() < TOL
+    assert np.abs(orc.mdm_forward(sd, x, t, {**y, "uncond": True}).numpy() - g["out_uncond"]).max() < TOL
+    assert np.abs(orc.cfg_forward(sd, x, t, y).numpy() - g["out_cfg"]).max() < TOL
+    # target-conditioned DiP forward, every encoder flavour
+    g = _load(golden_dir, "dip_target_fwd_B4")
+    ys = int(g["y_seed"])
+    y = {**synth_dip_y(4, 40, 20, seed=ys, text_lengths=list(g["text_lengths"])), **synth_target_y(4, seed=ys)}
+    x = torch.randn(4, 263, 1, 40, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    t = torch.from_numpy(g["t"])
+    for kind in ("single", "split", "multi"):
+        sd = {**synth_dip_state_dict(seed=0), **synth_target_params(kind, seed=0)}
+        kw = dict(context_len=20, goal_joint_names=HML_GOAL_JOINT_NAMES)
+        assert np.abs(dip.dip_forward(sd, x, t, y, **kw).numpy() - g["out_cond_" + kind]).max() < TOL, kind
+        assert np.abs(dip.dip_forward(sd, x, t, {**y, "uncond": True}, **kw).numpy() - g["out_uncond_" + kind]).max() < TOL, kind
+
+
+def test_full_length_trans_dec_golden(golden_dir):
+    """The trans_dec restatement without a prefix (README.md:254's checkpoint shape) against the reference's forward at T = 196."""
+    from oracle import dip_oracle as dip
+    from oracle.synth import synth_dip_state_dict, synth_dip_y
+    g = _load(golden_dir, "transdec_B2_T196")
+    sd = synth_dip_state_dict(seed=0)
+    y = synth_dip_y(2, 196, 1, seed=int(g["y_seed"]), text_lengths=list(g["text_lengths"]), lengths=list(g["lengths"]), scale=float(g["scale"]))
+    y.pop("prefix")
+    x = torch.randn(2, 263, 1, 196, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    t = torch.from_numpy(g["t"])
+    assert np.abs(dip.dip_forward(sd, x, t, y, context_len=0, mask_frames=True).numpy() - g["out_cond"]).max() < TOL
+    assert np.abs(dip.dip_cfg_forward(sd, x, t, y, context_len=0, mask_frames=True).numpy() - g["out_cfg"]).max() < TOL
