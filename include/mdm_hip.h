@@ -126,6 +126,14 @@ void mdm_destroy(mdm_model_t* m);
  *                                 the accumulators and requests the next (sequence, head)'s first key tiles in front of those stores,
  *                                 instead of staging the output through its LDS ring (A/B of round 5: profiles/r05e_attention_direct.md). */
 #define MDM_OPT_ATTN_DIRECT_OUT 5
+/*   MDM_OPT_DEC_TIME_TOKEN        a MODEL-STRUCTURE switch (ABI 10; set once, before the first forward): `--emb_trans_dec` (model/mdm.py:101,
+ *                                 :245-247, :256-257, :269-270 -- the `humanml-decoder-with-emb-512` checkpoint): the timestep embedding
+ *                                 leads the trans_dec tgt sequence as a class token.  Create the model with context_len = 1 -- that row
+ *                                 is the class token: always a valid key, dropped from the output like a prefix frame -- pass a
+ *                                 `prefix_dev` of B zero frames [B, njoints, nfeats, 1] (a placeholder; the library overwrites the row it
+ *                                 embeds to with time_embed(t) (+ the mdm_set_time_add row) + pe[0] in every branch), and count the row
+ *                                 in `lengths_dev` as context rows are.  0 (default): context rows are embedded prefix frames (DiP). */
+#define MDM_OPT_DEC_TIME_TOKEN 6
 int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value);
 int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value);
 

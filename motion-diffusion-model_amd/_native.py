@@ -30,7 +30,8 @@ EXPORTED_SYMBOLS = [
 PROBE_SYMBOLS = ["mdm_debug_set", "mdm_debug_get", "mdm_linear_f16f6", "mdm_linear_f16f6_scratch_bytes", "mdm_probe_in_proj"]
 ABI_VERSION = 10
 # include/mdm_hip.h MDM_OPT_*: per-handle run-time options (the library reads no environment variable)
-OPTIONS = {"small_gemm_max_seqs": 1, "small_gemm_row_tiles": 2, "dec_fused_xattn": 3, "dec_fused_selfattn": 4, "attn_direct_out": 5}
+OPTIONS = {"small_gemm_max_seqs": 1, "small_gemm_row_tiles": 2, "dec_fused_xattn": 3, "dec_fused_selfattn": 4, "attn_direct_out": 5,
+           "dec_time_token": 6}
 ARCH = {"trans_enc": 0, "trans_dec": 1}
 
 

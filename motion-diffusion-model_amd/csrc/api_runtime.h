@@ -131,6 +131,7 @@ struct mdm_model {
   const float* time_add_next = nullptr;
   int time_add_B = 0;
   const float* time_add = nullptr;
+  bool dec_time_token = false;   // MDM_OPT_DEC_TIME_TOKEN: row 0 of a trans_dec sequence is the timestep embedding (emb_trans_dec)
   int jf = 0, jf_pad = 0;
   int precision = MDM_PREC_F16X3;
   struct LayerPlanes { X3Weights in_proj, out_proj, linear1, linear2; };

@@ -90,7 +90,23 @@ struct DecHoist {         // step k of a window loop: where the hoisted projecti
   const float* kv_text = nullptr;   // [nbranch * kv_B * ntok][L][2D]: row stride L * 2D, layer l at + l * 2D
   const float* kv_time = nullptr;   // [nsteps][L][2D]
   int kv_B = 0, kv_b0 = 0;          // this pass covers samples kv_b0 .. kv_b0 + B - 1 of kv_B
+  int t_model = 0;                  // the step's model timestep (the class token of MDM_OPT_DEC_TIME_TOKEN needs its table row)
 };
+// `--emb_trans_dec` (model/mdm.py:256-257, the `humanml-decoder-with-emb-512` checkpoint): the TIMESTEP embedding leads the decoder's
+// tgt sequence as a class token.  The library sees it as the one context row of a context_len = 1 model (always a valid key, dropped
+// from the output like a prefix frame); the embedding GEMM has written an embedded placeholder frame there -- overwritten here, in
+// every branch, with time_embed(t) (+ the target embedding) + pe[0], as fp32 and / or planes.
+int dec_time_token_rows(mdm_model_t* m, float* tok, p16_t* th, p16_t* tl, const int64_t* timesteps, const DecHoist& hz, int B, int nseq,
+                        int S, hipStream_t s) {
+  if (!m->dec_time_token) return MDM_OK;
+  const int D = m->cfg.latent_dim;
+  ProfScope ps(&m->prof, MDM_PROF_ELEMENTWISE, 0.0, s);
+  MDM_LAUNCH(cond_token_kernel, dim3(nseq), dim3(128), 0, s, tok, (const float*)nullptr, (const float*)nullptr,
+             (const float*)m->time_table, reinterpret_cast<const long long*>(hz.step >= 0 ? nullptr : timesteps), hz.t_model,
+             m->W("sequence_pos_encoder.pe"), B, S, D, 0, (int)m->cfg.max_len, th, tl,
+             m->time_add != nullptr ? m->time_add + (size_t)hz.kv_b0 * D : (const float*)nullptr);
+  return rt_launch_status();
+}
 // The sampler update of a window-loop step, handed DOWN to the plane route: its transposing tail kernel (outproj_finish_kernel
 // mode 1) then performs guidance combine + inpainting blend + clamp + posterior / DDIM update + inline Philox in place on x, exactly
 // as the encoder loop's tail does -- one launch and one [nseq, J, P] round trip through memory fewer per step than
@@ -131,9 +147,9 @@ inline bool dec_on_planes(const mdm_model* m, int M, int S, const DecHoist& hz, 
          (hz.step < 0 || (hz.kv_b0 == 0 && hz.kv_B == B));
 }
 
-int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x, const float* prefix, const int32_t* text_lengths,
-                          const int32_t* len, int B, int pred_len, int ntok, int nbranch, float* out, hipStream_t s,
-                          const DecHoist& hz, DecTail* tail) {
+int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x, const float* prefix, const int64_t* timesteps,
+                          const int32_t* text_lengths, const int32_t* len, int B, int pred_len, int ntok, int nbranch, float* out,
+                          hipStream_t s, const DecHoist& hz, DecTail* tail) {
   const int C = m->cfg.context_len, S = C + pred_len, D = m->cfg.latent_dim, H = m->cfg.num_heads, FF = m->cfg.ff_size;
   const int nseq = nbranch * B, M = nseq * S, Mm = nseq * ntok;
   Profiler* pf = &m->prof;
@@ -149,6 +165,7 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
     launch_gemm_f32(al, bl, ep, B * S, D, m->jf_pad, s, true);
     if (int rc = rt_launch_status()) return rc;
   }
+  if (int rc = dec_time_token_rows(m, ws.tok, ws.xh[cur], ws.xl[cur], timesteps, hz, B, nseq, S, s)) return rc;
   const X3sShape shape = x3s_shape(m->x3s, (M + 196) / 197);   // the encoder's 32- / 64-row threshold, in its token rows
   // Which GEMM kernel: the row tiles of gemm_x3s.h (DiP's windows at every batch size: a 60-token sequence fills a quarter of a
   // sequence tile) -- or, for LONG sequences at LARGE batch, gemm_x3.h's sequence-sized tiles exactly as the encoder chooses them
@@ -344,7 +361,7 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
     if (int rc = rt_launch_status()) return rc;
   }
   if (dec_on_planes(m, M, S, hz, B))
-    return decoder_layers_planes(m, ws, x, prefix, text_lengths, len, B, pred_len, ntok, nbranch, out, s, hz,
+    return decoder_layers_planes(m, ws, x, prefix, timesteps, text_lengths, len, B, pred_len, ntok, nbranch, out, s, hz,
                                  (tail != nullptr && (nbranch == 1) == (tail->scale == nullptr)) ? tail : nullptr);
   // ---- tgt tokens: InputProcess over cat(prefix, x) + positional rows (mdm.py:203-206, :239, :259-260); both branches
   {
@@ -356,6 +373,7 @@ int decoder_pass(mdm_model_t* m, const DecWorkspace& ws, const float* x, const f
     launch_gemm_f32(al, bl, ep, B * S, D, m->jf_pad, s, x3);
     if (int rc = rt_launch_status()) return rc;
   }
+  if (int rc = dec_time_token_rows(m, ws.tok, nullptr, nullptr, timesteps, hz, B, nseq, S, s)) return rc;
   // ---- nn.TransformerDecoder (mdm.py:265; post-norm layers, no final norm).  The three LayerNorms of a layer are folded
   // into the GEMMs around them (gemm_f32.h LnFold): ws.tok holds the PRE-norm sums y, `pend` says which LayerNorm its readers
   // have to apply (none for the embedded tokens entering layer 0); only the last norm3 runs as a kernel, for OutputProcess.

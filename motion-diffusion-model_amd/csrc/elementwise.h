@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void cond_token_kernel(float* __restrict__ tok
   if (t < 0) t = 0;
   if (t >= table_rows) t = table_rows - 1;
   for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
-    const float4 e = (br >= uncond_from_branch || cond_emb == nullptr) ? ld4(text_bias + c)
+    // (text_bias == null: a token that is the timestep embedding alone -- the class token of a trans_dec sequence, mdm.py:256-257)
+    const float4 e = (br >= uncond_from_branch || cond_emb == nullptr) ? (text_bias != nullptr ? ld4(text_bias + c) : zero4())
                                                                       : ld4(cond_emb + (size_t)b * D + c);
     const float4 tt = time_row(time_table, t, tadd, b, D, c);
     const float4 p0 = ld4(pe + c);

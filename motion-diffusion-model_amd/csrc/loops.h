@@ -213,6 +213,7 @@ int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float
       wg.out += (size_t)g * nseq_g * per_sample;
       DecHoist hz;
       hz.step = k; hz.nsteps = nsteps; hz.kv_text = ws.kv_text; hz.kv_time = ws.kv_time; hz.kv_B = B; hz.kv_b0 = b0;
+      hz.t_model = p->timestep_map[i];
       const float* prefix_g = pd->prefix_dev != nullptr ? pd->prefix_dev + (size_t)b0 * m->jf * m->cfg.context_len : nullptr;
       // CFG combine + posterior / DDIM update, in place on x (each element is read, then written, by the same lane): inside the
       // plane route's tail kernel (DecTail), else as a kernel of its own behind the denoiser

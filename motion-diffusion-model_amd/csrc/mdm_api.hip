@@ -164,6 +164,12 @@ int mdm_set_option(mdm_model_t* m, int32_t key, int32_t value) {
       if (value != 0 && value != 1) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_ATTN_DIRECT_OUT must be 0 or 1");
       m->attn_direct = value != 0;
       return MDM_OK;
+    case MDM_OPT_DEC_TIME_TOKEN:
+      if (value != 0 && value != 1) return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_DEC_TIME_TOKEN must be 0 or 1");
+      if (value == 1 && (m->cfg.arch != MDM_ARCH_TRANS_DEC || m->cfg.context_len != 1))
+        return fail(MDM_EINVAL, "mdm_set_option: MDM_OPT_DEC_TIME_TOKEN needs a trans_dec model created with context_len = 1 (the class-token row)");
+      m->dec_time_token = value != 0;
+      return MDM_OK;
     default:
       return fail(MDM_EINVAL, "mdm_set_option: unknown key " + std::to_string(key));
   }
@@ -186,6 +192,7 @@ int mdm_get_option(const mdm_model_t* m, int32_t key, int32_t* value) {
     case MDM_OPT_DEC_FUSED_XATTN: *value = m->fused_xattn; return MDM_OK;
     case MDM_OPT_DEC_FUSED_SELFATTN: *value = m->fused_selfattn ? 1 : 0; return MDM_OK;
     case MDM_OPT_ATTN_DIRECT_OUT: *value = m->attn_direct ? 1 : 0; return MDM_OK;
+    case MDM_OPT_DEC_TIME_TOKEN: *value = m->dec_time_token ? 1 : 0; return MDM_OK;
     default: return fail(MDM_EINVAL, "mdm_get_option: unknown key " + std::to_string(key));
   }
 }

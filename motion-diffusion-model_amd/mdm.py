@@ -247,8 +247,11 @@ class MDM(nn.Module):
             if self.text_encoder_type != 'clip' and 'text' in self.cond_mode:
                 raise NotImplementedError("text_encoder_type='bert' belongs to the DiP (trans_dec) path")
         else:
-            if emb_trans_dec or 'text' not in self.cond_mode:
-                raise NotImplementedError("trans_dec: emb_trans_dec=False with text conditioning (the DiP configuration)")
+            if 'text' not in self.cond_mode:
+                raise NotImplementedError("trans_dec: text conditioning only (model/mdm.py:261-267 builds the memory from the text)")
+            if emb_trans_dec and self.is_prefix_comp:
+                raise NotImplementedError("emb_trans_dec (the class-token decoder of the original paper) and prefix completion (DiP) "
+                                          "are separate checkpoints upstream; the combination is not built")
             if self.text_encoder_type not in ('clip', 'bert'):
                 raise ValueError('We only support [CLIP, BERT] text encoders')
             if self.text_encoder_type == 'bert':
@@ -342,11 +345,18 @@ class MDM(nn.Module):
         return int(self.sequence_pos_encoder.pe.shape[0])
 
     @property
+    def lead_rows(self):
+        """Rows in front of the frames of a trans_dec sequence, as the library counts them (its `context_len`): the prefix frames of
+        prefix completion (model/mdm.py:203-206), or ONE row for `emb_trans_dec` -- the timestep embedding as a class token
+        (model/mdm.py:256-257; include/mdm_hip.h MDM_OPT_DEC_TIME_TOKEN)."""
+        return 1 if self.emb_trans_dec else int(self.context_len)
+
+    @property
     def MAX_FRAMES(self):     # trans_enc: the condition token takes one row of the positional table
-        return self.MAX_TOKENS - 1 if self.arch == 'trans_enc' else self.MAX_TOKENS - int(self.context_len)
+        return self.MAX_TOKENS - 1 if self.arch == 'trans_enc' else self.MAX_TOKENS - self.lead_rows
 
     def _check_frames(self, T):
-        if (T + 1 if self.arch == 'trans_enc' else self.context_len + T) > self.MAX_TOKENS:
+        if (T + 1 if self.arch == 'trans_enc' else self.lead_rows + T) > self.MAX_TOKENS:
             raise nat.MdmError(f"{T} frames: the sequence does not fit the positional table ({self.MAX_TOKENS} rows, "
                                f"pos_embed_max_len; model/mdm.py:55)")
 
@@ -387,8 +397,11 @@ class MDM(nn.Module):
             cfg = dict(njoints=self.njoints, nfeats=self.nfeats, latent_dim=self.latent_dim, ff_size=self.ff_size,
                        num_layers=self.num_layers, num_heads=self.num_heads, clip_dim=self.cond_dim,
                        max_len=self.sequence_pos_encoder.pe.shape[0], mask_frames=int(bool(self.mask_frames)),
-                       arch=nat.ARCH[self.arch], context_len=int(self.context_len) if self.arch == 'trans_dec' else 0)
-            eng = Engine(cfg, lib=self._native_lib, precision=self.precision, options=self.engine_options)
+                       arch=nat.ARCH[self.arch], context_len=self.lead_rows if self.arch == 'trans_dec' else 0)
+            opts = dict(self.engine_options)
+            if self.arch == 'trans_dec' and self.emb_trans_dec:
+                opts['dec_time_token'] = 1
+            eng = Engine(cfg, lib=self._native_lib, precision=self.precision, options=opts)
             eng.bind(self._native_state(), p.device)
             self._engine, self._engine_key = eng, key
         return self._engine
@@ -479,7 +492,9 @@ class MDM(nn.Module):
         from the reference's `y` contract (model/mdm.py:203-216, :242-244)."""
         dev, bs = x.device, x.shape[0]
         prefix = None
-        if self.context_len > 0:
+        if self.emb_trans_dec:      # the class-token row: a placeholder frame the library overwrites with the timestep embedding
+            prefix = torch.zeros(bs, self.njoints, self.nfeats, 1, dtype=torch.float32, device=dev)
+        elif self.context_len > 0:
             prefix = y['prefix'].to(device=dev, dtype=torch.float32).contiguous()
             assert prefix.shape == (bs, self.njoints, self.nfeats, self.context_len), prefix.shape
         enc = y['text_embed'] if 'text_embed' in y.keys() else self.encode_text(y['text'])
@@ -515,7 +530,8 @@ class MDM(nn.Module):
             if use_mask:
                 m2 = mask[..., :x.shape[-1]].reshape(bs, -1).to(dev).to(torch.bool)
                 # keys of the decoder's self-attention: the context_len prefix frames (always valid) + the window's frames
-                lengths = self.frame_mask_lengths(torch.cat([torch.ones(bs, self.context_len, dtype=torch.bool, device=dev),
+                # (emb_trans_dec: the class token is never masked, model/mdm.py:245-247 -- it is the one lead row)
+                lengths = self.frame_mask_lengths(torch.cat([torch.ones(bs, self.lead_rows, dtype=torch.bool, device=dev),
                                                              m2], dim=1))
             # the entry keeps the SOURCE tensors alive: a later batch of the same shape must not be able to land on a
             # recycled address with _version 0 and hit this entry

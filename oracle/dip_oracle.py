@@ -11,7 +11,8 @@ Reference lines restated (paths relative to the upstream tree):
   model/mdm.py:203-206    prefix completion: x = cat(prefix, x); mask gets `context_len` leading ones
   model/mdm.py:208-220    text memory: embed_text(mask_cond(enc_text)) + time_emb  (emb_policy 'add')
   model/mdm.py:241-247    frames mask (no leading step column for trans_dec without emb_trans_dec)
-  model/mdm.py:255-270    tgt = pos_enc(InputProcess(x)); decoder(tgt, memory, memory_key_padding_mask, tgt_key_padding_mask)
+  model/mdm.py:255-270    tgt = pos_enc(InputProcess(x)); decoder(tgt, memory, memory_key_padding_mask, tgt_key_padding_mask);
+                          with emb_trans_dec (the `humanml-decoder-with-emb-512` checkpoint) the timestep embedding leads tgt
   model/mdm.py:277-283    keep the completed suffix, OutputProcess
   utils/sampler_util.py:41-81   AutoRegressiveSampler.sample
 torch: nn.TransformerDecoderLayer.forward (norm_first=False): x = norm1(x + sa(x)); x = norm2(x + mha(x, mem)); x = norm3(x + ff(x))
@@ -56,7 +57,7 @@ def decoder_layer(sd, i, x, mem, tgt_pad, mem_pad, num_heads, dtype):
 
 
 def dip_forward(sd, x, timesteps, y, *, context_len, num_heads=4, mask_frames=False, pe=None, dtype=torch.float32,
-                goal_joint_names=()):
+                goal_joint_names=(), emb_trans_dec=False):
     """MDM.forward for arch='trans_dec', text_encoder_type='bert' (mdm.py:189-283).
 
     x [B, J, 1, pred_len]; y: 'prefix' [B, J, 1, context_len], 'text_embed' = (enc [Ntok, B, 768], pad [B, Ntok] bool,
@@ -91,9 +92,15 @@ def dip_forward(sd, x, timesteps, y, *, context_len, num_heads=4, mask_frames=Fa
     tgt_pad = None
     if mask_frames and mask.shape[-1] > 1:                                        # mdm.py:242-244
         tgt_pad = ~mask[..., :S].reshape(B, S)
-    seq = h + pe[:S][None]                                                        # mdm.py:259-260 (emb_trans_dec False)
+        if emb_trans_dec:                                                         # mdm.py:245-247: the step token is never masked
+            tgt_pad = torch.cat([torch.zeros(B, 1, dtype=torch.bool), tgt_pad], dim=1)
+    if emb_trans_dec:                                                             # mdm.py:256-257: the TIMESTEP embedding (not emb) leads tgt
+        h = torch.cat([time_emb[:, None, :], h], dim=1)
+    seq = h + pe[:h.shape[1]][None]                                               # mdm.py:259-260
     for i in range(L):
         seq = decoder_layer(sd, i, seq, mem, tgt_pad, text_pad, num_heads, dtype)  # mdm.py:265
+    if emb_trans_dec:
+        seq = seq[:, 1:]                                                          # mdm.py:269-270
     seq = seq[:, context_len:]                                                    # mdm.py:278-279
     out = orc._lin(seq, sd, "output_process.poseFinal", dtype)
     return out.reshape(B, S - context_len, J, Fe).permute(0, 2, 3, 1).contiguous()
@@ -107,7 +114,7 @@ def dip_cfg_forward(sd, x, timesteps, y, **kw):
 
 
 def dip_sample_loop(sd, tab, shape, y, x_T, step_noise, *, context_len, cfg=True, num_heads=4, mask_frames=False,
-                    dtype=torch.float32, goal_joint_names=()):
+                    dtype=torch.float32, goal_joint_names=(), emb_trans_dec=False):
     """p_sample_loop (gaussian_diffusion.py:591-727) of one prediction window with an injected noise sequence."""
     B = shape[0]
     pe = orc.positional_table(5000, sd["input_process.poseEmbedding.weight"].shape[0], dtype)
@@ -116,7 +123,7 @@ def dip_sample_loop(sd, tab, shape, y, x_T, step_noise, *, context_len, cfg=True
     for k, i in enumerate(range(tab.num_timesteps)[::-1]):
         t = torch.full((B,), i, dtype=torch.long)
         x0 = fwd(sd, img, t, y, context_len=context_len, num_heads=num_heads, mask_frames=mask_frames, pe=pe, dtype=dtype,
-                 goal_joint_names=goal_joint_names)
+                 goal_joint_names=goal_joint_names, emb_trans_dec=emb_trans_dec)
         img = orc.ddpm_step(tab, img, x0, t, step_noise[k].to(dtype))
     return img
 

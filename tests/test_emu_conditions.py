@@ -168,3 +168,39 @@ def test_target_modules_carry_the_reference_state_dict_keys():
     keys = set(model.state_dict())
     assert "embed_action.action_embedding" in keys and not any(k.startswith("embed_text.") for k in keys)
     assert model.input_process.poseEmbedding.weight.shape == (512, 150)
+
+
+@pytest.mark.parametrize("prec,route", [("f16x3", "planes"), ("f16x3", "skeleton"), ("f32", "skeleton")])
+def test_emulated_decoder_with_class_token(lib, engine_options, prec, route):
+    """`--emb_trans_dec` (README `humanml-decoder-with-emb-512`; model/mdm.py:245-247, :256-257, :269-270): the timestep embedding leads
+    the decoder's tgt sequence, over a one-token CLIP memory.  The library sees it as the context row of a context_len = 1 model whose
+    embedded placeholder is overwritten (include/mdm_hip.h MDM_OPT_DEC_TIME_TOKEN): forward with per-sample timesteps (cond / uncond /
+    guided, ragged frame masks), the window loop (uniform step timestep) and the step-by-step loop, on the operand-plane route and the
+    fp32 skeleton."""
+    from oracle.synth import synth_dip_state_dict
+    if route == "skeleton" and prec == "f16x3":
+        engine_options(small_gemm_max_seqs=0)
+    B, T, steps = 2, 12, 2
+    sd = synth_dip_state_dict(seed=0, latent_dim=256, num_layers=2, bert_dim=512)
+    model, diffusion = make_pair(sd, steps, "cpu", guided=True, native_lib=lib, precision=prec, text_encoder_type="clip",
+                                 emb_trans_dec=True, mask_frames=True)
+    assert model.model.lead_rows == 1 and model.model.engine().get_option("dec_time_token") == 1
+    y = synth_y(B, T, seed=5, lengths=[T, 7])
+    x = torch.randn(B, 263, 1, T, generator=torch.Generator().manual_seed(2))
+    t = torch.tensor([1, 0])
+    kw = dict(context_len=0, num_heads=2, mask_frames=True, emb_trans_dec=True)
+    want = dip.dip_forward(sd, x, t, y, **kw)
+    assert maxabs(want, dip.dip_forward(sd, x, t, y, context_len=0, num_heads=2, mask_frames=True)) > 1e-2     # the class token matters
+    assert maxabs(model.model(x, t, y=dict(y)), want) < 2e-5
+    assert maxabs(model.model(x, t, y={**y, "uncond": True}), dip.dip_forward(sd, x, t, {**y, "uncond": True}, **kw)) < 2e-5
+    assert maxabs(model(x, t, y=dict(y)), dip.dip_cfg_forward(sd, x, t, y, **kw)) < 5e-5
+    shape = (B, 263, 1, T)
+    x_T, noises = orc.make_noise(shape, steps, 11)
+    seq = [x_T] + [n.contiguous() for n in noises]
+    tab = orc.Tables(orc.named_betas("cosine", steps))
+    want = dip.dip_sample_loop(sd, tab, shape, y, x_T, noises, cfg=True, **kw)
+    run = lambda: diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": dict(y)}, noise_sequence=seq)   # noqa: E731
+    got = run()
+    assert maxabs(got, want) < 5e-5
+    diffusion.dip_stepwise = True
+    assert maxabs(run(), got) < 2e-5

@@ -192,3 +192,26 @@ def test_full_length_trans_dec_matches_reference_golden(golden_dir, engine_optio
     errs["loop10"] = maxabs(out.cpu(), g["final"])
     print(f"[parity] transdec_B2_T196 {route} {prec}: max-abs vs reference = {errs}")
     assert max(errs.values()) < TOL_LOOP, errs
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f32"])
+def test_decoder_with_class_token_matches_reference_golden(golden_dir, prec):
+    """README `humanml-decoder-with-emb-512` (`--arch trans_dec --emb_trans_dec`, CLIP memory): forward (cond / uncond / CFG, ragged frame
+    masks, per-sample timesteps) and a 10-step guided loop against the reference's own run (tests/golden/decemb_B3_T60.npz)."""
+    g = np.load(os.path.join(golden_dir, "decemb_B3_T60.npz"))
+    B, T, steps, seed = 3, 60, int(g["steps"]), int(g["seed"])
+    sd = memo("sd_dip_clip", lambda: synth_dip_state_dict(seed=0, bert_dim=512))
+    model, diffusion = make_pair(sd, steps, DEV, guided=True, precision=prec, text_encoder_type="clip", emb_trans_dec=True, mask_frames=True)
+    y = to_dev(synth_y(B, T, seed=int(g["y_seed"]), lengths=list(g["lengths"]), scale=float(g["scale"])), DEV)
+    x = torch.randn(B, 263, 1, T, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV)
+    t = torch.as_tensor(g["t"]).to(DEV)
+    errs = {"cond": maxabs(model.model(x, t, y=dict(y)).cpu(), g["out_cond"]),
+            "uncond": maxabs(model.model(x, t, y={**y, "uncond": True}).cpu(), g["out_uncond"]),
+            "cfg": maxabs(model(x, t, y=dict(y)).cpu(), g["out_cfg"])}
+    shape = (B, 263, 1, T)
+    x_T, noises = orc.make_noise(shape, steps, seed)
+    out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": dict(y)},
+                                  noise_sequence=[x_T] + [n.contiguous() for n in noises])
+    errs["loop10"] = maxabs(out.cpu(), g["final"])
+    print(f"[parity] decemb_B3_T60 {prec}: max-abs vs reference = {errs}")
+    assert max(errs.values()) < TOL_LOOP, errs

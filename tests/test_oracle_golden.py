@@ -226,7 +226,7 @@ def test_condition_goldens(golden_dir):
     from oracle.synth import (HML_GOAL_JOINT_NAMES, synth_a2m_state_dict, synth_dip_state_dict, synth_dip_y, synth_target_params,
                               synth_target_y)
     rep = json.load(open(os.path.join(golden_dir, "PIN_REPORT_r6b.json")))
-    assert len(rep["cases"]) == 10
+    assert len(rep["cases"]) == 12
     for name, rec in rep["cases"].items():
         for k, v in rec.items():
             if k == "effect_of_target":
@@ -269,3 +269,18 @@ def test_full_length_trans_dec_golden(golden_dir):
     t = torch.from_numpy(g["t"])
     assert np.abs(dip.dip_forward(sd, x, t, y, context_len=0, mask_frames=True).numpy() - g["out_cond"]).max() < TOL
     assert np.abs(dip.dip_cfg_forward(sd, x, t, y, context_len=0, mask_frames=True).numpy() - g["out_cfg"]).max() < TOL
+
+
+def test_decoder_with_class_token_golden(golden_dir):
+    """`--emb_trans_dec` (README humanml-decoder-with-emb-512): the restatement against the reference's forward."""
+    from oracle import dip_oracle as dip
+    from oracle.synth import synth_dip_state_dict
+    g = _load(golden_dir, "decemb_B3_T60")
+    sd = synth_dip_state_dict(seed=0, bert_dim=512)
+    y = synth_y(3, 60, seed=int(g["y_seed"]), lengths=list(g["lengths"]))
+    x = torch.randn(3, 263, 1, 60, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    t = torch.from_numpy(g["t"])
+    kw = dict(context_len=0, mask_frames=True, emb_trans_dec=True)
+    assert np.abs(dip.dip_forward(sd, x, t, y, **kw).numpy() - g["out_cond"]).max() < TOL
+    assert np.abs(dip.dip_forward(sd, x, t, {**y, "uncond": True}, **kw).numpy() - g["out_uncond"]).max() < TOL
+    assert np.abs(dip.dip_cfg_forward(sd, x, t, y, **kw).numpy() - g["out_cfg"]).max() < TOL
