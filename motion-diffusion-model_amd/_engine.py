@@ -71,7 +71,9 @@ class Engine:
           'dec_fused_selfattn'    1 (default) = in_proj + self-attention of a trans_dec layer as one kernel per (sequence, head)
                                   for sequences of <= 64 tokens, 0 = two launches
           'attn_direct_out'       0 (default); 1 = the encoder attention kernel stores its output planes straight from the
-                                  accumulators (measured slower, profiles/r05e_attention_direct.md; A/B only)"""
+                                  accumulators (measured slower, profiles/r05e_attention_direct.md; A/B only)
+          'dec_time_token'        a model-structure switch, set by MDM for `emb_trans_dec` checkpoints: 1 = the one context row of a
+                                  context_len = 1 trans_dec model is the timestep embedding (model/mdm.py:256-257), not a prefix frame"""
         if name not in nat.OPTIONS:
             raise ValueError(f"unknown engine option {name!r}: one of {sorted(nat.OPTIONS)}")
         self.lib.check(self.lib.mdm_set_option(self.handle, nat.OPTIONS[name], int(value)), f"mdm_set_option({name})")
