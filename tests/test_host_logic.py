@@ -104,10 +104,13 @@ def test_wrapper_and_scope_errors():
         from mdm_amd.cfg_sampler import ClassifierFreeSampleModel
         m0, _ = model_util.create_model_and_diffusion(model_util.default_args(cond_mask_prob=0.0, layers=1))
         ClassifierFreeSampleModel(m0)
-    for kw in (dict(arch="trans_dec", emb_trans_dec=True), dict(arch="gru"), dict(context_len=20, pred_len=40),
-               dict(text_encoder_type="bert")):
+    for kw in (dict(arch="trans_dec", emb_trans_dec=True, context_len=20, pred_len=40), dict(arch="gru"),
+               dict(context_len=20, pred_len=40), dict(text_encoder_type="bert"), dict(arch="trans_dec", dataset="humanact12")):
         with pytest.raises(NotImplementedError):
             model_util.create_model_and_diffusion(model_util.default_args(**kw))
+    # the class-token decoder (README humanml-decoder-with-emb-512) constructs: one lead row, no prefix
+    me, _ = model_util.create_model_and_diffusion(model_util.default_args(arch="trans_dec", emb_trans_dec=True, layers=1))
+    assert me.lead_rows == 1 and not me.is_prefix_comp and me.MAX_FRAMES == me.MAX_TOKENS - 1
     # DiP configuration (DiP.md): constructs, keeps the reference's state-dict keys
     md, _ = model_util.create_model_and_diffusion(model_util.default_args(
         arch="trans_dec", text_encoder_type="bert", context_len=20, pred_len=40, layers=1))
