@@ -44,5 +44,5 @@ g["bench_value"] = d["value"]; g["bench_lib_sha256"] = d["build"]["lib_sha256"]
 json.dump(g, open(out + "/closing_gate.json", "w"), indent=1)
 print({k: d[k] for k in ("value", "ms_per_step", "kernel_ms")}, d["roofline"]["frac"], d["roofline"]["traffic"], d["steps1000"]["value"], d["f32_mode"]["value"],
       d["dip"]["value"], d["dip"]["roofline"]["traffic"], d["dip"]["launches_per_motion_batch"], d["dip"].get("small_batch"), d["cpu_baseline"]["value"],
-      d["small_batch"]["B1"], d["small_batch"]["B6"], d["small_batch"]["B10"])
+      d["small_batch"]["B1"], d["small_batch"]["B6"], d["small_batch"]["B10"], d.get("trans_dec"))
 PY
