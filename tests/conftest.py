@@ -52,6 +52,17 @@ if os.environ.get("PYTEST_XDIST_WORKER"):     # one of several workers: the orac
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test")
+    # The GPU suite's wall time is the CHECKER's time: the torch-CPU oracle replays whole sampling loops (1000 steps at batch 1 in
+    # tests/test_gpu_round2.py) and torch's default intra-op pool is every hardware thread of the GPU box (256), which at these sizes is
+    # 5-10x SLOWER than a few cores (bench.py cpu_baseline: 1.4 s per 50-step loop at 16 threads, 5.3 s at 64): 423 s of a 926 s run
+    # were that one replay.  Bound the pool on a GPU box; the oracle's results do not depend on the thread count (bit-identical
+    # at 1 and 8 threads).
+    try:
+        import torch
+        if torch.cuda.is_available() and not os.environ.get("PYTEST_XDIST_WORKER"):
+            torch.set_num_threads(min(16, torch.get_num_threads()))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
