@@ -202,3 +202,24 @@ def test_emulated_decoder_with_class_token(lib, engine_options, prec, route):
     assert maxabs(got, want) < 5e-5
     diffusion.dip_stepwise = True
     assert maxabs(run(), got) < 2e-5
+
+
+def test_emulated_unconstrained_action_dataset_model(lib):
+    """README `humanact12_unconstrained` (`--unconstrained` on an action dataset: cond_mode='no_cond' over the 25 x 6 rot6d features,
+    model/mdm.py:227-229): the condition token is the timestep embedding alone; bare model, 2-step loop."""
+    B, T, steps = 2, 12, 2
+    sd = synth_a2m_state_dict(seed=0, latent_dim=256, num_layers=1)
+    del sd["embed_action.action_embedding"]
+    model, diffusion = make_pair(sd, steps, "cpu", guided=False, native_lib=lib, unconstrained=True, **A2M)
+    assert model.cond_mode == "no_cond" and model.njoints == 25
+    y = synth_y(B, T, seed=3, lengths=[12, 7])
+    del y["text_embed"]
+    x = torch.randn(B, 25, 6, T, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([1, 0])
+    assert maxabs(model(x, t, y=dict(y)), orc.mdm_forward(sd, x, t, y, num_heads=2)) < 2e-5
+    shape = (B, 25, 6, T)
+    x_T, noises = orc.make_noise(shape, steps, 11)
+    got = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": dict(y)},
+                                  noise_sequence=[x_T] + [n.contiguous() for n in noises])
+    want = orc.sample_loop(sd, orc.Tables(orc.named_betas("cosine", steps)), shape, y, x_T, noises, cfg=False, num_heads=2)
+    assert maxabs(got, want) < 5e-5
