@@ -278,14 +278,21 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       if (rc != 0) return fail(MDM_EUNSUPPORTED, "cross-attention block: unsupported shape");
       if (int rc2 = rt_launch_status()) return rc2;
     } else {
+    // sequence-tile route under guidance: the unconditional half (branch 1 = sequences B .. 2B-1) needs neither the q projection nor
+    // the attention -- every query's output is the sequence's one projected value row (elementwise.h uncond_xattn_rows_kernel); the
+    // cross out_proj below runs over all rows as before.  -75 us of a 1,138 us layer at B = 128 (profiles/r06h).
+    const bool skip_uncond = !small && nbranch == 2;
+    const int nseq_q = skip_uncond ? B : nseq, Mq = nseq_q * S;
     {
       LnArgs a = LN(); a.astat = sY; a.colsum = F.c_q;
-      if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 4, Y, P.q, F.b_q, a, q32, nullptr, nullptr, nullptr, M, D, D, S, D, D, qscale,
+      if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 4, Y, P.q, F.b_q, a, q32, nullptr, nullptr, nullptr, Mq, D, D, S, D, D, qscale,
                                 s)) return rc;
     }
+    const float* vsrc; const float* vadd = nullptr; size_t vstride; int vseq0;
     if (!hoisted) {
       const AttnF32Args a{q32, D, ws.kv, ws.kv + D, 2 * D, S, ntok, text_lengths, 0, B};
-      if (int rc = launch_attention_args(pf, a, nullptr, nseq, D, H, ws.atth, ws.attl, s)) return rc;
+      if (int rc = launch_attention_args(pf, a, nullptr, nseq_q, D, H, ws.atth, ws.attl, s)) return rc;
+      vsrc = ws.kv + D; vstride = (size_t)ntok * 2 * D; vseq0 = B;
     } else {
       const float* kvt = hz.kv_text + (size_t)l * 2 * D;
       const float* row = hz.kv_time + ((size_t)hz.step * m->cfg.num_layers + l) * 2 * D;
@@ -294,7 +301,14 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       a.vadd = row + D;
       a.kv_B = hz.kv_B;
       a.kv_b0 = hz.kv_b0;
-      if (int rc = launch_attention_args(pf, a, nullptr, nseq, D, H, ws.atth, ws.attl, s)) return rc;
+      if (int rc = launch_attention_args(pf, a, nullptr, nseq_q, D, H, ws.atth, ws.attl, s)) return rc;
+      vsrc = kvt + D; vadd = row + D; vstride = (size_t)ntok * m->cfg.num_layers * 2 * D; vseq0 = hz.kv_B + hz.kv_b0;
+    }
+    if (skip_uncond) {
+      ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
+      MDM_LAUNCH(uncond_xattn_rows_kernel, dim3(B * ((S + 15) / 16)), dim3(D / 4 > 256 ? 256 : D / 4), 0, s, ws.atth, ws.attl, vsrc,
+                 vstride, vadd, S, D, B, vseq0);
+      if (int rc = rt_launch_status()) return rc;
     }
     {
       LnArgs a = LN(); a.res = Y; a.rstat = sY; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias"); a.ostat = sX;

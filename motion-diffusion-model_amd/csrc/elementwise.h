@@ -118,6 +118,31 @@ __global__ __launch_bounds__(256) void text_memory_kernel(float* __restrict__ me
   }
 }
 
+// The UNCONDITIONAL branch's cross-attention over the text memory needs no attention.  mask_cond zeroes the text (model/mdm.py:155-156),
+// so every memory row of such a sequence is the same vector -- embed_text.bias + time_emb (+ target) (mdm.py:217-219) --, its projected
+// keys are identical, the scores of a query are equal over the valid tokens, the softmax is uniform and the output of EVERY query is the
+// one projected value row (sum_j p_j v = v).  This kernel writes that row (v of the sequence's first memory token, + the step's
+// projected time row in a window loop) into all S rows of the sequence's attention-output planes: the q projection and the attention
+// kernel then run on the conditional half of a guided batch only (csrc/decoder.h, sequence-tile route).
+// Grid = nseq_u * ceil(S / 16) blocks of D / 4 threads.
+__global__ __launch_bounds__(256) void uncond_xattn_rows_kernel(p16_t* __restrict__ oh, p16_t* __restrict__ ol, const float* __restrict__ v,
+                                                                size_t seq_stride, const float* __restrict__ vadd, int S, int D,
+                                                                int dst_seq0, int src_seq0) {
+  const int chunks = (S + 15) / 16, u = (int)blockIdx.x / chunks, r0 = ((int)blockIdx.x - u * chunks) * 16;
+  const float* src = v + (size_t)(src_seq0 + u) * seq_stride;
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+    float4 val = ld4(src + c);
+    if (vadd != nullptr) {
+      const float4 g = ld4(vadd + c);
+      val = make_float4(val.x + g.x, val.y + g.y, val.z + g.z, val.w + g.w);
+    }
+    for (int r = r0; r < min(r0 + 16, S); ++r) {
+      const size_t o = ((size_t)(dst_seq0 + u) * S + r) * D + c;
+      split4_store(oh + o, ol + o, val);
+    }
+  }
+}
+
 // Rows idx[0 .. n) of `table` [rows][D] -> dst [n][D]: the time-embedding rows of a window loop's steps (mdm_sample_loop_dec) in ONE
 // launch instead of one device-to-device copy per step (round 6).  Up to 64 rows per launch (the indices travel in the kernel argument).
 struct RowGather {
