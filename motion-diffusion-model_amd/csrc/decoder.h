@@ -177,6 +177,12 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
   auto LN = [&]() { LnArgs a; a.small = small; a.shape = shape; a.stat_cols = scols; a.parts = parts; a.inv_dim = inv_dim; return a; };
   const X3Operand attp{ws.atth, ws.attl}, ffnp{ws.ffnh, ws.ffnl};
   float* q32 = ws.tok;   // the projected cross-attention queries [M][D]
+  // A trans_dec tgt sequence carries no condition token (emb_trans_dec: the timestep embedding, the same in both branches), so under
+  // guidance the two branches enter layer 0 with IDENTICAL rows and stay identical through its self-attention block (in_proj,
+  // attention, out_proj + residual): they part at the first cross-attention.  The sequence-tile route (throughput-bound) runs that
+  // block on the conditional half and copies the result; bit-identical to computing it twice.
+  const bool share0 = !small && nbranch == 2 && !(m->fused_selfattn && selfattn_block_supported(D, S));
+  const int M0 = share0 ? B * S : M;
   for (int l = 0; l < m->cfg.num_layers; ++l) {
     const mdm_model::DecFold& F = m->dec_fold[l];
     const mdm_model::DecPlanes& P = m->dec_planes[l];
@@ -201,19 +207,26 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
     if (l == 0) {
       LnArgs a = LN();
       if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 6, X, P.in_proj, m->L(l, "self_attn.in_proj_bias"), a, nullptr, nullptr,
-                                nullptr, &ws.qp, M, 3 * D, D, S, D, D, qscale, s)) return rc;
+                                nullptr, &ws.qp, M0, 3 * D, D, S, D, D, qscale, s)) return rc;
     } else {
       LnArgs a = LN(); a.astat = sX; a.colsum = F.c_in;
       if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 0, X, P.in_proj, F.b_in, a, nullptr, nullptr, nullptr, &ws.qp, M, 3 * D, D,
                                 S, D, D, qscale, s)) return rc;
     }
-    if (int rc = launch_attention_x3(pf, ws.qp, len, nseq, B, S, D, nullptr, ws.atth, ws.attl, s, /*lead=*/0, m->attn_direct)) return rc;
+    if (int rc = launch_attention_x3(pf, ws.qp, len, share0 && l == 0 ? B : nseq, B, S, D, nullptr, ws.atth, ws.attl, s, /*lead=*/0,
+                                     m->attn_direct)) return rc;
     }   // !fused self-attention
     {
       LnArgs a = LN(); a.res = X; a.ostat = sY;
       if (l >= 1) { a.rstat = sX; a.rgamma = m->L(l - 1, "norm3.weight"); a.rbeta = m->L(l - 1, "norm3.bias"); }
       if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, l == 0 ? 1 : 2, attp, P.out_proj, m->L(l, "self_attn.out_proj.bias"), a,
-                                nullptr, Yh, Yl, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
+                                nullptr, Yh, Yl, nullptr, l == 0 ? M0 : M, D, D, S, D, 0, 1.f, s)) return rc;
+    }
+    if (share0 && l == 0) {   // the unconditional half of layer 0's self-attention block IS the conditional half: copy its rows
+      ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
+      if (int rc = rt_copy(Yh + (size_t)M0 * D, Yh, (size_t)M0 * D * sizeof(p16_t), s)) return rc;
+      if (int rc = rt_copy(Yl + (size_t)M0 * D, Yl, (size_t)M0 * D * sizeof(p16_t), s)) return rc;
+      if (int rc = rt_copy(sY + (size_t)M0 * parts * 2, sY, (size_t)M0 * parts * 2 * sizeof(float), s)) return rc;
     }
     // ---- X = norm1(Y) + multihead_attn(norm1(Y), memory, memory).  One kernel (xattn_block.h: q projection with norm1 folded ->
     // attention over the memory -> out_proj + norm1 residual + row statistics) where its shapes are covered; else three launches:
