@@ -215,3 +215,29 @@ def test_decoder_with_class_token_matches_reference_golden(golden_dir, prec):
     errs["loop10"] = maxabs(out.cpu(), g["final"])
     print(f"[parity] decemb_B3_T60 {prec}: max-abs vs reference = {errs}")
     assert max(errs.values()) < TOL_LOOP, errs
+
+
+def test_full_length_trans_dec_routes_agree_at_the_headline_batch(engine_options):
+    """The full-length trans_dec denoiser at B = 128 under guidance (256 sequences of 196 tokens, ragged frame masks and prompts,
+    production Philox noise, 10 steps): the sequence-tile route -- with layer 0's self-attention block shared between the branches and
+    no cross-attention work for the unconditional half (csrc/decoder.h) -- against the row-tile route, which takes neither shortcut:
+    two different arithmetic paths over the whole batch agree to the loop tolerance; and the sequence-tile run is reproducible bit for bit."""
+    B, T, steps = 128, 196, 10
+    sd = memo("sd_dip0", lambda: synth_dip_state_dict(seed=0))
+    g = torch.Generator().manual_seed(5)
+    tl = [int(v) for v in torch.randint(3, 25, (B,), generator=g)]
+    y = synth_dip_y(B, T, 1, seed=77, text_lengths=tl, lengths=[196 - (11 * i) % 157 for i in range(B)], scale=2.5)
+    y.pop("prefix")
+    y = to_dev(y, DEV)
+    outs = {}
+    for route, opts in (("sequence_tiles", {}), ("row_tiles", {"small_gemm_max_seqs": 100000})):
+        engine_options(**opts)
+        model, diffusion = make_pair(sd, steps, DEV, guided=True, context_len=0, pred_len=0, mask_frames=True)
+        run = lambda: diffusion.p_sample_loop(model, (B, 263, 1, T), clip_denoised=False, model_kwargs={"y": dict(y)}, seed=31)  # noqa: E731
+        outs[route] = run()
+        if route == "sequence_tiles":
+            assert torch.equal(run(), outs[route])
+    assert torch.isfinite(outs["row_tiles"]).all()
+    err = maxabs(outs["sequence_tiles"].cpu(), outs["row_tiles"].cpu())
+    print(f"[parity] transdec B=128 T=196 10 steps, sequence tiles (shared layer-0 block, no uncond cross-attention) vs row tiles: {err:.3e}")
+    assert err < TOL_LOOP and not torch.equal(outs["sequence_tiles"], outs["row_tiles"])
