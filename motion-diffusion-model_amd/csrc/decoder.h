@@ -19,6 +19,8 @@ struct DecWorkspace {
   float *kv_text;    // [nseq*ntok][L][2D]   Wkv_l . (text part of the memory)            (no bias)
   float *kv_time;    // [nsteps][L][2D]      Wkv_l . time_table[timestep of step k] + b_kv_l
   float *time_rows;  // [nsteps][D]          the gathered time-embedding rows
+  float *o_text;     // [L][B][D]            Wo_l . (value row of the unconditional sequence's text part) + bo_l   (sequence-tile route
+  float *o_time;     // [L][nsteps][D]       Wo_l . (value row of the step's time part)                              under guidance)
   size_t bytes;
 };
 DecWorkspace carve_dec(const mdm_model* m, int nseq, int S, int ntok, int B, void* base, int nsteps = 0, int pred_len = 0) {
@@ -56,13 +58,15 @@ DecWorkspace carve_dec(const mdm_model* m, int nseq, int S, int ntok, int B, voi
   w.proj = take((size_t)ntok * B * D);   // embed_text(enc_text), token-major
   w.stat[0] = take(M * (D / LN_PART_COLS) * 2);
   w.stat[1] = take(M * (D / LN_PART_COLS) * 2);
-  w.out = w.kv_text = w.kv_time = w.time_rows = nullptr;
+  w.out = w.kv_text = w.kv_time = w.time_rows = w.o_text = w.o_time = nullptr;
   if (nsteps > 0) {
     const size_t L = m->cfg.num_layers;
     w.out = take((size_t)nseq * m->jf * pred_len);
     w.kv_text = take(L * Mm * 2 * D);
     w.kv_time = take(L * nsteps * 2 * D);
     w.time_rows = take((size_t)nsteps * D);
+    w.o_text = take(L * (size_t)B * D);
+    w.o_time = take(L * (size_t)nsteps * D);
   }
   w.bytes = off;
   return w;
@@ -91,6 +95,9 @@ struct DecHoist {         // step k of a window loop: where the hoisted projecti
   const float* kv_time = nullptr;   // [nsteps][L][2D]
   int kv_B = 0, kv_b0 = 0;          // this pass covers samples kv_b0 .. kv_b0 + B - 1 of kv_B
   int t_model = 0;                  // the step's model timestep (the class token of MDM_OPT_DEC_TIME_TOKEN needs its table row)
+  // the unconditional half's cross-attention block as row constants, hoisted with the projections (null: made per step):
+  const float* o_text = nullptr;    // [L][kv_B][D]  Wo_l . v_text(unconditional sequence b) + bo_l
+  const float* o_time = nullptr;    // [L][nsteps][D]  Wo_l . v_time(step)
 };
 // `--emb_trans_dec` (model/mdm.py:256-257, the `humanml-decoder-with-emb-512` checkpoint): the TIMESTEP embedding leads the decoder's
 // tgt sequence as a class token.  The library sees it as the one context row of a context_len = 1 model (always a valid key, dropped
@@ -317,16 +324,42 @@ int decoder_layers_planes(mdm_model_t* m, const DecWorkspace& ws, const float* x
       if (int rc = launch_attention_args(pf, a, nullptr, nseq_q, D, H, ws.atth, ws.attl, s)) return rc;
       vsrc = kvt + D; vadd = row + D; vstride = (size_t)ntok * m->cfg.num_layers * 2 * D; vseq0 = hz.kv_B + hz.kv_b0;
     }
-    if (skip_uncond) {
+    // ... and with it the whole block of those sequences is a row-constant: x' = norm1(y) + (Wo . v + bo).  Where the statistics
+    // partials are 256 columns wide and D / 4 threads fit a workgroup (every latent_dim the route runs), one small GEMM makes the B
+    // vectors o and uncond_xblock_rows_kernel writes the rows; the cross out_proj then covers the conditional half only.
+    const bool xblock_uncond = skip_uncond && scols == 256 && D % 256 == 0 && D <= 1024;
+    if (skip_uncond && !xblock_uncond) {
       ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
       MDM_LAUNCH(uncond_xattn_rows_kernel, dim3(B * ((S + 15) / 16)), dim3(D / 4 > 256 ? 256 : D / 4), 0, s, ws.atth, ws.attl, vsrc,
                  vstride, vadd, S, D, B, vseq0);
       if (int rc = rt_launch_status()) return rc;
     }
+    if (xblock_uncond) {
+      const float* o1; const float* o2 = nullptr;
+      if (hoisted && hz.o_text != nullptr && hz.kv_b0 == 0 && hz.kv_B == B) {   // a window loop made the row constants once (loops.h)
+        o1 = hz.o_text + (size_t)l * B * D;
+        o2 = hz.o_time + ((size_t)l * hz.nsteps + hz.step) * D;
+      } else {
+        float* vs = q32 + (size_t)Mq * D;          // (the projected queries fill the conditional half of q32 only)
+        float* ov = vs + (size_t)B * D;
+        {
+          ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
+          MDM_LAUNCH(gather_value_rows_kernel, dim3(B), dim3(128), 0, s, vs, vsrc, vstride, vadd, D, vseq0);
+          if (int rc = rt_launch_status()) return rc;
+        }
+        if (int rc = launch_linear(pf, vs, D, m->L(l, "multihead_attn.out_proj.weight"), m->L(l, "multihead_attn.out_proj.bias"), nullptr,
+                                   ov, B, D, D, ACT_NONE, 0, 1.f, s)) return rc;
+        o1 = ov;
+      }
+      ProfScope ps(pf, MDM_PROF_ELEMENTWISE, 0.0, s);
+      MDM_LAUNCH(uncond_xblock_rows_kernel, dim3((Mq + 7) / 8), dim3(D / 4), 0, s, (const p16_t*)Yh, (const p16_t*)Yl, (const float*)sY,
+                 m->L(l, "norm1.weight"), m->L(l, "norm1.bias"), o1, o2, Xh, Xl, sX, Mq, Mq, S, D, inv_dim);
+      if (int rc = rt_launch_status()) return rc;
+    }
     {
       LnArgs a = LN(); a.res = Y; a.rstat = sY; a.rgamma = m->L(l, "norm1.weight"); a.rbeta = m->L(l, "norm1.bias"); a.ostat = sX;
       if (int rc = launch_x3_ln(pf, MDM_PROF_LINEAR, 2, attp, P.out_proj2, m->L(l, "multihead_attn.out_proj.bias"), a, nullptr,
-                                Xh, Xl, nullptr, M, D, D, S, D, 0, 1.f, s)) return rc;
+                                Xh, Xl, nullptr, xblock_uncond ? Mq : M, D, D, S, D, 0, 1.f, s)) return rc;
     }
     }   // !fused
     // ---- Y = norm2(X) + linear2(gelu(linear1(norm2(X))))

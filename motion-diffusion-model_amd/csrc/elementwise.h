@@ -143,6 +143,72 @@ __global__ __launch_bounds__(256) void uncond_xattn_rows_kernel(p16_t* __restric
   }
 }
 
+// v [+ vadd] of sequences src_seq0 .. + n - 1 (first memory token each) -> dst [n][D]  (the one value row of an unconditional sequence)
+__global__ __launch_bounds__(128) void gather_value_rows_kernel(float* __restrict__ dst, const float* __restrict__ v, size_t seq_stride,
+                                                                const float* __restrict__ vadd, int D, int src_seq0) {
+  const float* src = v + (size_t)(src_seq0 + (int)blockIdx.x) * seq_stride;
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+    float4 val = ld4(src + c);
+    if (vadd != nullptr) {
+      const float4 g = ld4(vadd + c);
+      val = make_float4(val.x + g.x, val.y + g.y, val.z + g.z, val.w + g.w);
+    }
+    st4(dst + (size_t)blockIdx.x * D + c, val);
+  }
+}
+
+// ... and therefore the unconditional half's whole cross-attention BLOCK is a row-constant: x' = norm1(y) + (Wo . v + bo) with ONE
+// vector o = Wo . v + bo per sequence (mdm.py:85-93, torch _mha_block + the residual).  This kernel is that block for the rows of the
+// unconditional sequences on the sequence-tile route: norm1(y) rebuilt from y's planes and its partial row statistics (256 columns per
+// partial, merged by Chan's formula exactly as gemm_x3.h does), + o, written as operand planes with the row's partial statistics in
+// the producer format every consumer merges ((sum, centred sum of squares) per 256 columns).  One wave = one 256-column partial;
+// block = D / 4 threads = one row at a time over 8 rows; grid = rows / 8.
+__global__ __launch_bounds__(256) void uncond_xblock_rows_kernel(const p16_t* __restrict__ yh, const p16_t* __restrict__ yl,
+                                                                 const float* __restrict__ ystat, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ o,
+                                                                 const float* __restrict__ o2,   // null or [D]: added to every o row
+                                                                 p16_t* __restrict__ oh, p16_t* __restrict__ ol, float* __restrict__ ostat,
+                                                                 int row0, int rows, int S, int D, float inv_dim) {
+  const int parts = D / 256, c = threadIdx.x * 4, part = threadIdx.x >> 6;
+  const float4 g4 = ld4(gamma + c);
+  float4 b4 = ld4(beta + c);
+  if (o2 != nullptr) {
+    const float4 t4 = ld4(o2 + c);
+    b4 = make_float4(b4.x + t4.x, b4.y + t4.y, b4.z + t4.z, b4.w + t4.w);
+  }
+  for (int i = 0; i < 8; ++i) {
+    const int r = (int)blockIdx.x * 8 + i;
+    if (r >= rows) break;
+    const size_t row = (size_t)row0 + r;
+    float s1 = 0.f;
+    for (int p = 0; p < parts; ++p) s1 += ystat[(row * parts + p) * 2];
+    const float mean = s1 * inv_dim;
+    float m2 = 0.f;
+    for (int p = 0; p < parts; ++p) {
+      const float dm = ystat[(row * parts + p) * 2] * (1.0f / 256.0f) - mean;
+      m2 += ystat[(row * parts + p) * 2 + 1] + 256.0f * dm * dm;
+    }
+    const float rstd = 1.0f / sqrtf(m2 * inv_dim + 1e-5f);
+    const size_t off = row * D + c;
+    const uint2 a = *reinterpret_cast<const uint2*>(yh + off), b = *reinterpret_cast<const uint2*>(yl + off);
+    const float x0 = p16_to_f32((p16_t)(a.x & 0xffff)) + p16_to_f32((p16_t)(b.x & 0xffff));
+    const float x1 = p16_to_f32((p16_t)(a.x >> 16)) + p16_to_f32((p16_t)(b.x >> 16));
+    const float x2 = p16_to_f32((p16_t)(a.y & 0xffff)) + p16_to_f32((p16_t)(b.y & 0xffff));
+    const float x3 = p16_to_f32((p16_t)(a.y >> 16)) + p16_to_f32((p16_t)(b.y >> 16));
+    const float4 o4 = ld4(o + (size_t)(r / S) * D + c);
+    const float4 v = make_float4((x0 - mean) * rstd * g4.x + b4.x + o4.x, (x1 - mean) * rstd * g4.y + b4.y + o4.y,
+                                 (x2 - mean) * rstd * g4.z + b4.z + o4.z, (x3 - mean) * rstd * g4.w + b4.w + o4.w);
+    split4_store(oh + off, ol + off, v);
+    float t = (v.x + v.y) + (v.z + v.w);
+    for (int k = 1; k < 64; k <<= 1) t += shfl_xor_f32(t, k);
+    const float mw = t * (1.0f / 256.0f);
+    const float dx = v.x - mw, dy = v.y - mw, dz = v.z - mw, dw = v.w - mw;
+    float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    for (int k = 1; k < 64; k <<= 1) q += shfl_xor_f32(q, k);
+    if ((threadIdx.x & 63) == 0) *reinterpret_cast<float2*>(ostat + (row * parts + part) * 2) = make_float2(t, q);
+  }
+}
+
 // Rows idx[0 .. n) of `table` [rows][D] -> dst [n][D]: the time-embedding rows of a window loop's steps (mdm_sample_loop_dec) in ONE
 // launch instead of one device-to-device copy per step (round 6).  Up to 64 rows per launch (the indices travel in the kernel argument).
 struct RowGather {

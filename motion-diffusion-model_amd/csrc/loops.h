@@ -168,6 +168,18 @@ int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float
   // ALL layers in one launch each (round 6; 2 L launches of 15 us before): rows of kv_text / kv_time are [L * 2D] wide, layer l at + l * 2D
   if (int rc = launch_linear(pf, ws.mem, D, m->wkv_all, nullptr, nullptr, ws.kv_text, Mm, L * 2 * D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
   if (int rc = launch_linear(pf, ws.time_rows, D, m->wkv_all, m->bkv_all, nullptr, ws.kv_time, nsteps, L * 2 * D, D, ACT_NONE, 0, 1.f, s, x3)) return rc;
+  // sequence-tile route under guidance (csrc/decoder.h): the unconditional half's cross-attention block is one row constant per
+  // sequence, layer and step -- Wo . (v_text + v_time) + bo -- linear in its two parts: both made here, once per window
+  const bool o_hoist = cfg && x3 && dec_sequence_tiles(m, nseq, m->cfg.context_len + P);
+  if (o_hoist)
+    for (int l = 0; l < L; ++l) {
+      const float* wo = m->L(l, "multihead_attn.out_proj.weight");
+      const float* vt = ws.kv_text + (size_t)B * ntok * L * 2 * D + (size_t)l * 2 * D + D;     // first memory token of unconditional sequence 0
+      if (int rc = launch_linear(pf, vt, ntok * L * 2 * D, wo, m->L(l, "multihead_attn.out_proj.bias"), nullptr,
+                                 ws.o_text + (size_t)l * B * D, B, D, D, ACT_NONE, 0, 1.f, s)) return rc;
+      if (int rc = launch_linear(pf, ws.kv_time + (size_t)l * 2 * D + D, L * 2 * D, wo, nullptr, nullptr,
+                                 ws.o_time + (size_t)l * nsteps * D, nsteps, D, D, ACT_NONE, 0, 1.f, s)) return rc;
+    }
 
   // ---- the steps.  The loop is written over G sample groups (each owns the rows [g * Mg, (g + 1) * Mg) of the activation
   // buffers and reads the hoisted text K / V of the whole batch through the attention kernel's (branch, sample) remap);
@@ -214,6 +226,7 @@ int mdm_sample_loop_dec(mdm_model_t* m, const mdm_sample_dec_params_t* pd, float
       DecHoist hz;
       hz.step = k; hz.nsteps = nsteps; hz.kv_text = ws.kv_text; hz.kv_time = ws.kv_time; hz.kv_B = B; hz.kv_b0 = b0;
       hz.t_model = p->timestep_map[i];
+      if (o_hoist) { hz.o_text = ws.o_text; hz.o_time = ws.o_time; }
       const float* prefix_g = pd->prefix_dev != nullptr ? pd->prefix_dev + (size_t)b0 * m->jf * m->cfg.context_len : nullptr;
       // CFG combine + posterior / DDIM update, in place on x (each element is read, then written, by the same lane): inside the
       // plane route's tail kernel (DecTail), else as a kernel of its own behind the denoiser
